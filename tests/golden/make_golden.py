@@ -1,0 +1,357 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE itself.
+
+This script is the only place in the repo that imports /root/reference.  It runs
+in the build container only (the GPU box has no /root/reference) and writes
+small .npz fixtures = inputs + parameters + the reference's outputs.  Nothing
+from the reference's source travels: fixtures are data.
+
+Import recipe: the reference needs yacs / cv2 / imageio /
+memory_profiler / colorama / matplotlib at import time and hard-codes .cuda();
+none of that is on the tensor path, so they are replaced by inert stubs and
+.cuda() is made a no-op so the reference's own torch-CPU arithmetic runs
+verbatim.
+
+    python tests/golden/make_golden.py [--reference /root/reference]
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SEED = 20260928
+
+
+# --------------------------------------------------------------------------- #
+# stubs
+# --------------------------------------------------------------------------- #
+class _CfgNode(dict):
+    """Minimal attribute-dict standing in for yacs.config.CfgNode."""
+
+    def __init__(self, init=None, new_allowed=False):
+        super().__init__()
+        if init:
+            for k, v in init.items():
+                self[k] = _CfgNode(v) if isinstance(v, dict) else v
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def _merge(self, other):
+        for k, v in other.items():
+            if isinstance(v, dict):
+                if k not in self or not isinstance(self[k], _CfgNode):
+                    self[k] = _CfgNode()
+                self[k]._merge(v)
+            else:
+                self[k] = v
+
+    def merge_from_file(self, path):
+        import yaml
+
+        with open(path) as f:
+            self._merge(yaml.safe_load(f))
+
+    def merge_from_list(self, lst):
+        pass
+
+    def freeze(self):
+        pass
+
+    def defrost(self):
+        pass
+
+
+def install_stubs():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    yacs = mod("yacs")
+    yacs.config = mod("yacs.config", CfgNode=_CfgNode)
+    for name in ("cv2", "imageio", "colorama", "psutil_stub"):
+        mod(name)
+    sys.modules["colorama"].Fore = types.SimpleNamespace(RED="", GREEN="", RESET="", YELLOW="", BLUE="")
+    sys.modules["colorama"].Style = types.SimpleNamespace(RESET_ALL="")
+    mod("memory_profiler", profile=lambda f: f)
+    if "matplotlib" not in sys.modules:
+        try:
+            import matplotlib  # noqa: F401
+            import matplotlib.pyplot  # noqa: F401
+        except Exception:
+            mpl = mod("matplotlib")
+            mpl.pyplot = mod("matplotlib.pyplot")
+    # the reference hard-codes .cuda(); keep its arithmetic on the CPU path
+    torch.cuda.is_available = lambda: True
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    import torch.utils.model_zoo as mz
+
+    mz.load_url = lambda *a, **k: {}
+    if not hasattr(np, "float"):
+        np.float = float
+    if not hasattr(np, "int"):
+        np.int = int
+
+
+def rng(tag: int):
+    return np.random.default_rng(SEED + tag)
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
+    print(f"  wrote {name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def relu_normal(g, shape):
+    return np.maximum(g.standard_normal(shape, dtype=np.float32), 0.0)
+
+
+# --------------------------------------------------------------------------- #
+# generators
+# --------------------------------------------------------------------------- #
+def gen_xcorr(ref_xcorr):
+    cases = {
+        # name: (B, C, Hx, Wx, Hk, Wk)
+        "prod_5x29": (2, 16, 29, 29, 5, 5),
+        "cfg5_5x35": (1, 8, 35, 35, 5, 5),
+        "north_31x61": (1, 4, 61, 61, 31, 31),
+        "ragged_3x4_in_7x9": (2, 3, 7, 9, 3, 4),
+        "full_size_kernel": (1, 5, 6, 6, 6, 6),
+        "one_by_one": (3, 2, 4, 5, 1, 1),
+    }
+    out = {}
+    for i, (name, (B, C, Hx, Wx, Hk, Wk)) in enumerate(cases.items()):
+        g = rng(100 + i)
+        x = relu_normal(g, (B, C, Hx, Wx))
+        k = relu_normal(g, (B, C, Hk, Wk))
+        if name == "ragged_3x4_in_7x9":  # signed inputs too
+            x = g.standard_normal((B, C, Hx, Wx), dtype=np.float32)
+            k = g.standard_normal((B, C, Hk, Wk), dtype=np.float32)
+        y = ref_xcorr.xcorr_depthwise(t(x), t(k)).numpy()
+        out[name + "__x"] = x
+        out[name + "__k"] = k
+        out[name + "__y"] = y
+    save("xcorr_depthwise", **out)
+
+    # full-channel cases: inputs are re-derived from the seed in the test, outputs are sampled
+    samp = {}
+    for j, (name, (B, C, Hx, Wx, Hk, Wk)) in enumerate(
+        {"prod256_5x29": (1, 256, 29, 29, 5, 5), "north256_31x61": (1, 256, 61, 61, 31, 31)}.items()
+    ):
+        g = rng(150 + j)
+        x = relu_normal(g, (B, C, Hx, Wx))
+        k = relu_normal(g, (B, C, Hk, Wk))
+        y = ref_xcorr.xcorr_depthwise(t(x), t(k)).numpy()
+        idx = rng(160 + j).choice(y.size, size=1024, replace=False)
+        samp[name + "__shape"] = np.array([B, C, Hx, Wx, Hk, Wk])
+        samp[name + "__idx"] = idx.astype(np.int64)
+        samp[name + "__val"] = y.reshape(-1)[idx]
+        samp[name + "__sum"] = np.array(y.astype(np.float64).sum())
+    save("xcorr_depthwise_sampled", **samp)
+
+    cases_c = {
+        "prod_13x13": (2, 16, 13, 13, 13, 13),
+        "even_8x10_k3x5": (1, 4, 8, 10, 3, 5),
+        "odd_7x5_k7x5": (2, 3, 7, 5, 7, 5),
+        "small_k_2x2_in_6x6": (1, 2, 6, 6, 2, 2),
+    }
+    out = {}
+    for i, (name, (B, C, Hx, Wx, Hk, Wk)) in enumerate(cases_c.items()):
+        g = rng(200 + i)
+        x = g.standard_normal((B, C, Hx, Wx), dtype=np.float32)
+        k = g.standard_normal((B, C, Hk, Wk), dtype=np.float32)
+        y = ref_xcorr.xcorr_depthwise_circular(t(x), t(k)).numpy()
+        out[name + "__x"] = x
+        out[name + "__k"] = k
+        out[name + "__y"] = y
+    save("xcorr_depthwise_circular", **out)
+
+
+def seeded_bn_(bn, g):
+    """Non-trivial eval-mode BN statistics so that folding bugs show."""
+    n = bn.num_features
+    bn.weight.data = t(g.uniform(0.5, 1.5, n).astype(np.float32))
+    bn.bias.data = t(g.uniform(-0.3, 0.3, n).astype(np.float32))
+    bn.running_mean.data = t(g.uniform(-0.5, 0.5, n).astype(np.float32))
+    bn.running_var.data = t(g.uniform(0.5, 2.0, n).astype(np.float32))
+
+
+def gen_share_feature(ref_pre):
+    torch.manual_seed(SEED)
+    m = ref_pre.PreShareFeature().eval()
+    g = rng(300)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            seeded_bn_(mod, g)
+    x = g.standard_normal((2, 1, 127, 127), dtype=np.float32)
+    x_small = g.standard_normal((1, 1, 9, 21), dtype=np.float32)
+    with torch.no_grad():
+        y = m(t(x)).numpy()
+        y_small = m(t(x_small)).numpy()
+    sd = {k.replace(".", "__"): v.numpy() for k, v in m.state_dict().items()}
+    save("share_feature", x=x, y=y, x_small=x_small, y_small=y_small, **{"sd__" + k: v for k, v in sd.items()})
+    return m
+
+
+def gen_dlt(ref_utils):
+    g = rng(400)
+    src = np.tile(np.array([0, 0, 0, 127, 127, 127, 127, 0], np.float32), (64, 1))
+    off = (8.0 * g.standard_normal((64, 8))).astype(np.float32)
+    off[0] = 0.0  # identity
+    off[1] = np.array([3.25, -1.5] * 4, np.float32)  # pure shift
+    H = ref_utils.DLT_solve(t(src), t(off)).numpy()
+    # general (non-square) source quadrilaterals, as training uses GT polys (model_builder…:502)
+    src2 = src[:16] + (4.0 * g.standard_normal((16, 8))).astype(np.float32)
+    off2 = (6.0 * g.standard_normal((16, 8))).astype(np.float32)
+    H2 = ref_utils.DLT_solve(t(src2), t(off2)).numpy()
+    save("dlt_solve", src=src, off=off, H=H, src2=src2, off2=off2, H2=H2)
+
+
+def M_mats(B):
+    M = torch.tensor([[63.5, 0.0, 63.5], [0.0, 63.5, 63.5], [0.0, 0.0, 1.0]])
+    Minv = torch.inverse(M)
+    return M.unsqueeze(0).expand(B, 3, 3), Minv.unsqueeze(0).expand(B, 3, 3)
+
+
+def gen_transform(ref_utils):
+    g = rng(500)
+    B, Hh, Ww = 6, 127, 127
+    img = g.standard_normal((B, 1, Hh, Ww), dtype=np.float32)
+    src = np.tile(np.array([0, 0, 0, 127, 127, 127, 127, 0], np.float32), (B, 1))
+    off = np.zeros((B, 8), np.float32)
+    off[1] = np.array([2.3, -4.7] * 4, np.float32)  # non-integer shift
+    off[2] = (3.0 * g.standard_normal(8)).astype(np.float32)  # mild perspective
+    off[3] = (8.0 * g.standard_normal(8)).astype(np.float32)
+    off[4] = (16.0 * g.standard_normal(8)).astype(np.float32)  # large
+    off[5] = (8.0 * g.standard_normal(8)).astype(np.float32)
+    H = ref_utils.DLT_solve(t(src), t(off)).squeeze(1)
+    # sample 5: a hand-made H with a strong projective row (t varies 0.7..1.3 over the patch)
+    Hn = H.clone()
+    Hn[5] = torch.tensor([[1.0, 0.02, 1.5], [0.01, 1.0, -2.0], [2.0e-3, -1.0e-3, 1.0]])
+    M, Minv = M_mats(B)
+    pidx = torch.arange(Hh * Ww, dtype=torch.float32).unsqueeze(0).expand(B, -1)
+    base = (torch.arange(B) * Hh * Ww).unsqueeze(1).expand(B, Hh * Ww).reshape(-1)
+    y = ref_utils.transform(Hh, Ww, Minv, Hn, M, t(img), pidx, base).numpy()
+    save("transform", img=img, H=Hn.numpy(), y=y)
+
+    # transformer() alone on a non-square image, C=1
+    img2 = g.standard_normal((2, 1, 20, 33), dtype=np.float32)
+    th = torch.tensor(
+        [[[1.0, 0.05, 0.02], [-0.03, 0.97, 0.01], [0.01, -0.02, 1.0]], [[0.9, 0.0, 0.1], [0.0, 1.1, -0.1], [0.0, 0.0, 1.0]]]
+    )
+    y2, cond = ref_utils.transformer(t(img2), th, (20, 33))
+    # degenerate denominators: t = x_t exactly (third row [1,0,0]) crosses 0 at the centre column of an
+    # odd-width grid, which exercises the reference's `|t| < 1e-7 -> t += 1e-6` nudge (utils.py:237-240)
+    img3 = g.standard_normal((1, 1, 15, 17), dtype=np.float32)
+    th3 = torch.tensor([[[0.5, 0.0, 0.0], [0.0, 0.5, 0.0], [1.0, 0.0, 0.0]]])
+    y3, cond3 = ref_utils.transformer(t(img3), th3, (15, 17))
+    save("transformer", img=img2, theta=th.numpy(), y=y2.numpy(), cond=np.array(float(cond)),
+         img3=img3, theta3=th3.numpy(), y3=y3.numpy(), cond3=np.array(float(cond3)))
+
+
+def gen_homo_model(ref_hmb, ref_gi):
+    """HomoModelBuilder.forward / track_proj on cfg-1 style inputs (B=2), seeded weights.
+
+    The 85 MB trunk state_dict is NOT committed: the trunk's output x[B,8] is saved
+    as an intermediate so the HIP stages after it are pinned, and trunk parity
+    (own ResNet34 vs the reference's, same state_dict) is checked in this container
+    by tests/test_trunk_vs_reference.py when /root/reference exists.
+    """
+    torch.manual_seed(SEED + 1)
+    m = ref_hmb.HomoModelBuilder(pretrained=False).eval()
+    g = rng(600)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            seeded_bn_(mod, g)
+    # small regressor head so the offsets are a few px
+    m.fc.weight.data = t((0.002 * g.standard_normal((8, 512))).astype(np.float32))
+    m.fc.bias.data = t((2.0 * g.standard_normal(8)).astype(np.float32))
+    B = 2
+    datas = []
+    for b in range(B):
+        tmp3 = g.integers(0, 256, (127, 127, 3)).astype(np.float64)
+        sea3 = g.integers(0, 256, (127, 127, 3)).astype(np.float64)
+        mean = np.reshape(np.array([118.93, 113.97, 102.60]), (1, 1, 3))
+        std = np.reshape(np.array([69.85, 68.81, 72.45]), (1, 1, 3))
+        tmp = np.transpose(np.mean((tmp3 - mean) / std, axis=2, keepdims=True), [2, 0, 1])
+        sea = np.transpose(np.mean((sea3 - mean) / std, axis=2, keepdims=True), [2, 0, 1])
+        datas.append(ref_gi.merge_tmp_search(tmp, sea))
+    data = {
+        "org_imgs": torch.stack([torch.Tensor(d["org_imgs"]).float() for d in datas]),
+        "input_tensors": torch.stack([torch.Tensor(d["input_tensors"]).float() for d in datas]),
+        "patch_indices": torch.stack([torch.Tensor(d["patch_indices"]).float() for d in datas]),
+        "h4p": torch.stack([torch.Tensor(d["four_points"]).float() for d in datas]),
+    }
+    with torch.no_grad():
+        out = m(data)
+    sf = {("sf__" + k.replace(".", "__")): v.numpy() for k, v in m.ShareFeature.state_dict().items()}
+    save(
+        "homo_forward",
+        org_imgs=data["org_imgs"].numpy(),
+        input_tensors=data["input_tensors"].numpy(),
+        patch_indices=data["patch_indices"].numpy(),
+        h4p=data["h4p"].numpy(),
+        x=out["x"].numpy(),
+        H_mat=out["H_mat"].numpy(),
+        feature_loss=out["feature_loss"].numpy(),
+        pred_I2_d=out["pred_I2_d"].numpy(),
+        patch_2_res_d=out["patch_2_res_d"].numpy(),
+        pred_I2_CnnFeature_d=out["pred_I2_CnnFeature_d"].numpy(),
+        homo_neg_loss=np.array(float(out["homo_neg_loss"])),
+        fc_w=m.fc.weight.data.numpy(),
+        fc_b=m.fc.bias.data.numpy(),
+        **sf,
+    )
+    return m, data
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reference", default="/root/reference")
+    args = ap.parse_args()
+    if not os.path.isdir(args.reference):
+        sys.exit(f"reference tree not found at {args.reference}")
+    install_stubs()
+    sys.path.insert(0, args.reference)
+    torch.set_num_threads(1)
+
+    import hdn.core.xcorr as ref_xcorr
+    from hdn.core.config import cfg
+
+    cfg.merge_from_file(os.path.join(args.reference, "experiments/tracker_homo_config/proj_e2e_GOT_unconstrained_v2.yaml"))
+    import homo_estimator.Deep_homography.Oneline_DLTv1.utils as ref_utils
+    import homo_estimator.Deep_homography.Oneline_DLTv1.preprocess.input_feature_extractor as ref_pre
+    import homo_estimator.Deep_homography.Oneline_DLTv1.models.homo_model_builder as ref_hmb
+    import homo_estimator.Deep_homography.Oneline_DLTv1.tools.get_img_info as ref_gi
+
+    print("generating golden vectors from", args.reference)
+    gen_xcorr(ref_xcorr)
+    gen_share_feature(ref_pre)
+    gen_dlt(ref_utils)
+    gen_transform(ref_utils)
+    gen_homo_model(ref_hmb, ref_gi)
+    print("torch", torch.__version__, "numpy", np.__version__)
+
+
+if __name__ == "__main__":
+    main()
