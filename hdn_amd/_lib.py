@@ -1,0 +1,116 @@
+"""ctypes binding of libhdn_hip.so (the C ABI declared in include/hdn_hip.h).
+
+There is no CPU fallback: if the shared library is missing, or a tensor is not on a
+ROCm device, the call raises.  PyTorch is used for device memory and streams only.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = "libhdn_hip.so"
+LIB_PATH = os.path.join(_HERE, LIB_NAME)
+ABI_VERSION = 1
+
+_c_float_p = ctypes.c_void_p  # device pointers travel as integers
+_i = ctypes.c_int
+
+# name -> (restype, argtypes); mirrors include/hdn_hip.h one to one
+SIGNATURES = {
+    "hdn_abi_version": (_i, []),
+    "hdn_last_xcorr_variant": (ctypes.c_char_p, []),
+    "hdn_xcorr_depthwise_f32": (_i, [_c_float_p] * 3 + [_i] * 6 + [ctypes.c_void_p]),
+    "hdn_xcorr_depthwise_circ_f32": (_i, [_c_float_p] * 3 + [_i] * 6 + [ctypes.c_void_p]),
+    "hdn_xcorr_depthwise_multi_f32": (
+        _i,
+        [ctypes.POINTER(ctypes.c_void_p)] * 3 + [_i, _i] + [_i] * 6 + [ctypes.c_void_p],
+    ),
+    "hdn_share_feature_f32": (_i, [_c_float_p] * 3 + [_i] * 3 + [ctypes.c_void_p]),
+    "hdn_dlt_solve_f32": (_i, [_c_float_p] * 3 + [_i, ctypes.c_void_p]),
+    "hdn_warp_f32": (_i, [_c_float_p] * 3 + [_i] * 4 + [ctypes.c_void_p]),
+    "hdn_dlt_warp_f32": (_i, [_c_float_p] * 5 + [_i] * 3 + [ctypes.c_void_p]),
+    "hdn_l1_score_f32": (_i, [_c_float_p] * 3 + [_i, ctypes.c_float, ctypes.c_void_p]),
+}
+
+ERRORS = {
+    -1: "HDN_E_NULL: a required pointer is NULL",
+    -2: "HDN_E_SHAPE: non-positive size, or correlation kernel larger than the search plane",
+    -3: "HDN_E_LIMIT: size exceeds what the kernels support",
+    -4: "HDN_E_ALIAS: output aliases an input",
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+class HdnHipError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load libhdn_hip.so (built in-tree by __graft_entry__.build()).  Raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise HdnHipError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  hdn_amd has no CPU fallback."
+            )
+        # torch is imported first so that the HIP runtime torch bundles (SONAME libamdhip64.so.7) is the one
+        # this library binds to: device pointers and streams are then shared with torch.
+        lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        got = lib.hdn_abi_version()
+        if got != ABI_VERSION:
+            raise HdnHipError(f"{LIB_NAME} ABI version {got} != expected {ABI_VERSION}; rebuild")
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc == 0:
+        return
+    if rc in ERRORS:
+        raise ValueError(f"{what}: {ERRORS[rc]}")
+    if rc <= -1000:
+        raise HdnHipError(f"{what}: HIP launch failed with hipError_t {-rc - 1000}")
+    raise HdnHipError(f"{what}: unknown error code {rc}")
+
+
+def require_device(*tensors: torch.Tensor) -> torch.device:
+    """All tensors must be fp32 tensors on one ROCm device.  No silent CPU path."""
+    dev = None
+    for t in tensors:
+        if not isinstance(t, torch.Tensor):
+            raise TypeError(f"expected a torch.Tensor, got {type(t).__name__}")
+        if not t.is_cuda:
+            raise HdnHipError(
+                "hdn_amd runs on the GPU only (tensor is on %s); there is no CPU fallback" % t.device
+            )
+        if t.dtype != torch.float32:
+            raise TypeError(f"hdn_amd kernels compute in fp32; got {t.dtype}")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise HdnHipError(f"tensors on different devices: {dev} vs {t.device}")
+    return dev
+
+
+def stream_ptr(device: torch.device) -> ctypes.c_void_p:
+    """The hipStream_t torch is currently issuing work on for `device`."""
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t: torch.Tensor) -> ctypes.c_void_p:
+    return ctypes.c_void_p(t.data_ptr())

@@ -1,0 +1,266 @@
+// 4-point DLT solve + projective bilinear warp for gfx950.
+// Reference: homo_estimator/Deep_homography/Oneline_DLTv1/utils.py:7-67 (DLT_solve),
+//            :70-254 (transformer), :257-274 (transform).
+//
+// DLT: the 8x8 system is solved by 8 lanes (lane r owns row r of [A|b], 9 float64 registers)
+// with Gauss-Jordan elimination and partial pivoting; pivot search and pivot-row broadcast are
+// wave shuffles, so nothing touches memory.  The reference inverts A in fp32 and multiplies;
+// for the production corners its result is within 7e-7 of the exact solution, which is what
+// this kernel returns (rounded once to fp32).
+//
+// Warp: one lane per output pixel (4 per thread), taps gathered from L2 (a 127x127 image is
+// 64 KB).  The arithmetic follows the reference's op order with un-fused multiplies/adds where
+// the reference's CPU kernels do not fuse, so that tap selection and the degenerate cases
+// (both taps clamped to one index -> exact cancellation, |t| < 1e-7 nudge, float->int
+// conversion of out-of-range coordinates) come out as the reference's PyTorch-CPU path gives
+// them.  See DESIGN.md "warp semantics".
+#include "hdn_common.h"
+
+namespace hdn {
+
+constexpr int WARP_PX_PER_THREAD = 4;
+constexpr int WARP_PX_PER_BLOCK = HDN_BLOCK * WARP_PX_PER_THREAD;
+
+// reference point order inside the solve: utils.py:18-26 gathers columns [0,1,2,3,6,7,4,5]
+__device__ __forceinline__ int dlt_point(int p) { return p == 2 ? 3 : (p == 3 ? 2 : p); }
+
+// All 64 lanes call this; each aligned group of 8 lanes solves the same system redundantly.
+// Returns h[r] for r = lane & 7 (the r-th of the 8 unknowns).
+__device__ __forceinline__ double dlt_solve_rows(const float* __restrict__ src, const float* __restrict__ off,
+                                                 int lane) {
+  const int r = lane & 7;
+  const int p = dlt_point(r >> 1);
+  const double x = (double)src[2 * p], y = (double)src[2 * p + 1];
+  // dst = src + off is an fp32 add in the reference (utils.py:36)
+  const double u = (double)__fadd_rn(src[2 * p], off[2 * p]);
+  const double v = (double)__fadd_rn(src[2 * p + 1], off[2 * p + 1]);
+  double a[9];
+  if ((r & 1) == 0) {
+    a[0] = x; a[1] = y; a[2] = 1.0; a[3] = 0.0; a[4] = 0.0; a[5] = 0.0; a[6] = -u * x; a[7] = -u * y; a[8] = u;
+  } else {
+    a[0] = 0.0; a[1] = 0.0; a[2] = 0.0; a[3] = x; a[4] = y; a[5] = 1.0; a[6] = -v * x; a[7] = -v * y; a[8] = v;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    // partial pivoting over rows >= k; ties resolve to the lowest row (as LAPACK's idamax does)
+    double best = (r >= k) ? fabs(a[k]) : -1.0;
+    int bidx = r;
+#pragma unroll
+    for (int m = 4; m >= 1; m >>= 1) {
+      const double ob = __shfl_xor(best, m, 8);
+      const int oi = __shfl_xor(bidx, m, 8);
+      if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+    }
+    double prow[9], krow[9];
+#pragma unroll
+    for (int j = k; j < 9; ++j) {
+      prow[j] = __shfl(a[j], bidx, 8);
+      krow[j] = __shfl(a[j], k, 8);
+    }
+    if (r == k) {
+#pragma unroll
+      for (int j = k; j < 9; ++j) a[j] = prow[j];
+    } else if (r == bidx) {
+#pragma unroll
+      for (int j = k; j < 9; ++j) a[j] = krow[j];
+    }
+    if (r != k) {
+      const double f = a[k] / prow[k];
+#pragma unroll
+      for (int j = k; j < 9; ++j) a[j] = fma(-f, prow[j], a[j]);
+    }
+  }
+  // after Gauss-Jordan row r is [0 .. a[r] .. 0 | a[8]]
+  double diag = a[0];
+#pragma unroll
+  for (int j = 1; j < 8; ++j) diag = (r == j) ? a[j] : diag;
+  return a[8] / diag;
+}
+
+// theta = Minv * H * M with M = [[ax,0,ax],[0,ay,ay],[0,0,1]], each 3x3 product accumulated in
+// k order with one fused step per term, which is what the reference's fp32 bmm produces.
+__device__ __forceinline__ void mat3_mul(const float* A, const float* B, float* C) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      C[i * 3 + j] = __builtin_fmaf(A[i * 3 + 2], B[6 + j], __builtin_fmaf(A[i * 3 + 1], B[3 + j], __fmul_rn(A[i * 3], B[j])));
+}
+
+__device__ __forceinline__ void normalise_H(const float* Hm, float ax, float ay, float* theta) {
+  const float Minv[9] = {__fdiv_rn(1.f, ax), 0.f, -1.f, 0.f, __fdiv_rn(1.f, ay), -1.f, 0.f, 0.f, 1.f};
+  const float M[9] = {ax, 0.f, ax, 0.f, ay, ay, 0.f, 0.f, 1.f};
+  float P[9];
+  mat3_mul(Minv, Hm, P);
+  mat3_mul(P, M, theta);
+}
+
+// torch.linspace(-1, 1, n)[i] on the CPU: start + step*i below the midpoint, end - step*(n-1-i)
+// above, each with a single rounding (verified bit-for-bit in tests/test_host_logic.py).
+__device__ __forceinline__ float grid_coord(int i, int n) {
+  const float step = __fdiv_rn(2.0f, (float)(n - 1));
+  return i < n / 2 ? __builtin_fmaf(step, (float)i, -1.0f) : __builtin_fmaf(-step, (float)(n - 1 - i), 1.0f);
+}
+
+// float -> int32 as the reference's x86 path converts it: out-of-range and NaN give INT_MIN.
+__device__ __forceinline__ int f2i_x86(float f) {
+  return (f >= -2147483648.0f && f < 2147483648.0f) ? (int)f : (int)0x80000000;
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// One output pixel (row i, column j) of image `img` (C planes of H x W, plane stride H*W) written to
+// out[(i*W + j)*C + c].
+__device__ __forceinline__ void warp_pixel(const float* __restrict__ img, const float* th, float* __restrict__ out,
+                                           int i, int j, int C, int H, int W) {
+  const float gx = grid_coord(j, W), gy = grid_coord(i, H);
+  // T = theta @ [gx, gy, 1]: fma(t1, gy, t0*gx) + t2   (the reference's sgemm order; utils.py:230)
+  const float T0 = __fadd_rn(__builtin_fmaf(th[1], gy, __fmul_rn(th[0], gx)), th[2]);
+  const float T1 = __fadd_rn(__builtin_fmaf(th[4], gy, __fmul_rn(th[3], gx)), th[5]);
+  float t = __fadd_rn(__builtin_fmaf(th[7], gy, __fmul_rn(th[6], gx)), th[8]);
+  // utils.py:236-240: t += 1e-6 * (1 - [|t| >= 1e-7])
+  t = __fadd_rn(t, __fmul_rn(1e-6f, (fabsf(t) >= 1e-7f) ? 0.0f : 1.0f));
+  const float xs = __fdiv_rn(T0, t), ys = __fdiv_rn(T1, t);
+  // utils.py:128-129: x = (x_s + 1) * W / 2
+  const float x = __fmul_rn(__fmul_rn(__fadd_rn(xs, 1.0f), (float)W), 0.5f);
+  const float y = __fmul_rn(__fmul_rn(__fadd_rn(ys, 1.0f), (float)H), 0.5f);
+  const int xf = f2i_x86(floorf(x)), yf = f2i_x86(floorf(y));
+  const int x0 = clampi(xf, 0, W - 1), x1 = clampi((int)((unsigned)xf + 1u), 0, W - 1);
+  const int y0 = clampi(yf, 0, H - 1), y1 = clampi((int)((unsigned)yf + 1u), 0, H - 1);
+  // utils.py:181-184: weights from the CLAMPED taps and the UNCLAMPED coordinate
+  const float x0f = (float)x0, x1f = (float)x1, y0f = (float)y0, y1f = (float)y1;
+  const float wa = __fmul_rn(__fsub_rn(x1f, x), __fsub_rn(y1f, y));
+  const float wb = __fmul_rn(__fsub_rn(x1f, x), __fsub_rn(y, y0f));
+  const float wc = __fmul_rn(__fsub_rn(x, x0f), __fsub_rn(y1f, y));
+  const float wd = __fmul_rn(__fsub_rn(x, x0f), __fsub_rn(y, y0f));
+  const size_t HW = size_t(H) * W;
+  float* o = out + (size_t(i) * W + j) * C;
+  for (int c = 0; c < C; ++c) {
+    const float* pl = img + c * HW;
+    const float Ia = pl[y0 * W + x0], Ib = pl[y1 * W + x0], Ic = pl[y0 * W + x1], Id = pl[y1 * W + x1];
+    // utils.py:185: wa*Ia + wb*Ib + wc*Ic + wd*Id, left to right, no fusion
+    o[c] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(wa, Ia), __fmul_rn(wb, Ib)), __fmul_rn(wc, Ic)), __fmul_rn(wd, Id));
+  }
+}
+
+__global__ __launch_bounds__(HDN_BLOCK) void dlt_solve_kernel(const float* __restrict__ src,
+                                                              const float* __restrict__ off,
+                                                              float* __restrict__ H_out, int B) {
+  // one 8-lane group per sample
+  const int gid = (blockIdx.x * HDN_BLOCK + threadIdx.x) >> 3;
+  const int b = min(gid, B - 1);  // keep every lane in the shuffles
+  const int lane = threadIdx.x & (HDN_WAVE - 1);
+  const double h = dlt_solve_rows(src + size_t(b) * 8, off + size_t(b) * 8, lane);
+  if (gid < B) {
+    H_out[size_t(b) * 9 + (lane & 7)] = (float)h;
+    if ((lane & 7) == 0) H_out[size_t(b) * 9 + 8] = 1.0f;
+  }
+}
+
+__global__ __launch_bounds__(HDN_BLOCK) void warp_kernel(const float* __restrict__ img,
+                                                         const float* __restrict__ theta, float* __restrict__ out,
+                                                         int C, int H, int W) {
+  const int b = blockIdx.y;
+  const size_t HW = size_t(H) * W;
+  float th[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) th[q] = theta[size_t(b) * 9 + q];
+  const float* im = img + size_t(b) * C * HW;
+  float* ob = out + size_t(b) * C * HW;
+  const int base = blockIdx.x * WARP_PX_PER_BLOCK + threadIdx.x;
+#pragma unroll
+  for (int q = 0; q < WARP_PX_PER_THREAD; ++q) {
+    const int pix = base + q * HDN_BLOCK;
+    if (pix < H * W) warp_pixel(im, th, ob, pix / W, pix - (pix / W) * W, C, H, W);
+  }
+}
+
+__global__ __launch_bounds__(HDN_BLOCK) void dlt_warp_kernel(const float* __restrict__ h4p,
+                                                             const float* __restrict__ off,
+                                                             const float* __restrict__ img,
+                                                             float* __restrict__ H_out, float* __restrict__ warped,
+                                                             int H, int W) {
+  __shared__ float sH[9];
+  const int b = blockIdx.y;
+  const int tid = threadIdx.x;
+  if (tid < HDN_WAVE) {  // wave 0 solves (wave-uniform branch)
+    const double h = dlt_solve_rows(h4p + size_t(b) * 8, off + size_t(b) * 8, tid);
+    if (tid < 8) sH[tid] = (float)h;
+    if (tid == 8) sH[8] = 1.0f;
+  }
+  __syncthreads();
+  float Hm[9], th[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) Hm[q] = sH[q];
+  if (blockIdx.x == 0 && tid < 9) H_out[size_t(b) * 9 + tid] = Hm[tid];
+  normalise_H(Hm, __fmul_rn((float)W, 0.5f), __fmul_rn((float)H, 0.5f), th);
+  const size_t HW = size_t(H) * W;
+  const int base = blockIdx.x * WARP_PX_PER_BLOCK + tid;
+#pragma unroll
+  for (int q = 0; q < WARP_PX_PER_THREAD; ++q) {
+    const int pix = base + q * HDN_BLOCK;
+    if (pix < H * W) warp_pixel(img + size_t(b) * HW, th, warped + size_t(b) * HW, pix / W, pix - (pix / W) * W, 1, H, W);
+  }
+}
+
+// sum |a-b| * scale, one workgroup, fixed reduction tree (deterministic)
+__global__ __launch_bounds__(HDN_BLOCK) void l1_score_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                             float* __restrict__ out, int n, float scale) {
+  __shared__ float part[HDN_BLOCK / HDN_WAVE];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += HDN_BLOCK) s += fabsf(a[i] - b[i]);
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, HDN_WAVE);
+  if ((threadIdx.x & (HDN_WAVE - 1)) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (part[0] + part[1] + part[2] + part[3]) * scale;
+}
+
+}  // namespace hdn
+
+extern "C" {
+
+int hdn_dlt_solve_f32(const float* src, const float* off, float* H_out, int B, void* stream) {
+  if (!src || !off || !H_out) return HDN_E_NULL;
+  if (B <= 0) return HDN_E_SHAPE;
+  if (B > (1 << 24)) return HDN_E_LIMIT;
+  const int groups_per_block = HDN_BLOCK / 8;
+  hipLaunchKernelGGL(hdn::dlt_solve_kernel, dim3(hdn::cdiv(B, groups_per_block)), dim3(HDN_BLOCK), 0,
+                     static_cast<hipStream_t>(stream), src, off, H_out, B);
+  return hdn::launch_status();
+}
+
+int hdn_warp_f32(const float* img, const float* theta, float* out, int B, int C, int H, int W, void* stream) {
+  if (!img || !theta || !out) return HDN_E_NULL;
+  if (B <= 0 || C <= 0 || H <= 1 || W <= 1) return HDN_E_SHAPE;  // linspace(-1,1,1) has no step
+  if (B > 65535 || (long long)H * W > (1LL << 30) || (long long)C * H * W > 0x7fffffffLL) return HDN_E_LIMIT;
+  if (out == img) return HDN_E_ALIAS;
+  dim3 grid(hdn::cdiv(H * W, hdn::WARP_PX_PER_BLOCK), B);
+  hipLaunchKernelGGL(hdn::warp_kernel, grid, dim3(HDN_BLOCK), 0, static_cast<hipStream_t>(stream), img, theta, out, C,
+                     H, W);
+  return hdn::launch_status();
+}
+
+int hdn_dlt_warp_f32(const float* h4p, const float* off, const float* img, float* H_out, float* warped, int B, int H,
+                     int W, void* stream) {
+  if (!h4p || !off || !img || !H_out || !warped) return HDN_E_NULL;
+  if (B <= 0 || H <= 1 || W <= 1) return HDN_E_SHAPE;
+  if (B > 65535 || (long long)H * W > (1LL << 30)) return HDN_E_LIMIT;
+  if (warped == img) return HDN_E_ALIAS;
+  dim3 grid(hdn::cdiv(H * W, hdn::WARP_PX_PER_BLOCK), B);
+  hipLaunchKernelGGL(hdn::dlt_warp_kernel, grid, dim3(HDN_BLOCK), 0, static_cast<hipStream_t>(stream), h4p, off, img,
+                     H_out, warped, H, W);
+  return hdn::launch_status();
+}
+
+int hdn_l1_score_f32(const float* a, const float* b, float* out, int n, float scale, void* stream) {
+  if (!a || !b || !out) return HDN_E_NULL;
+  if (n <= 0) return HDN_E_SHAPE;
+  hipLaunchKernelGGL(hdn::l1_score_kernel, dim3(1), dim3(HDN_BLOCK), 0, static_cast<hipStream_t>(stream), a, b, out, n,
+                     scale);
+  return hdn::launch_status();
+}
+
+int hdn_abi_version(void) { return HDN_ABI_VERSION; }
+
+}  // extern "C"

@@ -1,0 +1,123 @@
+"""HomoModelBuilder / track_proj: the deep-homography head wired onto the HIP kernels.
+
+    HomoModelBuilder.forward(data) -> dict   <- .../Oneline_DLTv1/models/homo_model_builder.py:115-217
+    track_proj(model, data, tmp_mask)        <- hdn/models/model_builder_e2e_unconstrained_v2.py:161-217
+
+Per pair the HIP path is: PreShareFeature(template), PreShareFeature(search) -> [PyTorch-ROCm ResNet-34
++ avgpool + fc -> 8 corner offsets] -> fused DLT + projective warp -> PreShareFeature(warped) -> L1 scores.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import homography as G
+from .share_feature import PreShareFeature
+from .trunk import resnet34_homo
+
+
+def _regress(net, feats):
+    x = net.backbone(feats)
+    x = net.avgpool(x)
+    x = x.view(x.size(0), -1)
+    return net.fc(x)
+
+
+def _share(net, x):
+    return net.ShareFeature(x)
+
+
+def _check_data(data):
+    for k in ("org_imgs", "input_tensors", "h4p", "patch_indices"):
+        if k not in data:
+            raise KeyError(f"data['{k}'] missing (homo_model_builder.py:116-119)")
+    org, inp = data["org_imgs"], data["input_tensors"]
+    if org.dim() != 4 or org.shape[1] != 2 or inp.shape != org.shape:
+        raise ValueError(f"org_imgs / input_tensors must both be [B,2,H,W] full patches, got {tuple(org.shape)} / {tuple(inp.shape)}")
+    B, _, H, W = org.shape
+    if tuple(data["patch_indices"].shape) != (B, H * W):
+        raise ValueError("patch_indices must be the [B, H*W] full-patch index (get_img_info.py:88-92)")
+    return B, H, W
+
+
+def homo_stages(net, data, cached_patch_1=None):
+    """ShareFeature x2 -> trunk -> fused DLT+warp -> ShareFeature.  Returns the intermediates.
+
+    `cached_patch_1`: ShareFeature(template) is constant for a whole sequence; pass it to skip
+    one of the three ShareFeature launches.
+    """
+    B, H, W = _check_data(data)
+    org, inp, h4p = data["org_imgs"], data["input_tensors"], data["h4p"]
+    with torch.no_grad():
+        if cached_patch_1 is None:
+            # one launch for both channels: [B,2,H,W] viewed as 2B single-channel images
+            both = _share(net, inp.reshape(B * 2, 1, H, W)).reshape(B, 2, H, W)
+            p1, p2 = both[:, :1], both[:, 1:]
+            feats = both
+        else:
+            p1 = cached_patch_1
+            p2 = _share(net, inp[:, 1:].contiguous())
+            feats = torch.cat((p1, p2), dim=1)
+        x = _regress(net, feats)
+        H_mat, pred = G.dlt_warp(h4p, x, org[:, :1])
+        pf = _share(net, pred)
+    return {"x": x, "H_mat": H_mat, "pred_I2": pred, "patch_1": p1, "patch_2": p2, "pred_feat": pf}
+
+
+def track_proj(net, data, tmp_mask=None, cached_patch_1=None):
+    """(H_mat [B,3,3], similarity_norm, similarity_norm_simi) as ModelBuilder.track_proj returns them.
+
+    `net` is the HomoModelBuilder (the reference passes self.hm_net's sub-modules); tmp_mask is accepted and
+    unused, as in the reference.
+    """
+    st = homo_stages(net, data, cached_patch_1)
+    # model_builder…:213-216 — sample 0 / channel 0 only, divided by the literal 127*127
+    inv = 1.0 / (127 * 127)
+    score = G.l1_score(st["patch_2"][0, 0], st["pred_feat"][0, 0], inv)
+    score_simi = G.l1_score(st["patch_2"][0, 0], st["patch_1"][0, 0], inv)
+    return st["H_mat"], score, score_simi
+
+
+class HomoModelBuilder(nn.Module):
+    """Same sub-module names as the reference (ShareFeature, backbone, avgpool, fc) so snapshots load."""
+
+    def __init__(self, pretrained: bool = False):
+        super().__init__()
+        # `pretrained` fetched ImageNet weights over the network in the reference (backbone/__init__.py:39-49);
+        # there is no network here, weights come from the tracker snapshot (hdn/utils/model_load.py).
+        self.ShareFeature = PreShareFeature()
+        self.backbone = resnet34_homo()
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.fc = nn.Linear(512, 8)
+
+    def track_proj(self, data, tmp_mask=None, cached_patch_1=None):
+        return track_proj(self, data, tmp_mask, cached_patch_1)
+
+    def forward(self, data):
+        """Inference-mode forward with the reference's output keys (homo_model_builder.py:212-215).
+
+        if_pos / if_unsup / search_window follow the reference's defaults (all ones; the 'search_windowx'
+        typo at :122 means the window is always ones there too).  The negative-sample branch (if_pos == 0)
+        is training-only and not implemented.
+        """
+        if "if_pos" in data and bool((data["if_pos"] == 0).any()):
+            raise NotImplementedError("negative samples (if_pos == 0) are a training-only branch")
+        st = homo_stages(self, data)
+        p1, p2, pf, pred, x = st["patch_1"], st["patch_2"], st["pred_feat"], st["pred_I2"], st["x"]
+        B = x.shape[0]
+        with torch.no_grad():
+            # TripletMarginLoss(margin=1, p=1, reduce=False): pairwise L1 over the last dim, eps 1e-6
+            d_ap = ((p2 - pf) + 1e-6).abs().sum(-1)
+            d_an = ((p2 - p1) + 1e-6).abs().sum(-1)
+            loss_mat = (d_ap - d_an + 1.0).clamp_min(0.0)
+            n_pos = B * p1.shape[2] * p1.shape[3]
+            feature_loss = (loss_mat.sum() / n_pos / (127 * 127)).reshape(1)
+        return {
+            "feature_loss": feature_loss,
+            "pred_I2_d": pred[:1],
+            "x": x,
+            "H_mat": st["H_mat"],
+            "patch_2_res_d": p2[:1],
+            "pred_I2_CnnFeature_d": pf[:1],
+            "homo_neg_loss": torch.zeros((), device=x.device),
+        }

@@ -1,0 +1,119 @@
+"""Drop-ins for the Oneline_DLTv1 geometry helpers, on HIP kernels.
+
+    DLT_solve(src_p, off_set)                  <- homo_estimator/Deep_homography/Oneline_DLTv1/utils.py:7-67
+    transformer(U, theta, out_size)            <- utils.py:70-254
+    transform(ph, pw, M_inv, H, M, I1, pidx, base)   <- utils.py:257-274   (alias Homo_STN)
+    dlt_warp(h4p, off, img)                    fused DLT_solve + transform for the full-patch case
+
+Signatures, argument meaning and output shapes follow the reference.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+
+def DLT_solve(src_p: torch.Tensor, off_set: torch.Tensor) -> torch.Tensor:
+    """4-point DLT.  src_p, off_set: [B, 8] -> H [B, 1, 3, 3] mapping src -> src + off (H[2,2] = 1).
+
+    Like the reference (utils.py:12: divide = int(sqrt(len/2) - 1)) only the single-quad case (8 values
+    per sample) is meaningful; other lengths are rejected.
+    """
+    if src_p.dim() != 2 or src_p.shape[1] != 8 or off_set.shape != src_p.shape:
+        raise ValueError(f"DLT_solve expects [B,8] corner / offset tensors, got {tuple(src_p.shape)} and {tuple(off_set.shape)}")
+    dev = _lib.require_device(src_p, off_set)
+    s, o = src_p.detach().contiguous(), off_set.detach().contiguous()
+    B = s.shape[0]
+    if B == 0:
+        raise ValueError("empty batch")
+    H = torch.empty((B, 9), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.load().hdn_dlt_solve_f32(_lib.ptr(s), _lib.ptr(o), _lib.ptr(H), B, _lib.stream_ptr(dev))
+    _lib.check(rc, "DLT_solve")
+    return H.view(B, 1, 3, 3)
+
+
+def transformer(U: torch.Tensor, theta: torch.Tensor, out_size, **kwargs):
+    """Projective spatial transformer: U [B,C,H,W], theta [B,3,3] (or [B,9]) -> ([B,H,W,C], condition).
+
+    `condition` (the count of |t| > 1e-7, utils.py:241) is unused by every caller in the reference; it is
+    returned as None here rather than paying a reduction for it.
+    """
+    if U.dim() != 4:
+        raise ValueError(f"U must be [B,C,H,W], got {tuple(U.shape)}")
+    B, C, H, W = U.shape
+    if tuple(out_size) != (H, W):
+        # the reference's idx.expand(height*width*num_batch, C) (utils.py:164) only works in this case
+        raise ValueError(f"out_size {tuple(out_size)} must equal the input size {(H, W)} (as in the reference)")
+    dev = _lib.require_device(U, theta)
+    th = theta.detach().reshape(-1, 9).contiguous()
+    if th.shape[0] != B:
+        raise ValueError(f"theta batch {th.shape[0]} != image batch {B}")
+    img = U.detach().contiguous()
+    out = torch.empty((B, H, W, C), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.load().hdn_warp_f32(_lib.ptr(img), _lib.ptr(th), _lib.ptr(out), B, C, H, W, _lib.stream_ptr(dev))
+    _lib.check(rc, "transformer")
+    return out, None
+
+
+def _is_full_patch(patch_indices: torch.Tensor, B: int, ph: int, pw: int, H: int, W: int) -> bool:
+    return (ph, pw) == (H, W) and tuple(patch_indices.shape) == (B, H * W)
+
+
+def transform(patch_size_h, patch_size_w, M_tile_inv, H_mat, M_tile, I1, patch_indices, batch_indices_tensor,
+              assume_identity_patch: bool = False):
+    """Warp I1 by M_inv @ H @ M and gather the patch pixels -> [B, C, ph, pw].
+
+    With `assume_identity_patch=True` the final gather (utils.py:268-272) is skipped; that is exact when
+    patch_indices is the row-major index of the full image (get_img_info.py:88-92), which is how the
+    tracker always calls it.
+    """
+    B, C, H, W = I1.shape
+    dev = _lib.require_device(I1, H_mat)
+    Hn = torch.matmul(torch.matmul(M_tile_inv.to(dev), H_mat), M_tile.to(dev))
+    warped, _ = transformer(I1, Hn, (H, W))
+    if assume_identity_patch and _is_full_patch(patch_indices, B, patch_size_h, patch_size_w, H, W):
+        return warped.permute(0, 3, 1, 2)
+    flat = warped.reshape(-1, C)
+    pix = patch_indices.reshape(-1).long().to(dev) + batch_indices_tensor.to(dev)
+    return flat[pix].reshape(B, patch_size_h, patch_size_w, C).permute(0, 3, 1, 2)
+
+
+Homo_STN = transform  # the name model_builder_e2e_unconstrained_v2.py:30 imports it under
+
+
+def dlt_warp(h4p: torch.Tensor, off_set: torch.Tensor, img: torch.Tensor):
+    """Fused DLT_solve + transform (full patch, M = [[W/2,0,W/2],[0,H/2,H/2],[0,0,1]]).
+
+    h4p, off_set: [B,8]; img: [B,1,H,W] -> (H_mat [B,3,3], warped [B,1,H,W]).
+    Replaces model_builder_e2e_unconstrained_v2.py:195-210 / homo_model_builder.py:166-170.
+    """
+    if img.dim() != 4 or img.shape[1] != 1:
+        raise ValueError(f"img must be [B,1,H,W], got {tuple(img.shape)}")
+    B, _, H, W = img.shape
+    if tuple(h4p.shape) != (B, 8) or tuple(off_set.shape) != (B, 8):
+        raise ValueError(f"h4p / off_set must be [{B},8], got {tuple(h4p.shape)} and {tuple(off_set.shape)}")
+    dev = _lib.require_device(h4p, off_set, img)
+    p, o, im = h4p.detach().contiguous(), off_set.detach().contiguous(), img.detach().contiguous()
+    Hm = torch.empty((B, 9), dtype=torch.float32, device=dev)
+    warped = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.load().hdn_dlt_warp_f32(_lib.ptr(p), _lib.ptr(o), _lib.ptr(im), _lib.ptr(Hm), _lib.ptr(warped), B, H, W,
+                                          _lib.stream_ptr(dev))
+    _lib.check(rc, "dlt_warp")
+    return Hm.view(B, 3, 3), warped
+
+
+def l1_score(a: torch.Tensor, b: torch.Tensor, scale: float) -> torch.Tensor:
+    """sum |a - b| * scale as a 0-dim device tensor (track_proj's similarity scores)."""
+    dev = _lib.require_device(a, b)
+    if a.numel() != b.numel() or a.numel() == 0:
+        raise ValueError("l1_score needs two non-empty tensors of equal size")
+    ac, bc = a.detach().contiguous(), b.detach().contiguous()
+    out = torch.empty((1,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.load().hdn_l1_score_f32(_lib.ptr(ac), _lib.ptr(bc), _lib.ptr(out), ac.numel(), float(scale), _lib.stream_ptr(dev))
+    _lib.check(rc, "l1_score")
+    return out[0]

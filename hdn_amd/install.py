@@ -1,0 +1,81 @@
+"""Rebind the reference's hot-path symbols to the HIP implementations.
+
+    import hdn_amd.install as hi; hi.install()     # after the reference packages are importable
+
+so that tools/test.py / tools/demo.py of the reference run unchanged.  Each rebinding site is the module
+attribute the reference resolves at call time:
+
+    hdn.core.xcorr.xcorr_depthwise{,_circular}           definitions
+    hdn.models.head.ban.xcorr_depthwise                  ban.py:10 (from-import binding used at ban.py:76)
+    hdn.models.head.ban_lp.xcorr_depthwise_circular      ban_lp.py:10 (used at ban_lp.py:38)
+    ...Oneline_DLTv1.utils.{DLT_solve,transform,transformer}
+    ...models.homo_model_builder.{DLT_solve,transform}   homo_model_builder.py:13
+    hdn.models.model_builder_e2e_unconstrained_v2.{DLT_solve,Homo_STN}   :29-30
+    ...preprocess.head['PreShareFeature']                registry used by get_pre(), preprocess/__init__.py:18-26
+    ModelBuilder.track_proj                              replaced by the fused version
+"""
+from __future__ import annotations
+
+import importlib
+import types
+
+from . import homo_model, homography, share_feature, xcorr
+
+_DLT = "homo_estimator.Deep_homography.Oneline_DLTv1"
+
+REBINDINGS = (
+    ("hdn.core.xcorr", "xcorr_depthwise", xcorr.xcorr_depthwise),
+    ("hdn.core.xcorr", "xcorr_depthwise_circular", xcorr.xcorr_depthwise_circular),
+    ("hdn.models.head.ban", "xcorr_depthwise", xcorr.xcorr_depthwise),
+    ("hdn.models.head.ban_lp", "xcorr_depthwise", xcorr.xcorr_depthwise),
+    ("hdn.models.head.ban_lp", "xcorr_depthwise_circular", xcorr.xcorr_depthwise_circular),
+    (_DLT + ".utils", "DLT_solve", homography.DLT_solve),
+    (_DLT + ".utils", "transform", homography.transform),
+    (_DLT + ".utils", "transformer", homography.transformer),
+    (_DLT + ".models.homo_model_builder", "DLT_solve", homography.DLT_solve),
+    (_DLT + ".models.homo_model_builder", "transform", homography.transform),
+    ("hdn.models.model_builder_e2e_unconstrained_v2", "DLT_solve", homography.DLT_solve),
+    ("hdn.models.model_builder_e2e_unconstrained_v2", "Homo_STN", homography.transform),
+)
+
+
+def _track_proj_method(self, data, tmp_mask):
+    """ModelBuilder.track_proj with the fused stages; self.hm_net supplies ShareFeature/backbone/avgpool/fc."""
+    return homo_model.track_proj(self.hm_net, data, tmp_mask)
+
+
+def install(strict: bool = False, modules: dict = None) -> list:
+    """Apply the rebindings.  `modules` (name -> module) lets tests supply stand-in modules; by default the
+    real reference modules are imported.  Returns the list of (module, attribute) pairs that were rebound;
+    with strict=True a site that cannot be imported raises instead of being skipped."""
+    done = []
+
+    def get(name):
+        if modules is not None:
+            return modules.get(name)
+        try:
+            return importlib.import_module(name)
+        except Exception:
+            if strict:
+                raise
+            return None
+
+    for mod_name, attr, fn in REBINDINGS:
+        m = get(mod_name)
+        if m is None:
+            continue
+        if not hasattr(m, attr) and strict:
+            raise AttributeError(f"{mod_name}.{attr} not found: reference layout changed?")
+        setattr(m, attr, fn)
+        done.append((mod_name, attr))
+
+    pre = get(_DLT + ".preprocess")
+    if pre is not None and isinstance(getattr(pre, "head", None), dict):
+        pre.head["PreShareFeature"] = share_feature.PreShareFeature
+        done.append((_DLT + ".preprocess", "head['PreShareFeature']"))
+
+    mb = get("hdn.models.model_builder_e2e_unconstrained_v2")
+    if mb is not None and hasattr(mb, "ModelBuilder"):
+        mb.ModelBuilder.track_proj = _track_proj_method
+        done.append(("hdn.models.model_builder_e2e_unconstrained_v2", "ModelBuilder.track_proj"))
+    return done

@@ -1,0 +1,68 @@
+"""The homography regressor trunk: a 2-channel-input ResNet-34 kept on PyTorch-ROCm (MIOpen).
+
+Reference: homo_estimator/Deep_homography/Oneline_DLTv1/backbone/resnet.py:137-194 with
+BasicBlock x [3,4,6,3], conv1 = Conv2d(2,64,7,2,3), used_layers=[4] (returns layer4 only).
+Parameter names match the reference (conv1, bn1, layerN.M.{conv1,bn1,conv2,bn2,downsample.0,downsample.1})
+so its state_dict loads unchanged.  This is a dense MFMA-bound contraction and legitimately a library job
+(SURVEY.md §8f rank 4); it is plumbing here, not one of the hand-written kernels.
+"""
+from __future__ import annotations
+
+import torch.nn as nn
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        y += idt
+        return self.relu(y)
+
+
+class HomoResNet(nn.Module):
+    def __init__(self, layers=(3, 4, 6, 3), in_channels=2):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(in_channels, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        self.layer1 = self._stage(64, layers[0], 1)
+        self.layer2 = self._stage(128, layers[1], 2)
+        self.layer3 = self._stage(256, layers[2], 2)
+        self.layer4 = self._stage(512, layers[3], 2)
+        for m in self.modules():  # resnet.py:154-159
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight)
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+
+    def _stage(self, planes, blocks, stride):
+        down = None
+        if stride != 1 or self.inplanes != planes:
+            down = nn.Sequential(nn.Conv2d(self.inplanes, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
+        mods = [BasicBlock(self.inplanes, planes, stride, down)]
+        self.inplanes = planes
+        mods += [BasicBlock(planes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*mods)
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        return self.layer4(self.layer3(self.layer2(self.layer1(x))))
+
+
+def resnet34_homo():
+    return HomoResNet((3, 4, 6, 3))

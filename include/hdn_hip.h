@@ -1,0 +1,121 @@
+/*
+ * hdn_hip.h — C ABI of libhdn_hip.so: the MI355X (gfx950) implementation of HDN's
+ * per-frame homography-estimation hot path.
+ *
+ * The reference (zhanxinrui/HDN) has no native plugin ABI: its extension points are
+ * module-level Python functions that are rebound.  Each entry point
+ * below is what a binding for one of those functions calls; the reference interface it
+ * replaces is cited as file:line under /root/reference.  INTEGRATION.md shows the
+ * ctypes stub a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 unless stated otherwise;
+ *   - tensors are NCHW exactly as the reference's torch tensors are laid out;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all calls are
+ *     asynchronous on it and never synchronise or allocate;
+ *   - return 0 on success, HDN_E_* (< 0) for argument errors, or -(1000 + hipError_t)
+ *     when the launch itself failed; nothing is written on an argument error.
+ */
+#ifndef HDN_HIP_H
+#define HDN_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HDN_OK 0
+#define HDN_E_NULL (-1)  /* a required pointer is NULL            */
+#define HDN_E_SHAPE (-2) /* non-positive size, or kernel > search */
+#define HDN_E_LIMIT (-3) /* size exceeds what the kernels support */
+#define HDN_E_ALIAS (-4) /* output aliases an input               */
+
+/* ABI version of this header; hdn_abi_version() of the loaded library must match. */
+#define HDN_ABI_VERSION 1
+int hdn_abi_version(void);
+
+/* Name of the kernel variant the last hdn_xcorr_* call on this thread dispatched to
+ * ("f1_61x61_31x31", "generic_lds", ...).  For tests and profiles. */
+const char* hdn_last_xcorr_variant(void);
+
+/*
+ * Depthwise (per batch, per channel) valid cross-correlation, stride 1, no flip:
+ *   out[b,c,i,j] = sum_{u,v} x[b,c,i+u,j+v] * k[b,c,u,v]
+ *   x[B,C,Hx,Wx], k[B,C,Hk,Wk] -> out[B,C,Hx-Hk+1,Wx-Wk+1]
+ * Replaces xcorr_depthwise(x, kernel), hdn/core/xcorr.py:37-46
+ * (called from DepthwiseXCorr.forward, hdn/models/head/ban.py:76).
+ */
+int hdn_xcorr_depthwise_f32(const float* x, const float* k, float* out,
+                            int B, int C, int Hx, int Wx, int Hk, int Wk, void* stream);
+
+/*
+ * The log-polar variant: x is first padded by Hx/2 rows on each side CIRCULARLY
+ * (rows = angle), then by Wx/2 columns on each side by edge REPLICATION (columns =
+ * log-radius), then correlated as above.  The pad is never materialised in HBM.
+ *   out[B,C,Hx+2*(Hx/2)-Hk+1, Wx+2*(Wx/2)-Wk+1]
+ * Replaces xcorr_depthwise_circular(x, kernel), hdn/core/xcorr.py:48-61
+ * (called from DepthwiseXCorrCirc.forward, hdn/models/head/ban_lp.py:38).
+ */
+int hdn_xcorr_depthwise_circ_f32(const float* x, const float* k, float* out,
+                                 int B, int C, int Hx, int Wx, int Hk, int Wk, void* stream);
+
+/*
+ * Several correlations of one frame in ONE launch (the 3 levels x
+ * {cls,loc} of MultiBAN, ban.py:102-109, or of MultiCircBAN, ban_lp.py:69-73).
+ * xs/ks/outs are HOST arrays of n device pointers; every problem has the same shape.
+ */
+int hdn_xcorr_depthwise_multi_f32(const float* const* xs, const float* const* ks, float* const* outs, int n,
+                                  int circular, int B, int C, int Hx, int Wx, int Hk, int Wk, void* stream);
+
+/*
+ * PreShareFeature.forward in eval mode, fused: 3 x (conv3x3 pad 1, no bias -> BatchNorm
+ * (running stats) -> ReLU), channels 1 -> 4 -> 8 -> 1, img[B,1,H,W] -> out[B,1,H,W].
+ * `folded` (HDN_SF_PARAMS floats, device) = conv weights re-laid for the kernel followed
+ * by the per-channel BN scale/shift; build it with hdn_amd.share_feature.fold_params().
+ *   [0,36)    w1t[k][co]          k = ky*3+kx, co in 0..3      (from ShareFeature.0.weight[co,0,ky,kx])
+ *   [36,324)  w2t[ci][k][co]      ci in 0..3, co in 0..7       (from ShareFeature.3.weight[co,ci,ky,kx])
+ *   [324,396) w3t[ci][k]          ci in 0..7                   (from ShareFeature.6.weight[0,ci,ky,kx])
+ *   [396,409) alpha[13]           gamma / sqrt(var + 1e-5), layers concatenated (4+8+1)
+ *   [409,422) beta[13]            bias - mean * alpha
+ * Replaces PreShareFeature.forward, .../Oneline_DLTv1/preprocess/input_feature_extractor.py:27-29.
+ */
+#define HDN_SF_PARAMS 422
+int hdn_share_feature_f32(const float* img, const float* folded, float* out, int B, int H, int W, void* stream);
+
+/*
+ * 4-point DLT: H (3x3, H[2][2] = 1) with H * src_i ~ src_i + off_i.
+ *   src[B,8], off[B,8] = (x,y) of 4 points in the caller's order (the reference's internal
+ *   reordering, utils.py:18-26, does not change the solution); H_out[B,9] row-major.
+ * The 8x8 system is solved in float64 (Gauss-Jordan, partial pivoting) and rounded once.
+ * Replaces DLT_solve(src_p, off_set), .../Oneline_DLTv1/utils.py:7-67.
+ */
+int hdn_dlt_solve_f32(const float* src, const float* off, float* H_out, int B, void* stream);
+
+/*
+ * Projective bilinear sampler on the [-1,1]^2 grid with the reference's exact tap/clamp
+ * /weight rules (see DESIGN.md "warp semantics"): img[B,C,H,W] (NCHW), theta[B,9]
+ * -> out[B,H,W,C] (NHWC, as the reference returns it).
+ * Replaces transformer(U, theta, out_size), .../Oneline_DLTv1/utils.py:70-254.
+ */
+int hdn_warp_f32(const float* img, const float* theta, float* out, int B, int C, int H, int W, void* stream);
+
+/*
+ * Fused DLT_solve + transform for the full-patch case: H = DLT(h4p, off);
+ * theta = M^-1 H M with M = [[W/2,0,W/2],[0,H/2,H/2],[0,0,1]]; warped = sampler(img, theta).
+ *   h4p[B,8], off[B,8], img[B,1,H,W] -> H_out[B,9] (the un-normalised H), warped[B,1,H,W]
+ * Replaces the DLT_solve + Homo_STN pair of ModelBuilder.track_proj,
+ * hdn/models/model_builder_e2e_unconstrained_v2.py:195-210, and of HomoModelBuilder.forward,
+ * .../models/homo_model_builder.py:166-170.
+ */
+int hdn_dlt_warp_f32(const float* h4p, const float* off, const float* img, float* H_out, float* warped,
+                     int B, int H, int W, void* stream);
+
+/*
+ * sum_i |a[i] - b[i]| * scale over n floats into out[0] (one block, deterministic order).
+ * The two feature-distance scores of track_proj, model_builder_e2e_unconstrained_v2.py:213-216.
+ */
+int hdn_l1_score_f32(const float* a, const float* b, float* out, int n, float scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HDN_HIP_H */

@@ -1,0 +1,403 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle and the
+golden vectors captured from the reference.
+
+Tolerances (fp32 path, BASELINE.json north_star: 1e-4 abs on the predicted corner displacements):
+  * correlations: a tap sum of n products is only defined to fp32 summation order.  Bound used:
+        |hip - ref| <= 1e-4 + 2e-6 * sum|x*k|        (abs 1e-4 for the O(1..10) production outputs)
+    and, against the float64 truth, the HIP error may not exceed twice the reference's own worst error.
+  * PreShareFeature / warp / scores: 1e-4 abs (observed ~1e-6).
+  * DLT H_mat: 1e-5 abs for the production corners; the fp32 reference is itself ~1.5e-4 off the exact
+    solution for general quadrilaterals (tests/test_oracle_golden.py::test_dlt_solve), so those compare to
+    the float64 solution at 1e-5 and to the reference at 5e-4.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_rng, load_golden, relu_normal
+from oracle import hdn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+torch.set_num_threads(max(1, torch.get_num_threads()))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+import hdn_amd  # noqa: E402
+from hdn_amd import homography as G  # noqa: E402
+from hdn_amd import xcorr as X  # noqa: E402
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def cases(npz, suffix="__x"):
+    return sorted(k[: -len(suffix)] for k in npz.files if k.endswith(suffix))
+
+
+def check_xcorr(got, x, k, ref, circular, name):
+    truth = (O.xcorr_depthwise_circular_f64 if circular else O.xcorr_depthwise_f64)(x, k)
+    mag = (O.xcorr_depthwise_circular_f64 if circular else O.xcorr_depthwise_f64)(np.abs(x), np.abs(k))
+    got = got.cpu().numpy()
+    assert got.shape == ref.shape, name
+    assert np.all(np.abs(got - ref) <= 1e-4 + 2e-6 * mag), f"{name}: max|hip-ref|={np.abs(got - ref).max():.3e}"
+    e_hip, e_ref = np.abs(got - truth).max(), np.abs(ref - truth).max()
+    assert e_hip <= 2 * e_ref + 1e-6, f"{name}: hip err {e_hip:.3e} vs reference err {e_ref:.3e} against float64"
+
+
+# --------------------------------------------------------------------------- correlations
+def test_xcorr_depthwise_golden(dev):
+    g = load_golden("xcorr_depthwise")
+    seen = set()
+    for n in cases(g):
+        x, k = g[n + "__x"], g[n + "__k"]
+        y = hdn_amd.xcorr_depthwise(T(x).to(dev), T(k).to(dev))
+        seen.add(X.last_variant())
+        check_xcorr(y, x, k, g[n + "__y"], False, n)
+    # the fixtures exercise the three specialised kernels and the generic one
+    assert {"f1_29x29_5x5", "f1_35x35_5x5", "f1_61x61_31x31", "generic_lds"} <= seen, seen
+
+
+def test_xcorr_depthwise_sampled_full_channel(dev):
+    g = load_golden("xcorr_depthwise_sampled")
+    for j, n in enumerate(["prod256_5x29", "north256_31x61"]):
+        B, C, Hx, Wx, Hk, Wk = (int(v) for v in g[n + "__shape"])
+        r = golden_rng(150 + j)
+        x, k = relu_normal(r, (B, C, Hx, Wx)), relu_normal(r, (B, C, Hk, Wk))
+        y = hdn_amd.xcorr_depthwise(T(x).to(dev), T(k).to(dev)).cpu().numpy()
+        val = y.reshape(-1)[g[n + "__idx"]]
+        ref = g[n + "__val"]
+        assert np.all(np.abs(val - ref) <= 1e-4 + 1e-5 * np.abs(ref)), (n, np.abs(val - ref).max())
+        s = y.astype(np.float64).sum()
+        assert abs(s - float(g[n + "__sum"])) <= 1e-6 * abs(float(g[n + "__sum"])), n
+
+
+def test_xcorr_depthwise_circular_golden(dev):
+    g = load_golden("xcorr_depthwise_circular")
+    seen = set()
+    for n in cases(g):
+        x, k = g[n + "__x"], g[n + "__k"]
+        y = hdn_amd.xcorr_depthwise_circular(T(x).to(dev), T(k).to(dev))
+        seen.add(X.last_variant())
+        check_xcorr(y, x, k, g[n + "__y"], True, n)
+    assert {"f1c_13x13_13x13", "generic_lds"} <= seen, seen
+
+
+@pytest.mark.parametrize("shape", [(5, 7, 29, 29, 5, 5), (3, 5, 61, 61, 31, 31), (2, 9, 35, 35, 5, 5), (1, 1, 29, 29, 5, 5)])
+def test_xcorr_ragged_plane_counts_vs_oracle(dev, shape):
+    """Plane counts that are not a multiple of the planes-per-workgroup group (tail workgroups, unaligned tails)."""
+    B, C, Hx, Wx, Hk, Wk = shape
+    r = np.random.default_rng(sum(shape))
+    x, k = relu_normal(r, (B, C, Hx, Wx)), relu_normal(r, (B, C, Hk, Wk))
+    y = hdn_amd.xcorr_depthwise(T(x).to(dev), T(k).to(dev))
+    check_xcorr(y, x, k, O.xcorr_depthwise(T(x), T(k)).numpy(), False, str(shape))
+
+
+@pytest.mark.parametrize("shape", [(3, 7, 13, 13, 13, 13), (1, 1, 13, 13, 13, 13), (2, 3, 9, 12, 4, 6), (1, 2, 5, 5, 9, 9)])
+def test_xcorr_circular_ragged_vs_oracle(dev, shape):
+    B, C, Hx, Wx, Hk, Wk = shape
+    r = np.random.default_rng(sum(shape) + 1)
+    x = r.standard_normal((B, C, Hx, Wx), dtype=np.float32)
+    k = r.standard_normal((B, C, Hk, Wk), dtype=np.float32)
+    y = hdn_amd.xcorr_depthwise_circular(T(x).to(dev), T(k).to(dev))
+    check_xcorr(y, x, k, O.xcorr_depthwise_circular(T(x), T(k)).numpy(), True, str(shape))
+
+
+def test_xcorr_generic_large_plane_uses_l2_path(dev):
+    r = np.random.default_rng(5)
+    x, k = relu_normal(r, (1, 2, 150, 140)), relu_normal(r, (1, 2, 3, 2))
+    y = hdn_amd.xcorr_depthwise(T(x).to(dev), T(k).to(dev))
+    assert X.last_variant() == "generic_l2"
+    check_xcorr(y, x, k, O.xcorr_depthwise(T(x), T(k)).numpy(), False, "large plane")
+
+
+def test_xcorr_unaligned_and_strided_inputs(dev):
+    """A sliced tensor gives a base pointer that is only 4-byte aligned and a non-contiguous view."""
+    r = np.random.default_rng(11)
+    xb, kb = relu_normal(r, (3, 6, 29, 29)), relu_normal(r, (3, 6, 5, 5))
+    xd, kd = T(xb).to(dev), T(kb).to(dev)
+    flat = torch.zeros(xd.numel() + 1, device=dev)
+    flat[1:] = xd.reshape(-1)
+    x_off = flat[1:].view_as(xd)  # data_ptr % 16 == 4
+    assert x_off.data_ptr() % 16 != 0
+    ref = O.xcorr_depthwise(T(xb), T(kb)).numpy()
+    check_xcorr(hdn_amd.xcorr_depthwise(x_off, kd), xb, kb, ref, False, "unaligned")
+    x_nc = xd.permute(0, 1, 3, 2).contiguous().permute(0, 1, 3, 2)  # same values, non-contiguous strides
+    assert not x_nc.is_contiguous()
+    check_xcorr(hdn_amd.xcorr_depthwise(x_nc, kd), xb, kb, ref, False, "strided")
+    assert torch.equal(xd.cpu(), T(xb)) and torch.equal(kd.cpu(), T(kb))  # inputs not mutated
+
+
+def test_xcorr_multi_launch_equals_single(dev):
+    r = np.random.default_rng(21)
+    xs = [T(relu_normal(r, (2, 32, 29, 29))).to(dev) for _ in range(6)]
+    ks = [T(relu_normal(r, (2, 32, 5, 5))).to(dev) for _ in range(6)]
+    outs = hdn_amd.xcorr_depthwise_multi(xs, ks)
+    for x, k, o in zip(xs, ks, outs):
+        assert torch.equal(o, hdn_amd.xcorr_depthwise(x, k))
+    xs = [T(r.standard_normal((2, 32, 13, 13), dtype=np.float32)).to(dev) for _ in range(6)]
+    ks = [T(r.standard_normal((2, 32, 13, 13), dtype=np.float32)).to(dev) for _ in range(6)]
+    outs = hdn_amd.xcorr_depthwise_multi(xs, ks, circular=True)
+    for x, k, o in zip(xs, ks, outs):
+        assert torch.equal(o, hdn_amd.xcorr_depthwise_circular(x, k))
+
+
+def _full_size_properties(dev, fn, ofn, shape_x, shape_k, signed):
+    """BASELINE full sizes (B=64, C=256): size-independent properties + oracle on a few sampled planes."""
+    gen = torch.Generator(device="cpu").manual_seed(20260928)
+    mk = (lambda s: torch.randn(s, generator=gen)) if signed else (lambda s: torch.randn(s, generator=gen).clamp_min(0))
+    x, k, k2 = mk(shape_x), mk(shape_k), mk(shape_k)
+    xd, kd, k2d = x.to(dev), k.to(dev), k2.to(dev)
+    y = fn(xd, kd)
+    # (1) determinism / idempotence
+    assert torch.equal(y, fn(xd, kd))
+    # (2) linearity in the kernel: corr(x, k + 2*k2) == corr(x,k) + 2*corr(x,k2)
+    lhs = fn(xd, kd + 2 * k2d)
+    rhs = y + 2 * fn(xd, k2d)
+    mag = fn(xd.abs(), (kd.abs() + 2 * k2d.abs()))
+    assert bool(((lhs - rhs).abs() <= 1e-4 + 4e-6 * mag).all())
+    # (3) checksum of checksums: sum_ij out[p] == sum_uv k[p,u,v] * S[p,u,v], S = window sums of x (float64 on CPU)
+    ysum = y.double().sum(dim=(2, 3)).cpu()
+    planes = [(0, 0), (shape_x[0] - 1, shape_x[1] - 1), (shape_x[0] // 2, 7), (3, shape_x[1] // 2)]
+    for (b, c) in planes:
+        ref = ofn(x[b:b + 1, c:c + 1], k[b:b + 1, c:c + 1])
+        got = y[b, c].cpu()
+        tol = 1e-4 + 1e-5 * ref.abs().max().item()
+        assert (got - ref[0, 0]).abs().max().item() <= tol, (b, c)
+        assert abs(ysum[b, c].item() - ref.double().sum().item()) <= 1e-5 * abs(ref.double().sum().item()) + 1e-3
+    # (4) every plane is finite and planes are not mixed up: zero one plane's kernel -> only that plane is zero
+    kz = kd.clone()
+    kz[5, 17] = 0
+    yz = fn(xd, kz)
+    assert bool((yz[5, 17] == 0).all())
+    yz[5, 17] = y[5, 17]
+    assert torch.equal(yz, y)
+
+
+def test_xcorr_full_size_production(dev):
+    _full_size_properties(dev, hdn_amd.xcorr_depthwise, O.xcorr_depthwise, (64, 256, 29, 29), (64, 256, 5, 5), False)
+    assert X.last_variant() == "f1_29x29_5x5"
+
+
+def test_xcorr_full_size_north_star(dev):
+    _full_size_properties(dev, hdn_amd.xcorr_depthwise, O.xcorr_depthwise, (64, 256, 61, 61), (64, 256, 31, 31), False)
+    assert X.last_variant() == "f1_61x61_31x31"
+
+
+def test_xcorr_full_size_circular(dev):
+    _full_size_properties(dev, hdn_amd.xcorr_depthwise_circular, O.xcorr_depthwise_circular, (64, 256, 13, 13), (64, 256, 13, 13), True)
+    assert X.last_variant() == "f1c_13x13_13x13"
+
+
+def test_xcorr_circular_wraps_rows_and_clamps_columns(dev):
+    """Rolling x by one row rolls the output by one row (circular axis); the column axis does not wrap."""
+    r = np.random.default_rng(3)
+    x = T(r.standard_normal((1, 4, 13, 13), dtype=np.float32)).to(dev)
+    k = T(r.standard_normal((1, 4, 13, 13), dtype=np.float32)).to(dev)
+    y = hdn_amd.xcorr_depthwise_circular(x, k)
+    y_roll = hdn_amd.xcorr_depthwise_circular(torch.roll(x, 1, dims=2), k)
+    assert torch.allclose(torch.roll(y, 1, dims=2), y_roll, atol=1e-5)
+    y_rollc = hdn_amd.xcorr_depthwise_circular(torch.roll(x, 1, dims=3), k)
+    assert not torch.allclose(torch.roll(y, 1, dims=3), y_rollc, atol=1e-3)
+
+
+# --------------------------------------------------------------------------- PreShareFeature
+def share_sd(npz, prefix):
+    return {k[len(prefix):].replace("__", "."): torch.from_numpy(npz[k]) for k in npz.files if k.startswith(prefix)}
+
+
+def test_share_feature_golden(dev):
+    g = load_golden("share_feature")
+    m = hdn_amd.PreShareFeature()
+    m.load_state_dict(share_sd(g, "sd__"))
+    m = m.to(dev).eval()
+    for xin, yout in (("x", "y"), ("x_small", "y_small")):
+        y = m(T(g[xin]).to(dev)).cpu().numpy()
+        assert y.shape == g[yout].shape
+        np.testing.assert_allclose(y, g[yout], rtol=0, atol=1e-4)
+        assert np.abs(y - g[yout]).max() < 2e-5  # observed: a few ulp
+    # parameters changed in place -> folded block is rebuilt
+    y0 = m(T(g["x_small"]).to(dev))
+    m.ShareFeature[7].bias.data.add_(0.5)
+    y1 = m(T(g["x_small"]).to(dev))
+    assert float((y1 - y0).abs().max()) > 0.1
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1, 1), (3, 1, 5, 131), (2, 1, 130, 7), (64, 1, 127, 127), (2, 1, 255, 255)])
+def test_share_feature_shapes_vs_oracle(dev, shape):
+    torch.manual_seed(sum(shape))
+    m = hdn_amd.PreShareFeature().eval()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.uniform_(-0.5, 0.5)
+            mod.running_var.uniform_(0.5, 2.0)
+            mod.weight.data.uniform_(0.5, 1.5)
+            mod.bias.data.uniform_(-0.3, 0.3)
+    x = torch.randn(shape)
+    sd = {"ShareFeature." + k: v.clone() for k, v in m.ShareFeature.state_dict().items()}
+    ref = O.share_feature(x, sd)
+    y = m.to(dev)(x.to(dev)).cpu()
+    assert y.shape == ref.shape
+    assert float((y - ref).abs().max()) <= 1e-4 + 1e-5 * float(ref.abs().max())
+
+
+# --------------------------------------------------------------------------- DLT / warp
+def test_dlt_solve_golden(dev):
+    g = load_golden("dlt_solve")
+    H = hdn_amd.DLT_solve(T(g["src"]).to(dev), T(g["off"]).to(dev)).cpu().numpy()
+    assert H.shape == g["H"].shape == (64, 1, 3, 3)
+    np.testing.assert_allclose(H, g["H"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(H.reshape(-1, 3, 3), O.dlt_solve_f64(g["src"], g["off"]), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(H[0, 0], np.eye(3), atol=1e-6)
+    H2 = hdn_amd.DLT_solve(T(g["src2"]).to(dev), T(g["off2"]).to(dev)).cpu().numpy()
+    np.testing.assert_allclose(H2.reshape(-1, 3, 3), O.dlt_solve_f64(g["src2"], g["off2"]), rtol=0, atol=1e-5)
+    np.testing.assert_allclose(H2, g["H2"], rtol=0, atol=5e-4)
+
+
+def test_dlt_solve_batch_sizes_and_point_order(dev):
+    r = np.random.default_rng(9)
+    for B in (1, 7, 33, 1000):
+        src = np.tile(np.array([0, 0, 0, 127, 127, 127, 127, 0], np.float32), (B, 1))
+        off = (8 * r.standard_normal((B, 8))).astype(np.float32)
+        H = hdn_amd.DLT_solve(T(src).to(dev), T(off).to(dev)).cpu().numpy().reshape(B, 3, 3)
+        np.testing.assert_allclose(H, O.dlt_solve_f64(src, off), rtol=0, atol=5e-6)
+        # H maps every source corner onto its displaced position
+        pts = np.concatenate([src.reshape(B, 4, 2), np.ones((B, 4, 1), np.float32)], axis=2).astype(np.float64)
+        q = np.einsum("bij,bkj->bki", H.astype(np.float64), pts)
+        np.testing.assert_allclose(q[..., :2] / q[..., 2:], (src + off).reshape(B, 4, 2), atol=2e-3)
+
+
+def test_transformer_golden_including_nudge_branch(dev):
+    g = load_golden("transformer")
+    y, cond = hdn_amd.transformer(T(g["img"]).to(dev), T(g["theta"]).to(dev), (20, 33))
+    np.testing.assert_allclose(y.cpu().numpy(), g["y"], rtol=0, atol=1e-4)
+    assert np.abs(y.cpu().numpy() - g["y"]).max() < 1e-5
+    y3, _ = hdn_amd.transformer(T(g["img3"]).to(dev), T(g["theta3"]).to(dev), (15, 17))
+    np.testing.assert_allclose(y3.cpu().numpy(), g["y3"], rtol=0, atol=1e-4)
+    with pytest.raises(ValueError):
+        hdn_amd.transformer(T(g["img"]).to(dev), T(g["theta"]).to(dev), (10, 10))
+
+
+def test_transform_golden(dev):
+    g = load_golden("transform")
+    img, H = T(g["img"]).to(dev), T(g["H"]).to(dev)
+    B, _, Hh, Ww = img.shape
+    M, Minv = O.norm_matrices(B)
+    pidx, base = O.full_patch_indices(B, Hh, Ww)
+    y = hdn_amd.transform(Hh, Ww, Minv, H, M, img, pidx.to(dev), base.to(dev))
+    assert y.shape == (B, 1, Hh, Ww)
+    np.testing.assert_allclose(y.cpu().numpy(), g["y"], rtol=0, atol=1e-4)
+    y_fast = hdn_amd.transform(Hh, Ww, Minv, H, M, img, pidx.to(dev), base.to(dev), assume_identity_patch=True)
+    assert torch.equal(y_fast.contiguous(), y.contiguous())
+    # multi-channel input goes through the same kernel (NCHW in, NHWC out)
+    img3 = torch.randn(2, 3, 31, 17)
+    th = torch.tensor([[[1.0, 0.1, 0.0], [0.05, 0.9, 0.1], [0.02, 0.0, 1.0]]]).repeat(2, 1, 1)
+    ref, _ = O.transformer(img3, th, (31, 17))
+    got, _ = hdn_amd.transformer(img3.to(dev), th.to(dev), (31, 17))
+    assert got.shape == (2, 31, 17, 3)
+    np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=0, atol=1e-5)
+
+
+def test_dlt_warp_fused_golden_and_full_batch(dev):
+    g = load_golden("homo_forward")
+    Hm, warped = hdn_amd.dlt_warp(T(g["h4p"]).to(dev), T(g["x"]).to(dev), T(g["org_imgs"][:, :1]).to(dev))
+    np.testing.assert_allclose(Hm.cpu().numpy(), g["H_mat"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(warped.cpu().numpy()[:1], g["pred_I2_d"], rtol=0, atol=1e-4)
+    # B=64 (BASELINE config 2): offsets N(0, 8^2) px
+    r = np.random.default_rng(64)
+    img = T(r.standard_normal((64, 1, 127, 127), dtype=np.float32))
+    h4p = T(np.tile(np.array([0, 0, 0, 127, 127, 127, 127, 0], np.float32), (64, 1)))
+    off = T((8 * r.standard_normal((64, 8))).astype(np.float32))
+    Href, wref = O.dlt_warp(h4p, off, img)
+    Hm, w = hdn_amd.dlt_warp(h4p.to(dev), off.to(dev), img.to(dev))
+    np.testing.assert_allclose(Hm.cpu().numpy(), Href.numpy(), rtol=0, atol=1e-5)
+    # the two paths hold H to ~1e-6, so sampling positions agree to ~1e-4 px; white-noise images have
+    # O(1) gradients per pixel, hence the 5e-4 bound here (smooth crops are far tighter)
+    assert float((w.cpu() - wref).abs().max()) < 5e-4
+    # fused == two-step (same device code path for the warp)
+    M, Minv = O.norm_matrices(64)
+    pidx, base = O.full_patch_indices(64, 127, 127)
+    two = hdn_amd.transform(127, 127, Minv, Hm, M, img.to(dev), pidx.to(dev), base.to(dev))
+    assert float((two - w).abs().max()) < 1e-5
+
+
+# --------------------------------------------------------------------------- whole head
+def _seeded_net():
+    torch.manual_seed(123)
+    net = hdn_amd.HomoModelBuilder().eval()
+    gen = torch.Generator().manual_seed(5)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.empty_like(m.running_mean).uniform_(-0.2, 0.2, generator=gen))
+            m.running_var.copy_(torch.empty_like(m.running_var).uniform_(0.8, 1.2, generator=gen))
+    net.fc.weight.data.mul_(0.01)
+    net.fc.bias.data.copy_(torch.tensor([3.0, -2.0, 1.5, 4.0, -3.5, 2.5, 0.5, -1.0]))
+    return net
+
+
+def _cfg1_data(B, seed):
+    r = np.random.default_rng(seed)
+    datas = []
+    for _ in range(B):
+        tmp = O.gray_normalise(r.integers(0, 256, (127, 127, 3)))
+        sea = O.gray_normalise(r.integers(0, 256, (127, 127, 3)))
+        datas.append(O.merge_pair(tmp, sea))
+    st = lambda k: torch.stack([torch.Tensor(d[k]).float() for d in datas])
+    return {"org_imgs": st("org_imgs"), "input_tensors": st("input_tensors"), "patch_indices": st("patch_indices"), "h4p": st("four_points")}
+
+
+def test_homo_forward_golden_post_trunk(dev):
+    """HomoModelBuilder.forward with the reference trunk's output injected: every HIP stage against the fixture."""
+    g = load_golden("homo_forward")
+    net = hdn_amd.HomoModelBuilder().eval()
+    net.ShareFeature.load_state_dict(share_sd(g, "sf__"))
+    net = net.to(dev)
+    xfix = T(g["x"]).to(dev)
+    net.fc = torch.nn.Identity()
+    net.avgpool = torch.nn.Identity()
+
+    class Inject(torch.nn.Module):
+        def forward(self, feats):
+            return xfix
+
+    net.backbone = Inject()
+    data = {k: T(g[k]).to(dev) for k in ("org_imgs", "input_tensors", "h4p", "patch_indices")}
+    out = net(data)
+    assert set(out) == {"feature_loss", "pred_I2_d", "x", "H_mat", "patch_2_res_d", "pred_I2_CnnFeature_d", "homo_neg_loss"}
+    np.testing.assert_allclose(out["H_mat"].cpu().numpy(), g["H_mat"], atol=1e-5)
+    np.testing.assert_allclose(out["pred_I2_d"].cpu().numpy(), g["pred_I2_d"], atol=1e-4)
+    np.testing.assert_allclose(out["patch_2_res_d"].cpu().numpy(), g["patch_2_res_d"], atol=1e-4)
+    np.testing.assert_allclose(out["pred_I2_CnnFeature_d"].cpu().numpy(), g["pred_I2_CnnFeature_d"], atol=1e-4)
+    np.testing.assert_allclose(out["feature_loss"].cpu().numpy(), g["feature_loss"], rtol=1e-3, atol=1e-8)
+    assert float(out["homo_neg_loss"]) == 0.0
+
+
+def test_track_proj_end_to_end_corner_offsets(dev):
+    """Full head incl. the PyTorch-ROCm trunk vs the CPU oracle: predicted corner displacements within 1e-4."""
+    net = _seeded_net()
+    data = _cfg1_data(4, 77)
+    sd = {k: v.clone() for k, v in net.ShareFeature.state_dict().items()}
+    with torch.no_grad():
+        Href, sref, ssref, aux = O.track_proj(data, sd, lambda f: net.fc(net.avgpool(net.backbone(f)).flatten(1)))
+    netd = net.to(dev)
+    dd = {k: v.to(dev) for k, v in data.items()}
+    from hdn_amd.homo_model import homo_stages
+    st = homo_stages(netd, dd)
+    x = st["x"].cpu()
+    err = O.corner_error(x.numpy(), aux["x"].numpy())
+    assert float((x - aux["x"]).abs().max()) <= 1e-4, float((x - aux["x"]).abs().max())
+    assert err.max() <= 1e-4
+    Hm, s, ss = netd.track_proj(dd, None)
+    assert Hm.shape == (4, 3, 3) and s.dim() == 0
+    np.testing.assert_allclose(Hm.cpu().numpy(), Href.numpy(), atol=2e-5)
+    assert abs(float(s) - float(sref)) <= 1e-4 and abs(float(ss) - float(ssref)) <= 1e-4
+    # cached template features give the same answer
+    Hm2, s2, ss2 = netd.track_proj(dd, None, cached_patch_1=st["patch_1"].contiguous())
+    assert float((Hm2 - Hm).abs().max()) < 1e-5 and abs(float(s2) - float(s)) < 1e-5

@@ -1,0 +1,222 @@
+"""CPU-only tests: C-ABI surface, host-side logic, error behaviour.  No kernel is launched here."""
+import ctypes
+import os
+import re
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+from oracle import hdn_oracle as O
+
+import hdn_amd
+from hdn_amd import _lib, dist as hdist, install as hinstall, share_feature as SF, xcorr as X
+
+
+def declared_functions():
+    hdr = open(os.path.join(ROOT, "include", "hdn_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(hdn_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = declared_functions()
+    assert len(names) >= 10
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/hdn_hip.h but not exported"
+    assert set(names) == set(_lib.SIGNATURES), "python binding table out of sync with the header"
+
+
+def test_library_loads_and_reports_abi():
+    lib = _lib.load()
+    assert lib.hdn_abi_version() == _lib.ABI_VERSION == 1
+    assert lib.hdn_last_xcorr_variant() == b"none"
+
+
+def test_c_abi_argument_errors_need_no_gpu():
+    """Argument validation happens before any launch, so the error codes can be checked on a CPU box."""
+    lib = _lib.load()
+    one = ctypes.c_void_p(16)
+    assert lib.hdn_xcorr_depthwise_f32(None, one, one, 1, 1, 5, 5, 3, 3, None) == -1
+    assert lib.hdn_xcorr_depthwise_f32(one, one, ctypes.c_void_p(32), 1, 1, 3, 3, 5, 5, None) == -2  # kernel > search
+    assert lib.hdn_xcorr_depthwise_f32(one, one, ctypes.c_void_p(32), 0, 1, 5, 5, 3, 3, None) == -2
+    assert lib.hdn_xcorr_depthwise_f32(one, one, one, 1, 1, 5, 5, 3, 3, None) == -4  # out aliases x
+    assert lib.hdn_share_feature_f32(one, one, ctypes.c_void_p(32), 1, 0, 5, None) == -2
+    assert lib.hdn_share_feature_f32(one, one, one, 1, 5, 5, None) == -4
+    assert lib.hdn_dlt_solve_f32(one, one, None, 1, None) == -1
+    assert lib.hdn_warp_f32(one, one, ctypes.c_void_p(32), 1, 1, 1, 5, None) == -2  # linspace(-1,1,1)
+    assert lib.hdn_dlt_warp_f32(one, one, one, one, ctypes.c_void_p(32), 70000, 5, 5, None) == -3
+    with pytest.raises(ValueError):
+        _lib.check(-2, "x")
+    with pytest.raises(_lib.HdnHipError):
+        _lib.check(-1098, "x")
+
+
+def test_no_cpu_fallback():
+    with pytest.raises(_lib.HdnHipError, match="no CPU fallback"):
+        hdn_amd.xcorr_depthwise(torch.zeros(1, 1, 5, 5), torch.zeros(1, 1, 3, 3))
+    with pytest.raises(_lib.HdnHipError):
+        hdn_amd.DLT_solve(torch.zeros(1, 8), torch.zeros(1, 8))
+    m = hdn_amd.PreShareFeature().eval()
+    with pytest.raises(_lib.HdnHipError):
+        m(torch.zeros(1, 1, 8, 8))
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "hdn_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in src.replace("# oracle", ""), fn
+
+
+def test_xcorr_output_shapes_and_errors():
+    assert X.out_shape((2, 256, 29, 29), (2, 256, 5, 5), False) == (2, 256, 25, 25)
+    assert X.out_shape((1, 256, 61, 61), (1, 256, 31, 31), False) == (1, 256, 31, 31)
+    assert X.out_shape((1, 256, 35, 35), (1, 256, 5, 5), False) == (1, 256, 31, 31)
+    assert X.out_shape((3, 256, 13, 13), (3, 256, 13, 13), True) == (3, 256, 13, 13)
+    assert X.out_shape((1, 4, 8, 10), (1, 4, 3, 5), True) == (1, 4, 14, 16)  # even sizes: pad = size//2 per side
+    for bad in (((1, 2, 5, 5), (1, 3, 3, 3)), ((1, 2, 3, 3), (1, 2, 5, 5)), ((2, 5, 5), (2, 3, 3)), ((0, 2, 5, 5), (0, 2, 3, 3))):
+        with pytest.raises(ValueError):
+            X.out_shape(bad[0], bad[1], False)
+    # the oracle agrees on the shape rule
+    y = O.xcorr_depthwise_circular(torch.zeros(1, 4, 8, 10), torch.zeros(1, 4, 3, 5))
+    assert tuple(y.shape) == (1, 4, 14, 16)
+
+
+def _apply_folded(x, f):
+    """Evaluate the folded parameter block with plain torch ops in the kernel's layout (host-side check)."""
+    f = f.double()
+    w1 = f[0:36].reshape(9, 4).t().reshape(4, 1, 3, 3)
+    w2 = f[36:324].reshape(4, 9, 8).permute(2, 0, 1).reshape(8, 4, 3, 3)
+    w3 = f[324:396].reshape(1, 8, 3, 3)
+    al, be = f[396:409], f[409:422]
+    y = x.double()
+    for w, sl in ((w1, slice(0, 4)), (w2, slice(4, 12)), (w3, slice(12, 13))):
+        y = torch.nn.functional.conv2d(y, w, padding=1)
+        y = torch.relu(y * al[sl].view(1, -1, 1, 1) + be[sl].view(1, -1, 1, 1))
+    return y.float()
+
+
+def test_fold_params_layout_and_bn_folding():
+    g = load_golden("share_feature")
+    sd = {k[4:].replace("__", "."): torch.from_numpy(g[k]) for k in g.files if k.startswith("sd__")}
+    f = SF.fold_params(sd)
+    assert f.shape == (SF.N_PARAMS,) and f.dtype == torch.float32
+    y = _apply_folded(torch.from_numpy(g["x_small"]), f)
+    np.testing.assert_allclose(y.numpy(), g["y_small"], atol=2e-6)
+    # BN folding is bit-identical to what PyTorch's CPU eval path uses
+    xs = torch.linspace(-3, 3, 101).view(1, 1, 1, -1).repeat(1, 4, 1, 1)
+    p = lambda n: sd[f"ShareFeature.1.{n}"]
+    ref = torch.nn.functional.batch_norm(xs, p("running_mean"), p("running_var"), p("weight"), p("bias"), False, 0.1, 1e-5)
+    got = torch.from_numpy(np.float32(xs.double().numpy() * f[396:400].double().view(1, 4, 1, 1).numpy() + f[409:413].double().view(1, 4, 1, 1).numpy()))
+    assert (got == ref).float().mean() > 0.999  # fma(x, alpha, beta): single rounding, emulated in float64
+
+
+def test_preshare_module_state_dict_is_reference_compatible():
+    g = load_golden("share_feature")
+    sd = {k[4:].replace("__", "."): torch.from_numpy(g[k]) for k in g.files if k.startswith("sd__")}
+    m = hdn_amd.PreShareFeature()
+    assert set(m.state_dict().keys()) == set(sd.keys())
+    m.load_state_dict(sd, strict=True)
+    # training mode runs the stock layers (PyTorch path), eval mode insists on the GPU kernel
+    m.train()
+    assert m(torch.zeros(2, 1, 8, 8)).shape == (2, 1, 8, 8)
+    # folded cache is invalidated when a parameter changes in place
+    m.eval()
+    k1 = m._param_key("cpu")
+    m.ShareFeature[1].running_mean.add_(1.0)
+    assert m._param_key("cpu") != k1
+
+
+def test_homo_model_builder_names_match_reference_layout():
+    m = hdn_amd.HomoModelBuilder()
+    keys = set(m.state_dict().keys())
+    for k in ("ShareFeature.ShareFeature.0.weight", "backbone.conv1.weight", "backbone.layer1.0.conv1.weight",
+              "backbone.layer2.0.downsample.0.weight", "backbone.layer4.2.bn2.running_var", "fc.weight", "fc.bias"):
+        assert k in keys, k
+    assert m.backbone.conv1.weight.shape == (64, 2, 7, 7)
+    n = sum(p.numel() for p in m.parameters())
+    assert n == 21_286_062  # = the reference HomoModelBuilder (21.29 M)
+    with torch.no_grad():
+        assert m.backbone(torch.zeros(1, 2, 127, 127)).shape == (1, 512, 4, 4)
+
+
+def test_linspace_formula_used_by_the_warp_kernel():
+    """grid_coord() in dlt_warp.hip: fma(step, i, -1) below n/2, fma(-step, n-1-i, 1) above; bit-equal to torch."""
+    for n in (127, 20, 33, 15, 17, 255, 2):
+        ref = torch.linspace(-1.0, 1.0, n).numpy()
+        step = np.float32(2.0) / np.float32(n - 1)
+        i = np.arange(n)
+        lo = np.float32(np.float64(step) * i - 1.0)
+        hi = np.float32(1.0 - np.float64(step) * (n - 1 - i))
+        np.testing.assert_array_equal(np.where(i < n // 2, lo, hi).astype(np.float32), ref)
+
+
+def test_shard_range_partitions_every_pair_once():
+    for n, w in ((512, 8), (64, 1), (10, 4), (3, 8), (0, 2)):
+        spans = [hdist.shard_range(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [e - s for s, e in spans]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        hdist.shard_range(4, 4, 4)
+
+
+def test_install_rebinds_the_reference_sites():
+    names = ["hdn.core.xcorr", "hdn.models.head.ban", "hdn.models.head.ban_lp",
+             "homo_estimator.Deep_homography.Oneline_DLTv1.utils",
+             "homo_estimator.Deep_homography.Oneline_DLTv1.models.homo_model_builder",
+             "homo_estimator.Deep_homography.Oneline_DLTv1.preprocess",
+             "hdn.models.model_builder_e2e_unconstrained_v2"]
+    mods = {n: types.ModuleType(n) for n in names}
+    sentinel = object()
+    for n in names:
+        for a in ("xcorr_depthwise", "xcorr_depthwise_circular", "DLT_solve", "transform", "transformer", "Homo_STN"):
+            setattr(mods[n], a, sentinel)
+    mods[names[5]].head = {"PreShareFeature": sentinel}
+
+    class ModelBuilder:
+        def track_proj(self, data, tmp_mask):
+            return sentinel
+
+    mods[names[6]].ModelBuilder = ModelBuilder
+    done = hinstall.install(modules=mods)
+    assert len(done) == len(hinstall.REBINDINGS) + 2
+    assert mods["hdn.models.head.ban"].xcorr_depthwise is hdn_amd.xcorr_depthwise
+    assert mods["hdn.models.head.ban_lp"].xcorr_depthwise_circular is hdn_amd.xcorr_depthwise_circular
+    assert mods[names[6]].Homo_STN is hdn_amd.transform and mods[names[6]].DLT_solve is hdn_amd.DLT_solve
+    assert mods[names[5]].head["PreShareFeature"] is hdn_amd.PreShareFeature
+    assert ModelBuilder.track_proj is hinstall._track_proj_method
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference tree only exists in the build container")
+def test_trunk_matches_reference_trunk_on_cpu():
+    """Own ResNet-34 definition vs the reference's, same seeded state_dict (CPU, this container only)."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, torch, numpy as np
+sys.path.insert(0, "%s"); sys.path.insert(0, "%s/tests/golden")
+import make_golden as mg
+mg.install_stubs(); sys.path.insert(0, "/root/reference")
+import homo_estimator.Deep_homography.Oneline_DLTv1.backbone.resnet as rr
+torch.manual_seed(3)
+ref = rr.resnet34(used_layers=[4]).eval()
+from hdn_amd.trunk import resnet34_homo
+mine = resnet34_homo().eval()
+assert list(ref.state_dict().keys()) == list(mine.state_dict().keys())
+mine.load_state_dict(ref.state_dict(), strict=True)
+x = torch.randn(2, 2, 127, 127)
+with torch.no_grad():
+    a, b = ref(x), mine(x)
+assert a.shape == b.shape == (2, 512, 4, 4)
+assert torch.equal(a, b), float((a - b).abs().max())
+print("TRUNK_OK")
+''' % (ROOT, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert "TRUNK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
