@@ -207,8 +207,19 @@ __global__ __launch_bounds__(HDN_BLOCK) void dlt_warp_kernel(const float* __rest
 __global__ __launch_bounds__(HDN_BLOCK) void l1_score_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                              float* __restrict__ out, int n, float scale) {
   __shared__ float part[HDN_BLOCK / HDN_WAVE];
-  float s = 0.f;
-  for (int i = threadIdx.x; i < n; i += HDN_BLOCK) s += fabsf(a[i] - b[i]);
+  // 8 independent loads per operand in flight per thread; the partial sums are combined in a fixed order
+  float p[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) p[q] = 0.f;
+  for (int i0 = threadIdx.x; i0 < n; i0 += 8 * HDN_BLOCK) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = i0 + q * HDN_BLOCK;
+      const float av = a[min(i, n - 1)], bv = b[min(i, n - 1)];
+      p[q] += i < n ? fabsf(av - bv) : 0.f;
+    }
+  }
+  float s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, HDN_WAVE);
   if ((threadIdx.x & (HDN_WAVE - 1)) == 0) part[threadIdx.x >> 6] = s;

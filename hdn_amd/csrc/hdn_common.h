@@ -45,4 +45,62 @@ __device__ __forceinline__ void copy_l2g(const float* src, float* __restrict__ d
   }
 }
 
+// Same copy for a compile-time float count when the workgroup owns a full plane group: every thread issues ALL of
+// its 16-byte loads before the first LDS write, so one HBM round trip covers the whole group (the runtime-count
+// loop above gets serialised load -> wait -> write by the compiler).
+template <int NFLOATS>
+__device__ __forceinline__ void copy_g2l_full(const float* __restrict__ src, float* dst, int tid) {
+  static_assert(NFLOATS % 4 == 0, "plane groups are multiples of 4 floats");
+  constexpr int N4 = NFLOATS / 4;
+  constexpr int ITER = cdiv(N4, HDN_BLOCK);
+  const float4* s4 = reinterpret_cast<const float4*>(src);
+  float4* d4 = reinterpret_cast<float4*>(dst);
+  float4 r[ITER];
+#pragma unroll
+  for (int q = 0; q < ITER; ++q) r[q] = s4[min(tid + q * HDN_BLOCK, N4 - 1)];  // unconditional: stays in registers
+#pragma unroll
+  for (int q = 0; q < ITER; ++q) {
+    const int i = tid + q * HDN_BLOCK;
+    if (i < N4) d4[i] = r[q];
+  }
+}
+
+template <int NFLOATS>
+__device__ __forceinline__ void copy_l2g_full(const float* src, float* __restrict__ dst, int tid) {
+  static_assert(NFLOATS % 4 == 0, "plane groups are multiples of 4 floats");
+  constexpr int N4 = NFLOATS / 4;
+  constexpr int ITER = cdiv(N4, HDN_BLOCK);
+  const float4* s4 = reinterpret_cast<const float4*>(src);
+  float4* d4 = reinterpret_cast<float4*>(dst);
+#pragma unroll
+  for (int q = 0; q < ITER; ++q) {
+    const int i = tid + q * HDN_BLOCK;
+    if (i < N4) d4[i] = s4[i];
+  }
+}
+
+__device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+// LDS byte address of a __shared__ pointer (low 32 bits of the flat address are the LDS offset).
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p)); }
+
+// One ds_read2_b32: the pair (lds[addr + 4*O0], lds[addr + 4*O1]) lands in an aligned VGPR pair, ready to be a
+// v_pk_fma_f32 operand.  Issued through inline asm so that LLVM cannot merge the two halves with other loads of
+// the same dwords and rebuild the pair with v_mov (which it does for the C++ form).  The load is NOT tracked by
+// the compiler's s_waitcnt insertion: consume only after lds_wait_all().
+template <int O0, int O1>
+__device__ __forceinline__ float2v lds_read_pair(uint32_t addr) {
+  static_assert(O0 >= 0 && O0 < 256 && O1 >= 0 && O1 < 256, "ds_read2_b32 offsets are 8-bit dword counts");
+  float2v r;
+  asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(r) : "v"(addr), "n"(O0), "n"(O1) : "memory");
+  return r;
+}
+
+__device__ __forceinline__ void lds_wait_all() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// Make `v` opaque at this point so no consumer of it can be scheduled above (cdna guide §5.7 item 3).
+__device__ __forceinline__ void pin(float2v& v) { asm volatile("" : "+v"(v)); }
+
 }  // namespace hdn

@@ -78,7 +78,8 @@ __global__ __launch_bounds__(HDN_BLOCK) void xcorr_f1_kernel(XcorrPtrs P, int pl
   // ---- stage the x planes of this workgroup in LDS ------------------------------------
   const float* xg = x + size_t(plane0) * (HX * WX);
   if constexpr (!Cfg::CIRC && SX == WX) {
-    copy_g2l(xg, sx, np * HX * WX, tid);
+    if (np == PPB && aligned16(xg)) copy_g2l_full<PPB * HX * WX>(xg, sx, tid);  // all loads in flight at once
+    else copy_g2l(xg, sx, np * HX * WX, tid);
   } else if constexpr (!Cfg::CIRC) {
     for (int idx = tid; idx < np * HX * WX; idx += HDN_BLOCK) {
       const int p = idx / (HX * WX), rem = idx - p * (HX * WX);
@@ -159,13 +160,231 @@ __global__ __launch_bounds__(HDN_BLOCK) void xcorr_f1_kernel(XcorrPtrs P, int pl
   // ---- contiguous store of the workgroup's output planes -------------------------------
   float* og = out + size_t(plane0) * OPLANE;
   if constexpr (!Cfg::REUSE) {
-    copy_l2g(so, og, np * OPLANE, tid);
+    if (np == PPB && aligned16(og)) copy_l2g_full<PPB * OPLANE>(so, og, tid);
+    else copy_l2g(so, og, np * OPLANE, tid);
   } else {
     for (int idx = tid; idx < np * OPLANE; idx += HDN_BLOCK) {
       const int p = idx / OPLANE, rem = idx - p * OPLANE;
       og[idx] = so[p * XPLANE + rem];
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------
+// 31x31 (x) 61x61 -> 31x31 (BASELINE.json north-star shape).  fp32-FMA-bound: 1.85 MFLOP per 23 KB plane.
+//
+// gfx950 only reaches its fp32 vector peak through v_pk_fma_f32 (measured: 151 TF vs 75 TF for v_fma_f32,
+// profiles/round1_ubench_fma.txt), so the kernel is built around packed FMAs with no register shuffles:
+//   * a lane owns 16 outputs of one row as 8 pairs (out[j], out[j+8]); the matching operand pair
+//     (x[c], x[c+8]) is ONE ds_read2_b32, so every tap is `acc[j] += P[j+v] * k[v]` on aligned pairs,
+//     whatever the parity of v (adjacent-column pairs would need a shifted copy for odd v);
+//   * the plane sits in LDS as a linear image (row stride 61, odd => conflict-free b32 reads) filled by
+//     16-byte loads that are all in flight at once;
+//   * the 31 taps of a kernel row are wave-uniform: scalar loads into SGPRs, broadcast by op_sel;
+//   * tap row u+1 (38 LDS pairs + 31 SGPRs) is fetched while row u's 248 packed FMAs issue.
+// ---------------------------------------------------------------------------------------
+namespace north {
+constexpr int HX = 61, WX = 61, HK = 31, WK = 31, HO = 31, WO = 31;
+constexpr int PPB = 4;                  // planes per workgroup = one per wave
+constexpr int XPLANE = HX * WX;         // 3721, linear image
+constexpr int OPLANE = HO * WO;         // 961
+constexpr int NPAIR = 38;               // (x[c], x[c+8]) for c = 0..37 covers 16 outputs x 31 taps
+constexpr int XFLOATS = round_up(PPB * XPLANE + 64, 4);  // + slack: the last row's pairs over-read <= 8 floats
+constexpr int LDS_FLOATS = XFLOATS + PPB * OPLANE;
+constexpr size_t LDS_BYTES = size_t(LDS_FLOATS) * sizeof(float);
+
+struct Row {
+  float2v P[NPAIR];
+  float k[WK];
+};
+
+template <int C>
+__device__ __forceinline__ void issue_pairs(Row& R, uint32_t a) {
+  if constexpr (C < NPAIR) {
+    R.P[C] = lds_read_pair<C, C + 8>(a);
+    issue_pairs<C + 1>(R, a);
+  }
+}
+
+// Issue the 38 LDS pair reads and the 31 scalar tap loads of one kernel row.  Nothing is waited for here.
+__device__ __forceinline__ void load_row(Row& R, uint32_t xaddr, const float* __restrict__ kr) {
+  issue_pairs<0>(R, xaddr);
+#pragma unroll
+  for (int v = 0; v < WK; ++v) R.k[v] = kr[v];
+}
+
+// All outstanding LDS reads have landed; pin the pairs so no FMA that reads them floats above the wait.
+__device__ __forceinline__ void land_row(Row& R) {
+  lds_wait_all();
+#pragma unroll
+  for (int c = 0; c < NPAIR; ++c) pin(R.P[c]);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+__device__ __forceinline__ void fma_row(float2v (&acc)[8], const Row& R) {
+#pragma unroll
+  for (int v = 0; v < WK; ++v) {
+    const float2v kk = {R.k[v], R.k[v]};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = __builtin_elementwise_fma(R.P[j + v], kk, acc[j]);
+  }
+}
+}  // namespace north
+
+__global__ __launch_bounds__(HDN_BLOCK, 2) void xcorr_north_kernel(XcorrPtrs P, int planes) {
+  using namespace north;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sx = smem;
+  float* so = smem + XFLOATS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & (HDN_WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int prob = blockIdx.y;
+  const float* __restrict__ x = P.x[prob];
+  const float* __restrict__ k = P.k[prob];
+  float* __restrict__ out = P.out[prob];
+  const int plane0 = blockIdx.x * PPB;
+  const int np = min(PPB, planes - plane0);
+
+  const float* xg = x + size_t(plane0) * XPLANE;
+  if (np == PPB && aligned16(xg)) copy_g2l_full<PPB * XPLANE>(xg, sx, tid);
+  else copy_g2l(xg, sx, np * XPLANE, tid);
+  __syncthreads();
+
+  if (wave < np) {  // wave-uniform
+    const float* __restrict__ kp = k + size_t(plane0 + wave) * (HK * WK);
+    const int i = min(lane & 31, HO - 1);  // output row (lanes 31 and 63 shadow row 30 and do not store)
+    const int s = lane >> 5;               // output columns [16 s, 16 s + 16)
+    const uint32_t xa = lds_addr(sx + wave * XPLANE + i * WX + s * 16);
+    float2v acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = float2v{0.f, 0.f};
+    Row A, B;
+    load_row(A, xa, kp);
+    land_row(A);
+#pragma unroll 1
+    for (int u = 0; u < HK - 1; u += 2) {
+      load_row(B, xa + (u + 1) * (WX * 4), kp + (u + 1) * WK);
+      __builtin_amdgcn_sched_barrier(0);
+      fma_row(acc, A);
+      land_row(B);
+      load_row(A, xa + (u + 2) * (WX * 4), kp + (u + 2) * WK);
+      __builtin_amdgcn_sched_barrier(0);
+      fma_row(acc, B);
+      land_row(A);
+    }
+    fma_row(acc, A);  // u = 30
+    if ((lane & 31) < HO) {
+      float* os = so + wave * OPLANE + i * WO + s * 16;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        os[j] = acc[j].x;
+        if (s * 16 + j + 8 < WO) os[j + 8] = acc[j].y;
+      }
+    }
+  }
+  __syncthreads();
+  float* og = out + size_t(plane0) * OPLANE;
+  if (np == PPB && aligned16(og)) copy_l2g_full<PPB * OPLANE>(so, og, tid);
+  else copy_l2g(so, og, np * OPLANE, tid);
+}
+
+// ---------------------------------------------------------------------------------------
+// circular 13x13 (x) 13x13 -> 13x13 (log-polar head, ban_lp.py:38).  ~ridge: 28 FLOP/B.
+//
+// The 25x25 padded plane is never built: x and k stay in LDS as raw 13x13 linear images (both are contiguous
+// 16-plane chunks in HBM -> two all-in-flight 16-byte copies), and the wrap / clamp is folded into addresses:
+//   padded row  (i+u)  -> source row (i+u+7) mod 13      (rows = angle, wraps)
+//   padded col  c      -> source col clamp(c-6, 0, 12)   (cols = log-radius, replicates) : a compile-time index
+// A lane owns one output row of one plane (13 lanes per plane, 4 planes per wave) as 7 pairs (out[j], out[j+7]);
+// the operand pair (xp[c], xp[c+7]) is one ds_read2_b32 with two static column offsets, so all taps are packed
+// FMAs on aligned pairs.  k rows are read from LDS (same address across a plane's 13 lanes: broadcast).
+// ---------------------------------------------------------------------------------------
+namespace circ13 {
+constexpr int N = 13, PL = N * N;       // 169
+constexpr int PPW = 4, PPB = 16;        // planes per wave / per workgroup
+constexpr int NPAIR = 19;               // (xp[c], xp[c+7]), c = 0..18
+constexpr int LDS_FLOATS = 3 * PPB * PL + 16;
+__host__ __device__ constexpr int clampc(int c) { return c < 6 ? 0 : (c > 18 ? 12 : c - 6); }
+template <int C>
+__device__ __forceinline__ void issue_pairs(float2v (&Pp)[NPAIR], uint32_t a) {
+  if constexpr (C < NPAIR) {
+    Pp[C] = lds_read_pair<clampc(C), clampc(C + 7)>(a);
+    issue_pairs<C + 1>(Pp, a);
+  }
+}
+}  // namespace circ13
+
+__global__ __launch_bounds__(HDN_BLOCK) void xcorr_circ13_kernel(XcorrPtrs P, int planes) {
+  using namespace circ13;
+  __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
+  float* sx = smem;
+  float* sk = smem + PPB * PL;
+  float* so = smem + 2 * PPB * PL;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & (HDN_WAVE - 1);
+  const int wave = tid >> 6;
+  const int prob = blockIdx.y;
+  const int plane0 = blockIdx.x * PPB;
+  const int np = min(PPB, planes - plane0);
+  const float* xg = P.x[prob] + size_t(plane0) * PL;
+  const float* kg = P.k[prob] + size_t(plane0) * PL;
+  float* og = P.out[prob] + size_t(plane0) * PL;
+
+  if (np == PPB && aligned16(xg) && aligned16(kg)) {
+    copy_g2l_full<PPB * PL>(xg, sx, tid);
+    copy_g2l_full<PPB * PL>(kg, sk, tid);
+  } else {
+    copy_g2l(xg, sx, np * PL, tid);
+    copy_g2l(kg, sk, np * PL, tid);
+  }
+  __syncthreads();
+
+  const int q = min(lane / N, PPW - 1);       // lanes 52..63 shadow plane 3 and do not store
+  const int i = lane - (lane / N) * N;        // output row
+  const int slot = min(wave * PPW + q, np - 1);
+  const bool live = lane < PPW * N && wave * PPW + q < np;
+  const float* xs = sx + slot * PL;
+  const float* ks = sk + slot * PL;
+  float2v acc[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) acc[j] = float2v{0.f, 0.f};
+  int r = i + 7;  // source row of padded row i + u, u = 0
+  r = r >= N ? r - N : r;
+#pragma unroll 1
+  for (int u = 0; u < N; ++u) {
+    const float* xr = xs + r * N;
+    const float* kr = ks + u * N;
+    float2v Pp[NPAIR];
+    circ13::issue_pairs<0>(Pp, lds_addr(xr));
+    float kv_[N];
+#pragma unroll
+    for (int v = 0; v < N; ++v) kv_[v] = kr[v];
+    lds_wait_all();
+#pragma unroll
+    for (int c = 0; c < NPAIR; ++c) pin(Pp[c]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int v = 0; v < N; ++v) {
+      const float2v kk = {kv_[v], kv_[v]};
+#pragma unroll
+      for (int j = 0; j < 7; ++j) acc[j] = __builtin_elementwise_fma(Pp[j + v], kk, acc[j]);
+    }
+    r = (r + 1 == N) ? 0 : r + 1;
+  }
+  if (live) {
+    float* os = so + slot * PL + i * N;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      os[j] = acc[j].x;
+      if (j + 7 < N) os[j + 7] = acc[j].y;
+    }
+  }
+  __syncthreads();
+  if (np == PPB && aligned16(og)) copy_l2g_full<PPB * PL>(so, og, tid);
+  else copy_l2g(so, og, np * PL, tid);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -249,11 +468,29 @@ static int launch_f1(const XcorrPtrs& P, int n, int planes, hipStream_t stream, 
   return launch_status();
 }
 
+static int launch_north(const XcorrPtrs& P, int n, int planes, hipStream_t stream) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xcorr_north_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)north::LDS_BYTES);
+    if (e != hipSuccess) return -(1000 + (int)e);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(xcorr_north_kernel, dim3(cdiv(planes, north::PPB), n), dim3(HDN_BLOCK), north::LDS_BYTES, stream, P,
+                     planes);
+  g_last_variant = "north_61x61_31x31";
+  return launch_status();
+}
+
+static int launch_circ13(const XcorrPtrs& P, int n, int planes, hipStream_t stream) {
+  hipLaunchKernelGGL(xcorr_circ13_kernel, dim3(cdiv(planes, circ13::PPB), n), dim3(HDN_BLOCK), 0, stream, P, planes);
+  g_last_variant = "circ13";
+  return launch_status();
+}
+
 //                 HX  WX  HK  WK  TW  SX  PPW  CIRC   REUSE
 using F1_29_5 = F1Cfg<29, 29, 5, 5, 5, 29, 2, false, false>;      // production: 3 levels x {cls,loc}, ban.py:76
 using F1_35_5 = F1Cfg<35, 35, 5, 5, 8, 35, 2, false, false>;      // INSTANCE_SIZE 303 (BASELINE config 5)
-using F1_61_31 = F1Cfg<61, 61, 31, 31, 16, 68, 1, false, true>;   // north-star stress shape (BASELINE config 2)
-using F1_13c13 = F1Cfg<13, 13, 13, 13, 4, 28, 2, true, false>;    // log-polar head, ban_lp.py:38
 
 static int xcorr_dispatch(const XcorrPtrs& P, int n, int circular, int B, int C, int Hx, int Wx, int Hk, int Wk,
                           hipStream_t stream) {
@@ -266,11 +503,9 @@ static int xcorr_dispatch(const XcorrPtrs& P, int n, int circular, int B, int C,
   if (!circular) {
     if (Hx == 29 && Wx == 29 && Hk == 5 && Wk == 5) return launch_f1<F1_29_5>(P, n, planes, stream, "f1_29x29_5x5");
     if (Hx == 35 && Wx == 35 && Hk == 5 && Wk == 5) return launch_f1<F1_35_5>(P, n, planes, stream, "f1_35x35_5x5");
-    if (Hx == 61 && Wx == 61 && Hk == 31 && Wk == 31)
-      return launch_f1<F1_61_31>(P, n, planes, stream, "f1_61x61_31x31");
+    if (Hx == 61 && Wx == 61 && Hk == 31 && Wk == 31) return launch_north(P, n, planes, stream);
   } else {
-    if (Hx == 13 && Wx == 13 && Hk == 13 && Wk == 13)
-      return launch_f1<F1_13c13>(P, n, planes, stream, "f1c_13x13_13x13");
+    if (Hx == 13 && Wx == 13 && Hk == 13 && Wk == 13) return launch_circ13(P, n, planes, stream);
   }
   const size_t lds = (size_t(HP) * WP + size_t(Hk) * Wk) * sizeof(float);
   dim3 grid(planes, n);

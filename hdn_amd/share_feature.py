@@ -100,6 +100,16 @@ class PreShareFeature(nn.Module):
             self._folded_key = key
         return self._folded
 
+    def refresh(self):
+        """Drop the cached folded block.  Needed only after writing parameters through `.data`, which bypasses
+        the tensor version counters the cache is keyed on (load_state_dict / .to() / in-place ops are tracked)."""
+        self._folded = None
+        self._folded_key = None
+
+    def train(self, mode: bool = True):
+        self.refresh()
+        return super().train(mode)
+
     def forward(self, x):
         if self.training:
             return self.ShareFeature(x)
