@@ -173,60 +173,146 @@ __global__ __launch_bounds__(HDN_BLOCK) void xcorr_f1_kernel(XcorrPtrs P, int pl
 // ---------------------------------------------------------------------------------------
 // 31x31 (x) 61x61 -> 31x31 (BASELINE.json north-star shape).  fp32-FMA-bound: 1.85 MFLOP per 23 KB plane.
 //
-// gfx950 only reaches its fp32 vector peak through v_pk_fma_f32 (measured: 151 TF vs 75 TF for v_fma_f32,
-// profiles/round1_ubench_fma.txt), so the kernel is built around packed FMAs with no register shuffles:
-//   * a lane owns 16 outputs of one row as 8 pairs (out[j], out[j+8]); the matching operand pair
-//     (x[c], x[c+8]) is ONE ds_read2_b32, so every tap is `acc[j] += P[j+v] * k[v]` on aligned pairs,
-//     whatever the parity of v (adjacent-column pairs would need a shifted copy for odd v);
-//   * the plane sits in LDS as a linear image (row stride 61, odd => conflict-free b32 reads) filled by
-//     16-byte loads that are all in flight at once;
-//   * the 31 taps of a kernel row are wave-uniform: scalar loads into SGPRs, broadcast by op_sel;
-//   * tap row u+1 (38 LDS pairs + 31 SGPRs) is fetched while row u's 248 packed FMAs issue.
+// gfx950 only reaches its fp32 vector peak through v_pk_fma_f32 (measured 151 TF vs 75 TF for v_fma_f32,
+// profiles/round1_ubench_fma.txt), and at the 2 waves/SIMD this kernel's LDS footprint allows only 16-byte
+// LDS reads run at full rate.  Both are met with adjacent-column operand pairs R[m] = (x[2m], x[2m+1]):
+//   * even taps v = 2w update even-aligned output pairs  accE[j] = (out[2j],   out[2j+1]) += R[j+w] * k[v]
+//   * odd  taps v = 2w+1 update ODD-aligned output pairs accO[j] = (out[2j-1], out[2j])   += R[j+w] * k[v]
+//     (the operand pair of an odd tap is aligned again once the OUTPUT pair is shifted by one column),
+//   and out[2j] = accE[j].lo + accO[j].hi, out[2j+1] = accE[j].hi + accO[j+1].lo at the end of the plane.
+//   No register shuffles, every LDS read is a 16-byte ds_read_b128, 17 independent accumulator chains.
+//   * a lane owns 16 outputs of one row (62 lanes per plane); a tap row costs 12 ds_read_b128 and
+//     16*8 + 15*9 = 263 packed FMAs (248 would be the minimum: the two odd-aligned edge pairs are half-used);
+//   * the 31 taps of a kernel row are wave-uniform: s_load into SGPRs, broadcast by op_sel;
+//   * tap row u+1 (LDS + SGPRs) is fetched while row u's FMAs issue.
+// Waves are autonomous and persistent: a wave owns an LDS slot (rows re-strided to 68 floats so the b128 reads
+// of 16 consecutive rows hit 64 distinct banks) and streams planes through it; the NEXT plane's 15 x 16-byte
+// global loads are in flight in registers while the current plane is correlated, and results go straight to HBM.
+// There is no workgroup barrier and no bulk fill/compute/store phase.
+// LDS reads, LDS writes and scalar tap loads are inline asm (ordered among themselves, waited for by hand:
+// cdna guide §5.7); the compiler only sees global loads/stores, address arithmetic and the FMAs.
 // ---------------------------------------------------------------------------------------
 namespace north {
 constexpr int HX = 61, WX = 61, HK = 31, WK = 31, HO = 31, WO = 31;
-constexpr int PPB = 4;                  // planes per workgroup = one per wave
-constexpr int XPLANE = HX * WX;         // 3721, linear image
+constexpr int XPLANE = HX * WX;         // 3721
 constexpr int OPLANE = HO * WO;         // 961
-constexpr int NPAIR = 38;               // (x[c], x[c+8]) for c = 0..37 covers 16 outputs x 31 taps
-constexpr int XFLOATS = round_up(PPB * XPLANE + 64, 4);  // + slack: the last row's pairs over-read <= 8 floats
-constexpr int LDS_FLOATS = XFLOATS + PPB * OPLANE;
-constexpr size_t LDS_BYTES = size_t(LDS_FLOATS) * sizeof(float);
+constexpr int SX = 68;                  // LDS row stride (floats): 16-byte aligned, 68 = 4 mod 64
+constexpr int NQUAD = 12;               // ds_read_b128 per tap row: x[16s .. 16s+47]
+constexpr int NQ = 15;                  // 16-byte global loads per lane per plane: 64*15*4 = 3840 >= 3721 + 3
+constexpr int WINDOW = NQ * HDN_WAVE * 4;
+constexpr int GUARD_ROWS_BEFORE = 1, GUARD_ROWS_AFTER = 3;  // window floats outside the plane land here
+constexpr int SLOT = (GUARD_ROWS_BEFORE + HX + GUARD_ROWS_AFTER) * SX;  // 4420 floats per wave
+constexpr size_t LDS_BYTES = size_t(4 * SLOT) * sizeof(float);          // 70,720 B: two workgroups per CU
 
-struct Row {
-  float2v P[NPAIR];
-  float k[WK];
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f8v __attribute__((ext_vector_type(8)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+struct Taps {  // one kernel row in SGPRs: k[0..15], k[16..23], k[24..27], k[28..29], k[30]
+  f16v a;
+  f8v b;
+  f4v c;
+  float2v d;
+  float e;
+  __device__ __forceinline__ float get(int v) const {
+    return v < 16 ? a[v] : (v < 24 ? b[v - 16] : (v < 28 ? c[v - 24] : (v < 30 ? d[v - 28] : e)));
+  }
 };
 
-template <int C>
-__device__ __forceinline__ void issue_pairs(Row& R, uint32_t a) {
-  if constexpr (C < NPAIR) {
-    R.P[C] = lds_read_pair<C, C + 8>(a);
-    issue_pairs<C + 1>(R, a);
+struct Row {
+  f4v Q[NQUAD];  // Q[m] = x[4m .. 4m+3] of the lane's 48-float window; pair R[n] = (x[2n], x[2n+1])
+  Taps k;
+  __device__ __forceinline__ float2v pair(int n) const { return (n & 1) ? Q[n >> 1].zw : Q[n >> 1].xy; }
+};
+
+template <int M>
+__device__ __forceinline__ void issue_quads(Row& R, uint32_t a) {
+  if constexpr (M < NQUAD) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(R.Q[M]) : "v"(a), "n"(M * 16));
+    issue_quads<M + 1>(R, a);
   }
 }
 
-// Issue the 38 LDS pair reads and the 31 scalar tap loads of one kernel row.  Nothing is waited for here.
-__device__ __forceinline__ void load_row(Row& R, uint32_t xaddr, const float* __restrict__ kr) {
-  issue_pairs<0>(R, xaddr);
-#pragma unroll
-  for (int v = 0; v < WK; ++v) R.k[v] = kr[v];
+// Issue the 12 LDS reads and the 31 scalar tap loads of one kernel row.  Nothing is waited for here.
+__device__ __forceinline__ void load_row(Row& R, uint32_t xaddr, const float* kr) {
+  issue_quads<0>(R, xaddr);
+  asm volatile(
+      "s_nop 4\n\t"
+      "s_load_dwordx16 %0, %5, 0x0\n\t"
+      "s_load_dwordx8 %1, %5, 0x40\n\t"
+      "s_load_dwordx4 %2, %5, 0x60\n\t"
+      "s_load_dwordx2 %3, %5, 0x70\n\t"
+      "s_load_dword %4, %5, 0x78"
+      : "=&s"(R.k.a), "=&s"(R.k.b), "=&s"(R.k.c), "=&s"(R.k.d), "=&s"(R.k.e)
+      : "s"(kr));
 }
 
-// All outstanding LDS reads have landed; pin the pairs so no FMA that reads them floats above the wait.
+// All outstanding LDS reads and scalar loads have landed; pin their destinations so no FMA floats above the wait.
 __device__ __forceinline__ void land_row(Row& R) {
   lds_wait_all();
 #pragma unroll
-  for (int c = 0; c < NPAIR; ++c) pin(R.P[c]);
+  for (int m = 0; m < NQUAD; ++m) asm volatile("" : "+v"(R.Q[m]));
+  asm volatile("" : "+s"(R.k.a), "+s"(R.k.b), "+s"(R.k.c), "+s"(R.k.d), "+s"(R.k.e));
   __builtin_amdgcn_sched_barrier(0);
 }
 
-__device__ __forceinline__ void fma_row(float2v (&acc)[8], const Row& R) {
+__device__ __forceinline__ void fma_row(float2v (&accE)[8], float2v (&accO)[9], const Row& R) {
 #pragma unroll
-  for (int v = 0; v < WK; ++v) {
-    const float2v kk = {R.k[v], R.k[v]};
+  for (int w = 0; w < 16; ++w) {
+    {
+      const float kv = R.k.get(2 * w);
+      const float2v kk = {kv, kv};
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = __builtin_elementwise_fma(R.P[j + v], kk, acc[j]);
+      for (int j = 0; j < 8; ++j) accE[j] = __builtin_elementwise_fma(R.pair(j + w), kk, accE[j]);
+    }
+    if (w < 15) {
+      const float kv = R.k.get(2 * w + 1);
+      const float2v kk = {kv, kv};
+#pragma unroll
+      for (int j = 0; j < 9; ++j) accO[j] = __builtin_elementwise_fma(R.pair(j + w), kk, accO[j]);
+    }
+  }
+}
+
+// The 16-byte-aligned window [first, first + 3840) floats that contains a plane (first = plane start rounded down
+// to 16 B).  Lane l holds float4 #(l + 64 q).  Windows that would leave the tensor use guarded scalar loads.
+__device__ __forceinline__ void fetch_plane(f4v (&R)[NQ], const float* __restrict__ x, long long first, long long total,
+                                            int lane) {
+  const bool inside = first >= 0 && first + WINDOW <= total;  // wave-uniform
+  if (inside) {
+    const f4v* w = reinterpret_cast<const f4v*>(x + first);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) R[q] = w[lane + q * HDN_WAVE];
+  } else {
+#pragma unroll 1
+    for (int q = 0; q < NQ; ++q) {
+      const long long f = first + 4 * (lane + q * HDN_WAVE);
+      f4v v;
+      v.x = (f + 0 >= 0 && f + 0 < total) ? x[f + 0] : 0.f;
+      v.y = (f + 1 >= 0 && f + 1 < total) ? x[f + 1] : 0.f;
+      v.z = (f + 2 >= 0 && f + 2 < total) ? x[f + 2] : 0.f;
+      v.w = (f + 3 >= 0 && f + 3 < total) ? x[f + 3] : 0.f;
+#pragma unroll
+      for (int qq = 0; qq < NQ; ++qq)
+        if (qq == q) R[qq] = v;  // static register indices
+    }
+  }
+}
+
+// Scatter the window into the wave's slot with rows re-strided to SX.  Window float f is plane element f - shift;
+// elements outside [0, 3721) fall into the guard rows.  slot_a = byte address of the slot.
+__device__ __forceinline__ void stash_plane(const f4v (&R)[NQ], uint32_t slot_a, int shift, int lane) {
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int e = 4 * (lane + q * HDN_WAVE) - shift + WX;  // >= 58: one guard row of bias keeps the division unsigned
+    const int row = e / WX, col = e - row * WX;            // row 0 = guard row before the plane
+    const uint32_t a = slot_a + uint32_t(row * SX + col) * 4u;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      // element t sits at column col + t, or wraps into the next row (+SX - WX floats further on)
+      const uint32_t at = a + 4u * t + ((col + t >= WX) ? uint32_t(SX - WX) * 4u : 0u);
+      asm volatile("ds_write_b32 %0, %1" : : "v"(at), "v"(R[q][t]));
+    }
   }
 }
 }  // namespace north
@@ -234,60 +320,71 @@ __device__ __forceinline__ void fma_row(float2v (&acc)[8], const Row& R) {
 __global__ __launch_bounds__(HDN_BLOCK, 2) void xcorr_north_kernel(XcorrPtrs P, int planes) {
   using namespace north;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sx = smem;
-  float* so = smem + XFLOATS;
 
-  const int tid = threadIdx.x;
-  const int lane = tid & (HDN_WAVE - 1);
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = threadIdx.x & (HDN_WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int prob = blockIdx.y;
   const float* __restrict__ x = P.x[prob];
   const float* __restrict__ k = P.k[prob];
   float* __restrict__ out = P.out[prob];
-  const int plane0 = blockIdx.x * PPB;
-  const int np = min(PPB, planes - plane0);
+  const int gw = blockIdx.x * 4 + wave;  // this wave's id; it owns planes gw, gw + nw, ...
+  const int nw = gridDim.x * 4;
+  if (gw >= planes) return;
 
-  const float* xg = x + size_t(plane0) * XPLANE;
-  if (np == PPB && aligned16(xg)) copy_g2l_full<PPB * XPLANE>(xg, sx, tid);
-  else copy_g2l(xg, sx, np * XPLANE, tid);
-  __syncthreads();
+  const uint32_t slot_a = lds_addr(smem + wave * SLOT);
+  const uint32_t plane_a = slot_a + uint32_t(GUARD_ROWS_BEFORE * SX) * 4u;  // LDS address of plane element (0,0)
+  const long long total = (long long)planes * XPLANE;
+  // x may be any 4-byte aligned pointer: mis = float offset of x inside its 16-byte line
+  const int mis = int((reinterpret_cast<uintptr_t>(x) >> 2) & 3);
 
-  if (wave < np) {  // wave-uniform
-    const float* __restrict__ kp = k + size_t(plane0 + wave) * (HK * WK);
-    const int i = min(lane & 31, HO - 1);  // output row (lanes 31 and 63 shadow row 30 and do not store)
-    const int s = lane >> 5;               // output columns [16 s, 16 s + 16)
-    const uint32_t xa = lds_addr(sx + wave * XPLANE + i * WX + s * 16);
-    float2v acc[8];
+  const int i = min(lane & 31, HO - 1);  // output row (lanes 31 and 63 shadow row 30 and do not store)
+  const int s = lane >> 5;               // output columns [16 s, 16 s + 16)
+  const bool live = (lane & 31) < HO;
+  const uint32_t xa = plane_a + uint32_t(i * SX + s * 16) * 4u;
+
+  f4v R[NQ];
+  {
+    const long long start = (long long)gw * XPLANE;
+    fetch_plane(R, x, start - ((start + mis) & 3), total, lane);
+  }
+#pragma unroll 1
+  for (int plane = gw; plane < planes; plane += nw) {
+    const long long start = (long long)plane * XPLANE;
+    stash_plane(R, slot_a, int((start + mis) & 3), lane);
+    if (plane + nw < planes) {  // wave-uniform: next plane's loads fly during this plane's FMAs
+      const long long nstart = (long long)(plane + nw) * XPLANE;
+      fetch_plane(R, x, nstart - ((nstart + mis) & 3), total, lane);
+    }
+    const float* kp = k + size_t(plane) * (HK * WK);
+    float2v accE[8], accO[9];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = float2v{0.f, 0.f};
+    for (int j = 0; j < 8; ++j) accE[j] = float2v{0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 9; ++j) accO[j] = float2v{0.f, 0.f};
     Row A, B;
     load_row(A, xa, kp);
     land_row(A);
 #pragma unroll 1
     for (int u = 0; u < HK - 1; u += 2) {
-      load_row(B, xa + (u + 1) * (WX * 4), kp + (u + 1) * WK);
+      load_row(B, xa + (u + 1) * (SX * 4), kp + (u + 1) * WK);
       __builtin_amdgcn_sched_barrier(0);
-      fma_row(acc, A);
+      fma_row(accE, accO, A);
       land_row(B);
-      load_row(A, xa + (u + 2) * (WX * 4), kp + (u + 2) * WK);
+      load_row(A, xa + (u + 2) * (SX * 4), kp + (u + 2) * WK);
       __builtin_amdgcn_sched_barrier(0);
-      fma_row(acc, B);
+      fma_row(accE, accO, B);
       land_row(A);
     }
-    fma_row(acc, A);  // u = 30
-    if ((lane & 31) < HO) {
-      float* os = so + wave * OPLANE + i * WO + s * 16;
+    fma_row(accE, accO, A);  // u = 30
+    if (live) {
+      float* o = out + size_t(plane) * OPLANE + i * WO + s * 16;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        os[j] = acc[j].x;
-        if (s * 16 + j + 8 < WO) os[j + 8] = acc[j].y;
+        o[2 * j] = accE[j].x + accO[j].y;
+        if (s * 16 + 2 * j + 1 < WO) o[2 * j + 1] = accE[j].y + accO[j + 1].x;
       }
     }
   }
-  __syncthreads();
-  float* og = out + size_t(plane0) * OPLANE;
-  if (np == PPB && aligned16(og)) copy_l2g_full<PPB * OPLANE>(so, og, tid);
-  else copy_l2g(so, og, np * OPLANE, tid);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -469,15 +566,16 @@ static int launch_f1(const XcorrPtrs& P, int n, int planes, hipStream_t stream, 
 }
 
 static int launch_north(const XcorrPtrs& P, int n, int planes, hipStream_t stream) {
-  static bool attr_done = false;
+  static bool attr_done = false;  // dynamic LDS above 64 KiB needs the opt-in once
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xcorr_north_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)north::LDS_BYTES);
     if (e != hipSuccess) return -(1000 + (int)e);
     attr_done = true;
   }
-  hipLaunchKernelGGL(xcorr_north_kernel, dim3(cdiv(planes, north::PPB), n), dim3(HDN_BLOCK), north::LDS_BYTES, stream, P,
-                     planes);
+  // persistent: 2 workgroups per CU x 256 CUs (fewer if there are fewer planes); n problems share the grid
+  const int per_problem = max(1, min(cdiv(planes, 4), 512 / n));
+  hipLaunchKernelGGL(xcorr_north_kernel, dim3(per_problem, n), dim3(HDN_BLOCK), north::LDS_BYTES, stream, P, planes);
   g_last_variant = "north_61x61_31x31";
   return launch_status();
 }
