@@ -9,7 +9,7 @@
 // Each nn.Conv2d zero-pads ITS OWN input, so intermediate activations that fall outside
 // the image are forced to 0 (they are not "what the conv would give on an extended image").
 // The 396 weights + 26 BN scale/shift values are wave-uniform: they are read through the
-// scalar cache (layout chosen so that each tap's output channels are contiguous).
+// scalar cache (layout: even/odd input-channel pairs adjacent, see include/hdn_hip.h).
 #include "hdn_common.h"
 
 namespace hdn {
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(HDN_BLOCK) void share_feature_kernel(const float* _
           const float v = s_a[ci * SF_A_N + (r + ky) * SF_A_W + c + kx];
 #pragma unroll
           for (int co = 0; co < 8; ++co)
-            acc[co] = __builtin_fmaf(v, prm[SF_W2 + (ci * 9 + ky * 3 + kx) * 8 + co], acc[co]);
+            acc[co] = __builtin_fmaf(v, prm[SF_W2 + (((ci >> 1) * 9 + ky * 3 + kx) * 8 + co) * 2 + (ci & 1)], acc[co]);
         }
     const bool inside = gr >= 0 && gr < H && gc >= 0 && gc < W;
 #pragma unroll
@@ -113,9 +113,163 @@ __global__ __launch_bounds__(HDN_BLOCK) void share_feature_kernel(const float* _
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
-          acc = __builtin_fmaf(s_b[ci * SF_B_N + (r + ky) * SF_B_W + c + kx], prm[SF_W3 + ci * 9 + ky * 3 + kx], acc);
+          acc = __builtin_fmaf(s_b[ci * SF_B_N + (r + ky) * SF_B_W + c + kx],
+                               prm[SF_W3 + ((ci >> 1) * 9 + ky * 3 + kx) * 2 + (ci & 1)], acc);
     const float y = __builtin_fmaf(acc, prm[SF_ALPHA + 12], prm[SF_BETA + 12]);
     out[plane + size_t(gr) * W + gc] = fmaxf(y, 0.f);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// W <= 128 (the 127x127 crops of the tracker): one workgroup = 4 output rows x the full width.
+//   * no horizontal halo recompute: columns outside the image are the convs' own zero padding;
+//   * all three layers issue v_pk_fma_f32 on natural pairs: the intermediates live in LDS as
+//     (channel 2p, channel 2p+1) float2 per pixel, the weights as (w[2p], w[2p+1]) SGPR pairs, and each
+//     accumulator pair holds the partial sums over even / odd input channels (added once at the end);
+//   * pixel = lane index: 8/6/4 rows x 128 columns = exactly 4/3/2 full rounds of 256 threads.
+// ---------------------------------------------------------------------------------------
+// A wave-uniform pointer into the (read-only) parameter block, re-typed to the constant address space so its loads
+// are scalar (s_load), and passed through an empty asm so the compiler cannot hoist every weight of the layer out of
+// the tap loop (which overflows the ~100 SGPRs and spills through v_readlane/v_writelane).
+typedef const float2v __attribute__((address_space(4))) cfloat2v;
+__device__ __forceinline__ const cfloat2v* opaque_const(const float2v* p) {
+  uint64_t a = reinterpret_cast<uint64_t>(p);
+  asm volatile("" : "+s"(a));
+  return (const cfloat2v*)a;
+}
+
+namespace sfw {
+constexpr int R = 4, CS = 130;                 // output rows per workgroup; LDS row stride (cols -1..128)
+constexpr int IN_H = R + 6, A_H = R + 4, B_H = R + 2;
+constexpr int IN_N = IN_H * CS, A_N = A_H * CS, B_N = B_H * CS;
+constexpr int LDS_FLOATS = IN_N + 2 * (2 * A_N) + 2 * (4 * B_N);
+}  // namespace sfw
+
+__global__ __launch_bounds__(HDN_BLOCK) void share_feature_w128_kernel(const float* __restrict__ img,
+                                                                       const float* __restrict__ prm,
+                                                                       float* __restrict__ out, int H, int W) {
+  using namespace sfw;
+  __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
+  float* s_in = smem;
+  float2v* s_a = reinterpret_cast<float2v*>(smem + IN_N);            // [2][A_H][CS]
+  float2v* s_b = reinterpret_cast<float2v*>(smem + IN_N + 4 * A_N);  // [4][B_H][CS]
+  const float2v* w2p = reinterpret_cast<const float2v*>(prm + SF_W2);  // [2][9][8]
+  const float2v* w3p = reinterpret_cast<const float2v*>(prm + SF_W3);  // [4][9]
+
+  const int tid = threadIdx.x;
+  const int r0 = blockIdx.x * R;
+  const size_t plane = size_t(blockIdx.y) * H * W;
+  const float* __restrict__ src = img + plane;
+  const int c = tid & 127, rr = tid >> 7;  // pixel column, row parity inside a round
+
+  // input rows r0-3 .. r0+R+2, columns -1 .. 128; zero outside the image
+  for (int idx = tid; idx < IN_N; idx += HDN_BLOCK) {
+    const int r = idx / CS, cc = idx - r * CS;
+    const int gr = r0 - 3 + r, gc = cc - 1;
+    s_in[idx] = (gr >= 0 && gr < H && gc >= 0 && gc < W) ? src[gr * W + gc] : 0.f;
+  }
+  // zero the halo columns (-1 and 128) of both intermediates
+  if (tid < 2 * (2 * A_H + 4 * B_H)) {
+    const int side = tid & 1, row = tid >> 1;
+    if (row < 2 * A_H) s_a[row * CS + side * (CS - 1)] = float2v{0.f, 0.f};
+    else s_b[(row - 2 * A_H) * CS + side * (CS - 1)] = float2v{0.f, 0.f};
+  }
+  __syncthreads();
+
+  // ---- layer 1: 1 -> 4 at rows r0-2 .. r0+R+1 -------------------------------------------
+#pragma unroll 1
+  for (int q = 0; q < A_H / 2; ++q) {
+    const int r = 2 * q + rr;
+    const int gr = r0 - 2 + r;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const float v = s_in[(r + ky) * CS + c + kx];
+#pragma unroll
+        for (int co = 0; co < 4; ++co) acc[co] = __builtin_fmaf(v, prm[SF_W1 + (ky * 3 + kx) * 4 + co], acc[co]);
+      }
+    const bool inside = gr >= 0 && gr < H && c < W;
+    float y[4];
+#pragma unroll
+    for (int co = 0; co < 4; ++co)
+      y[co] = inside ? fmaxf(__builtin_fmaf(acc[co], prm[SF_ALPHA + co], prm[SF_BETA + co]), 0.f) : 0.f;
+    s_a[(0 * A_H + r) * CS + c + 1] = float2v{y[0], y[1]};
+    s_a[(1 * A_H + r) * CS + c + 1] = float2v{y[2], y[3]};
+  }
+  __syncthreads();
+
+  // ---- layer 2: 4 -> 8 at rows r0-1 .. r0+R ----------------------------------------------
+  // A thread owns the pixels (row 2q + rr, column c), q = 0..2, and walks the 6 (channel pair, ky) tap rows with
+  // the 48 weights of one tap row in SGPRs at a time (the pointer is made opaque per iteration so the compiler
+  // neither hoists all 288 weights out of the loop nor spills SGPRs through v_readlane).
+  {
+    constexpr int NPX = B_H / 2;
+    float2v acc[NPX][8];
+#pragma unroll
+    for (int q = 0; q < NPX; ++q)
+#pragma unroll
+      for (int co = 0; co < 8; ++co) acc[q][co] = float2v{0.f, 0.f};
+#pragma unroll 1
+    for (int t = 0; t < 6; ++t) {  // t = cp * 3 + ky
+      const int cp = t / 3, ky = t - cp * 3;
+      const cfloat2v* w = opaque_const(w2p + t * 24);  // [kx][co]
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        float2v v[NPX];
+#pragma unroll
+        for (int q = 0; q < NPX; ++q) v[q] = s_a[(cp * A_H + 2 * q + rr + ky) * CS + c + kx];
+#pragma unroll
+        for (int co = 0; co < 8; ++co) {
+          const float2v wv = w[kx * 8 + co];
+#pragma unroll
+          for (int q = 0; q < NPX; ++q) acc[q][co] = __builtin_elementwise_fma(v[q], wv, acc[q][co]);
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NPX; ++q) {
+      const int r = 2 * q + rr;
+      const int gr = r0 - 1 + r;
+      const bool inside = gr >= 0 && gr < H && c < W;
+      float y[8];
+#pragma unroll
+      for (int co = 0; co < 8; ++co)
+        y[co] = inside ? fmaxf(__builtin_fmaf(acc[q][co].x + acc[q][co].y, prm[SF_ALPHA + 4 + co], prm[SF_BETA + 4 + co]), 0.f) : 0.f;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) s_b[(p * B_H + r) * CS + c + 1] = float2v{y[2 * p], y[2 * p + 1]};
+    }
+  }
+  __syncthreads();
+
+  // ---- layer 3: 8 -> 1 at rows r0 .. r0+R-1, straight to HBM -------------------------------
+  {
+    constexpr int NPX = R / 2;
+    float2v acc[NPX];
+#pragma unroll
+    for (int q = 0; q < NPX; ++q) acc[q] = float2v{0.f, 0.f};
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {  // two channel pairs (36 weights) per iteration
+      const cfloat2v* w = opaque_const(w3p + h * 18);
+#pragma unroll
+      for (int cq = 0; cq < 2; ++cq)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const float2v wv = w[cq * 9 + ky * 3 + kx];
+#pragma unroll
+            for (int q = 0; q < NPX; ++q)
+              acc[q] = __builtin_elementwise_fma(s_b[((2 * h + cq) * B_H + 2 * q + rr + ky) * CS + c + kx], wv, acc[q]);
+          }
+    }
+#pragma unroll
+    for (int q = 0; q < NPX; ++q) {
+      const int gr = r0 + 2 * q + rr;
+      if (gr < H && c < W)
+        out[plane + size_t(gr) * W + c] = fmaxf(__builtin_fmaf(acc[q].x + acc[q].y, prm[SF_ALPHA + 12], prm[SF_BETA + 12]), 0.f);
+    }
   }
 }
 
@@ -127,6 +281,12 @@ extern "C" int hdn_share_feature_f32(const float* img, const float* folded, floa
   if (B <= 0 || H <= 0 || W <= 0) return HDN_E_SHAPE;
   if (B > 65535 || (long long)H * W > 0x7fffffffLL / 4) return HDN_E_LIMIT;
   if (out == img) return HDN_E_ALIAS;
+  if (W <= 128) {
+    dim3 g(hdn::cdiv(H, hdn::sfw::R), B);
+    hipLaunchKernelGGL(hdn::share_feature_w128_kernel, g, dim3(HDN_BLOCK), 0, static_cast<hipStream_t>(stream), img,
+                       folded, out, H, W);
+    return hdn::launch_status();
+  }
   dim3 grid(hdn::cdiv(W, hdn::SF_COLS), hdn::cdiv(H, hdn::SF_ROWS), B);
   if (grid.y > 65535) return HDN_E_LIMIT;
   hipLaunchKernelGGL(hdn::share_feature_kernel, grid, dim3(HDN_BLOCK), 0, static_cast<hipStream_t>(stream), img, folded,

@@ -19,7 +19,7 @@ _SLOTS = ((0, 1), (3, 4), (6, 7))  # (conv, bn) positions inside the nn.Sequenti
 def fold_params(state_dict: dict, prefix: str = "ShareFeature.") -> torch.Tensor:
     """Host-side folding of the 3 conv weights + eval-mode BatchNorms into the kernel's parameter block.
 
-    Layout: include/hdn_hip.h (w1t[k][co], w2t[ci][k][co], w3t[ci][k], alpha[13], beta[13]).
+    Layout: include/hdn_hip.h (w1t[k][co], w2p[ci/2][k][co][ci%2], w3p[ci/2][k][ci%2], alpha[13], beta[13]).
     BatchNorm folding follows PyTorch's CPU eval path bit for bit:
         invstd = 1/sqrt(var + eps)        (fp32)
         alpha  = gamma * invstd           (fp32)
@@ -31,8 +31,8 @@ def fold_params(state_dict: dict, prefix: str = "ShareFeature.") -> torch.Tensor
     if tuple(w1.shape) != (4, 1, 3, 3) or tuple(w2.shape) != (8, 4, 3, 3) or tuple(w3.shape) != (1, 8, 3, 3):
         raise ValueError("unexpected PreShareFeature conv shapes: %s %s %s" % (tuple(w1.shape), tuple(w2.shape), tuple(w3.shape)))
     w1t = w1.reshape(4, 9).t().contiguous()                     # [k][co]
-    w2t = w2.reshape(8, 4, 9).permute(1, 2, 0).contiguous()     # [ci][k][co]
-    w3t = w3.reshape(8, 9).contiguous()                         # [ci][k]
+    w2t = w2.reshape(8, 2, 2, 9).permute(1, 3, 0, 2).contiguous()   # [ci/2][k][co][ci%2]
+    w3t = w3.reshape(4, 2, 9).permute(0, 2, 1).contiguous()         # [ci/2][k][ci%2]
     alphas, betas = [], []
     for _, bn in _SLOTS:
         invstd = 1.0 / torch.sqrt(g(bn, "running_var") + BN_EPS)

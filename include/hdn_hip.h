@@ -72,8 +72,9 @@ int hdn_xcorr_depthwise_multi_f32(const float* const* xs, const float* const* ks
  * `folded` (HDN_SF_PARAMS floats, device) = conv weights re-laid for the kernel followed
  * by the per-channel BN scale/shift; build it with hdn_amd.share_feature.fold_params().
  *   [0,36)    w1t[k][co]          k = ky*3+kx, co in 0..3      (from ShareFeature.0.weight[co,0,ky,kx])
- *   [36,324)  w2t[ci][k][co]      ci in 0..3, co in 0..7       (from ShareFeature.3.weight[co,ci,ky,kx])
- *   [324,396) w3t[ci][k]          ci in 0..7                   (from ShareFeature.6.weight[0,ci,ky,kx])
+ *   [36,324)  w2p[ci/2][k][co][ci%2]   ci in 0..3, co in 0..7  (from ShareFeature.3.weight[co,ci,ky,kx])
+ *   [324,396) w3p[ci/2][k][ci%2]       ci in 0..7              (from ShareFeature.6.weight[0,ci,ky,kx])
+ *             (even/odd input channels adjacent: one SGPR pair feeds one v_pk_fma_f32)
  *   [396,409) alpha[13]           gamma / sqrt(var + 1e-5), layers concatenated (4+8+1)
  *   [409,422) beta[13]            bias - mean * alpha
  * Replaces PreShareFeature.forward, .../Oneline_DLTv1/preprocess/input_feature_extractor.py:27-29.

@@ -91,8 +91,8 @@ def _apply_folded(x, f):
     """Evaluate the folded parameter block with plain torch ops in the kernel's layout (host-side check)."""
     f = f.double()
     w1 = f[0:36].reshape(9, 4).t().reshape(4, 1, 3, 3)
-    w2 = f[36:324].reshape(4, 9, 8).permute(2, 0, 1).reshape(8, 4, 3, 3)
-    w3 = f[324:396].reshape(1, 8, 3, 3)
+    w2 = f[36:324].reshape(2, 9, 8, 2).permute(2, 0, 3, 1).reshape(8, 4, 3, 3)   # [ci/2][k][co][ci%2] -> [co][ci][k]
+    w3 = f[324:396].reshape(4, 9, 2).permute(0, 2, 1).reshape(1, 8, 3, 3)        # [ci/2][k][ci%2]     -> [0][ci][k]
     al, be = f[396:409], f[409:422]
     y = x.double()
     for w, sl in ((w1, slice(0, 4)), (w2, slice(4, 12)), (w3, slice(12, 13))):
