@@ -158,6 +158,19 @@ def main():
     north_gbps = NORTH_BYTES_PER_PAIR * PAIRS / (north_ms * 1e-3) / 1e9
     north_tflops = NORTH_FLOPS_PER_PAIR * PAIRS / (north_ms * 1e-3) / 1e12
 
+    # HBM traffic of the dominant kernel: measured with rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs,
+    # gfx950 x2 correction on the 16 B/lane stream) and committed under profiles/; bench.py cannot collect PMCs itself.
+    traffic, traffic_note = None, "no committed PMC measurement found"
+    try:
+        with open(os.path.join(ROOT, "profiles", "round1_pmc_hbm_traffic.json")) as f:
+            for name, rec in json.load(f).items():
+                if "xcorr_north_kernel" in name and "traffic_calibrated_bytes" in rec:
+                    traffic = rec["traffic_calibrated_bytes"]
+                    traffic_note = ("profiles/round1_pmc_hbm_traffic.txt: 2*(FETCH_SIZE - scalar tap bytes) + scalar tap bytes + WRITE_SIZE, "
+                                    "bytes per launch; FETCH_SIZE x2 on the whole counter would give %.0f" % (rec["fetch_x2_bytes"] + rec["write_counter_bytes"]))
+    except (OSError, ValueError):
+        pass
+
     result = {
         "metric": "frames/sec on 127/255 template/search pairs",
         "value": PAIRS * world * args.steps / elapsed,
@@ -187,10 +200,12 @@ def main():
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": north_gbps / HBM_PEAK_GBPS,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_source": traffic_note,
             "algorithmic_bytes_per_launch": NORTH_BYTES_PER_PAIR * PAIRS,
             "avg_launch_ms": north_ms,
-            "note": "exact-fp32 depthwise correlation at 81.8 FLOP/B is fp32-FMA-bound (ridge 19.7 FLOP/B): see valu_*",
+            "note": ("exact-fp32 depthwise correlation at 81.8 FLOP/B is fp32-FMA-bound (ridge 19.7 FLOP/B), and the packed-FMA pipe "
+                     "is saturated at the clock the power budget allows (profiles/round1_pmc_sq_north.txt): see valu_*"),
             "valu_achieved_tflops": north_tflops,
             "valu_peak_tflops": FP32_VALU_PEAK_TFLOPS,
             "valu_frac": north_tflops / FP32_VALU_PEAK_TFLOPS,

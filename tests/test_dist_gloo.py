@@ -1,0 +1,81 @@
+"""world_size-2 (and 3, ragged) CPU tests of the multi-GPU path: shard the pairs, one all-gather of the offsets.
+
+The data path of the product needs a GPU, so the per-rank "estimator" here is a deterministic stand-in that maps a
+pair to 8 numbers; what is under test is hdn_amd.dist (partition, padding of ragged shards, ordering, the single
+collective) over the gloo backend, exactly as it runs over RCCL on the GPUs.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from hdn_amd import dist as hdist
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_offsets(pairs: torch.Tensor) -> torch.Tensor:
+    """pairs [n, 2, 4, 4] -> [n, 8]; any fixed per-pair function will do."""
+    return torch.stack([pairs[:, 0].reshape(len(pairs), -1)[:, :4].sum(1) * (j + 1) + pairs[:, 1].mean((1, 2)) for j in range(8)], dim=1)
+
+
+def _worker(rank, world, port, n_pairs, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        g = torch.Generator().manual_seed(1234)
+        pairs = torch.randn(n_pairs, 2, 4, 4, generator=g)  # every rank holds the same global batch
+        s, e = hdist.shard_range(n_pairs, rank, world)
+        local = _fake_offsets(pairs[s:e])
+        full = hdist.all_gather_offsets(local, n_pairs)
+        ref = _fake_offsets(pairs)
+        ok = full.shape == (n_pairs, 8) and torch.equal(full, ref)
+        # checksum equality across ranks (SURVEY §8d cfg 3)
+        cs = torch.tensor([full.double().sum().item()], dtype=torch.float64)
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        ok = ok and lo.item() == hi.item()
+        # a wrong local size is rejected rather than silently mis-ordered
+        if n_pairs >= world and e - s >= 1:
+            try:
+                hdist.all_gather_offsets(local[:-1] if e - s > 1 else torch.cat([local, local]), n_pairs)
+                bad_ok = False
+            except ValueError:
+                bad_ok = True
+            # keep the ranks in step after the deliberate failure
+            dist.barrier()
+            ok = ok and bad_ok
+        q.put((rank, bool(ok)))
+        dist.destroy_process_group()
+    except Exception as ex:  # pragma: no cover
+        q.put((rank, repr(ex)))
+
+
+@pytest.mark.parametrize("world,n_pairs", [(2, 64), (2, 7), (3, 10)])
+def test_sharded_offsets_all_gather(world, n_pairs):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_pairs, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, True) for r in range(world)], res
+
+
+def test_all_gather_is_identity_without_process_group():
+    x = torch.arange(16.0).reshape(2, 8)
+    assert hdist.all_gather_offsets(x) is x
