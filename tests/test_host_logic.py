@@ -220,3 +220,35 @@ print("TRUNK_OK")
 ''' % (ROOT, ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert "TRUNK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference tree only exists in the build container")
+def test_install_against_the_real_reference_modules():
+    """install(strict=True) finds every rebinding site in the actual reference, and a ModelBuilder built afterwards
+    carries hdn_amd.PreShareFeature and the fused track_proj (CPU, this container only; nothing is launched)."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, torch
+sys.path.insert(0, "%s"); sys.path.insert(0, "%s/tests/golden")
+import make_golden as mg
+mg.install_stubs(); sys.path.insert(0, "/root/reference")
+from hdn.core.config import cfg
+cfg.merge_from_file("/root/reference/experiments/tracker_homo_config/proj_e2e_GOT_unconstrained_v2.yaml")
+import hdn_amd, hdn_amd.install as hi
+done = hi.install(strict=True)
+assert len(done) == len(hi.REBINDINGS) + 2, done
+import hdn.models.head.ban as ban, hdn.models.head.ban_lp as ban_lp
+assert ban.xcorr_depthwise is hdn_amd.xcorr_depthwise and ban_lp.xcorr_depthwise_circular is hdn_amd.xcorr_depthwise_circular
+from hdn.models.model_builder_e2e_unconstrained_v2 import ModelBuilder
+m = ModelBuilder()
+assert isinstance(m.hm_net.ShareFeature, hdn_amd.PreShareFeature)
+assert ModelBuilder.track_proj is hi._track_proj_method
+# the reference's own HomoModelBuilder and ours agree on parameter names, so snapshots load either way
+ours = hdn_amd.HomoModelBuilder()
+assert list(m.hm_net.state_dict().keys()) == list(ours.state_dict().keys())
+ours.load_state_dict(m.hm_net.state_dict(), strict=True)
+print("INSTALL_OK")
+''' % (ROOT, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert "INSTALL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
