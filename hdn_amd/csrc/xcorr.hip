@@ -49,8 +49,7 @@ struct F1Cfg {
   static constexpr int LDS_FLOATS = XFLOATS + (REUSE ? 0 : round_up(PPB * OPLANE, 4));
   static constexpr size_t LDS_BYTES = size_t(LDS_FLOATS) * sizeof(float);
   static_assert(SX >= WP, "row stride shorter than the plane");
-  static_assert(!REUSE || UNITS <= HDN_WAVE, "output staging may reuse the x region only with one strip round");
-  static_assert(!REUSE || OPLANE <= XPLANE, "output does not fit the reused region");
+  static_assert(!REUSE || (OPLANE <= XPLANE && PPW == 1), "outputs reuse the x region: one plane per wave, and they must fit");
   static_assert((NSEG - 1) * TW + XW <= SX + SLACK, "strip over-read exceeds the slack");
 };
 
@@ -107,12 +106,13 @@ __global__ __launch_bounds__(HDN_BLOCK) void xcorr_f1_kernel(XcorrPtrs P, int pl
     if (slot < np) {
       const float* __restrict__ kp = k + size_t(plane0 + slot) * (HK * WK);  // wave-uniform -> scalar loads
       const float* xs = sx + slot * XPLANE;
-      float* os = so + slot * (Cfg::REUSE ? XPLANE : OPLANE);
-#pragma unroll 1
-      for (int unit0 = 0; unit0 < UNITS; unit0 += HDN_WAVE) {
-        const int unit = unit0 + lane;
-        const bool live = unit < UNITS;
-        const int uu = live ? unit : UNITS - 1;
+      float* os = so + slot * OPLANE;  // REUSE: compact image over the (by then dead) x planes
+      constexpr int ROUNDS = cdiv(UNITS, HDN_WAVE);
+      float res[ROUNDS][TW];  // a lane's strips of this plane stay in registers until every strip is done
+#pragma unroll
+      for (int rd = 0; rd < ROUNDS; ++rd) {
+        const int unit = rd * HDN_WAVE + lane;
+        const int uu = unit < UNITS ? unit : UNITS - 1;
         const int i = uu / NSEG, s = uu - i * NSEG;
         const float* xr = xs + i * SX + s * TW;
         float acc[TW];
@@ -146,28 +146,30 @@ __global__ __launch_bounds__(HDN_BLOCK) void xcorr_f1_kernel(XcorrPtrs P, int pl
             }
           }
         }
-        if constexpr (Cfg::REUSE) __builtin_amdgcn_wave_barrier();  // every lane's x reads precede the overwrite
-        if (live) {
+#pragma unroll
+        for (int j = 0; j < TW; ++j) res[rd][j] = acc[j];
+      }
+      if constexpr (Cfg::REUSE) __syncthreads();  // every wave's x reads precede the overwrite (np < 4: see below)
+#pragma unroll
+      for (int rd = 0; rd < ROUNDS; ++rd) {
+        const int unit = rd * HDN_WAVE + lane;
+        if (unit < UNITS) {
+          const int i = unit / NSEG, s = unit - i * NSEG;
 #pragma unroll
           for (int j = 0; j < TW; ++j)
-            if (s * TW + j < WO) os[i * WO + s * TW + j] = acc[j];
+            if (s * TW + j < WO) os[i * WO + s * TW + j] = res[rd][j];
         }
       }
+    } else if constexpr (Cfg::REUSE) {
+      __syncthreads();  // idle wave of a tail workgroup: keep the barrier count equal
     }
   }
   __syncthreads();
 
   // ---- contiguous store of the workgroup's output planes -------------------------------
   float* og = out + size_t(plane0) * OPLANE;
-  if constexpr (!Cfg::REUSE) {
-    if (np == PPB && aligned16(og)) copy_l2g_full<PPB * OPLANE>(so, og, tid);
-    else copy_l2g(so, og, np * OPLANE, tid);
-  } else {
-    for (int idx = tid; idx < np * OPLANE; idx += HDN_BLOCK) {
-      const int p = idx / OPLANE, rem = idx - p * OPLANE;
-      og[idx] = so[p * XPLANE + rem];
-    }
-  }
+  if (np == PPB && aligned16(og)) copy_l2g_full<PPB * OPLANE>(so, og, tid);
+  else copy_l2g(so, og, np * OPLANE, tid);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -180,9 +182,10 @@ __global__ __launch_bounds__(HDN_BLOCK) void xcorr_f1_kernel(XcorrPtrs P, int pl
 //   * odd  taps v = 2w+1 update ODD-aligned output pairs accO[j] = (out[2j-1], out[2j])   += R[j+w] * k[v]
 //     (the operand pair of an odd tap is aligned again once the OUTPUT pair is shifted by one column),
 //   and out[2j] = accE[j].lo + accO[j].hi, out[2j+1] = accE[j].hi + accO[j+1].lo at the end of the plane.
-//   No register shuffles, every LDS read is a 16-byte ds_read_b128, 17 independent accumulator chains.
-//   * a lane owns 16 outputs of one row (62 lanes per plane); a tap row costs 12 ds_read_b128 and
-//     16*8 + 15*9 = 263 packed FMAs (248 would be the minimum: the two odd-aligned edge pairs are half-used);
+//   No register shuffles, every LDS read is a 16-byte ds_read_b128, 16 independent accumulator chains.
+//   * a lane owns 16 outputs of one row (2 lanes per row, 62 per plane); a tap row costs 12 ds_read_b128 and
+//     16*8 + 15*8 = 248 packed FMAs, the minimum: the odd-aligned pair straddling the two lanes of a row is
+//     accumulated by the right-hand lane only and handed over with one cross-lane read per plane;
 //   * the 31 taps of a kernel row are wave-uniform: s_load into SGPRs, broadcast by op_sel;
 //   * tap row u+1 (LDS + SGPRs) is fetched while row u's FMAs issue.
 // Waves are autonomous and persistent: a wave owns an LDS slot (rows re-strided to 68 floats so the b128 reads
@@ -256,7 +259,7 @@ __device__ __forceinline__ void land_row(Row& R) {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-__device__ __forceinline__ void fma_row(float2v (&accE)[8], float2v (&accO)[9], const Row& R) {
+__device__ __forceinline__ void fma_row(float2v (&accE)[8], float2v (&accO)[8], const Row& R) {
 #pragma unroll
   for (int w = 0; w < 16; ++w) {
     {
@@ -269,7 +272,7 @@ __device__ __forceinline__ void fma_row(float2v (&accE)[8], float2v (&accO)[9], 
       const float kv = R.k.get(2 * w + 1);
       const float2v kk = {kv, kv};
 #pragma unroll
-      for (int j = 0; j < 9; ++j) accO[j] = __builtin_elementwise_fma(R.pair(j + w), kk, accO[j]);
+      for (int j = 0; j < 8; ++j) accO[j] = __builtin_elementwise_fma(R.pair(j + w), kk, accO[j]);
     }
   }
 }
@@ -356,11 +359,9 @@ __global__ __launch_bounds__(HDN_BLOCK, 2) void xcorr_north_kernel(XcorrPtrs P, 
       fetch_plane(R, x, nstart - ((nstart + mis) & 3), total, lane);
     }
     const float* kp = k + size_t(plane) * (HK * WK);
-    float2v accE[8], accO[9];
+    float2v accE[8], accO[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) accE[j] = float2v{0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < 9; ++j) accO[j] = float2v{0.f, 0.f};
+    for (int j = 0; j < 8; ++j) accE[j] = accO[j] = float2v{0.f, 0.f};
     Row A, B;
     load_row(A, xa, kp);
     land_row(A);
@@ -376,13 +377,17 @@ __global__ __launch_bounds__(HDN_BLOCK, 2) void xcorr_north_kernel(XcorrPtrs P, 
       land_row(A);
     }
     fma_row(accE, accO, A);  // u = 30
+    // accO[0] of the right-hand lane (s = 1) is (col 15, col 16): its low half is the odd-tap sum of the left-hand
+    // lane's last column, fetched across the half-waves once per plane instead of accumulating a 9th pair per row.
+    const float odd15 = __shfl(accO[0].x, (lane & 31) + 32, HDN_WAVE);
     if (live) {
       float* o = out + size_t(plane) * OPLANE + i * WO + s * 16;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         o[2 * j] = accE[j].x + accO[j].y;
-        if (s * 16 + 2 * j + 1 < WO) o[2 * j + 1] = accE[j].y + accO[j + 1].x;
+        if (j < 7) o[2 * j + 1] = accE[j].y + accO[j + 1].x;
       }
+      if (s == 0) o[15] = accE[7].y + odd15;  // column 31 (s = 1) does not exist
     }
   }
 }
@@ -391,26 +396,17 @@ __global__ __launch_bounds__(HDN_BLOCK, 2) void xcorr_north_kernel(XcorrPtrs P, 
 // circular 13x13 (x) 13x13 -> 13x13 (log-polar head, ban_lp.py:38).  ~ridge: 28 FLOP/B.
 //
 // The 25x25 padded plane is never built: x and k stay in LDS as raw 13x13 linear images (both are contiguous
-// 16-plane chunks in HBM -> two all-in-flight 16-byte copies), and the wrap / clamp is folded into addresses:
-//   padded row  (i+u)  -> source row (i+u+7) mod 13      (rows = angle, wraps)
-//   padded col  c      -> source col clamp(c-6, 0, 12)   (cols = log-radius, replicates) : a compile-time index
-// A lane owns one output row of one plane (13 lanes per plane, 4 planes per wave) as 7 pairs (out[j], out[j+7]);
-// the operand pair (xp[c], xp[c+7]) is one ds_read2_b32 with two static column offsets, so all taps are packed
-// FMAs on aligned pairs.  k rows are read from LDS (same address across a plane's 13 lanes: broadcast).
+// 16-plane chunks in HBM -> two all-in-flight 16-byte copies), and the wrap / clamp is folded into the operands:
+//   padded row  (i+u)  -> source row (i+u+7) mod 13      (rows = angle, wraps): one add per tap row
+//   padded cols 0..5 / 19..24 replicate x[0] / x[12]:   broadcast pairs (op_sel), no loads at all
+// A lane owns one output row of one plane (13 lanes per plane, 4 planes per wave).  Same even/odd scheme as the
+// 31x31 kernel: operand pairs R[n] = (xp[2n], xp[2n+1]); even taps accumulate (out[2j], out[2j+1]), odd taps
+// (out[2j-1], out[2j]).  Per tap row: 7 + 7 two-dword LDS reads (x row, k row) and 91 packed FMAs.
 // ---------------------------------------------------------------------------------------
 namespace circ13 {
 constexpr int N = 13, PL = N * N;       // 169
 constexpr int PPW = 4, PPB = 16;        // planes per wave / per workgroup
-constexpr int NPAIR = 19;               // (xp[c], xp[c+7]), c = 0..18
 constexpr int LDS_FLOATS = 3 * PPB * PL + 16;
-__host__ __device__ constexpr int clampc(int c) { return c < 6 ? 0 : (c > 18 ? 12 : c - 6); }
-template <int C>
-__device__ __forceinline__ void issue_pairs(float2v (&Pp)[NPAIR], uint32_t a) {
-  if constexpr (C < NPAIR) {
-    Pp[C] = lds_read_pair<clampc(C), clampc(C + 7)>(a);
-    issue_pairs<C + 1>(Pp, a);
-  }
-}
 }  // namespace circ13
 
 __global__ __launch_bounds__(HDN_BLOCK) void xcorr_circ13_kernel(XcorrPtrs P, int planes) {
@@ -445,29 +441,36 @@ __global__ __launch_bounds__(HDN_BLOCK) void xcorr_circ13_kernel(XcorrPtrs P, in
   const bool live = lane < PPW * N && wave * PPW + q < np;
   const float* xs = sx + slot * PL;
   const float* ks = sk + slot * PL;
-  float2v acc[7];
+  float2v accE[7], accO[7];
 #pragma unroll
-  for (int j = 0; j < 7; ++j) acc[j] = float2v{0.f, 0.f};
+  for (int j = 0; j < 7; ++j) accE[j] = accO[j] = float2v{0.f, 0.f};
   int r = i + 7;  // source row of padded row i + u, u = 0
   r = r >= N ? r - N : r;
-#pragma unroll 1
+#pragma unroll
   for (int u = 0; u < N; ++u) {
     const float* xr = xs + r * N;
     const float* kr = ks + u * N;
-    float2v Pp[NPAIR];
-    circ13::issue_pairs<0>(Pp, lds_addr(xr));
-    float kv_[N];
+    float2v X[7], K[7];  // (x[2m], x[2m+1]) and (k[2m], k[2m+1]); the 14th element of each is never used
 #pragma unroll
-    for (int v = 0; v < N; ++v) kv_[v] = kr[v];
-    lds_wait_all();
+    for (int m = 0; m < 7; ++m) {
+      X[m] = float2v{xr[2 * m], xr[2 * m + 1]};
+      K[m] = float2v{kr[2 * m], kr[2 * m + 1]};
+    }
+    const float2v lo = X[0].xx, hi = X[6].xx;  // replicated columns: (x0,x0) and (x12,x12)
+    // R[n] = (xp[2n], xp[2n+1]) of the clamped padded row, n = 0..12
+    auto R = [&](int n) -> float2v { return n < 3 ? lo : (n < 9 ? X[n - 3] : hi); };
 #pragma unroll
-    for (int c = 0; c < NPAIR; ++c) pin(Pp[c]);
-    __builtin_amdgcn_sched_barrier(0);
+    for (int w = 0; w < 7; ++w) {
+      {
+        const float2v kk = K[w].xx;  // tap 2w
 #pragma unroll
-    for (int v = 0; v < N; ++v) {
-      const float2v kk = {kv_[v], kv_[v]};
+        for (int j = 0; j < 7; ++j) accE[j] = __builtin_elementwise_fma(R(j + w), kk, accE[j]);
+      }
+      if (w < 6) {
+        const float2v kk = K[w].yy;  // tap 2w+1
 #pragma unroll
-      for (int j = 0; j < 7; ++j) acc[j] = __builtin_elementwise_fma(Pp[j + v], kk, acc[j]);
+        for (int j = 0; j < 7; ++j) accO[j] = __builtin_elementwise_fma(R(j + w), kk, accO[j]);
+      }
     }
     r = (r + 1 == N) ? 0 : r + 1;
   }
@@ -475,8 +478,8 @@ __global__ __launch_bounds__(HDN_BLOCK) void xcorr_circ13_kernel(XcorrPtrs P, in
     float* os = so + slot * PL + i * N;
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
-      os[j] = acc[j].x;
-      if (j + 7 < N) os[j + 7] = acc[j].y;
+      os[2 * j] = accE[j].x + accO[j].y;
+      if (j < 6) os[2 * j + 1] = accE[j].y + accO[j + 1].x;
     }
   }
   __syncthreads();
@@ -587,8 +590,8 @@ static int launch_circ13(const XcorrPtrs& P, int n, int planes, hipStream_t stre
 }
 
 //                 HX  WX  HK  WK  TW  SX  PPW  CIRC   REUSE
-using F1_29_5 = F1Cfg<29, 29, 5, 5, 5, 29, 2, false, false>;      // production: 3 levels x {cls,loc}, ban.py:76
-using F1_35_5 = F1Cfg<35, 35, 5, 5, 8, 35, 2, false, false>;      // INSTANCE_SIZE 303 (BASELINE config 5)
+using F1_29_5 = F1Cfg<29, 29, 5, 5, 5, 29, 1, false, false>;      // production: 3 levels x {cls,loc}, ban.py:76
+using F1_35_5 = F1Cfg<35, 35, 5, 5, 8, 35, 1, false, false>;      // INSTANCE_SIZE 303 (BASELINE config 5)
 
 static int xcorr_dispatch(const XcorrPtrs& P, int n, int circular, int B, int C, int Hx, int Wx, int Hk, int Wk,
                           hipStream_t stream) {
