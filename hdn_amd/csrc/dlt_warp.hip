@@ -203,28 +203,38 @@ __global__ __launch_bounds__(HDN_BLOCK) void dlt_warp_kernel(const float* __rest
   }
 }
 
-// sum |a-b| * scale, one workgroup, fixed reduction tree (deterministic)
-__global__ __launch_bounds__(HDN_BLOCK) void l1_score_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                             float* __restrict__ out, int n, float scale) {
-  __shared__ float part[HDN_BLOCK / HDN_WAVE];
-  // 8 independent loads per operand in flight per thread; the partial sums are combined in a fixed order
-  float p[8];
+// sum |a-b| * scale, one 1024-thread workgroup, fixed reduction tree (deterministic).  The 127x127 planes of the
+// two scores are 16 elements per thread: every load is issued before the first add, so the kernel costs one
+// L2 round trip instead of a chain of them.
+constexpr int L1_THREADS = 1024, L1_PER_THREAD = 16;
+__global__ __launch_bounds__(L1_THREADS) void l1_score_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                              float* __restrict__ out, int n, float scale) {
+  __shared__ float part[L1_THREADS / HDN_WAVE];
+  float s = 0.f;
+  for (int base = 0; base < n; base += L1_THREADS * L1_PER_THREAD) {
+    float av[L1_PER_THREAD], bv[L1_PER_THREAD];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) p[q] = 0.f;
-  for (int i0 = threadIdx.x; i0 < n; i0 += 8 * HDN_BLOCK) {
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int i = i0 + q * HDN_BLOCK;
-      const float av = a[min(i, n - 1)], bv = b[min(i, n - 1)];
-      p[q] += i < n ? fabsf(av - bv) : 0.f;
+    for (int q = 0; q < L1_PER_THREAD; ++q) {
+      const int i = min(base + q * L1_THREADS + (int)threadIdx.x, n - 1);
+      av[q] = a[i];
+      bv[q] = b[i];
     }
+    float p[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < L1_PER_THREAD; ++q)
+      p[q & 3] += (base + q * L1_THREADS + (int)threadIdx.x < n) ? fabsf(av[q] - bv[q]) : 0.f;
+    s += (p[0] + p[1]) + (p[2] + p[3]);
   }
-  float s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, HDN_WAVE);
   if ((threadIdx.x & (HDN_WAVE - 1)) == 0) part[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) out[0] = (part[0] + part[1] + part[2] + part[3]) * scale;
+  if (threadIdx.x < HDN_WAVE) {
+    float t = threadIdx.x < L1_THREADS / HDN_WAVE ? part[threadIdx.x] : 0.f;
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) t += __shfl_xor(t, m, HDN_WAVE);
+    if (threadIdx.x == 0) out[0] = t * scale;
+  }
 }
 
 }  // namespace hdn
@@ -267,8 +277,8 @@ int hdn_dlt_warp_f32(const float* h4p, const float* off, const float* img, float
 int hdn_l1_score_f32(const float* a, const float* b, float* out, int n, float scale, void* stream) {
   if (!a || !b || !out) return HDN_E_NULL;
   if (n <= 0) return HDN_E_SHAPE;
-  hipLaunchKernelGGL(hdn::l1_score_kernel, dim3(1), dim3(HDN_BLOCK), 0, static_cast<hipStream_t>(stream), a, b, out, n,
-                     scale);
+  hipLaunchKernelGGL(hdn::l1_score_kernel, dim3(1), dim3(hdn::L1_THREADS), 0, static_cast<hipStream_t>(stream), a, b, out,
+                     n, scale);
   return hdn::launch_status();
 }
 

@@ -142,7 +142,8 @@ namespace sfw {
 constexpr int R = 4, CS = 130;                 // output rows per workgroup; LDS row stride (cols -1..128)
 constexpr int IN_H = R + 6, A_H = R + 4, B_H = R + 2;
 constexpr int IN_N = IN_H * CS, A_N = A_H * CS, B_N = B_H * CS;
-constexpr int LDS_FLOATS = IN_N + 2 * (2 * A_N) + 2 * (4 * B_N);
+constexpr int W_N = 424;                       // parameter block staged in LDS (422 floats, padded)
+constexpr int LDS_FLOATS = IN_N + 2 * (2 * A_N) + 2 * (4 * B_N) + W_N;
 }  // namespace sfw
 
 __global__ __launch_bounds__(HDN_BLOCK) void share_feature_w128_kernel(const float* __restrict__ img,
@@ -153,11 +154,13 @@ __global__ __launch_bounds__(HDN_BLOCK) void share_feature_w128_kernel(const flo
   float* s_in = smem;
   float2v* s_a = reinterpret_cast<float2v*>(smem + IN_N);            // [2][A_H][CS]
   float2v* s_b = reinterpret_cast<float2v*>(smem + IN_N + 4 * A_N);  // [4][B_H][CS]
-  const float2v* w2p = reinterpret_cast<const float2v*>(prm + SF_W2);  // [2][9][8]
-  const float2v* w3p = reinterpret_cast<const float2v*>(prm + SF_W3);  // [4][9]
+  float* s_w = smem + IN_N + 4 * A_N + 8 * B_N;                      // the 422 parameters, read back as broadcasts
+  const float2v* w2p = reinterpret_cast<const float2v*>(s_w + SF_W2);  // [2][9][8]
+  const float2v* w3p = reinterpret_cast<const float2v*>(s_w + SF_W3);  // [4][9]
 
   const int tid = threadIdx.x;
   const int r0 = blockIdx.x * R;
+  for (int idx = tid; idx < HDN_SF_PARAMS; idx += HDN_BLOCK) s_w[idx] = prm[idx];
   const size_t plane = size_t(blockIdx.y) * H * W;
   const float* __restrict__ src = img + plane;
   const int c = tid & 127, rr = tid >> 7;  // pixel column, row parity inside a round
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(HDN_BLOCK) void share_feature_w128_kernel(const flo
 #pragma unroll 1
     for (int t = 0; t < 6; ++t) {  // t = cp * 3 + ky
       const int cp = t / 3, ky = t - cp * 3;
-      const cfloat2v* w = opaque_const(w2p + t * 24);  // [kx][co]
+      const float2v* w = w2p + t * 24;  // [kx][co]
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
         float2v v[NPX];
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(HDN_BLOCK) void share_feature_w128_kernel(const flo
     for (int q = 0; q < NPX; ++q) acc[q] = float2v{0.f, 0.f};
 #pragma unroll 1
     for (int h = 0; h < 2; ++h) {  // two channel pairs (36 weights) per iteration
-      const cfloat2v* w = opaque_const(w3p + h * 18);
+      const float2v* w = w3p + h * 18;
 #pragma unroll
       for (int cq = 0; cq < 2; ++cq)
 #pragma unroll
