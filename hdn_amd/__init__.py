@@ -7,5 +7,6 @@ from .xcorr import xcorr_depthwise, xcorr_depthwise_circular, xcorr_depthwise_mu
 from .homography import DLT_solve, transform, transformer, Homo_STN, dlt_warp  # noqa: F401
 from .share_feature import PreShareFeature, fold_params  # noqa: F401
 from .homo_model import HomoModelBuilder, track_proj  # noqa: F401
+from .logpolar import STN_Polar  # noqa: F401
 
 __version__ = "0.1.0"

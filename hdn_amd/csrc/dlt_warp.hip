@@ -16,6 +16,10 @@
 // them.  See DESIGN.md "warp semantics".
 #include "hdn_common.h"
 
+// The reference's CPU kernels round after every multiply and add here: rn_mul/rn_add/rn_sub/rn_div (hdn_common.h) are
+// compiled with contraction off; fusion is spelled out with __builtin_fmaf where the reference fuses.
+#pragma clang fp contract(off)
+
 namespace hdn {
 
 constexpr int WARP_PX_PER_THREAD = 4;
@@ -32,8 +36,8 @@ __device__ __forceinline__ double dlt_solve_rows(const float* __restrict__ src, 
   const int p = dlt_point(r >> 1);
   const double x = (double)src[2 * p], y = (double)src[2 * p + 1];
   // dst = src + off is an fp32 add in the reference (utils.py:36)
-  const double u = (double)__fadd_rn(src[2 * p], off[2 * p]);
-  const double v = (double)__fadd_rn(src[2 * p + 1], off[2 * p + 1]);
+  const double u = (double)rn_add(src[2 * p], off[2 * p]);
+  const double v = (double)rn_add(src[2 * p + 1], off[2 * p + 1]);
   double a[9];
   if ((r & 1) == 0) {
     a[0] = x; a[1] = y; a[2] = 1.0; a[3] = 0.0; a[4] = 0.0; a[5] = 0.0; a[6] = -u * x; a[7] = -u * y; a[8] = u;
@@ -84,11 +88,11 @@ __device__ __forceinline__ void mat3_mul(const float* A, const float* B, float* 
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j)
-      C[i * 3 + j] = __builtin_fmaf(A[i * 3 + 2], B[6 + j], __builtin_fmaf(A[i * 3 + 1], B[3 + j], __fmul_rn(A[i * 3], B[j])));
+      C[i * 3 + j] = __builtin_fmaf(A[i * 3 + 2], B[6 + j], __builtin_fmaf(A[i * 3 + 1], B[3 + j], rn_mul(A[i * 3], B[j])));
 }
 
 __device__ __forceinline__ void normalise_H(const float* Hm, float ax, float ay, float* theta) {
-  const float Minv[9] = {__fdiv_rn(1.f, ax), 0.f, -1.f, 0.f, __fdiv_rn(1.f, ay), -1.f, 0.f, 0.f, 1.f};
+  const float Minv[9] = {rn_div(1.f, ax), 0.f, -1.f, 0.f, rn_div(1.f, ay), -1.f, 0.f, 0.f, 1.f};
   const float M[9] = {ax, 0.f, ax, 0.f, ay, ay, 0.f, 0.f, 1.f};
   float P[9];
   mat3_mul(Minv, Hm, P);
@@ -98,7 +102,7 @@ __device__ __forceinline__ void normalise_H(const float* Hm, float ax, float ay,
 // torch.linspace(-1, 1, n)[i] on the CPU: start + step*i below the midpoint, end - step*(n-1-i)
 // above, each with a single rounding (verified bit-for-bit in tests/test_host_logic.py).
 __device__ __forceinline__ float grid_coord(int i, int n) {
-  const float step = __fdiv_rn(2.0f, (float)(n - 1));
+  const float step = rn_div(2.0f, (float)(n - 1));
   return i < n / 2 ? __builtin_fmaf(step, (float)i, -1.0f) : __builtin_fmaf(-step, (float)(n - 1 - i), 1.0f);
 }
 
@@ -115,31 +119,31 @@ __device__ __forceinline__ void warp_pixel(const float* __restrict__ img, const 
                                            int i, int j, int C, int H, int W) {
   const float gx = grid_coord(j, W), gy = grid_coord(i, H);
   // T = theta @ [gx, gy, 1]: fma(t1, gy, t0*gx) + t2   (the reference's sgemm order; utils.py:230)
-  const float T0 = __fadd_rn(__builtin_fmaf(th[1], gy, __fmul_rn(th[0], gx)), th[2]);
-  const float T1 = __fadd_rn(__builtin_fmaf(th[4], gy, __fmul_rn(th[3], gx)), th[5]);
-  float t = __fadd_rn(__builtin_fmaf(th[7], gy, __fmul_rn(th[6], gx)), th[8]);
+  const float T0 = rn_add(__builtin_fmaf(th[1], gy, rn_mul(th[0], gx)), th[2]);
+  const float T1 = rn_add(__builtin_fmaf(th[4], gy, rn_mul(th[3], gx)), th[5]);
+  float t = rn_add(__builtin_fmaf(th[7], gy, rn_mul(th[6], gx)), th[8]);
   // utils.py:236-240: t += 1e-6 * (1 - [|t| >= 1e-7])
-  t = __fadd_rn(t, __fmul_rn(1e-6f, (fabsf(t) >= 1e-7f) ? 0.0f : 1.0f));
-  const float xs = __fdiv_rn(T0, t), ys = __fdiv_rn(T1, t);
+  t = rn_add(t, rn_mul(1e-6f, (fabsf(t) >= 1e-7f) ? 0.0f : 1.0f));
+  const float xs = rn_div(T0, t), ys = rn_div(T1, t);
   // utils.py:128-129: x = (x_s + 1) * W / 2
-  const float x = __fmul_rn(__fmul_rn(__fadd_rn(xs, 1.0f), (float)W), 0.5f);
-  const float y = __fmul_rn(__fmul_rn(__fadd_rn(ys, 1.0f), (float)H), 0.5f);
+  const float x = rn_mul(rn_mul(rn_add(xs, 1.0f), (float)W), 0.5f);
+  const float y = rn_mul(rn_mul(rn_add(ys, 1.0f), (float)H), 0.5f);
   const int xf = f2i_x86(floorf(x)), yf = f2i_x86(floorf(y));
   const int x0 = clampi(xf, 0, W - 1), x1 = clampi((int)((unsigned)xf + 1u), 0, W - 1);
   const int y0 = clampi(yf, 0, H - 1), y1 = clampi((int)((unsigned)yf + 1u), 0, H - 1);
   // utils.py:181-184: weights from the CLAMPED taps and the UNCLAMPED coordinate
   const float x0f = (float)x0, x1f = (float)x1, y0f = (float)y0, y1f = (float)y1;
-  const float wa = __fmul_rn(__fsub_rn(x1f, x), __fsub_rn(y1f, y));
-  const float wb = __fmul_rn(__fsub_rn(x1f, x), __fsub_rn(y, y0f));
-  const float wc = __fmul_rn(__fsub_rn(x, x0f), __fsub_rn(y1f, y));
-  const float wd = __fmul_rn(__fsub_rn(x, x0f), __fsub_rn(y, y0f));
+  const float wa = rn_mul(rn_sub(x1f, x), rn_sub(y1f, y));
+  const float wb = rn_mul(rn_sub(x1f, x), rn_sub(y, y0f));
+  const float wc = rn_mul(rn_sub(x, x0f), rn_sub(y1f, y));
+  const float wd = rn_mul(rn_sub(x, x0f), rn_sub(y, y0f));
   const size_t HW = size_t(H) * W;
   float* o = out + (size_t(i) * W + j) * C;
   for (int c = 0; c < C; ++c) {
     const float* pl = img + c * HW;
     const float Ia = pl[y0 * W + x0], Ib = pl[y1 * W + x0], Ic = pl[y0 * W + x1], Id = pl[y1 * W + x1];
     // utils.py:185: wa*Ia + wb*Ib + wc*Ic + wd*Id, left to right, no fusion
-    o[c] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(wa, Ia), __fmul_rn(wb, Ib)), __fmul_rn(wc, Ic)), __fmul_rn(wd, Id));
+    o[c] = rn_add(rn_add(rn_add(rn_mul(wa, Ia), rn_mul(wb, Ib)), rn_mul(wc, Ic)), rn_mul(wd, Id));
   }
 }
 
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(HDN_BLOCK) void dlt_warp_kernel(const float* __rest
 #pragma unroll
   for (int q = 0; q < 9; ++q) Hm[q] = sH[q];
   if (blockIdx.x == 0 && tid < 9) H_out[size_t(b) * 9 + tid] = Hm[tid];
-  normalise_H(Hm, __fmul_rn((float)W, 0.5f), __fmul_rn((float)H, 0.5f), th);
+  normalise_H(Hm, rn_mul((float)W, 0.5f), rn_mul((float)H, 0.5f), th);
   const size_t HW = size_t(H) * W;
   const int base = blockIdx.x * WARP_PX_PER_BLOCK + tid;
 #pragma unroll

@@ -79,6 +79,16 @@ __device__ __forceinline__ void copy_l2g_full(const float* src, float* __restric
   }
 }
 
+// Individually rounded fp32 operations.  In this toolchain __fmul_rn/__fadd_rn/... are plain operators compiled under
+// the default -ffp-contract=fast, so `__fadd_rn(__fmul_rn(a, b), c)` may still become one fma.  These helpers are
+// compiled with contraction off: a product feeding a sum stays two roundings, as in the reference's CPU kernels.
+#pragma clang fp contract(off)
+__device__ __forceinline__ float rn_mul(float a, float b) { return a * b; }
+__device__ __forceinline__ float rn_add(float a, float b) { return a + b; }
+__device__ __forceinline__ float rn_sub(float a, float b) { return a - b; }
+__device__ __forceinline__ float rn_div(float a, float b) { return a / b; }  // IEEE-correct (v_div_scale/fmas/fixup)
+#pragma clang fp contract(fast)
+
 __device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 typedef float float2v __attribute__((ext_vector_type(2)));

@@ -13,13 +13,14 @@ attribute the reference resolves at call time:
     hdn.models.model_builder_e2e_unconstrained_v2.{DLT_solve,Homo_STN}   :29-30
     ...preprocess.head['PreShareFeature']                registry used by get_pre(), preprocess/__init__.py:18-26
     ModelBuilder.track_proj                              replaced by the fused version
+    hdn.models.logpolar.STN_Polar (+ its from-import in model_builder…:24)   device-resident log-polar sampler
 """
 from __future__ import annotations
 
 import importlib
 import types
 
-from . import homo_model, homography, share_feature, xcorr
+from . import homo_model, homography, logpolar, share_feature, xcorr
 
 _DLT = "homo_estimator.Deep_homography.Oneline_DLTv1"
 
@@ -36,6 +37,9 @@ REBINDINGS = (
     (_DLT + ".models.homo_model_builder", "transform", homography.transform),
     ("hdn.models.model_builder_e2e_unconstrained_v2", "DLT_solve", homography.DLT_solve),
     ("hdn.models.model_builder_e2e_unconstrained_v2", "Homo_STN", homography.transform),
+    # class rebinding: ModelBuilder.__init__ instantiates it (model_builder…:42), so install() must run first
+    ("hdn.models.logpolar", "STN_Polar", logpolar.STN_Polar),
+    ("hdn.models.model_builder_e2e_unconstrained_v2", "STN_Polar", logpolar.STN_Polar),
 )
 
 

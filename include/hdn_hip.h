@@ -116,6 +116,20 @@ int hdn_dlt_warp_f32(const float* h4p, const float* off, const float* img, float
  */
 int hdn_l1_score_f32(const float* a, const float* b, float* out, int n, float scale, void* stream);
 
+/*
+ * Log-polar resample of the search crop: out[b,c,a,r] = bilinear(img[b,c], p(a,r)) with
+ *   g = (rho[r]*cos_theta[a] + polar[b,0], rho[r]*sin_theta[a] + polar[b,1]) / (size//2)   (the reference's grid)
+ *   p = PyTorch grid_sample's align_corners=False pixel position, padding_mode='border'.
+ * img[B,C,H,W], polar[B,2], rho[S], cos_theta[S], sin_theta[S] -> out[B,C,S,S]; grid_or_null[B,S,S,2] receives g.
+ * The three tables are rho[r] = exp(r*log(S/2)/S) - 1 and cos/sin(a*2*pi/S + rot): build them with
+ * hdn_amd.logpolar.tables() (host, same ops as the reference) and keep them on the device.
+ * Replaces STN_Polar.forward(x, polar, delta), hdn/models/logpolar.py:58-74,100-124
+ * (called from ModelBuilder.track_new_lp, model_builder_e2e_unconstrained_v2.py:147).
+ */
+int hdn_logpolar_sample_f32(const float* img, const float* polar, const float* rho, const float* cos_theta,
+                            const float* sin_theta, float* out, float* grid_or_null, int B, int C, int H, int W,
+                            int S, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

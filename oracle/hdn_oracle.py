@@ -317,3 +317,32 @@ def corner_error(pred_off: np.ndarray, ref_off: np.ndarray) -> np.ndarray:
     """sqrt(sum ||delta||^2 / 4) per sample — toolkit/utils/statistics.py:206-218 (success_4pts_error)."""
     d = (np.asarray(pred_off, np.float64) - np.asarray(ref_off, np.float64)).reshape(-1, 4, 2)
     return np.sqrt((d ** 2).sum(axis=(1, 2)) / 4.0)
+
+
+# --------------------------------------------------------------------------- #
+# log-polar resample (SURVEY §8f rank 2)
+# --------------------------------------------------------------------------- #
+def logpolar_tables(size: int, rot: float = 0.0):
+    """The 1-D factors of STN_Polar._prepare_grid (hdn/models/logpolar.py:58-74) for an output of size x size:
+    rho[b] = exp(b * log(size/2)/size) - 1,  cos/sin(theta[a]) with theta[a] = a * 2*pi/size + rot."""
+    ls = torch.linspace(0, size - 1, size)
+    mag = math.log(size / 2) / size
+    rho = torch.exp(mag * ls) - 1.0
+    theta = ls * 2.0 * math.pi / size + rot
+    return rho, torch.cos(theta), torch.sin(theta)
+
+
+def logpolar_sample(x: torch.Tensor, polar: torch.Tensor, delta=(0, 0)):
+    """STN_Polar(image_sz=x.shape[-1]).forward(x, polar, delta) -> (x_lp [B,C,S,S], grid [B,S,S,2]), S = image_sz//2.
+
+    Reference: hdn/models/logpolar.py:100-124: grid = (rho*cos(theta) + polar_x, rho*sin(theta) + polar_y) / (size//2),
+    then F.grid_sample(bilinear, padding_mode='border', align_corners=False)."""
+    B, C, H, W = x.shape
+    S = W // 2
+    rho, c, s = logpolar_tables(S, float(delta[1]))
+    ix = rho.unsqueeze(0) * c.unsqueeze(1)   # [a][b] = rho[b] * cos(theta[a])
+    iy = rho.unsqueeze(0) * s.unsqueeze(1)
+    gx = (ix.unsqueeze(0) + polar[:, 0].reshape(B, 1, 1)) / (H // 2)
+    gy = (iy.unsqueeze(0) + polar[:, 1].reshape(B, 1, 1)) / (W // 2)
+    grid = torch.stack([gx, gy], dim=3)
+    return F.grid_sample(x, grid, mode="bilinear", padding_mode="border", align_corners=False), grid

@@ -325,6 +325,30 @@ def gen_homo_model(ref_hmb, ref_gi):
     return m, data
 
 
+def gen_logpolar(ref_lp):
+    """STN_Polar.forward (hdn/models/logpolar.py:50-134) = the log-polar resample of track_new_lp."""
+    out = {}
+    # small case, full tensors: 31x31 crops -> 15x15 log-polar map
+    g = rng(700)
+    img = (255.0 * g.random((2, 3, 31, 31))).astype(np.float32)
+    polar = np.array([[0.0, 0.0], [1.75, -2.5]], np.float32)
+    st = ref_lp.STN_Polar(31)
+    y, grid = st(t(img), t(polar), [0, 0])
+    y2, grid2 = st(t(img), t(polar), [0, 0.3])
+    out.update(small_img=img, small_polar=polar, small_y=y.numpy(), small_grid=grid.numpy(), small_y_rot=y2.numpy(),
+               small_grid_rot=grid2.numpy())
+    # production size: 255x255 -> 127x127; the image is re-derived from the seed in the test, outputs are sampled
+    g = rng(701)
+    img = (255.0 * g.random((2, 3, 255, 255))).astype(np.float32)
+    polar = np.array([[0.0, 0.0], [3.5, -2.25]], np.float32)
+    st = ref_lp.STN_Polar(255)
+    y, grid = st(t(img), t(polar), [0, 0])
+    idx = rng(702).choice(y.numel(), size=4096, replace=False)
+    out.update(prod_polar=polar, prod_idx=idx.astype(np.int64), prod_val=y.numpy().reshape(-1)[idx],
+               prod_sum=np.array(y.double().sum().item()), prod_grid=grid.numpy()[:, ::9, ::9, :])
+    save("logpolar", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
@@ -350,6 +374,8 @@ def main():
     gen_dlt(ref_utils)
     gen_transform(ref_utils)
     gen_homo_model(ref_hmb, ref_gi)
+    import hdn.models.logpolar as ref_lp
+    gen_logpolar(ref_lp)
     print("torch", torch.__version__, "numpy", np.__version__)
 
 

@@ -338,6 +338,43 @@ def test_dlt_warp_fused_golden_and_full_batch(dev):
     assert float((two - w).abs().max()) < 1e-5
 
 
+# --------------------------------------------------------------------------- log-polar sampler (§8f rank 2)
+def test_logpolar_golden(dev):
+    """Crops are raw 0..255 images, so the 1e-4 bound is relative to that amplitude (2.55e-2 abs); observed <= 2e-3
+    against the fixture (host-CPU table differences on white noise) and exact against the oracle on the same host."""
+    g = load_golden("logpolar")
+    m = hdn_amd.STN_Polar(31)
+    img, polar = T(g["small_img"]).to(dev), T(g["small_polar"]).to(dev)
+    for delta, ky, kg in (([0, 0], "small_y", "small_grid"), ([0, 0.3], "small_y_rot", "small_grid_rot")):
+        y, grid = m(img, polar, delta)
+        assert y.shape == (2, 3, 15, 15) and grid.shape == (2, 15, 15, 2)
+        # the tables come from torch's CPU exp/sin/cos, whose vector paths differ by an ulp between host CPUs: the
+        # fixture (made in the build container) is matched to 1e-6 here, and bit-for-bit against the oracle on THIS
+        # host in test_logpolar_vs_oracle_offsets_and_border
+        np.testing.assert_allclose(grid.cpu().numpy(), g[kg], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(y.cpu().numpy(), g[ky], rtol=0, atol=1e-4 * 255)
+        assert np.abs(y.cpu().numpy() - g[ky]).max() < 1e-3
+    r = golden_rng(701)
+    big = (255.0 * r.random((2, 3, 255, 255))).astype(np.float32)
+    y, grid = hdn_amd.STN_Polar(255)(T(big).to(dev), T(g["prod_polar"]).to(dev))
+    yv = y.cpu().numpy().reshape(-1)[g["prod_idx"]]
+    assert np.abs(yv - g["prod_val"]).max() < 1e-4 * 255  # white-noise 0..255 crop x ~1e-5 px table difference
+    np.testing.assert_allclose(grid.cpu().numpy()[:, ::9, ::9, :], g["prod_grid"], rtol=0, atol=1e-6)
+    assert abs(y.double().sum().item() - float(g["prod_sum"])) < 1e-6 * float(g["prod_sum"])
+
+
+def test_logpolar_vs_oracle_offsets_and_border(dev):
+    """Large offsets push samples off the crop: border padding clamps, east/south taps at the last index are masked."""
+    r = np.random.default_rng(12)
+    img = T((255.0 * r.random((3, 2, 63, 63))).astype(np.float32))
+    polar = T(np.array([[0, 0], [40.0, -35.0], [-100.0, 90.0]], np.float32))
+    for delta in ([0, 0], [0, -1.1]):
+        ref, gref = O.logpolar_sample(img, polar, delta)
+        y, grid = hdn_amd.STN_Polar(63)(img.to(dev), polar.to(dev), delta)
+        np.testing.assert_array_equal(grid.cpu().numpy(), gref.numpy())
+        assert float((y.cpu() - ref).abs().max()) < 1e-3
+
+
 # --------------------------------------------------------------------------- whole head
 def _seeded_net():
     torch.manual_seed(123)

@@ -172,11 +172,11 @@ def test_install_rebinds_the_reference_sites():
              "homo_estimator.Deep_homography.Oneline_DLTv1.utils",
              "homo_estimator.Deep_homography.Oneline_DLTv1.models.homo_model_builder",
              "homo_estimator.Deep_homography.Oneline_DLTv1.preprocess",
-             "hdn.models.model_builder_e2e_unconstrained_v2"]
+             "hdn.models.model_builder_e2e_unconstrained_v2", "hdn.models.logpolar"]
     mods = {n: types.ModuleType(n) for n in names}
     sentinel = object()
     for n in names:
-        for a in ("xcorr_depthwise", "xcorr_depthwise_circular", "DLT_solve", "transform", "transformer", "Homo_STN"):
+        for a in ("xcorr_depthwise", "xcorr_depthwise_circular", "DLT_solve", "transform", "transformer", "Homo_STN", "STN_Polar"):
             setattr(mods[n], a, sentinel)
     mods[names[5]].head = {"PreShareFeature": sentinel}
 
@@ -192,6 +192,20 @@ def test_install_rebinds_the_reference_sites():
     assert mods[names[6]].Homo_STN is hdn_amd.transform and mods[names[6]].DLT_solve is hdn_amd.DLT_solve
     assert mods[names[5]].head["PreShareFeature"] is hdn_amd.PreShareFeature
     assert ModelBuilder.track_proj is hinstall._track_proj_method
+    assert mods["hdn.models.logpolar"].STN_Polar is hdn_amd.STN_Polar and mods[names[6]].STN_Polar is hdn_amd.STN_Polar
+
+
+def test_logpolar_tables_match_oracle_and_module_signature():
+    from hdn_amd import logpolar as LP
+    for size, rot in ((127, 0.0), (15, 0.3)):
+        for a, b in zip(LP.tables(size, rot), O.logpolar_tables(size, rot)):
+            assert torch.equal(a, b)
+    m = hdn_amd.STN_Polar(255)
+    assert m._orignal_sz == [127, 127]
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 3, 31, 31), torch.zeros(1, 2))
+    with pytest.raises(_lib.HdnHipError):
+        m(torch.zeros(1, 3, 255, 255), torch.zeros(1, 2))
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference tree only exists in the build container")
@@ -243,6 +257,7 @@ assert ban.xcorr_depthwise is hdn_amd.xcorr_depthwise and ban_lp.xcorr_depthwise
 from hdn.models.model_builder_e2e_unconstrained_v2 import ModelBuilder
 m = ModelBuilder()
 assert isinstance(m.hm_net.ShareFeature, hdn_amd.PreShareFeature)
+assert isinstance(m.logpolar_instance, hdn_amd.STN_Polar)
 assert ModelBuilder.track_proj is hi._track_proj_method
 # the reference's own HomoModelBuilder and ours agree on parameter names, so snapshots load either way
 ours = hdn_amd.HomoModelBuilder()

@@ -164,3 +164,23 @@ def test_corner_error_definition():
     a = np.zeros((1, 8))
     b = np.array([[3.0, 4.0] * 4])
     assert O.corner_error(a, b)[0] == pytest.approx(5.0)
+
+
+def test_logpolar_sample():
+    g = load_golden("logpolar")
+    img, polar = T(g["small_img"]), T(g["small_polar"])
+    # torch's CPU exp/sin/cos differ by an ulp between vector ISAs, so the fixture is matched to 1e-6 (grid) and
+    # 1e-3 (0..255 image samples) rather than bit-for-bit; on the generating host the match is exact
+    y, grid = O.logpolar_sample(img, polar, [0, 0])
+    np.testing.assert_allclose(y.numpy(), g["small_y"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(grid.numpy(), g["small_grid"], rtol=0, atol=1e-6)
+    y, grid = O.logpolar_sample(img, polar, [0, 0.3])
+    np.testing.assert_allclose(y.numpy(), g["small_y_rot"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(grid.numpy(), g["small_grid_rot"], rtol=0, atol=1e-6)
+    # production size: the image is re-derived from the seed
+    r = golden_rng(701)
+    big = (255.0 * r.random((2, 3, 255, 255))).astype(np.float32)
+    y, grid = O.logpolar_sample(T(big), T(g["prod_polar"]), [0, 0])
+    assert y.shape == (2, 3, 127, 127) and grid.shape == (2, 127, 127, 2)
+    np.testing.assert_allclose(y.numpy().reshape(-1)[g["prod_idx"]], g["prod_val"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(grid.numpy()[:, ::9, ::9, :], g["prod_grid"], rtol=0, atol=1e-6)
