@@ -1,0 +1,122 @@
+"""The correlation heads around the HIP correlations.
+
+    DepthwiseXCorr / DepthwiseBAN / MultiBAN             <- hdn/models/head/ban.py:51-127
+    DepthwiseXCorrCirc / DepthwiseCircBAN / MultiCircBAN <- hdn/models/head/ban_lp.py:14-92
+
+Same module / parameter names as the reference, so its snapshots load.  The 3x3 / 1x1 convolutions stay on
+PyTorch-ROCm (MIOpen); what changes is the schedule of a frame:
+  * all 3 levels x {cls, loc} correlations of a head are ONE launch (hdn_xcorr_depthwise_multi_f32);
+  * the template branch conv_kernel(z_f) is computed once per template (the reference recomputes it every
+    frame although self.zf only changes in template(), model_builder_e2e_unconstrained_v2.py:87-96, ban.py:74).
+`fused_forward` works on any object with the reference's attribute layout, so install() can bind it onto the
+reference's own MultiBAN / MultiCircBAN classes.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .xcorr import xcorr_depthwise, xcorr_depthwise_circular, xcorr_depthwise_multi
+
+
+def _conv_bn_relu(cin, cout, k):
+    return nn.Sequential(nn.Conv2d(cin, cout, kernel_size=k, bias=False), nn.BatchNorm2d(cout), nn.ReLU(inplace=True))
+
+
+class DepthwiseXCorr(nn.Module):
+    _circular = False
+
+    def __init__(self, in_channels, hidden, out_channels, kernel_size=3):
+        super().__init__()
+        self.conv_kernel = _conv_bn_relu(in_channels, hidden, kernel_size)
+        self.conv_search = _conv_bn_relu(in_channels, hidden, kernel_size)
+        self.head = nn.Sequential(
+            nn.Conv2d(hidden, hidden, kernel_size=1, bias=False), nn.BatchNorm2d(hidden), nn.ReLU(inplace=True),
+            nn.Conv2d(hidden, out_channels, kernel_size=1),
+        )
+
+    def forward(self, kernel, search):
+        kernel = self.conv_kernel(kernel)
+        search = self.conv_search(search)
+        corr = xcorr_depthwise_circular if self._circular else xcorr_depthwise
+        return self.head(corr(search, kernel))
+
+
+class DepthwiseXCorrCirc(DepthwiseXCorr):
+    _circular = True
+
+
+class DepthwiseBAN(nn.Module):
+    _xcorr = DepthwiseXCorr
+    _loc_out = 2
+
+    def __init__(self, in_channels=256, out_channels=256, cls_out_channels=2, weighted=False):
+        super().__init__()
+        self.cls = self._xcorr(in_channels, out_channels, cls_out_channels)
+        self.loc = self._xcorr(in_channels, out_channels, self._loc_out)
+
+    def forward(self, z_f, x_f):
+        return self.cls(z_f, x_f), self.loc(z_f, x_f)
+
+
+class DepthwiseCircBAN(DepthwiseBAN):
+    _xcorr = DepthwiseXCorrCirc
+    _loc_out = 4
+
+
+def _template_key(z_fs):
+    return tuple((id(z), z.data_ptr(), z._version) for z in z_fs)
+
+
+def fused_forward(self, z_fs, x_fs, circular=None):
+    """MultiBAN.forward / MultiCircBAN.forward (ban.py:102-127, ban_lp.py:66-92) with one correlation launch and
+    cached template-branch features.  `self` needs box2.., (cls|loc)_weight, loc_scale, weighted."""
+    n = len(z_fs)
+    boxes = [getattr(self, "box" + str(i + 2)) for i in range(n)]
+    if circular is None:
+        circular = bool(getattr(boxes[0].cls, "_circular", False)) or type(boxes[0].cls).__name__.endswith("Circ")
+    with torch.no_grad():
+        key = _template_key(z_fs) + (bool(self.training),)
+        cache = getattr(self, "_hdn_template_cache", None)
+        if cache is None or cache[0] != key:
+            kern = [br.conv_kernel(z) for box, z in zip(boxes, z_fs) for br in (box.cls, box.loc)]
+            cache = (key, kern)
+            object.__setattr__(self, "_hdn_template_cache", cache)
+        kern = cache[1]
+        srch = [br.conv_search(x) for box, x in zip(boxes, x_fs) for br in (box.cls, box.loc)]
+        same = all(k.shape == kern[0].shape for k in kern) and all(s.shape == srch[0].shape for s in srch)
+        if same and len(kern) <= 8:
+            feats = xcorr_depthwise_multi(srch, kern, circular=circular)
+        else:
+            one = xcorr_depthwise_circular if circular else xcorr_depthwise
+            feats = [one(s, k) for s, k in zip(srch, kern)]
+        cls = [boxes[i].cls.head(feats[2 * i]) for i in range(n)]
+        loc = [boxes[i].loc.head(feats[2 * i + 1]) * self.loc_scale[i] for i in range(n)]
+        if self.weighted:
+            cw, lw = F.softmax(self.cls_weight, 0), F.softmax(self.loc_weight, 0)
+            c = sum(cls[i] * cw[i] for i in range(n))
+            l = sum(loc[i] * lw[i] for i in range(n))
+            return c, l
+        return sum(cls) / n, sum(loc) / n
+
+
+class MultiBAN(nn.Module):
+    _box = DepthwiseBAN
+
+    def __init__(self, in_channels, cls_out_channels, weighted=False):
+        super().__init__()
+        self.weighted = weighted
+        for i in range(len(in_channels)):
+            self.add_module("box" + str(i + 2), self._box(in_channels[i], in_channels[i], cls_out_channels))
+        if self.weighted:
+            self.cls_weight = nn.Parameter(torch.ones(len(in_channels)))
+            self.loc_weight = nn.Parameter(torch.ones(len(in_channels)))
+        self.loc_scale = nn.Parameter(torch.ones(len(in_channels)))
+
+    def forward(self, z_fs, x_fs):
+        return fused_forward(self, z_fs, x_fs)
+
+
+class MultiCircBAN(MultiBAN):
+    _box = DepthwiseCircBAN

@@ -14,13 +14,14 @@ attribute the reference resolves at call time:
     ...preprocess.head['PreShareFeature']                registry used by get_pre(), preprocess/__init__.py:18-26
     ModelBuilder.track_proj                              replaced by the fused version
     hdn.models.logpolar.STN_Polar (+ its from-import in model_builder…:24)   device-resident log-polar sampler
+    MultiBAN.forward / MultiCircBAN.forward              one correlation launch per head + cached template branch
 """
 from __future__ import annotations
 
 import importlib
 import types
 
-from . import homo_model, homography, logpolar, share_feature, xcorr
+from . import heads, homo_model, homography, logpolar, share_feature, xcorr
 
 _DLT = "homo_estimator.Deep_homography.Oneline_DLTv1"
 
@@ -77,6 +78,13 @@ def install(strict: bool = False, modules: dict = None) -> list:
     if pre is not None and isinstance(getattr(pre, "head", None), dict):
         pre.head["PreShareFeature"] = share_feature.PreShareFeature
         done.append((_DLT + ".preprocess", "head['PreShareFeature']"))
+
+    # heads: keep the reference's classes (and their weights), swap the schedule of forward()
+    for mod_name, cls_name, circ in (("hdn.models.head.ban", "MultiBAN", False), ("hdn.models.head.ban_lp", "MultiCircBAN", True)):
+        m = get(mod_name)
+        if m is not None and hasattr(m, cls_name):
+            getattr(m, cls_name).forward = (lambda c: lambda self, z_fs, x_fs: heads.fused_forward(self, z_fs, x_fs, c))(circ)
+            done.append((mod_name, cls_name + ".forward"))
 
     mb = get("hdn.models.model_builder_e2e_unconstrained_v2")
     if mb is not None and hasattr(mb, "ModelBuilder"):

@@ -346,3 +346,34 @@ def logpolar_sample(x: torch.Tensor, polar: torch.Tensor, delta=(0, 0)):
     gy = (iy.unsqueeze(0) + polar[:, 1].reshape(B, 1, 1)) / (W // 2)
     grid = torch.stack([gx, gy], dim=3)
     return F.grid_sample(x, grid, mode="bilinear", padding_mode="border", align_corners=False), grid
+
+
+# --------------------------------------------------------------------------- #
+# correlation heads: MultiBAN / MultiCircBAN with a reference state_dict
+# --------------------------------------------------------------------------- #
+def _seq_conv_bn_relu(x, sd, prefix):
+    y = F.conv2d(x, sd[prefix + ".0.weight"])
+    y = F.batch_norm(y, sd[prefix + ".1.running_mean"], sd[prefix + ".1.running_var"], sd[prefix + ".1.weight"],
+                     sd[prefix + ".1.bias"], training=False, eps=BN_EPS)
+    return F.relu(y)
+
+
+def multi_ban(z_fs, x_fs, sd: dict, circular: bool):
+    """MultiBAN.forward (hdn/models/head/ban.py:102-127) / MultiCircBAN.forward (ban_lp.py:66-92), weighted=True.
+
+    Per level: cls/loc = head(xcorr(conv_search(x), conv_kernel(z))); loc *= loc_scale[i]; softmax-weighted sums."""
+    corr = xcorr_depthwise_circular if circular else xcorr_depthwise
+    cls, loc = [], []
+    for i, (z, x) in enumerate(zip(z_fs, x_fs)):
+        outs = []
+        for br in ("cls", "loc"):
+            p = f"box{i + 2}.{br}"
+            f = corr(_seq_conv_bn_relu(x, sd, p + ".conv_search"), _seq_conv_bn_relu(z, sd, p + ".conv_kernel"))
+            h = _seq_conv_bn_relu(f, sd, p + ".head")  # head.0 conv1x1, head.1 BN, head.2 ReLU
+            outs.append(F.conv2d(h, sd[p + ".head.3.weight"], sd[p + ".head.3.bias"]))
+        cls.append(outs[0])
+        loc.append(outs[1] * sd["loc_scale"][i])
+    cw, lw = F.softmax(sd["cls_weight"], 0), F.softmax(sd["loc_weight"], 0)
+    c = sum(cls[i] * cw[i] for i in range(len(cls)))
+    l = sum(loc[i] * lw[i] for i in range(len(loc)))
+    return c, l

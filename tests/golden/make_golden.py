@@ -349,6 +349,33 @@ def gen_logpolar(ref_lp):
     save("logpolar", **out)
 
 
+def gen_heads(ref_ban, ref_ban_lp):
+    """MultiBAN (ban.py:81-127) and MultiCircBAN (ban_lp.py:55-92), 16-channel replicas so the weights fit a fixture."""
+    out = {}
+    for tag, cls, zsz, xsz in (("ban", ref_ban.MultiBAN, 7, 31), ("circ", ref_ban_lp.MultiCircBAN, 15, 15)):
+        torch.manual_seed(SEED + (3 if tag == "ban" else 4))
+        m = cls([16, 16, 16], 2, weighted=True).eval()
+        g = rng(800 if tag == "ban" else 801)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                seeded_bn_(mod, g)
+        m.cls_weight.data = t(g.standard_normal(3).astype(np.float32))
+        m.loc_weight.data = t(g.standard_normal(3).astype(np.float32))
+        m.loc_scale.data = t(g.uniform(0.5, 1.5, 3).astype(np.float32))
+        zfs = [t(g.standard_normal((2, 16, zsz, zsz), dtype=np.float32)) for _ in range(3)]
+        xfs = [t(g.standard_normal((2, 16, xsz, xsz), dtype=np.float32)) for _ in range(3)]
+        with torch.no_grad():
+            c, l = m(zfs, xfs)
+        for i in range(3):
+            out[f"{tag}__zf{i}"] = zfs[i].numpy()
+            out[f"{tag}__xf{i}"] = xfs[i].numpy()
+        out[f"{tag}__cls"] = c.numpy()
+        out[f"{tag}__loc"] = l.numpy()
+        for k, v in m.state_dict().items():
+            out[f"{tag}__sd__" + k.replace(".", "__")] = v.numpy()
+    save("heads", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
@@ -376,6 +403,9 @@ def main():
     gen_homo_model(ref_hmb, ref_gi)
     import hdn.models.logpolar as ref_lp
     gen_logpolar(ref_lp)
+    import hdn.models.head.ban as ref_ban
+    import hdn.models.head.ban_lp as ref_ban_lp
+    gen_heads(ref_ban, ref_ban_lp)
     print("torch", torch.__version__, "numpy", np.__version__)
 
 

@@ -338,6 +338,36 @@ def test_dlt_warp_fused_golden_and_full_batch(dev):
     assert float((two - w).abs().max()) < 1e-5
 
 
+# --------------------------------------------------------------------------- correlation heads (§8a row 11, §8f rank 1)
+@pytest.mark.parametrize("tag,circular", [("ban", False), ("circ", True)])
+def test_multi_ban_fused_forward_golden(dev, tag, circular):
+    """MultiBAN / MultiCircBAN with the reference's weights: one correlation launch + cached template branch."""
+    from test_oracle_golden import heads_fixture
+    from hdn_amd import heads as HD
+    sd, zfs, xfs, cls, loc = heads_fixture(tag)
+    m = (HD.MultiCircBAN if circular else HD.MultiBAN)([16, 16, 16], 2, weighted=True)
+    assert set(m.state_dict().keys()) == set(sd.keys())
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).eval()
+    zd, xd = [z.to(dev) for z in zfs], [x.to(dev) for x in xfs]
+    c, l = m(zd, xd)
+    # conv / BN / 1x1 heads run on MIOpen: 1e-4 abs on O(1) outputs
+    np.testing.assert_allclose(c.cpu().numpy(), cls, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(l.cpu().numpy(), loc, rtol=0, atol=1e-4)
+    assert X.last_variant() in ("f1_29x29_5x5", "circ13")
+    # second frame, same template: cached template features, same answer; new template: cache refreshed
+    c2, l2 = m(zd, [x * 1.0 for x in xd])
+    assert torch.equal(c2, c) and torch.equal(l2, l)
+    zd2 = [z * 0.5 for z in zd]
+    c3, _ = m(zd2, xd)
+    assert float((c3 - c).abs().max()) > 1e-3
+    # fused schedule == the reference's per-branch schedule on the same device
+    per = [getattr(m, "box" + str(i + 2))(zd[i], xd[i]) for i in range(3)]
+    cw = torch.softmax(m.cls_weight, 0)
+    ref_c = sum(per[i][0] * cw[i] for i in range(3))
+    assert float((ref_c - c).abs().max()) < 1e-5
+
+
 # --------------------------------------------------------------------------- log-polar sampler (§8f rank 2)
 def test_logpolar_golden(dev):
     """Crops are raw 0..255 images, so the 1e-4 bound is relative to that amplitude (2.55e-2 abs); observed <= 2e-3

@@ -185,8 +185,18 @@ def test_install_rebinds_the_reference_sites():
             return sentinel
 
     mods[names[6]].ModelBuilder = ModelBuilder
+
+    class MultiBAN:
+        pass
+
+    class MultiCircBAN:
+        pass
+
+    mods["hdn.models.head.ban"].MultiBAN = MultiBAN
+    mods["hdn.models.head.ban_lp"].MultiCircBAN = MultiCircBAN
     done = hinstall.install(modules=mods)
-    assert len(done) == len(hinstall.REBINDINGS) + 2
+    assert len(done) == len(hinstall.REBINDINGS) + 4
+    assert "forward" in MultiBAN.__dict__ and "forward" in MultiCircBAN.__dict__
     assert mods["hdn.models.head.ban"].xcorr_depthwise is hdn_amd.xcorr_depthwise
     assert mods["hdn.models.head.ban_lp"].xcorr_depthwise_circular is hdn_amd.xcorr_depthwise_circular
     assert mods[names[6]].Homo_STN is hdn_amd.transform and mods[names[6]].DLT_solve is hdn_amd.DLT_solve
@@ -251,7 +261,7 @@ from hdn.core.config import cfg
 cfg.merge_from_file("/root/reference/experiments/tracker_homo_config/proj_e2e_GOT_unconstrained_v2.yaml")
 import hdn_amd, hdn_amd.install as hi
 done = hi.install(strict=True)
-assert len(done) == len(hi.REBINDINGS) + 2, done
+assert len(done) == len(hi.REBINDINGS) + 4, done
 import hdn.models.head.ban as ban, hdn.models.head.ban_lp as ban_lp
 assert ban.xcorr_depthwise is hdn_amd.xcorr_depthwise and ban_lp.xcorr_depthwise_circular is hdn_amd.xcorr_depthwise_circular
 from hdn.models.model_builder_e2e_unconstrained_v2 import ModelBuilder

@@ -184,3 +184,21 @@ def test_logpolar_sample():
     assert y.shape == (2, 3, 127, 127) and grid.shape == (2, 127, 127, 2)
     np.testing.assert_allclose(y.numpy().reshape(-1)[g["prod_idx"]], g["prod_val"], rtol=0, atol=1e-3)
     np.testing.assert_allclose(grid.numpy()[:, ::9, ::9, :], g["prod_grid"], rtol=0, atol=1e-6)
+
+
+def heads_fixture(tag):
+    g = load_golden("heads")
+    pre = tag + "__sd__"
+    sd = {k[len(pre):].replace("__", "."): torch.from_numpy(g[k]) for k in g.files if k.startswith(pre)}
+    zfs = [T(g[f"{tag}__zf{i}"]) for i in range(3)]
+    xfs = [T(g[f"{tag}__xf{i}"]) for i in range(3)]
+    return sd, zfs, xfs, g[f"{tag}__cls"], g[f"{tag}__loc"]
+
+
+@pytest.mark.parametrize("tag,circular", [("ban", False), ("circ", True)])
+def test_multi_ban_heads(tag, circular):
+    sd, zfs, xfs, cls, loc = heads_fixture(tag)
+    c, l = O.multi_ban(zfs, xfs, sd, circular)
+    assert c.shape == cls.shape and l.shape == loc.shape
+    np.testing.assert_allclose(c.numpy(), cls, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(l.numpy(), loc, rtol=0, atol=1e-5)
