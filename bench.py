@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle timing (profiling runs)")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the per-kernel breakdown after the timed region")
     ap.add_argument("--only-north", action="store_true", help="step = the north-star correlation only (profiling aid)")
+    ap.add_argument("--workload", choices=["kernels", "full"], default="kernels",
+                    help="kernels = BASELINE configs[1] (default); full = configs[2]: the whole HomoModelBuilder head "
+                         "incl. the PyTorch-ROCm ResNet-34 trunk on 64 pairs per GPU, then the offsets all-gather")
     return ap.parse_args()
 
 
@@ -114,8 +117,25 @@ def main():
     tmpl = d["imgs"][:, :1].contiguous()
 
     north_ev = []
+    full_net = full_data = None
+    if args.workload == "full":
+        from hdn_amd.homo_model import homo_stages
+        torch.manual_seed(SEED + 7)
+        full_net = hdn_amd.HomoModelBuilder().eval()
+        full_net.fc.weight.data.mul_(0.01)
+        torch.backends.cudnn.benchmark = True  # MIOpen find mode for the trunk's fixed shapes (searched during warm-up)
+        full_net = full_net.to(dev).optimize_for_inference(channels_last=True)
+        full_data = {"org_imgs": d["imgs"], "input_tensors": d["imgs"], "h4p": d["h4p"],
+                     "patch_indices": torch.arange(127 * 127, dtype=torch.float32, device=dev).repeat(PAIRS, 1)}
+
+    def step_full(record):
+        st = homo_stages(full_net, full_data)
+        if world > 1:
+            hdist.all_gather_offsets(st["x"], PAIRS * world)
 
     def step(record):
+        if args.workload == "full":
+            return step_full(record)
         if record:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -141,7 +161,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(args.warmup + (5 if args.workload == "full" else 0)):
         step(False)
     fence()
     t0 = time.perf_counter()
@@ -154,6 +174,20 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    if args.workload == "full":
+        if rank == 0:
+            print(json.dumps({
+                "metric": "frames/sec on 127/255 template/search pairs", "value": PAIRS * world * args.steps / elapsed,
+                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "BASELINE configs[2] per GPU: full HomoModelBuilder head (PreShareFeature x2 -> PyTorch-ROCm "
+                                       "ResNet-34 trunk -> fused DLT+warp -> PreShareFeature) on 64 pairs, offsets all-gathered",
+                           "pairs_per_gpu": PAIRS}}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     north_ms = float(np.mean([a.elapsed_time(b) for a, b in north_ev]))
     north_gbps = NORTH_BYTES_PER_PAIR * PAIRS / (north_ms * 1e-3) / 1e9
     north_tflops = NORTH_FLOPS_PER_PAIR * PAIRS / (north_ms * 1e-3) / 1e12

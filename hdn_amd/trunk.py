@@ -66,3 +66,37 @@ class HomoResNet(nn.Module):
 
 def resnet34_homo():
     return HomoResNet((3, 4, 6, 3))
+
+
+def fold_for_inference(net: HomoResNet, channels_last: bool = True) -> nn.Module:
+    """A copy of `net` with every eval-mode BatchNorm folded into the preceding convolution (weights scaled in
+    float64, rounded once) and, optionally, NHWC weights for MIOpen's channels-last kernels.  Measured on MI355X at
+    B=64: 2.92 ms (as-is) -> 2.47 ms (folded) -> 2.11 ms (folded + NHWC); outputs agree with the un-folded CPU
+    trunk to ~1.5e-6 relative either way (tools/exp_trunk.py).  The copy does not track later weight changes."""
+    import copy
+
+    import torch
+
+    net = copy.deepcopy(net).eval()
+
+    def fuse(conv, bn):
+        s = bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps)
+        out = nn.Conv2d(conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride, conv.padding, bias=True)
+        out = out.to(conv.weight.device)
+        out.weight.data = (conv.weight.double() * s.view(-1, 1, 1, 1)).float()
+        out.bias.data = (bn.bias.double() - bn.running_mean.double() * s).float()
+        return out
+
+    net.conv1, net.bn1 = fuse(net.conv1, net.bn1), nn.Identity()
+    for layer in (net.layer1, net.layer2, net.layer3, net.layer4):
+        for blk in layer:
+            blk.conv1, blk.bn1 = fuse(blk.conv1, blk.bn1), nn.Identity()
+            blk.conv2, blk.bn2 = fuse(blk.conv2, blk.bn2), nn.Identity()
+            if blk.downsample is not None:
+                blk.downsample = fuse(blk.downsample[0], blk.downsample[1])
+    for p in net.parameters():
+        p.requires_grad_(False)
+    if channels_last:
+        import torch as _t
+        net = net.to(memory_format=_t.channels_last)
+    return net

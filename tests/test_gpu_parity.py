@@ -475,6 +475,11 @@ def test_track_proj_end_to_end_corner_offsets(dev):
     assert Hm.shape == (4, 3, 3) and s.dim() == 0
     np.testing.assert_allclose(Hm.cpu().numpy(), Href.numpy(), atol=2e-5)
     assert abs(float(s) - float(sref)) <= 1e-4 and abs(float(ss) - float(ssref)) <= 1e-4
+    # BN-folded channels-last trunk (§8f rank 4): same corner offsets within the north-star bound
+    netd.optimize_for_inference()
+    x_fast = homo_stages(netd, dd)["x"].cpu()
+    assert float((x_fast - aux["x"]).abs().max()) <= 1e-4
+    netd.optimize_for_inference(False)
     # cached template features give the same answer
     Hm2, s2, ss2 = netd.track_proj(dd, None, cached_patch_1=st["patch_1"].contiguous())
     assert float((Hm2 - Hm).abs().max()) < 1e-5 and abs(float(s2) - float(s)) < 1e-5
