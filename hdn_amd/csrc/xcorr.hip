@@ -400,29 +400,36 @@ __global__ __launch_bounds__(HDN_BLOCK, 2) void xcorr_north_kernel(XcorrPtrs P, 
 // Every fp32 value is split into three bf16 pieces x = xh + xm + xl (8+8+8 mantissa bits: exact), products of pieces
 // are exact in the MFMA, and the six piece-products down to 2^-16 relative size are accumulated in fp32
 // (hh | hm, mh, mm, hl, lh): the dropped terms are < 2^-24 relative, i.e. below fp32 rounding of the result.
-// The correlation becomes, per tap COLUMN v, a GEMM with a Toeplitz left factor:
-//   out[i][j] += sum_r  k[r-i][v] * x[r][j+v]        M = i (31->32), N = j (31->32), K = r (61->64)
-//   B[r][j] = x[r][j+v]  : 8 consecutive r at column j+v = one aligned 16-byte read of a TRANSPOSED bf16 image in LDS
-//   A[i][r] = k[r-i][v]  : Toeplitz.  With the K index of an MFMA chosen as r = R_b - 32*(lane>>5) + t, lane l needs
-//                          s_v[R_b - l + t], t = 0..7 (s_v = column v of k): ONE LDS word per lane, then 7 DPP
+// The correlation becomes, per tap ROW u, a GEMM with a Toeplitz left factor (computing out^T):
+//   out[i][j] += sum_c  k[u][c-j] * x[i+u][c]        M = j (31->32), N = i (31->32), K = c (61->64)
+//   B[c][i] = x[i+u][c]  : 8 consecutive c of image row i+u = one aligned 16-byte read of a bf16 image in LDS
+//   A[j][c] = k[u][c-j]  : Toeplitz.  With the K index of an MFMA chosen as c = C_b - 32*(lane>>5) + t, lane l needs
+//                          s_u[C_b - l + t], t = 0..7 (s_u = row u of k): ONE LDS word per lane, then 7 DPP
 //                          wave-shifts (zero fill = the Toeplitz zeros) and 4 byte-permutes build the fragment.
-// Two waves share a plane (tap columns 0..15 / 16..30) and add their 32x32 accumulators through LDS.
-// 744 MFMAs (32x32x16 bf16) per plane instead of 7,688 packed fp32 FMAs per lane: the matrix pipe does 6x the
-// multiplies (pieces) on half-empty Toeplitz tiles and is still ~2x faster than the saturated vector pipe, at a
-// fraction of the power.  Summation order differs from the vector kernel; error class is the same (fp32 accumulate).
+// Two waves share a plane (tap rows 0..15 / 16..30) and add their 32x32 accumulators through LDS, which also
+// transposes out^T back for a contiguous store.  Workgroups are persistent: the next plane's global loads are in
+// flight in registers while the current one is on the matrix pipe.
+// 744 MFMAs (32x32x16 bf16) per plane instead of 7,688 packed fp32 FMAs per lane.  Summation order differs from the
+// vector kernel; the error class is the same (exact products, fp32 accumulation).
 // ---------------------------------------------------------------------------------------
+#ifndef NMF_UNROLL_U
+#define NMF_UNROLL_U 1
+#endif
 namespace nmf {
 constexpr int HX = 61, WX = 61, HK = 31, WK = 31, HO = 31, WO = 31;
 constexpr int XPLANE = HX * WX, KPLANE = HK * WK, OPLANE = HO * WO;
 constexpr int NS = 3;                       // bf16 pieces per value
-constexpr int XT_RS = 72;                   // bf16 per transposed row (64 rows r + pad): 144 B, conflict-free b128
-constexpr int XT_COLS = 62;                 // image columns 0..60 plus a zero column (junk lane j = 31)
-constexpr int XT_PIECE = XT_COLS * XT_RS;   // bf16 elements per piece image
-constexpr int KW_RS = 32;                   // words per tap column
-constexpr int KW_N = WK * KW_RS;
-constexpr int PLANE_BYTES = NS * XT_PIECE * 2 + 2 * KW_N * 4;  // 26,784 + 7,936 = 34,720
-constexpr int PPB = 2;                      // planes per workgroup (2 waves each)
-constexpr size_t LDS_BYTES = size_t(PPB) * PLANE_BYTES;        // 69,440 B: two workgroups per CU
+constexpr int XS_RS = 72;                   // bf16 per image row (61 + zero pad to 64 + 8): 144 B, conflict-free b128
+constexpr int XS_ROWS = 62;                 // rows 0..60 plus a zero row (junk lane i = 31)
+constexpr int XS_PIECE = XS_ROWS * XS_RS;   // bf16 elements per piece image
+constexpr int KW_RS = 32;                   // words per tap row
+constexpr int KW_N = HK * KW_RS;
+constexpr int RED_RS = 33;                  // floats per row of the reduction / transpose tile
+constexpr int RED_N = 32 * RED_RS;
+constexpr int PLANE_BYTES = NS * XS_PIECE * 2 + 2 * KW_N * 4 + RED_N * 4;  // 26,784 + 7,936 + 4,224 = 38,944
+constexpr int PPB = 2;                      // plane slots per workgroup (2 waves each)
+constexpr size_t LDS_BYTES = size_t(PPB) * PLANE_BYTES;        // 77,888 B: two workgroups per CU
+constexpr int XQ = cdiv(XPLANE, 128), KQ = cdiv(KPLANE, 128);  // elements per thread of a wave pair
 static_assert(PLANE_BYTES % 16 == 0, "plane slots must stay 16-byte aligned");
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -452,6 +459,14 @@ __device__ __forceinline__ unsigned wave_shr1(unsigned v) {
 __device__ __forceinline__ f32x16 mfma(const u32x4& a, const u32x4& b, const f32x16& c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+
+__device__ __forceinline__ void fetch(float (&xv)[XQ], float (&kv)[KQ], const float* __restrict__ xg,
+                                      const float* __restrict__ kg, int tp) {
+#pragma unroll
+  for (int q = 0; q < XQ; ++q) xv[q] = xg[min(tp + q * 128, XPLANE - 1)];
+#pragma unroll
+  for (int q = 0; q < KQ; ++q) kv[q] = kg[min(tp + q * 128, KPLANE - 1)];
+}
 }  // namespace nmf
 
 __global__ __launch_bounds__(HDN_BLOCK, 2) void xcorr_north_mfma_kernel(XcorrPtrs P, int planes) {
@@ -461,131 +476,143 @@ __global__ __launch_bounds__(HDN_BLOCK, 2) void xcorr_north_mfma_kernel(XcorrPtr
   const int tid = threadIdx.x;
   const int lane = tid & (HDN_WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int pl = wave >> 1;            // plane slot of this wave
-  const int half = wave & 1;           // which half of the tap columns
+  const int pl = wave >> 1;            // plane slot of this wave pair
+  const int half = wave & 1;           // which half of the tap rows
+  const int tp = tid & 127;            // thread inside the wave pair
   const int prob = blockIdx.y;
-  const int plane = blockIdx.x * PPB + pl;
-  const bool have = plane < planes;    // wave-uniform (tail workgroup)
-  const float* __restrict__ xg = P.x[prob] + size_t(have ? plane : 0) * XPLANE;
-  const float* __restrict__ kg = P.k[prob] + size_t(have ? plane : 0) * KPLANE;
-  float* __restrict__ og = P.out[prob] + size_t(have ? plane : 0) * OPLANE;
+  const float* __restrict__ x = P.x[prob];
+  const float* __restrict__ k = P.k[prob];
+  float* __restrict__ out = P.out[prob];
+  const int stride = gridDim.x * PPB;  // planes between two iterations of a wave pair
+  const int first = blockIdx.x * PPB + pl;
+  const int iters = cdiv(planes - blockIdx.x * PPB, stride);  // workgroup-uniform (>= 1)
 
   unsigned char* slot = lds + pl * PLANE_BYTES;
-  unsigned short* xt = reinterpret_cast<unsigned short*>(slot);                   // [NS][XT_COLS][XT_RS]
-  unsigned* kw = reinterpret_cast<unsigned*>(slot + NS * XT_PIECE * 2);          // [2][WK][KW_RS]
+  unsigned short* xs = reinterpret_cast<unsigned short*>(slot);                  // [NS][XS_ROWS][XS_RS]
+  unsigned* kw = reinterpret_cast<unsigned*>(slot + NS * XS_PIECE * 2);         // [2][HK][KW_RS]
+  float* red = reinterpret_cast<float*>(slot + NS * XS_PIECE * 2 + 2 * KW_N * 4);  // [32][RED_RS]
 
-  // ---- P0: zero the transposed images (rows 61..71 and column 61 are the GEMM's zero padding) -------------
+  // zero once: image columns 61..71 and row 61 are the GEMM's zero padding and are never written again
   {
     u32x4* z = reinterpret_cast<u32x4*>(lds);
     constexpr int NZ = int(LDS_BYTES / 16);
     for (int q = tid; q < NZ; q += HDN_BLOCK) z[q] = u32x4{0u, 0u, 0u, 0u};
   }
+  float xv[XQ], kv[KQ];
+  if (first < planes) fetch(xv, kv, x + size_t(first) * XPLANE, k + size_t(first) * KPLANE, tp);
   __syncthreads();
 
-  // ---- P1: load, split into bf16 pieces, store transposed ----------------------------------------------
-  if (have) {
-    const int tp = tid & 127;  // thread inside the plane's wave pair
-    constexpr int XQ = cdiv(XPLANE, 128);
-    float xv[XQ];
-#pragma unroll
-    for (int q = 0; q < XQ; ++q) xv[q] = xg[min(tp + q * 128, XPLANE - 1)];
-    constexpr int KQ = cdiv(KPLANE, 128);
-    float kv[KQ];
-#pragma unroll
-    for (int q = 0; q < KQ; ++q) kv[q] = kg[min(tp + q * 128, KPLANE - 1)];
-#pragma unroll
-    for (int q = 0; q < XQ; ++q) {
-      const int e = tp + q * 128;
-      if (e < XPLANE) {
-        const int r = e / WX, c = e - r * WX;
-        unsigned p0, p1, p2;
-        split3(xv[q], p0, p1, p2);
-        const int a = c * XT_RS + r;
-        xt[a] = (unsigned short)p0;
-        xt[XT_PIECE + a] = (unsigned short)p1;
-        xt[2 * XT_PIECE + a] = (unsigned short)p2;
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < KQ; ++q) {
-      const int e = tp + q * 128;
-      if (e < KPLANE) {
-        const int u = e / WK, v = e - u * WK;
-        unsigned p0, p1, p2;
-        split3(kv[q], p0, p1, p2);
-        kw[v * KW_RS + u] = p0 | (p1 << 16);
-        kw[KW_N + v * KW_RS + u] = p2;
-      }
-    }
-  }
-  __syncthreads();
-
-  // ---- P2: 31 tap columns x 4 K-blocks x 6 piece products ------------------------------------------------
-  f32x16 acc0, acc1, acc2;
-#pragma unroll
-  for (int g = 0; g < 16; ++g) acc0[g] = acc1[g] = acc2[g] = 0.f;
-  if (have) {
-    const int h = lane >> 5, j = lane & 31;
-    const int v0 = half ? 16 : 0, v1 = half ? WK : 16;
 #pragma unroll 1
-    for (int v = v0; v < v1; ++v) {
-      const unsigned* kv1 = kw + v * KW_RS;
-      const unsigned* kv2 = kw + KW_N + v * KW_RS;
-      const unsigned short* xcol = xt + (j + v) * XT_RS - 32 * h;
+  for (int it = 0; it < iters; ++it) {
+    const int plane = first + it * stride;
+    const bool have = plane < planes;  // uniform per wave pair
+
+    // ---- split into bf16 pieces, store the images --------------------------------------------------------
+#ifdef NMF_SKIP_P1
+    if (have && it == 0) {
+#else
+    if (have) {
+#endif
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int Rb = 32 + 8 * b;
-        // A: lane l holds s_v[Rb - l + t], t = 0..7, for the three pieces
-        const int n = Rb - lane;
-        const bool valid = (unsigned)n <= (unsigned)(HK - 1);
-        const int nc = valid ? n : 0;
-        unsigned w1[8], w2[8];
-        w1[0] = valid ? kv1[nc] : 0u;
-        w2[0] = valid ? kv2[nc] : 0u;
-#pragma unroll
-        for (int t = 1; t < 8; ++t) {
-          w1[t] = wave_shr1(w1[t - 1]);
-          w2[t] = wave_shr1(w2[t - 1]);
+      for (int q = 0; q < XQ; ++q) {
+        const int e = tp + q * 128;
+        if (e < XPLANE) {
+          const int r = e / WX, c = e - r * WX;
+          unsigned p0, p1, p2;
+          split3(xv[q], p0, p1, p2);
+          const int a = r * XS_RS + c;
+          xs[a] = (unsigned short)p0;
+          xs[XS_PIECE + a] = (unsigned short)p1;
+          xs[2 * XS_PIECE + a] = (unsigned short)p2;
         }
-        u32x4 Ah, Am, Al;
+      }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          Ah[q] = __builtin_amdgcn_perm(w1[2 * q + 1], w1[2 * q], 0x05040100u);
-          Am[q] = __builtin_amdgcn_perm(w1[2 * q + 1], w1[2 * q], 0x07060302u);
-          Al[q] = __builtin_amdgcn_perm(w2[2 * q + 1], w2[2 * q], 0x05040100u);
+      for (int q = 0; q < KQ; ++q) {
+        const int e = tp + q * 128;
+        if (e < KPLANE) {
+          const int u = e / WK, n = e - u * WK;
+          unsigned p0, p1, p2;
+          split3(kv[q], p0, p1, p2);
+          kw[u * KW_RS + n] = p0 | (p1 << 16);
+          kw[KW_N + u * KW_RS + n] = p2;
         }
-        // B: x[Rb - 32h + t][j + v], t = 0..7: one aligned 16-byte read per piece
-        const u32x4 Bh = *reinterpret_cast<const u32x4*>(xcol + Rb);
-        const u32x4 Bm = *reinterpret_cast<const u32x4*>(xcol + XT_PIECE + Rb);
-        const u32x4 Bl = *reinterpret_cast<const u32x4*>(xcol + 2 * XT_PIECE + Rb);
-        acc0 = mfma(Ah, Bh, acc0);
-        acc1 = mfma(Ah, Bm, acc1);
-        acc2 = mfma(Am, Bh, acc2);
-        acc1 = mfma(Am, Bm, acc1);
-        acc2 = mfma(Ah, Bl, acc2);
-        acc1 = mfma(Al, Bh, acc1);
       }
     }
-  }
-  __syncthreads();  // every wave is done with its plane's images: the slot is reused for the cross-wave sum
+    // next plane's loads fly while this one is on the matrix pipe
+    if (plane + stride < planes) fetch(xv, kv, x + size_t(plane + stride) * XPLANE, k + size_t(plane + stride) * KPLANE, tp);
+    __syncthreads();
 
-  // ---- P3: add the two halves, store -------------------------------------------------------------------
-  float* red = reinterpret_cast<float*>(slot);
-  f32x16 acc;
+    // ---- 31 tap rows x 4 K-blocks x 6 piece products -----------------------------------------------------
+    f32x16 acc0, acc1, acc2;
 #pragma unroll
-  for (int g = 0; g < 16; ++g) acc[g] = acc0[g] + (acc1[g] + acc2[g]);
-  if (half == 1) {
+    for (int g = 0; g < 16; ++g) acc0[g] = acc1[g] = acc2[g] = 0.f;
+#ifndef NMF_SKIP_P2
+    if (have) {
+      const int h = lane >> 5, i = lane & 31;
+      const int u0 = half ? 16 : 0, u1 = half ? HK : 16;
+#pragma unroll NMF_UNROLL_U
+      for (int u = u0; u < u1; ++u) {
+        const unsigned* ku1 = kw + u * KW_RS;
+        const unsigned* ku2 = kw + KW_N + u * KW_RS;
+        const unsigned short* xrow = xs + (i + u) * XS_RS - 32 * h;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) red[g * HDN_WAVE + lane] = acc[g];
-  }
-  __syncthreads();
-  if (half == 0 && have) {
-    const int h = lane >> 5, j = lane & 31;
+        for (int b = 0; b < 4; ++b) {
+          const int Cb = 32 + 8 * b;
+          // A: lane l holds s_u[Cb - l + t], t = 0..7, for the three pieces
+          // (unconditional reads at a clamped index, then masked: a predicated read would put the whole K-block
+          //  behind a branch and serialise LDS latency -> DPP chain -> MFMAs)
+          const int n = Cb - lane;
+          const unsigned keep = ((unsigned)n <= (unsigned)(WK - 1)) ? 0xffffffffu : 0u;
+          const int nc = min(max(n, 0), KW_RS - 1);
+          unsigned w1[8], w2[8];
+          w1[0] = ku1[nc] & keep;
+          w2[0] = ku2[nc] & keep;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      const int i = (g & 3) + 8 * (g >> 2) + 4 * h;
-      if (i < HO && j < WO) og[i * WO + j] = acc[g] + red[g * HDN_WAVE + lane];
+          for (int t = 1; t < 8; ++t) {
+            w1[t] = wave_shr1(w1[t - 1]);
+            w2[t] = wave_shr1(w2[t - 1]);
+          }
+          u32x4 Ah, Am, Al;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            Ah[q] = __builtin_amdgcn_perm(w1[2 * q + 1], w1[2 * q], 0x05040100u);
+            Am[q] = __builtin_amdgcn_perm(w1[2 * q + 1], w1[2 * q], 0x07060302u);
+            Al[q] = __builtin_amdgcn_perm(w2[2 * q + 1], w2[2 * q], 0x05040100u);
+          }
+          // B: x[i + u][Cb - 32h + t], t = 0..7: one aligned 16-byte read per piece
+          const u32x4 Bh = *reinterpret_cast<const u32x4*>(xrow + Cb);
+          const u32x4 Bm = *reinterpret_cast<const u32x4*>(xrow + XS_PIECE + Cb);
+          const u32x4 Bl = *reinterpret_cast<const u32x4*>(xrow + 2 * XS_PIECE + Cb);
+          acc0 = mfma(Ah, Bh, acc0);
+          acc1 = mfma(Ah, Bm, acc1);
+          acc2 = mfma(Am, Bh, acc2);
+          acc1 = mfma(Am, Bm, acc1);
+          acc2 = mfma(Ah, Bl, acc2);
+          acc1 = mfma(Al, Bh, acc1);
+        }
+      }
     }
+#endif
+
+    // ---- add the two halves (D = out^T: lane column = i, register row = j), store contiguously -----------
+    const int h = lane >> 5, i = lane & 31;
+    if (half == 1) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) red[i * RED_RS + (g & 3) + 8 * (g >> 2) + 4 * h] = acc0[g] + (acc1[g] + acc2[g]);
+    }
+    __syncthreads();
+    if (half == 0) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) red[i * RED_RS + (g & 3) + 8 * (g >> 2) + 4 * h] += acc0[g] + (acc1[g] + acc2[g]);
+      if (have) {
+        float* og = out + size_t(plane) * OPLANE;
+        for (int e = lane; e < OPLANE; e += HDN_WAVE) {
+          const int oi = e / WO, oj = e - oi * WO;
+          og[e] = red[oi * RED_RS + oj];
+        }
+      }
+    }
+    __syncthreads();  // the images and the tile are free for the next plane
   }
 }
 
@@ -788,8 +815,9 @@ static int launch_north_mfma(const XcorrPtrs& P, int n, int planes, hipStream_t 
     if (e != hipSuccess) return -(1000 + (int)e);
     attr_done = true;
   }
-  hipLaunchKernelGGL(xcorr_north_mfma_kernel, dim3(cdiv(planes, nmf::PPB), n), dim3(HDN_BLOCK), nmf::LDS_BYTES, stream, P,
-                     planes);
+  // persistent: 2 workgroups per CU x 256 CUs (fewer if there are fewer planes); n problems share the grid
+  const int per_problem = max(1, min(cdiv(planes, nmf::PPB), 512 / n));
+  hipLaunchKernelGGL(xcorr_north_mfma_kernel, dim3(per_problem, n), dim3(HDN_BLOCK), nmf::LDS_BYTES, stream, P, planes);
   g_last_variant = "north_mfma_61x61_31x31";
   return launch_status();
 }
@@ -816,9 +844,10 @@ static int xcorr_dispatch(const XcorrPtrs& P, int n, int circular, int B, int C,
     if (Hx == 29 && Wx == 29 && Hk == 5 && Wk == 5) return launch_f1<F1_29_5>(P, n, planes, stream, "f1_29x29_5x5");
     if (Hx == 35 && Wx == 35 && Hk == 5 && Wk == 5) return launch_f1<F1_35_5>(P, n, planes, stream, "f1_35x35_5x5");
     if (Hx == 61 && Wx == 61 && Hk == 31 && Wk == 31) {
-      // HDN_NORTH_VALU=1 selects the packed-FMA vector kernel (kept for comparison and as the exact-order reference)
-      static const bool valu = [] { const char* e = getenv("HDN_NORTH_VALU"); return e && e[0] == '1'; }();
-      return valu ? launch_north(P, n, planes, stream) : launch_north_mfma(P, n, planes, stream);
+      // Default: the packed-FMA vector kernel (one fp32 fma chain per output, 325 us at B=64).  HDN_NORTH_MFMA=1 selects
+      // the split-bf16 matrix-core kernel: same error class, measured 345 us (6 piece products).
+      static const bool use_mfma = [] { const char* e = getenv("HDN_NORTH_MFMA"); return e && e[0] == '1'; }();
+      return use_mfma ? launch_north_mfma(P, n, planes, stream) : launch_north(P, n, planes, stream);
     }
   } else {
     if (Hx == 13 && Wx == 13 && Hk == 13 && Wk == 13) return launch_circ13(P, n, planes, stream);

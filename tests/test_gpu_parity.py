@@ -62,7 +62,7 @@ def test_xcorr_depthwise_golden(dev):
         seen.add(X.last_variant())
         check_xcorr(y, x, k, g[n + "__y"], False, n)
     # the fixtures exercise the three specialised kernels and the generic one
-    assert {"f1_29x29_5x5", "f1_35x35_5x5", "north_mfma_61x61_31x31", "generic_lds"} <= seen, seen
+    assert {"f1_29x29_5x5", "f1_35x35_5x5", "north_61x61_31x31", "generic_lds"} <= seen, seen
 
 
 def test_xcorr_depthwise_sampled_full_channel(dev):
@@ -188,12 +188,13 @@ def test_xcorr_full_size_production(dev):
 
 def test_xcorr_full_size_north_star(dev):
     _full_size_properties(dev, hdn_amd.xcorr_depthwise, O.xcorr_depthwise, (64, 256, 61, 61), (64, 256, 31, 31), False)
-    assert X.last_variant() == "north_mfma_61x61_31x31"
+    assert X.last_variant() == "north_61x61_31x31"
 
 
-def test_xcorr_north_vector_kernel_variant(dev):
-    """HDN_NORTH_VALU=1 selects the packed-FMA vector kernel for the 31x31 (x) 61x61 shape; same parity bar.
-    The switch is read once per process, so the variant runs in a child process."""
+def test_xcorr_north_matrix_core_variant(dev):
+    """HDN_NORTH_MFMA=1 selects the split-bf16 MFMA kernel for the 31x31 (x) 61x61 shape (three bf16 pieces per
+    value, six piece products, fp32 accumulate); same parity bar.  The switch is read once per process, so the variant
+    runs in a child process."""
     import os
     import subprocess
     import sys
@@ -205,15 +206,15 @@ from hdn_amd import xcorr as X
 from oracle import hdn_oracle as O
 from test_gpu_parity import check_xcorr
 r = np.random.default_rng(31)
-for B, C in ((1, 4), (3, 5), (2, 64)):
+for B, C in ((1, 4), (3, 5), (2, 64), (5, 205)):  # 1025 planes: more than one persistent pass + a tail
     x = np.maximum(r.standard_normal((B, C, 61, 61), dtype=np.float32), 0)
     k = np.maximum(r.standard_normal((B, C, 31, 31), dtype=np.float32), 0)
     y = hdn_amd.xcorr_depthwise(torch.from_numpy(x).cuda(), torch.from_numpy(k).cuda())
-    assert X.last_variant() == "north_61x61_31x31", X.last_variant()
-    check_xcorr(y, x, k, O.xcorr_depthwise(torch.from_numpy(x), torch.from_numpy(k)).numpy(), False, "valu")
+    assert X.last_variant() == "north_mfma_61x61_31x31", X.last_variant()
+    check_xcorr(y, x, k, O.xcorr_depthwise(torch.from_numpy(x), torch.from_numpy(k)).numpy(), False, "mfma")
 print("VALU_OK")
 ''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    env = dict(os.environ, HDN_NORTH_VALU="1")
+    env = dict(os.environ, HDN_NORTH_MFMA="1")
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert "VALU_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
 
