@@ -175,6 +175,111 @@ __global__ __launch_bounds__(HDN_BLOCK) void xcorr_f1_kernel(XcorrPtrs P, int pl
 }
 
 // ---------------------------------------------------------------------------------------
+// 5x5 (x) 29x29 -> 25x25: the production correlation (3 levels x {cls,loc} per frame, ban.py:76).  HBM-bound.
+//
+// Same workgroup structure as the f1 family (4 planes = one contiguous HBM range in, one out, one wave per plane,
+// taps in SGPRs), with the LDS access pattern made conflict-free: PMC on the f1 version showed 43 % of its LDS
+// cycles were bank conflicts (horizontal 1x5 strips at row stride 29 put lanes 2-way on a bank).  Here a lane owns a
+// VERTICAL 5x1 strip (5-row block b, column j; j fastest across lanes) and the plane rows are re-strided to 37
+// floats: 25 consecutive columns of one block, then 5*37 = 185 = 25 (mod 32) for the next block => the 32 lanes of
+// a bank group always hit 32 distinct banks.  Per tap column a lane reads 9 floats and issues 25 FMAs.
+// ---------------------------------------------------------------------------------------
+namespace prod29 {
+constexpr int HX = 29, WX = 29, HK = 5, WK = 5, HO = 25, WO = 25;
+constexpr int XPLANE = HX * WX, OPLANE = HO * WO, KPLANE = HK * WK;
+constexpr int SX = 37, LPLANE = HX * SX;   // re-strided LDS plane (1073 floats)
+constexpr int PPB = 4;
+constexpr int UNITS = 5 * WO;              // 5 row blocks x 25 columns = 125 strips
+constexpr int XFLOATS = round_up(PPB * LPLANE + 8, 4);
+constexpr int LDS_FLOATS = XFLOATS + PPB * OPLANE;
+constexpr int N4 = PPB * XPLANE / 4;       // 841 16-byte loads per workgroup
+constexpr int ITER = cdiv(N4, HDN_BLOCK);
+}  // namespace prod29
+
+__global__ __launch_bounds__(HDN_BLOCK) void xcorr_prod29_kernel(XcorrPtrs P, int planes) {
+  using namespace prod29;
+  __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
+  float* sx = smem;
+  float* so = smem + XFLOATS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & (HDN_WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int prob = blockIdx.y;
+  const float* __restrict__ x = P.x[prob];
+  const float* __restrict__ k = P.k[prob];
+  float* __restrict__ out = P.out[prob];
+  const int plane0 = blockIdx.x * PPB;
+  const int np = min(PPB, planes - plane0);
+  const float* xg = x + size_t(plane0) * XPLANE;
+
+  // ---- stage: all 16-byte loads in flight, then scatter into the re-strided image ------------------------
+  if (np == PPB && aligned16(xg)) {
+    const float4* s4 = reinterpret_cast<const float4*>(xg);
+    float4 r[ITER];
+#pragma unroll
+    for (int q = 0; q < ITER; ++q) r[q] = s4[min(tid + q * HDN_BLOCK, N4 - 1)];
+#pragma unroll
+    for (int q = 0; q < ITER; ++q) {
+      const int i4 = tid + q * HDN_BLOCK;
+      if (i4 < N4) {
+        const float v[4] = {r[q].x, r[q].y, r[q].z, r[q].w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int e = 4 * i4 + t;
+          const int p = e / XPLANE, rem = e - p * XPLANE;
+          const int rr = rem / WX, c = rem - rr * WX;
+          sx[p * LPLANE + rr * SX + c] = v[t];
+        }
+      }
+    }
+  } else {
+    for (int e = tid; e < np * XPLANE; e += HDN_BLOCK) {
+      const int p = e / XPLANE, rem = e - p * XPLANE;
+      const int rr = rem / WX, c = rem - rr * WX;
+      sx[p * LPLANE + rr * SX + c] = xg[e];
+    }
+  }
+  __syncthreads();
+
+  // ---- correlate: one wave per plane, one lane per 5x1 output strip --------------------------------------
+  if (wave < np) {  // wave-uniform
+    const float* __restrict__ kp = k + size_t(plane0 + wave) * KPLANE;  // wave-uniform -> scalar loads
+    const float* xs = sx + wave * LPLANE;
+    float* os = so + wave * OPLANE;
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+      const int unit = rd * HDN_WAVE + lane;
+      const int uu = min(unit, UNITS - 1);
+      const int b = uu / WO, j = uu - b * WO;
+      const float* xc = xs + (5 * b) * SX + j;
+      float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int v = 0; v < WK; ++v) {
+        float col[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) col[r] = xc[r * SX + v];
+#pragma unroll
+        for (int u = 0; u < HK; ++u) {
+          const float kv = kp[u * WK + v];
+#pragma unroll
+          for (int t = 0; t < 5; ++t) acc[t] = __builtin_fmaf(col[t + u], kv, acc[t]);
+        }
+      }
+      if (unit < UNITS) {
+#pragma unroll
+        for (int t = 0; t < 5; ++t) os[(5 * b + t) * WO + j] = acc[t];
+      }
+    }
+  }
+  __syncthreads();
+
+  float* og = out + size_t(plane0) * OPLANE;
+  if (np == PPB && aligned16(og)) copy_l2g_full<PPB * OPLANE>(so, og, tid);
+  else copy_l2g(so, og, np * OPLANE, tid);
+}
+
+// ---------------------------------------------------------------------------------------
 // 31x31 (x) 61x61 -> 31x31 (BASELINE.json north-star shape).  fp32-FMA-bound: 1.85 MFLOP per 23 KB plane.
 //
 // gfx950 only reaches its fp32 vector peak through v_pk_fma_f32 (measured 151 TF vs 75 TF for v_fma_f32,
@@ -800,8 +905,10 @@ static int launch_north(const XcorrPtrs& P, int n, int planes, hipStream_t strea
     if (e != hipSuccess) return -(1000 + (int)e);
     attr_done = true;
   }
-  // persistent: 2 workgroups per CU x 256 CUs (fewer if there are fewer planes); n problems share the grid
-  const int per_problem = max(1, min(cdiv(planes, 4), 512 / n));
+  // persistent: 2 workgroups per CU x 256 CUs (fewer if there are fewer planes); n problems share the grid.
+  // HDN_NORTH_BLOCKS caps the grid (e.g. 256 = one workgroup per CU, leaving LDS for kernels on other streams).
+  static const int cap = [] { const char* e = getenv("HDN_NORTH_BLOCKS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+  const int per_problem = max(1, min(cdiv(planes, 4), cap / n));
   hipLaunchKernelGGL(xcorr_north_kernel, dim3(per_problem, n), dim3(HDN_BLOCK), north::LDS_BYTES, stream, P, planes);
   g_last_variant = "north_61x61_31x31";
   return launch_status();
@@ -819,6 +926,12 @@ static int launch_north_mfma(const XcorrPtrs& P, int n, int planes, hipStream_t 
   const int per_problem = max(1, min(cdiv(planes, nmf::PPB), 512 / n));
   hipLaunchKernelGGL(xcorr_north_mfma_kernel, dim3(per_problem, n), dim3(HDN_BLOCK), nmf::LDS_BYTES, stream, P, planes);
   g_last_variant = "north_mfma_61x61_31x31";
+  return launch_status();
+}
+
+static int launch_prod29(const XcorrPtrs& P, int n, int planes, hipStream_t stream) {
+  hipLaunchKernelGGL(xcorr_prod29_kernel, dim3(cdiv(planes, prod29::PPB), n), dim3(HDN_BLOCK), 0, stream, P, planes);
+  g_last_variant = "prod_29x29_5x5";
   return launch_status();
 }
 
@@ -841,7 +954,10 @@ static int xcorr_dispatch(const XcorrPtrs& P, int n, int circular, int B, int C,
   if ((long long)planes * HP * WP > 0x7fffffffLL) return HDN_E_LIMIT;  // 32-bit plane offsets inside a workgroup are
                                                                          // per-block; this bounds the total too
   if (!circular) {
-    if (Hx == 29 && Wx == 29 && Hk == 5 && Wk == 5) return launch_f1<F1_29_5>(P, n, planes, stream, "f1_29x29_5x5");
+    if (Hx == 29 && Wx == 29 && Hk == 5 && Wk == 5) {
+      static const bool f1 = [] { const char* e = getenv("HDN_PROD_F1"); return e && e[0] == '1'; }();  // A/B switch
+      return f1 ? launch_f1<F1_29_5>(P, n, planes, stream, "f1_29x29_5x5") : launch_prod29(P, n, planes, stream);
+    }
     if (Hx == 35 && Wx == 35 && Hk == 5 && Wk == 5) return launch_f1<F1_35_5>(P, n, planes, stream, "f1_35x35_5x5");
     if (Hx == 61 && Wx == 61 && Hk == 31 && Wk == 31) {
       // Default: the packed-FMA vector kernel (one fp32 fma chain per output, 325 us at B=64).  HDN_NORTH_MFMA=1 selects

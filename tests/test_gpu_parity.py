@@ -62,7 +62,7 @@ def test_xcorr_depthwise_golden(dev):
         seen.add(X.last_variant())
         check_xcorr(y, x, k, g[n + "__y"], False, n)
     # the fixtures exercise the three specialised kernels and the generic one
-    assert {"f1_29x29_5x5", "f1_35x35_5x5", "north_61x61_31x31", "generic_lds"} <= seen, seen
+    assert {"prod_29x29_5x5", "f1_35x35_5x5", "north_61x61_31x31", "generic_lds"} <= seen, seen
 
 
 def test_xcorr_depthwise_sampled_full_channel(dev):
@@ -183,7 +183,7 @@ def _full_size_properties(dev, fn, ofn, shape_x, shape_k, signed):
 
 def test_xcorr_full_size_production(dev):
     _full_size_properties(dev, hdn_amd.xcorr_depthwise, O.xcorr_depthwise, (64, 256, 29, 29), (64, 256, 5, 5), False)
-    assert X.last_variant() == "f1_29x29_5x5"
+    assert X.last_variant() == "prod_29x29_5x5"
 
 
 def test_xcorr_full_size_north_star(dev):
@@ -382,7 +382,7 @@ def test_multi_ban_fused_forward_golden(dev, tag, circular):
     # conv / BN / 1x1 heads run on MIOpen: 1e-4 abs on O(1) outputs
     np.testing.assert_allclose(c.cpu().numpy(), cls, rtol=0, atol=1e-4)
     np.testing.assert_allclose(l.cpu().numpy(), loc, rtol=0, atol=1e-4)
-    assert X.last_variant() in ("f1_29x29_5x5", "circ13")
+    assert X.last_variant() in ("prod_29x29_5x5", "circ13")
     # second frame, same template: cached template features, same answer; new template: cache refreshed
     c2, l2 = m(zd, [x * 1.0 for x in xd])
     assert torch.equal(c2, c) and torch.equal(l2, l)
