@@ -228,7 +228,7 @@ def main():
             "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective except the offsets all-gather",
         },
         "roofline": {
-            "kernel": "xcorr_f1_kernel<61x61 (x) 31x31> (hdn_xcorr_depthwise_f32)",
+            "kernel": "hdn::xcorr_north_kernel (hdn_xcorr_depthwise_f32, 31x31 (x) 61x61)",
             "bound": "hbm",
             "achieved": north_gbps,
             "peak": HBM_PEAK_GBPS,
