@@ -366,20 +366,40 @@ __device__ __forceinline__ void land_row(Row& R) {
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// A tap that is exactly +-0 contributes nothing (for finite x) and its 8 packed FMAs are skipped by a SCALAR branch:
+// taps live in SGPRs, so the test is wave-uniform and costs no divergence.  The correlation kernels are the outputs of
+// conv+BN+ReLU (ban.py:55-58): about half of their taps are exact zeros (50 % in the synthetic relu(N(0,1)) inputs
+// of BASELINE config 2).  Non-finite x under a zero tap is the only case where the result differs (NaN in the reference).
+// The FMAs are inline asm with the accumulator as a read-write operand: the update is in place by construction, so the
+// branches introduce no register copies at their join points (the C++ form got 282 v_mov_b64 from the compiler).
+__device__ __forceinline__ bool tap_nonzero(float kv) {
+  unsigned b;
+  asm("s_and_b32 %0, %1, 0x7fffffff" : "=s"(b) : "s"(kv));  // integer test on the SGPR: s_cmp + s_cbranch_scc
+  return b != 0u;
+}
+
+// acc += P * k.lo (LO) or P * k.hi (!LO), both halves of the result using the same tap (op_sel broadcast)
+template <bool LO>
+__device__ __forceinline__ void pk_fma_tap(float2v& acc, const float2v& P, const float2v& kpair) {
+  if constexpr (LO) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(P), "s"(kpair));
+  else asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(P), "s"(kpair));
+}
+
+template <bool SKIP_ZERO_TAPS>
 __device__ __forceinline__ void fma_row(float2v (&accE)[8], float2v (&accO)[8], const Row& R) {
 #pragma unroll
   for (int w = 0; w < 16; ++w) {
-    {
-      const float kv = R.k.get(2 * w);
-      const float2v kk = {kv, kv};
+    // taps 2w (even) and 2w+1 (odd) share the SGPR pair (k[2w], k[2w+1]); tap 30 has no partner
+    const float2v kp = {R.k.get(2 * w), w < 15 ? R.k.get(2 * w + 1) : 0.f};
+    if (!SKIP_ZERO_TAPS || tap_nonzero(kp.x)) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) accE[j] = __builtin_elementwise_fma(R.pair(j + w), kk, accE[j]);
+      for (int j = 0; j < 8; ++j) pk_fma_tap<true>(accE[j], R.pair(j + w), kp);
     }
     if (w < 15) {
-      const float kv = R.k.get(2 * w + 1);
-      const float2v kk = {kv, kv};
+      if (!SKIP_ZERO_TAPS || tap_nonzero(kp.y)) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) accO[j] = __builtin_elementwise_fma(R.pair(j + w), kk, accO[j]);
+        for (int j = 0; j < 8; ++j) pk_fma_tap<false>(accO[j], R.pair(j + w), kp);
+      }
     }
   }
 }
@@ -427,6 +447,32 @@ __device__ __forceinline__ void stash_plane(const f4v (&R)[NQ], uint32_t slot_a,
 }
 }  // namespace north
 
+// One plane: 31 tap rows, row u+1's operands in flight while row u's FMAs issue.
+template <bool SKIP_ZERO_TAPS>
+__device__ __forceinline__ void north_plane(float2v (&accE)[8], float2v (&accO)[8], uint32_t xa, const float* kp) {
+  using namespace north;
+  Row A, B;
+  load_row(A, xa, kp);
+  land_row(A);
+#pragma unroll 1
+  for (int u = 0; u < HK - 1; u += 2) {
+    load_row(B, xa + (u + 1) * (SX * 4), kp + (u + 1) * WK);
+    __builtin_amdgcn_sched_barrier(0);
+    fma_row<SKIP_ZERO_TAPS>(accE, accO, A);
+    land_row(B);
+    load_row(A, xa + (u + 2) * (SX * 4), kp + (u + 2) * WK);
+    __builtin_amdgcn_sched_barrier(0);
+    fma_row<SKIP_ZERO_TAPS>(accE, accO, B);
+    land_row(A);
+  }
+  fma_row<SKIP_ZERO_TAPS>(accE, accO, A);  // u = 30
+}
+
+// MODE 1 (default): exact-zero taps are skipped; MODE 0: dense FMA stream (HDN_NORTH_TAPS=dense).  A skipped tap costs a
+// taken scalar branch, ~20 clocks against 32 for its 8 packed FMAs; a kept one ~4 extra: skipping wins above ~25 % zero
+// taps (post-ReLU kernels: ~50 %), loses 12 % on fully dense taps.  A per-plane choice between both streams inside one
+// kernel was measured slower than either (register spills + two unrolled streams): profiles/round1_north_zero_taps.txt.
+template <int MODE>
 __global__ __launch_bounds__(HDN_BLOCK, 2) void xcorr_north_kernel(XcorrPtrs P, int planes) {
   using namespace north;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -469,21 +515,7 @@ __global__ __launch_bounds__(HDN_BLOCK, 2) void xcorr_north_kernel(XcorrPtrs P, 
     float2v accE[8], accO[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) accE[j] = accO[j] = float2v{0.f, 0.f};
-    Row A, B;
-    load_row(A, xa, kp);
-    land_row(A);
-#pragma unroll 1
-    for (int u = 0; u < HK - 1; u += 2) {
-      load_row(B, xa + (u + 1) * (SX * 4), kp + (u + 1) * WK);
-      __builtin_amdgcn_sched_barrier(0);
-      fma_row(accE, accO, A);
-      land_row(B);
-      load_row(A, xa + (u + 2) * (SX * 4), kp + (u + 2) * WK);
-      __builtin_amdgcn_sched_barrier(0);
-      fma_row(accE, accO, B);
-      land_row(A);
-    }
-    fma_row(accE, accO, A);  // u = 30
+    north_plane<MODE == 1>(accE, accO, xa, kp);
     // accO[0] of the right-hand lane (s = 1) is (col 15, col 16): its low half is the odd-tap sum of the left-hand
     // lane's last column, fetched across the half-waves once per plane instead of accumulating a 9th pair per row.
     const float odd15 = __shfl(accO[0].x, (lane & 31) + 32, HDN_WAVE);
@@ -898,10 +930,13 @@ static int launch_f1(const XcorrPtrs& P, int n, int planes, hipStream_t stream, 
 }
 
 static int launch_north(const XcorrPtrs& P, int n, int planes, hipStream_t stream) {
-  static bool attr_done = false;  // dynamic LDS above 64 KiB needs the opt-in once
+  // HDN_NORTH_TAPS = skip (default) | dense: see xcorr_north_kernel
+  static const int mode = [] { const char* e = getenv("HDN_NORTH_TAPS"); return (e && e[0] == 'd') ? 0 : 1; }();
+  void (*kern)(XcorrPtrs, int) = mode == 0 ? &xcorr_north_kernel<0> : &xcorr_north_kernel<1>;
+  static bool attr_done = false;  // dynamic LDS above 64 KiB needs the opt-in once per kernel
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xcorr_north_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)north::LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)north::LDS_BYTES);
     if (e != hipSuccess) return -(1000 + (int)e);
     attr_done = true;
   }
@@ -909,7 +944,7 @@ static int launch_north(const XcorrPtrs& P, int n, int planes, hipStream_t strea
   // HDN_NORTH_BLOCKS caps the grid (e.g. 256 = one workgroup per CU, leaving LDS for kernels on other streams).
   static const int cap = [] { const char* e = getenv("HDN_NORTH_BLOCKS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
   const int per_problem = max(1, min(cdiv(planes, 4), cap / n));
-  hipLaunchKernelGGL(xcorr_north_kernel, dim3(per_problem, n), dim3(HDN_BLOCK), north::LDS_BYTES, stream, P, planes);
+  hipLaunchKernelGGL(kern, dim3(per_problem, n), dim3(HDN_BLOCK), north::LDS_BYTES, stream, P, planes);
   g_last_variant = "north_61x61_31x31";
   return launch_status();
 }
