@@ -47,7 +47,14 @@ def all_gather_offsets(x_local: torch.Tensor, n_pairs: int = None, group=None) -
     if mine != cap:
         buf = torch.cat([buf, buf.new_zeros((cap - mine, D))], dim=0)
     out = buf.new_empty((world * cap, D))
-    dist.all_gather_into_tensor(out, buf, group=group)
+    if buf.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo has no device all-gather: stage through the host (CPU tests / single-GPU dry runs only; on the GPUs the
+        # backend is nccl = RCCL and the collective runs on device memory)
+        host = out.cpu()
+        dist.all_gather_into_tensor(host, buf.cpu(), group=group)
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out, buf, group=group)
     if n_pairs == world * cap:
         return out
     return torch.cat([out[r * cap: r * cap + (e - s)] for r, (s, e) in enumerate(sizes)], dim=0)
