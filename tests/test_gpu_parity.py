@@ -511,3 +511,20 @@ def test_track_proj_end_to_end_corner_offsets(dev):
     # cached template features give the same answer
     Hm2, s2, ss2 = netd.track_proj(dd, None, cached_patch_1=st["patch_1"].contiguous())
     assert float((Hm2 - Hm).abs().max()) < 1e-5 and abs(float(s2) - float(s)) < 1e-5
+
+
+def test_graphed_track_proj_matches_eager(dev):
+    """hipGraph replay of the per-frame head (B=1) gives the eager result on new inputs (static buffers refreshed)."""
+    from hdn_amd.graph import GraphedTrackProj
+    net = _seeded_net().to(dev)
+    frames = [{k: v.to(dev) for k, v in _cfg1_data(1, 500 + t).items()} for t in range(3)]
+    # same template in every frame (as in a tracked sequence)
+    for f in frames[1:]:
+        f["org_imgs"][:, :1] = frames[0]["org_imgs"][:, :1]
+        f["input_tensors"][:, :1] = frames[0]["input_tensors"][:, :1]
+    gr = GraphedTrackProj(net, frames[0], template_constant=True)
+    for f in frames:
+        He, se, sse = net.track_proj(f, None)
+        Hg, sg, ssg = gr(f)
+        assert float((He - Hg).abs().max()) < 1e-5
+        assert abs(float(se) - float(sg)) < 1e-5 and abs(float(sse) - float(ssg)) < 1e-5
