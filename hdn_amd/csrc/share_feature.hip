@@ -146,9 +146,25 @@ constexpr int W_N = 424;                       // parameter block staged in LDS 
 constexpr int LDS_FLOATS = IN_N + 2 * (2 * A_N) + 2 * (4 * B_N) + W_N;
 }  // namespace sfw
 
+__device__ __forceinline__ void sfw_fetch(float (&pin)[sfw::IN_H / 2], const float* __restrict__ img, int tile,
+                                          int tiles_per_img, int H, int W, int c, int rr) {
+  const int b = tile / tiles_per_img, r0 = (tile - b * tiles_per_img) * sfw::R;
+  const float* __restrict__ src = img + size_t(b) * H * W;
+#pragma unroll
+  for (int q = 0; q < sfw::IN_H / 2; ++q) {
+    const int gr = r0 - 3 + 2 * q + rr;
+    const bool ok = gr >= 0 && gr < H && c < W;
+    pin[q] = src[ok ? gr * W + c : 0];
+    pin[q] = ok ? pin[q] : 0.f;
+  }
+}
+
+// Persistent: a workgroup walks tiles (image b, 4-row block); the next tile's 10 input rows are in flight in registers
+// while the current tile runs its three layers out of LDS.
 __global__ __launch_bounds__(HDN_BLOCK) void share_feature_w128_kernel(const float* __restrict__ img,
                                                                        const float* __restrict__ prm,
-                                                                       float* __restrict__ out, int H, int W) {
+                                                                       float* __restrict__ out, int H, int W,
+                                                                       int tiles_per_img, int total_tiles) {
   using namespace sfw;
   __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
   float* s_in = smem;
@@ -159,24 +175,28 @@ __global__ __launch_bounds__(HDN_BLOCK) void share_feature_w128_kernel(const flo
   const float2v* w3p = reinterpret_cast<const float2v*>(s_w + SF_W3);  // [4][9]
 
   const int tid = threadIdx.x;
-  const int r0 = blockIdx.x * R;
-  for (int idx = tid; idx < HDN_SF_PARAMS; idx += HDN_BLOCK) s_w[idx] = prm[idx];
-  const size_t plane = size_t(blockIdx.y) * H * W;
-  const float* __restrict__ src = img + plane;
   const int c = tid & 127, rr = tid >> 7;  // pixel column, row parity inside a round
-
-  // input rows r0-3 .. r0+R+2, columns -1 .. 128; zero outside the image
-  for (int idx = tid; idx < IN_N; idx += HDN_BLOCK) {
-    const int r = idx / CS, cc = idx - r * CS;
-    const int gr = r0 - 3 + r, gc = cc - 1;
-    s_in[idx] = (gr >= 0 && gr < H && gc >= 0 && gc < W) ? src[gr * W + gc] : 0.f;
-  }
-  // zero the halo columns (-1 and 128) of both intermediates
+  for (int idx = tid; idx < HDN_SF_PARAMS; idx += HDN_BLOCK) s_w[idx] = prm[idx];
+  // zero, once, the halo columns (-1 and 128) of the input tile and of both intermediates
+  if (tid < 2 * IN_H) s_in[(tid >> 1) * CS + (tid & 1) * (CS - 1)] = 0.f;
   if (tid < 2 * (2 * A_H + 4 * B_H)) {
     const int side = tid & 1, row = tid >> 1;
     if (row < 2 * A_H) s_a[row * CS + side * (CS - 1)] = float2v{0.f, 0.f};
     else s_b[(row - 2 * A_H) * CS + side * (CS - 1)] = float2v{0.f, 0.f};
   }
+  float pin[IN_H / 2];
+  int tile = blockIdx.x;
+  if (tile < total_tiles) sfw_fetch(pin, img, tile, tiles_per_img, H, W, c, rr);
+
+#pragma unroll 1
+  for (; tile < total_tiles; tile += gridDim.x) {
+  const int bimg = tile / tiles_per_img;
+  const int r0 = (tile - bimg * tiles_per_img) * R;
+  const size_t plane = size_t(bimg) * H * W;
+  // input rows r0-3 .. r0+R+2 (columns 0..127 -> LDS columns 1..128; zero outside the image)
+#pragma unroll
+  for (int q = 0; q < IN_H / 2; ++q) s_in[(2 * q + rr) * CS + c + 1] = pin[q];
+  if (tile + (int)gridDim.x < total_tiles) sfw_fetch(pin, img, tile + gridDim.x, tiles_per_img, H, W, c, rr);
   __syncthreads();
 
   // ---- layer 1: 1 -> 4 at rows r0-2 .. r0+R+1 -------------------------------------------
@@ -274,6 +294,7 @@ __global__ __launch_bounds__(HDN_BLOCK) void share_feature_w128_kernel(const flo
         out[plane + size_t(gr) * W + c] = fmaxf(__builtin_fmaf(acc[q].x + acc[q].y, prm[SF_ALPHA + 12], prm[SF_BETA + 12]), 0.f);
     }
   }
+  }  // tile loop (the next iteration's first barrier orders this tile's LDS reads before the next tile's writes)
 }
 
 }  // namespace hdn
@@ -285,9 +306,12 @@ extern "C" int hdn_share_feature_f32(const float* img, const float* folded, floa
   if (B > 65535 || (long long)H * W > 0x7fffffffLL / 4) return HDN_E_LIMIT;
   if (out == img) return HDN_E_ALIAS;
   if (W <= 128) {
-    dim3 g(hdn::cdiv(H, hdn::sfw::R), B);
-    hipLaunchKernelGGL(hdn::share_feature_w128_kernel, g, dim3(HDN_BLOCK), 0, static_cast<hipStream_t>(stream), img,
-                       folded, out, H, W);
+    const int tiles_per_img = hdn::cdiv(H, hdn::sfw::R);
+    const long long total = (long long)tiles_per_img * B;
+    if (total > 0x7fffffffLL) return HDN_E_LIMIT;
+    const int grid = (int)(total < 768 ? total : 768);  // persistent: 3 workgroups per CU x 256 CUs
+    hipLaunchKernelGGL(hdn::share_feature_w128_kernel, dim3(grid), dim3(HDN_BLOCK), 0, static_cast<hipStream_t>(stream),
+                       img, folded, out, H, W, tiles_per_img, (int)total);
     return hdn::launch_status();
   }
   dim3 grid(hdn::cdiv(W, hdn::SF_COLS), hdn::cdiv(H, hdn::SF_ROWS), B);

@@ -135,6 +135,51 @@ def test_xcorr_unaligned_and_strided_inputs(dev):
     assert torch.equal(xd.cpu(), T(xb)) and torch.equal(kd.cpu(), T(kb))  # inputs not mutated
 
 
+@pytest.mark.parametrize("shape,circ", [((3, 7, 61, 61, 31, 31), False), ((5, 3, 13, 13, 13, 13), True), ((2, 9, 35, 35, 5, 5), False)])
+def test_xcorr_specialised_kernels_on_unaligned_pointers(dev, shape, circ):
+    """4-byte-aligned (not 16-byte) x / k / out base pointers and ragged plane counts through every specialised kernel:
+    the all-in-flight 16-byte staging paths must fall back correctly."""
+    B, C, Hx, Wx, Hk, Wk = shape
+    r = np.random.default_rng(sum(shape) + 7)
+    xb = relu_normal(r, (B, C, Hx, Wx)) if not circ else r.standard_normal((B, C, Hx, Wx), dtype=np.float32)
+    kb = relu_normal(r, (B, C, Hk, Wk)) if not circ else r.standard_normal((B, C, Hk, Wk), dtype=np.float32)
+
+    def shifted(a, off):
+        flat = torch.zeros(a.size + off, device=dev)
+        flat[off:] = T(a).to(dev).reshape(-1)
+        v = flat[off:].view(*a.shape)
+        assert v.data_ptr() % 16 == (4 * off) % 16
+        return v
+
+    fn = hdn_amd.xcorr_depthwise_circular if circ else hdn_amd.xcorr_depthwise
+    ofn = O.xcorr_depthwise_circular if circ else O.xcorr_depthwise
+    ref = ofn(T(xb), T(kb)).numpy()
+    for ox, ok in ((1, 0), (0, 3), (2, 1)):
+        y = fn(shifted(xb, ox), shifted(kb, ok))
+        check_xcorr(y, xb, kb, ref, circ, f"{shape} offsets {ox},{ok}")
+
+
+def test_xcorr_multi_eight_problems_and_limits(dev):
+    r = np.random.default_rng(88)
+    xs = [T(relu_normal(r, (1, 6, 29, 29))).to(dev) for _ in range(8)]
+    ks = [T(relu_normal(r, (1, 6, 5, 5))).to(dev) for _ in range(8)]
+    outs = hdn_amd.xcorr_depthwise_multi(xs, ks)
+    for x, k, o in zip(xs, ks, outs):
+        assert torch.equal(o, hdn_amd.xcorr_depthwise(x, k))
+    with pytest.raises(ValueError):
+        hdn_amd.xcorr_depthwise_multi(xs + xs[:1], ks + ks[:1])
+    with pytest.raises(ValueError):
+        hdn_amd.xcorr_depthwise_multi(xs[:2], [ks[0], ks[1][:, :, :3, :3]])
+    # zero taps are skipped by the 31x31 kernel: an all-zero kernel plane gives exact zeros, and a signed-zero tap too
+    x = T(relu_normal(r, (1, 4, 61, 61))).to(dev)
+    k = T(relu_normal(r, (1, 4, 31, 31))).to(dev)
+    k[0, 1] = 0
+    k[0, 2, 3, 4] = -0.0
+    y = hdn_amd.xcorr_depthwise(x, k)
+    assert bool((y[0, 1] == 0).all())
+    check_xcorr(y, x.cpu().numpy(), k.cpu().numpy(), O.xcorr_depthwise(x.cpu(), k.cpu()).numpy(), False, "zero taps")
+
+
 def test_xcorr_multi_launch_equals_single(dev):
     r = np.random.default_rng(21)
     xs = [T(relu_normal(r, (2, 32, 29, 29))).to(dev) for _ in range(6)]
