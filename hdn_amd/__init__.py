@@ -3,7 +3,7 @@
 Hand-written gfx950 HIP kernels behind a C ABI (include/hdn_hip.h, hdn_amd/libhdn_hip.so), exposed under
 the reference's own Python signatures.  See DESIGN.md and INTEGRATION.md.
 """
-from .xcorr import xcorr_depthwise, xcorr_depthwise_circular, xcorr_depthwise_multi  # noqa: F401
+from .xcorr import xcorr_depthwise, xcorr_depthwise_circular, xcorr_depthwise_multi, xcorr_fast, xcorr_slow  # noqa: F401
 from .homography import DLT_solve, transform, transformer, Homo_STN, dlt_warp  # noqa: F401
 from .share_feature import PreShareFeature, fold_params  # noqa: F401
 from .homo_model import HomoModelBuilder, track_proj  # noqa: F401

@@ -29,6 +29,7 @@ SIGNATURES = {
         _i,
         [ctypes.POINTER(ctypes.c_void_p)] * 3 + [_i, _i] + [_i] * 6 + [ctypes.c_void_p],
     ),
+    "hdn_xcorr_fast_f32": (_i, [_c_float_p] * 3 + [_i] * 7 + [ctypes.c_void_p]),
     "hdn_share_feature_f32": (_i, [_c_float_p] * 3 + [_i] * 3 + [ctypes.c_void_p]),
     "hdn_dlt_solve_f32": (_i, [_c_float_p] * 3 + [_i, ctypes.c_void_p]),
     "hdn_warp_f32": (_i, [_c_float_p] * 3 + [_i] * 4 + [ctypes.c_void_p]),

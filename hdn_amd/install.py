@@ -28,6 +28,9 @@ _DLT = "homo_estimator.Deep_homography.Oneline_DLTv1"
 REBINDINGS = (
     ("hdn.core.xcorr", "xcorr_depthwise", xcorr.xcorr_depthwise),
     ("hdn.core.xcorr", "xcorr_depthwise_circular", xcorr.xcorr_depthwise_circular),
+    ("hdn.core.xcorr", "xcorr_fast", xcorr.xcorr_fast),
+    ("hdn.core.xcorr", "xcorr_slow", xcorr.xcorr_slow),
+    ("hdn.models.head.ban", "xcorr_fast", xcorr.xcorr_fast),
     ("hdn.models.head.ban", "xcorr_depthwise", xcorr.xcorr_depthwise),
     ("hdn.models.head.ban_lp", "xcorr_depthwise", xcorr.xcorr_depthwise),
     ("hdn.models.head.ban_lp", "xcorr_depthwise_circular", xcorr.xcorr_depthwise_circular),

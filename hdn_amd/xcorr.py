@@ -96,6 +96,37 @@ def xcorr_depthwise_multi(xs: Sequence[torch.Tensor], kernels: Sequence[torch.Te
     return outs
 
 
+def xcorr_fast(x: torch.Tensor, kernel: torch.Tensor) -> torch.Tensor:
+    """group conv2d to calculate cross correlation (hdn/core/xcorr.py:26-34): x [B,C,H,W], kernel [B,O*C,h,w] ->
+    [B,O,H-h+1,W-w+1], contracting the channels.  Only the unselected UPChannelBAN head uses it (O = 2 or 4)."""
+    if x.dim() != 4 or kernel.dim() != 4 or x.shape[0] != kernel.shape[0]:
+        raise ValueError(f"expected x [B,C,H,W] and kernel [B,O*C,h,w], got {tuple(x.shape)} and {tuple(kernel.shape)}")
+    B, C, Hx, Wx = x.shape
+    OC, Hk, Wk = kernel.shape[1:]
+    if C <= 0 or OC % C != 0 or OC == 0:
+        raise ValueError(f"kernel channels {OC} are not a multiple of the search channels {C}")
+    O = OC // C
+    if O > 8:
+        raise ValueError("at most 8 output channels")
+    if Hk > Hx or Wk > Wx or min(B, Hx, Wx, Hk, Wk) <= 0:
+        raise ValueError(f"kernel {Hk}x{Wk} does not fit the search plane {Hx}x{Wx}")
+    dev, xc, kc = _prep(x, kernel)
+    out = torch.empty((B, O, Hx - Hk + 1, Wx - Wk + 1), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.load().hdn_xcorr_fast_f32(_lib.ptr(xc), _lib.ptr(kc), _lib.ptr(out), B, C, O, Hx, Wx, Hk, Wk,
+                                            _lib.stream_ptr(dev))
+    _lib.check(rc, "xcorr_fast")
+    return out
+
+
+def xcorr_slow(x: torch.Tensor, kernel: torch.Tensor) -> torch.Tensor:
+    """for-loop cross correlation (hdn/core/xcorr.py:10-23): per batch element conv2d(x[i], kernel[i]) with ALL kernel
+    channels contracted, i.e. kernel must be [B,C,h,w] and the result is [B,1,Ho,Wo] (= xcorr_fast with O = 1)."""
+    if x.dim() == 4 and kernel.dim() == 4 and kernel.shape[1] != x.shape[1]:
+        raise ValueError(f"xcorr_slow contracts every kernel channel: kernel {tuple(kernel.shape)} vs x {tuple(x.shape)}")
+    return xcorr_fast(x, kernel)
+
+
 def last_variant() -> str:
     """Name of the kernel the last correlation call dispatched to (tests / profiles)."""
     return _lib.load().hdn_last_xcorr_variant().decode()

@@ -67,6 +67,15 @@ int hdn_xcorr_depthwise_multi_f32(const float* const* xs, const float* const* ks
                                   int circular, int B, int C, int Hx, int Wx, int Hk, int Wk, void* stream);
 
 /*
+ * Channel-contracting correlation of the alternative UPChannelBAN head (not on the production path):
+ *   out[b,o,i,j] = sum_c sum_{u,v} x[b,c,i+u,j+v] * k[b,o*C+c,u,v]
+ *   x[B,C,Hx,Wx], k[B,O*C,Hk,Wk] -> out[B,O,Hx-Hk+1,Wx-Wk+1],  1 <= O <= 8
+ * Replaces xcorr_fast(x, kernel), hdn/core/xcorr.py:26-34, and xcorr_slow, :10-23 (same arithmetic).
+ */
+int hdn_xcorr_fast_f32(const float* x, const float* k, float* out, int B, int C, int O, int Hx, int Wx, int Hk,
+                       int Wk, void* stream);
+
+/*
  * PreShareFeature.forward in eval mode, fused: 3 x (conv3x3 pad 1, no bias -> BatchNorm
  * (running stats) -> ReLU), channels 1 -> 4 -> 8 -> 1, img[B,1,H,W] -> out[B,1,H,W].
  * `folded` (HDN_SF_PARAMS floats, device) = conv weights re-laid for the kernel followed

@@ -50,6 +50,16 @@ def xcorr_depthwise(x: torch.Tensor, kernel: torch.Tensor) -> torch.Tensor:
     return y.reshape(B, C, y.shape[2], y.shape[3])
 
 
+def xcorr_fast(x: torch.Tensor, kernel: torch.Tensor) -> torch.Tensor:
+    """out[b,o,i,j] = sum_c sum_uv x[b,c,i+u,j+v] * kernel[b,o*C+c,u,v].  Reference: hdn/core/xcorr.py:26-34
+    (xcorr_slow, :10-23, computes the same batch by batch)."""
+    B, C = x.shape[0], x.shape[1]
+    pk = kernel.reshape(-1, C, kernel.shape[2], kernel.shape[3])
+    px = x.reshape(1, -1, x.shape[2], x.shape[3])
+    po = F.conv2d(px, pk, groups=B)
+    return po.reshape(B, -1, po.shape[2], po.shape[3])
+
+
 def circular_pad_index(Hx: int, Wx: int):
     """Row / column source indices of the padded plane of xcorr.py:52-53.
 

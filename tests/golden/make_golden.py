@@ -169,6 +169,22 @@ def gen_xcorr(ref_xcorr):
         samp[name + "__sum"] = np.array(y.astype(np.float64).sum())
     save("xcorr_depthwise_sampled", **samp)
 
+    # channel-contracting variants (UPChannelBAN shapes, ban.py:26-47: O = 2 and O = 4)
+    fast = {}
+    for i, (name, (B, C, O, Hx, Hk)) in enumerate({"cls_o2": (2, 16, 2, 29, 5), "loc_o4": (1, 8, 4, 13, 3)}.items()):
+        g = rng(250 + i)
+        x = g.standard_normal((B, C, Hx, Hx), dtype=np.float32)
+        k = g.standard_normal((B, O * C, Hk, Hk), dtype=np.float32)
+        fast[name + "__x"], fast[name + "__k"] = x, k
+        fast[name + "__y"] = ref_xcorr.xcorr_fast(t(x), t(k)).numpy()
+    # xcorr_slow (xcorr.py:10-23) contracts ALL kernel channels: it only accepts kernel[B,C,h,w] (O = 1)
+    g = rng(259)
+    xs, ks = g.standard_normal((3, 6, 9, 11), dtype=np.float32), g.standard_normal((3, 6, 4, 3), dtype=np.float32)
+    fast["slow__x"], fast["slow__k"] = xs, ks
+    fast["slow__y"] = ref_xcorr.xcorr_slow(t(xs), t(ks)).numpy()
+    fast["slow__y_fast"] = ref_xcorr.xcorr_fast(t(xs), t(ks)).numpy()
+    save("xcorr_fast", **fast)
+
     cases_c = {
         "prod_13x13": (2, 16, 13, 13, 13, 13),
         "even_8x10_k3x5": (1, 4, 8, 10, 3, 5),

@@ -180,6 +180,23 @@ def test_xcorr_multi_eight_problems_and_limits(dev):
     check_xcorr(y, x.cpu().numpy(), k.cpu().numpy(), O.xcorr_depthwise(x.cpu(), k.cpu()).numpy(), False, "zero taps")
 
 
+def test_xcorr_fast_and_slow_golden(dev):
+    """The channel-contracting variants of hdn/core/xcorr.py (unselected UPChannelBAN head)."""
+    g = load_golden("xcorr_fast")
+    for n in ("cls_o2", "loc_o4"):
+        x, k = g[n + "__x"], g[n + "__k"]
+        y = hdn_amd.xcorr_fast(T(x).to(dev), T(k).to(dev)).cpu().numpy()
+        assert y.shape == g[n + "__y"].shape
+        mag = O.xcorr_fast(T(np.abs(x)), T(np.abs(k))).numpy()
+        assert np.all(np.abs(y - g[n + "__y"]) <= 1e-4 + 2e-6 * mag), n
+    ys = hdn_amd.xcorr_slow(T(g["slow__x"]).to(dev), T(g["slow__k"]).to(dev)).cpu().numpy()
+    np.testing.assert_allclose(ys, g["slow__y"], rtol=0, atol=1e-4)
+    with pytest.raises(ValueError):
+        hdn_amd.xcorr_slow(T(g["cls_o2__x"]).to(dev), T(g["cls_o2__k"]).to(dev))  # O = 2: the reference raises too
+    with pytest.raises(ValueError):
+        hdn_amd.xcorr_fast(torch.zeros(1, 3, 5, 5, device=dev), torch.zeros(1, 4, 3, 3, device=dev))
+
+
 def test_xcorr_multi_launch_equals_single(dev):
     r = np.random.default_rng(21)
     xs = [T(relu_normal(r, (2, 32, 29, 29))).to(dev) for _ in range(6)]

@@ -176,7 +176,7 @@ def test_install_rebinds_the_reference_sites():
     mods = {n: types.ModuleType(n) for n in names}
     sentinel = object()
     for n in names:
-        for a in ("xcorr_depthwise", "xcorr_depthwise_circular", "DLT_solve", "transform", "transformer", "Homo_STN", "STN_Polar"):
+        for a in ("xcorr_depthwise", "xcorr_depthwise_circular", "xcorr_fast", "xcorr_slow", "DLT_solve", "transform", "transformer", "Homo_STN", "STN_Polar"):
             setattr(mods[n], a, sentinel)
     mods[names[5]].head = {"PreShareFeature": sentinel}
 

@@ -202,3 +202,13 @@ def test_multi_ban_heads(tag, circular):
     assert c.shape == cls.shape and l.shape == loc.shape
     np.testing.assert_allclose(c.numpy(), cls, rtol=0, atol=1e-5)
     np.testing.assert_allclose(l.numpy(), loc, rtol=0, atol=1e-5)
+
+
+def test_xcorr_fast_and_slow():
+    g = load_golden("xcorr_fast")
+    for n in ("cls_o2", "loc_o4"):
+        y = O.xcorr_fast(T(g[n + "__x"]), T(g[n + "__k"])).numpy()
+        np.testing.assert_array_equal(y, g[n + "__y"])
+    y = O.xcorr_fast(T(g["slow__x"]), T(g["slow__k"])).numpy()
+    np.testing.assert_array_equal(y, g["slow__y_fast"])
+    np.testing.assert_allclose(y, g["slow__y"], rtol=0, atol=1e-5)  # the reference's two forms differ by rounding only
