@@ -23,6 +23,7 @@ _i = ctypes.c_int
 SIGNATURES = {
     "hdn_abi_version": (_i, []),
     "hdn_last_xcorr_variant": (ctypes.c_char_p, []),
+    "hdn_xcorr_north_variant": (_i, [_i]),
     "hdn_xcorr_depthwise_f32": (_i, [_c_float_p] * 3 + [_i] * 6 + [ctypes.c_void_p]),
     "hdn_xcorr_depthwise_circ_f32": (_i, [_c_float_p] * 3 + [_i] * 6 + [ctypes.c_void_p]),
     "hdn_xcorr_depthwise_multi_f32": (

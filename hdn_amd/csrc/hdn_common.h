@@ -89,7 +89,7 @@ __device__ __forceinline__ float rn_sub(float a, float b) { return a - b; }
 __device__ __forceinline__ float rn_div(float a, float b) { return a / b; }  // IEEE-correct (v_div_scale/fmas/fixup)
 #pragma clang fp contract(fast)
 
-__device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+__host__ __device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 typedef float float2v __attribute__((ext_vector_type(2)));
 

@@ -19,6 +19,8 @@
 //
 // Kernel "generic" (runtime shapes): one workgroup per plane, LDS-staged when the plane
 // fits, straight from L2 otherwise.  Correct for any Hk<=Hx, Wk<=Wx; not tuned.
+#include <atomic>
+
 #include "hdn_common.h"
 
 #include <cstdlib>
@@ -929,16 +931,37 @@ static int launch_f1(const XcorrPtrs& P, int n, int planes, hipStream_t stream, 
   return launch_status();
 }
 
-static int launch_north(const XcorrPtrs& P, int n, int planes, hipStream_t stream) {
-  // HDN_NORTH_TAPS = skip (default) | dense: see xcorr_north_kernel
-  static const int mode = [] { const char* e = getenv("HDN_NORTH_TAPS"); return (e && e[0] == 'd') ? 0 : 1; }();
+// Variant of the 31x31 (x) 61x61 kernel: set by hdn_xcorr_north_variant(), initially from the environment
+// (HDN_NORTH = fft | direct | dense | mfma; legacy: HDN_NORTH_MFMA=1, HDN_NORTH_TAPS=dense, HDN_NORTH_FFT=0).
+static std::atomic<int> g_north_variant{-1};
+static int north_variant() {
+  int v = g_north_variant.load(std::memory_order_relaxed);
+  if (v >= 0) return v;
+  v = HDN_NORTH_FFT;
+  const char* e = getenv("HDN_NORTH");
+  const char* m = getenv("HDN_NORTH_MFMA");
+  const char* t = getenv("HDN_NORTH_TAPS");
+  const char* f = getenv("HDN_NORTH_FFT");
+  if (e && e[0] == 'd' && e[1] == 'i') v = HDN_NORTH_DIRECT;
+  else if (e && e[0] == 'd') v = HDN_NORTH_DIRECT_DENSE;
+  else if (e && e[0] == 'm') v = HDN_NORTH_MFMA;
+  else if (e && e[0] == 'f') v = HDN_NORTH_FFT;
+  else if (m && m[0] == '1') v = HDN_NORTH_MFMA;
+  else if (t && t[0] == 'd') v = HDN_NORTH_DIRECT_DENSE;
+  else if (f && f[0] == '0') v = HDN_NORTH_DIRECT;
+  g_north_variant.store(v, std::memory_order_relaxed);
+  return v;
+}
+
+static int launch_north(const XcorrPtrs& P, int n, int planes, hipStream_t stream, int mode) {
+  // mode 1: zero taps skipped (default), 0: dense: see xcorr_north_kernel
   void (*kern)(XcorrPtrs, int) = mode == 0 ? &xcorr_north_kernel<0> : &xcorr_north_kernel<1>;
-  static bool attr_done = false;  // dynamic LDS above 64 KiB needs the opt-in once per kernel
-  if (!attr_done) {
+  static bool attr_done[2] = {false, false};  // dynamic LDS above 64 KiB needs the opt-in once per kernel
+  if (!attr_done[mode]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)north::LDS_BYTES);
     if (e != hipSuccess) return -(1000 + (int)e);
-    attr_done = true;
+    attr_done[mode] = true;
   }
   // persistent: 2 workgroups per CU x 256 CUs (fewer if there are fewer planes); n problems share the grid.
   // HDN_NORTH_BLOCKS caps the grid (e.g. 256 = one workgroup per CU, leaving LDS for kernels on other streams).
@@ -947,6 +970,21 @@ static int launch_north(const XcorrPtrs& P, int n, int planes, hipStream_t strea
   hipLaunchKernelGGL(kern, dim3(per_problem, n), dim3(HDN_BLOCK), north::LDS_BYTES, stream, P, planes);
   g_last_variant = "north_61x61_31x31";
   return launch_status();
+}
+
+// xcorr_fft.hip
+int launch_north_fft(const float* x, const float* k, float* out, int planes, int max_blocks, hipStream_t stream, int pair0);
+int launch_north_fft2(const float* x, const float* k, float* out, int planes, int max_blocks, hipStream_t stream);
+
+static int launch_north_fft_all(const XcorrPtrs& P, int n, int planes, hipStream_t stream) {
+  // persistent: 4 one-wave workgroups per CU x 256 CUs (LDS-limited); n problems run back to back
+  static const int cap = [] { const char* e = getenv("HDN_NORTH_BLOCKS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
+  for (int i = 0; i < n; ++i) {
+    const int rc = launch_north_fft2(P.x[i], P.k[i], P.out[i], planes, cap, stream);
+    if (rc) return rc;
+  }
+  g_last_variant = "north_fft_61x61_31x31";
+  return HDN_OK;
 }
 
 static int launch_north_mfma(const XcorrPtrs& P, int n, int planes, hipStream_t stream) {
@@ -995,10 +1033,18 @@ static int xcorr_dispatch(const XcorrPtrs& P, int n, int circular, int B, int C,
     }
     if (Hx == 35 && Wx == 35 && Hk == 5 && Wk == 5) return launch_f1<F1_35_5>(P, n, planes, stream, "f1_35x35_5x5");
     if (Hx == 61 && Wx == 61 && Hk == 31 && Wk == 31) {
-      // Default: the packed-FMA vector kernel (one fp32 fma chain per output, 325 us at B=64).  HDN_NORTH_MFMA=1 selects
-      // the split-bf16 matrix-core kernel: same error class, measured 345 us (6 piece products).
-      static const bool use_mfma = [] { const char* e = getenv("HDN_NORTH_MFMA"); return e && e[0] == '1'; }();
-      return use_mfma ? launch_north_mfma(P, n, planes, stream) : launch_north(P, n, planes, stream);
+      // Default: the FFT kernel (xcorr_fft.hip, ~125 us at B=64).  It needs 16-byte aligned x / k and 8-byte aligned
+      // out; otherwise, or on request (hdn_xcorr_north_variant / environment), one of the direct kernels runs:
+      // packed-FMA with zero-tap skipping (~255 us on post-ReLU data), the same without skipping, or split-bf16 MFMA.
+      const int v = north_variant();
+      if (v == HDN_NORTH_FFT) {
+        bool ok = true;
+        for (int i = 0; i < n; ++i)
+          ok = ok && aligned16(P.x[i]) && aligned16(P.k[i]) && (reinterpret_cast<uintptr_t>(P.out[i]) & 7u) == 0;
+        if (ok) return launch_north_fft_all(P, n, planes, stream);
+      }
+      if (v == HDN_NORTH_MFMA) return launch_north_mfma(P, n, planes, stream);
+      return launch_north(P, n, planes, stream, v == HDN_NORTH_DIRECT_DENSE ? 0 : 1);
     }
   } else {
     if (Hx == 13 && Wx == 13 && Hk == 13 && Wk == 13) return launch_circ13(P, n, planes, stream);
@@ -1028,6 +1074,15 @@ static int xcorr_check(int B, int C, int Hx, int Wx, int Hk, int Wk, int circula
 extern "C" {
 
 const char* hdn_last_xcorr_variant(void) { return hdn::g_last_variant; }
+
+int hdn_xcorr_north_variant(int v) {
+  const int prev = hdn::north_variant();
+  if (v >= 0) {
+    if (v > HDN_NORTH_MFMA) return HDN_E_LIMIT;
+    hdn::g_north_variant.store(v, std::memory_order_relaxed);
+  }
+  return prev;
+}
 
 int hdn_xcorr_depthwise_multi_f32(const float* const* xs, const float* const* ks, float* const* outs, int n,
                                   int circular, int B, int C, int Hx, int Wx, int Hk, int Wk, void* stream) {

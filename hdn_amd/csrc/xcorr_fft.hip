@@ -1,0 +1,875 @@
+// xcorr_fft.hip — the north-star correlation (31x31 taps over 61x61, hdn/core/xcorr.py:37-46) in the frequency domain.
+//
+// The direct kernel (xcorr.hip, xcorr_north_kernel) issues the minimum number of packed fp32 FMAs for the direct sum
+// (7,688 per plane and wave) and is bound by that.  This one does the same correlation with ~1,700 packed ops per
+// plane: a 64x64 FFT per plane held in registers + LDS, fp32 throughout, rounding error BELOW the direct sum's
+// (rms 1.8e-5 vs 3.6e-5 against float64 on post-ReLU data).
+//
+//   * one wave = one PAIR of planes (A, B), packed as the real and imaginary part of one complex signal;
+//   * 1-D transforms are 64-point radix-2 DIT FFTs held entirely in one lane's registers (lane = row, then
+//     lane = column); the "transposition" between the two is one trip through LDS (row stride 65 complex:
+//     conflict-free both ways);
+//   * along a row the transform is taken at HALF-bin frequencies f+1/2 (input pre-multiplied by e^{-i*pi*j/64}):
+//     a real row then has exactly 32 independent complex bins (no DC / Nyquist special case), so the two planes of
+//     the pair give 64 columns = 64 lanes for the column pass; circular wrap becomes nega-cyclic, which is
+//     irrelevant because the 31x31 valid outputs never wrap inside 64 points;
+//   * the real/imaginary split  2A(f) = C(f) + conj C(63-f),  2iB(f) = C(f) - conj C(63-f)  is done by the COLUMN
+//     lanes while they read (one fma with a per-lane sign), so the row pass stores raw spectra;
+//   * the kernel's transforms are pruned (31 non-zero inputs: even / odd bins are two 32-point FFTs), which also
+//     keeps the register footprint at 128 (X) + 64 (half of K);
+//   * product X * conj(K) in registers, inverse column FFT in registers, LDS, Hermitian re-packing of the pair,
+//     inverse row FFT, e^{+i*pi*j/64} / 16384, real part -> plane A, imaginary part -> plane B.
+// A butterfly with a general twiddle is 3 packed ops:  u = a + wr*b;  A = u + wi*(i b);  B = 2a - A.
+// Waves are autonomous (workgroup = 1 wave, 33 KB LDS, 4 per CU) and persistent.
+#include <hip/hip_runtime.h>
+
+#include "../../include/hdn_hip.h"
+#include "fft_twiddles.h"
+#include "hdn_common.h"
+
+namespace hdn {
+namespace nfft {
+
+typedef float2v cf;
+typedef float f4v __attribute__((ext_vector_type(4)));
+#define NF_DEV __device__ __forceinline__
+
+constexpr int N = 64, RS = 65;                 // row stride of the LDS spectrum image, in complex elements
+constexpr int HX = 61, HK = 31, HO = 31;
+constexpr int XPL = HX * HX, KPL = HK * HK, OPL = HO * HO;   // 3721, 961, 961
+constexpr int XQ = 30, KQ = 8;                 // 16-byte chunks per lane for the x / k window of a pair
+constexpr int KSTAGE = 4096;                   // float offset of the k staging area (beyond spectrum rows 0..30)
+constexpr int LDS_BYTES = N * RS * 8;          // 33,280
+
+NF_DEV constexpr int bitrev(int p, int bits) {
+  int r = 0;
+  for (int i = 0; i < bits; ++i) r |= ((p >> i) & 1) << (bits - 1 - i);
+  return r;
+}
+
+// ---- packed complex arithmetic (non-volatile asm: schedulable, dead results are removed) ----
+NF_DEV cf add(cf a, cf b) { cf r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+NF_DEV cf sub(cf a, cf b) {
+  cf r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// a + SIGN * i * b
+template <int SIGN>
+NF_DEV cf add_i(cf a, cf b) {
+  cf r;
+  if constexpr (SIGN > 0) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// conj(a) + i * conj(b) = (a.x + b.y, b.x - a.y)
+NF_DEV cf conj_add_i(cf a, cf b) {
+  cf r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// p + s * conj(q), s = (+-1, +-1) per lane
+NF_DEV cf split(cf p, cf q, cf s) {
+  cf r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 neg_hi:[1,0,0]" : "=v"(r) : "v"(q), "v"(s), "v"(p));
+  return r;
+}
+// c * t (CONJ = false) or c * conj(t); t = (re, im) wave-uniform in an SGPR pair
+template <bool CONJ>
+NF_DEV cf cmul_s(cf c, cf t) {
+  cf m, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(m) : "v"(c), "s"(t));
+  if constexpr (CONJ) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(c), "s"(t), "v"(m));
+  else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(c), "s"(t), "v"(m));
+  return r;
+}
+// (a, b) * conj(t) where a = A.lo|hi and b = B.lo|hi (HI selects), A and B being the register pairs two adjacent
+// samples of plane A / plane B arrive in (ds_read2_b32): no re-pairing moves.
+//   m = a * (tr, -ti);  r = b * (ti, tr) + m = (a tr + b ti, b tr - a ti)
+template <bool HI>
+NF_DEV cf twiddle_in(cf A, cf B, cf t) {
+  cf m, r;
+  if constexpr (HI) {
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_hi:[0,1]" : "=v"(m) : "v"(A), "s"(t));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(B), "s"(t), "v"(m));
+  } else {
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(m) : "v"(A), "s"(t));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(B), "s"(t), "v"(m));
+  }
+  return r;
+}
+// x * conj(k), both per lane
+NF_DEV cf cmul_conj_v(cf x, cf k) {
+  cf m, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(m) : "v"(x), "v"(k));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(x), "v"(k), "v"(m));
+  return r;
+}
+
+// Radix-2 DIT butterfly with twiddle w = exp(SIGN * 2*pi*i * e / 64):  a' = a + w b,  b' = a - w b.
+template <int SIGN>
+NF_DEV void bfly(cf& a, cf& b, int e) {
+  cf A, B;
+  if (e == 0) {
+    A = add(a, b);
+    B = sub(a, b);
+  } else if (e == 16) {
+    A = add_i<SIGN>(a, b);
+    B = add_i<-SIGN>(a, b);
+  } else {
+    const cf P = {NFFT_COS64[e], NFFT_SIN64[e]};
+    cf u;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(u) : "v"(b), "s"(P), "v"(a));
+    if constexpr (SIGN > 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(A) : "v"(b), "s"(P), "v"(u));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(A) : "v"(b), "s"(P), "v"(u));
+    asm("v_pk_fma_f32 %0, %1, 2.0, %2 op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(B) : "v"(a), "v"(A));
+  }
+  a = A;
+  b = B;
+}
+
+// In-register FFT of 2^LOGN points.  On entry v[p] holds input bitrev(p); on exit v[f] is bin f.
+// Inputs with index >= NZ are zero and v[] need not hold them (NZ > 2^(LOGN-1): only second operands of stage 0).
+template <int LOGN, int SIGN, int NZ>
+NF_DEV void fft_dit(cf (&v)[1 << LOGN]) {
+  constexpr int n = 1 << LOGN;
+#pragma unroll
+  for (int s = 0; s < LOGN; ++s) {
+    const int h = 1 << s;
+#pragma unroll
+    for (int i = 0; i < n; i += 2 * h) {
+#pragma unroll
+      for (int j = 0; j < h; ++j) {
+        if (s == 0 && bitrev(i + 1, LOGN) >= NZ) {
+          v[i + 1] = v[i];  // a + 0, a - 0
+        } else {
+          bfly<SIGN>(v[i + j], v[i + j + h], j * (32 >> s));
+        }
+      }
+    }
+  }
+}
+
+// 16-byte-aligned window of Q*256 floats starting at float offset `first`, all chunks in flight at once.  Only the
+// last windows of a tensor can leave it: those take the guarded path, which delivers zeros beyond the end (the
+// missing partner plane of an odd plane count is then a zero plane).
+template <int Q>
+NF_DEV void fetch(f4v (&R)[Q], const float* __restrict__ src, long long first, long long total, int lane) {
+  if (first + Q * 256 <= total) {  // wave-uniform
+#pragma unroll
+    for (int q = 0; q < Q; ++q) R[q] = *reinterpret_cast<const f4v*>(src + first + 4 * (lane + q * 64));
+  } else {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const long long f = first + 4 * (lane + q * 64);
+      f4v v = {0.f, 0.f, 0.f, 0.f};
+      if (f + 4 <= total) {
+        v = *reinterpret_cast<const f4v*>(src + f);
+      } else {
+        if (f + 0 < total) v.x = src[f + 0];
+        if (f + 1 < total) v.y = src[f + 1];
+        if (f + 2 < total) v.z = src[f + 2];
+      }
+      R[q] = v;
+    }
+  }
+}
+
+}  // namespace nfft
+
+// Pairs pair0 + first, pair0 + first + stride, ... of the tensor; any plane count, any window position.
+__device__ __forceinline__ void north_fft_v1_body(float* smem, const float* __restrict__ x, const float* __restrict__ k,
+                                                  float* __restrict__ out, int planes, int pair0, int first, int stride,
+                                                  const nfft::cf* __restrict__ tab) {
+  using namespace nfft;
+  cf* const T = reinterpret_cast<cf*>(smem);
+  f4v* const S4 = reinterpret_cast<f4v*>(smem);
+  const int lane = threadIdx.x;
+  const int npairs = (planes + 1) >> 1;
+  const long long xtotal = (long long)planes * XPL, ktotal = (long long)planes * KPL;
+
+  const int fc = lane & 31;                      // half-bin column of this lane's plane
+  const float sgn = lane < 32 ? 1.f : -1.f;      // plane A: C + conj C', plane B: C - conj C'
+  const cf sg = {sgn, sgn};
+  const cf* const colp = T + fc;
+  const cf* const colq = T + (63 - fc);
+
+  for (int p = pair0 + first; p < npairs; p += stride) {
+    const long long xbase = (long long)p * (2 * XPL), kbase = (long long)p * (2 * KPL);
+    const long long xfirst = xbase & ~3LL, kfirst = kbase & ~3LL;
+    const int offx = (int)(xbase - xfirst), offk = (int)(kbase - kfirst);
+
+    f4v Rx[XQ], Rk[KQ];
+    fetch<XQ>(Rx, x, xfirst, xtotal, lane);
+    fetch<KQ>(Rk, k, kfirst, ktotal, lane);
+
+    // ---- search pair -> LDS (linear), then row pass: lane = row
+#pragma unroll
+    for (int q = 0; q < XQ; ++q) S4[lane + 64 * q] = Rx[q];
+    {
+      const float* sa = smem + offx + min(lane, HX - 1) * HX;
+      cf v[N];
+#pragma unroll
+      for (int j = 0; j < HX; j += 2) {
+        const cf A = {sa[j], sa[j + 1]}, B = {sa[XPL + j], sa[XPL + j + 1]};  // [60],[61]: the second is not used
+        v[bitrev(j, 6)] = twiddle_in<false>(A, B, tab[NFFT_TAB_TAU + j]);
+        if (j + 1 < HX) v[bitrev(j + 1, 6)] = twiddle_in<true>(A, B, tab[NFFT_TAB_TAU + j + 1]);
+      }
+      fft_dit<6, -1, HX>(v);
+      if (lane < HX) {
+#pragma unroll
+        for (int f = 0; f < N; ++f) T[lane * RS + f] = v[f];
+      }
+    }
+
+    // ---- column pass: lane = (plane, half-bin column); rows 61..63 are zero
+    cf X[N];
+#pragma unroll
+    for (int r = 0; r < HX; ++r) X[bitrev(r, 6)] = split(colp[r * RS], colq[r * RS], sg);
+    fft_dit<6, -1, HX>(X);
+
+    // ---- kernel pair -> LDS (beyond spectrum rows 0..30), row pass in two pruned halves (even / odd bins)
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) S4[KSTAGE / 4 + lane + 64 * q] = Rk[q];
+    {
+      const float* sk = smem + KSTAGE + offk + min(lane, HK - 1) * HK;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        cf v[32];
+#pragma unroll
+        for (int j = 0; j < HK; j += 2) {
+          const cf A = {sk[j], sk[j + 1]}, B = {sk[KPL + j], sk[KPL + j + 1]};
+          const int tb = half ? NFFT_TAB_TAU3 : NFFT_TAB_TAU;
+          v[bitrev(j, 5)] = twiddle_in<false>(A, B, tab[tb + j]);
+          if (j + 1 < HK) v[bitrev(j + 1, 5)] = twiddle_in<true>(A, B, tab[tb + j + 1]);
+        }
+        fft_dit<5, -1, HK>(v);
+        if (lane < HK) {
+#pragma unroll
+          for (int g = 0; g < 32; ++g) T[lane * RS + 2 * g + half] = v[g];
+        }
+      }
+    }
+
+    // ---- kernel column pass (pruned halves) and product X * conj(K)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      cf K[32];
+#pragma unroll
+      for (int r = 0; r < HK; ++r) {
+        cf s = split(colp[r * RS], colq[r * RS], sg);
+        if (half && r > 0) {
+          const cf P = {NFFT_COS64[r], NFFT_SIN64[r]};
+          s = cmul_s<true>(s, P);
+        }
+        K[bitrev(r, 5)] = s;
+      }
+      fft_dit<5, -1, HK>(K);
+#pragma unroll
+      for (int g = 0; g < 32; ++g) X[2 * g + half] = cmul_conj_v(X[2 * g + half], K[g]);
+    }
+
+    // ---- inverse column pass (rows 0..30 needed), to LDS
+    {
+      cf V[N];
+#pragma unroll
+      for (int f = 0; f < N; ++f) V[bitrev(f, 6)] = X[f];
+      fft_dit<6, +1, N>(V);
+#pragma unroll
+      for (int r = 0; r < HO; ++r) T[r * RS + lane] = V[r];
+    }
+
+    // ---- inverse row pass: lane = output row; Hermitian re-packing of the pair
+    {
+      const cf* row = T + min(lane, HO - 1) * RS;
+      cf v[N];
+#pragma unroll
+      for (int f = 0; f < 32; ++f) {
+        const cf ya = row[f], yb = row[32 + f];
+        v[bitrev(f, 6)] = add_i<+1>(ya, yb);
+        v[bitrev(63 - f, 6)] = conj_add_i(ya, yb);
+      }
+      fft_dit<6, +1, N>(v);
+      if (lane < HO) {
+#pragma unroll
+        for (int j = 0; j < HO; ++j) {
+          const cf o = cmul_s<false>(v[j], tab[NFFT_TAB_POST + j]);
+          smem[lane * HO + j] = o.x;
+          smem[OPL + lane * HO + j] = o.y;
+        }
+      }
+    }
+
+    // ---- results: one contiguous 8-byte-aligned range per pair
+    {
+      float* og = out + (long long)p * (2 * OPL);
+      const bool both = 2 * p + 1 < planes;
+      const int words = both ? OPL : OPL / 2;  // float2 words
+      const cf* s2 = reinterpret_cast<const cf*>(smem);
+      cf* o2 = reinterpret_cast<cf*>(og);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int w = lane + 64 * q;
+        if (w < words) o2[w] = s2[w];
+      }
+      if (!both && lane == 0) og[OPL - 1] = smem[OPL - 1];
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void xcorr_north_fft_kernel(const float* __restrict__ x, const float* __restrict__ k,
+                                                             float* __restrict__ out, int planes, int pair0,
+                                                             const nfft::cf* __restrict__ tab) {
+  extern __shared__ __align__(16) float smem[];
+  north_fft_v1_body(smem, x, k, out, planes, pair0, blockIdx.x, gridDim.x, tab);
+}
+
+__device__ __attribute__((used)) nfft::cf g_nfft_tab[NFFT_TAB_LEN] = NFFT_TAB_INIT;
+
+static const nfft::cf* north_fft_table() {
+  static const nfft::cf* tab = nullptr;
+  if (!tab) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_nfft_tab)) != hipSuccess) return nullptr;
+    tab = static_cast<const nfft::cf*>(p);
+  }
+  return tab;
+}
+
+// x, k 16-byte aligned, out 8-byte aligned (the dispatcher checks); planes = B*C; pairs pair0.. only.
+int launch_north_fft(const float* x, const float* k, float* out, int planes, int max_blocks, hipStream_t stream, int pair0) {
+  const nfft::cf* tab = north_fft_table();
+  if (!tab) return -(1000 + (int)hipErrorInvalidSymbol);
+  const int npairs = (planes + 1) / 2 - pair0;
+  const int grid = npairs < max_blocks ? npairs : max_blocks;
+  hipLaunchKernelGGL(xcorr_north_fft_kernel, dim3(grid), dim3(64), nfft::LDS_BYTES, stream, x, k, out, planes, pair0, tab);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? HDN_OK : -(1000 + (int)e);
+}
+
+}  // namespace hdn
+
+// =======================================================================================
+// v2: same algorithm, hand-ordered.  One wave per SIMD means nothing but the wave's own instruction order hides
+// latency, and every instruction of any kind costs an issue slot.  So:
+//   * every LDS / global access and every packed op is a volatile asm statement: program order IS the schedule;
+//     all reads of a pass are issued before its first butterfly, waits are placed by hand;
+//   * the next pair's 38 x 16-byte global loads land in AGPRs (152 registers the arithmetic never needs) during the
+//     current pair and go from there to LDS: HBM latency is off the critical path;
+//   * the real/imaginary split of the search spectrum is done by the row lanes, so the column lanes read straight
+//     into X; independent butterflies are interleaved two by two inside one asm block;
+//   * all twiddles (butterflies, half-bin shifts, kernel pre-twiddle, final un-shift) come from ONE table of 17
+//     (cos, sin) pairs that stays in SGPRs: any angle pi*m/64 is a base pair up to a swap of its halves and signs,
+//     which the packed ops' operand selects do for free (the selects are passed to the asm as immediates).
+// Handles only pairs whose 16-byte-aligned load windows lie inside the tensors; the launcher gives the last pair(s)
+// to the v1 kernel above.
+// =======================================================================================
+#include <type_traits>
+
+namespace hdn {
+namespace nf2 {
+using nfft::bitrev;
+using nfft::cf;
+using nfft::f4v;
+using nfft::HK;
+using nfft::HO;
+using nfft::HX;
+using nfft::KPL;
+using nfft::KQ;
+using nfft::KSTAGE;
+using nfft::OPL;
+using nfft::RS;
+using nfft::XPL;
+using nfft::XQ;
+
+#define NF2_LAMBDA __attribute__((always_inline))
+
+template <int I, int E, class F>
+NF_DEV void sfor(F&& f) {
+  if constexpr (I < E) {
+    f(std::integral_constant<int, I>{});
+    sfor<I + 1, E>(static_cast<F&&>(f));
+  }
+}
+
+// ---- memory primitives: volatile, NOT tracked by the compiler's s_waitcnt insertion ----
+template <int OFF>
+NF_DEV cf lr64(uint32_t a) {
+  cf r;
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(a), "n"(OFF));
+  return r;
+}
+template <int O0, int O1>
+NF_DEV cf lr2x32(uint32_t a) {
+  cf r;
+  asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(r) : "v"(a), "n"(O0), "n"(O1));
+  return r;
+}
+template <int O0, int O1>  // two 8-byte words at a + 8*O0, a + 8*O1
+NF_DEV void lr2x64(uint32_t a, cf& r0, cf& r1) {
+  f4v r;
+  asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(r) : "v"(a), "n"(O0), "n"(O1));
+  r0 = cf{r.x, r.y};
+  r1 = cf{r.z, r.w};
+}
+template <int OFF>
+NF_DEV void lw64(uint32_t a, cf v) { asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(a), "v"(v), "n"(OFF)); }
+template <int O0, int O1>
+NF_DEV void lw2x64(uint32_t a, cf v0, cf v1) {
+  asm volatile("ds_write2_b64 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(a), "v"(v0), "v"(v1), "n"(O0), "n"(O1));
+}
+template <int O0, int O1>
+NF_DEV void lw2x32(uint32_t a, float v0, float v1) {
+  asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(a), "v"(v0), "v"(v1), "n"(O0), "n"(O1));
+}
+template <int OFF>
+NF_DEV void lw32(uint32_t a, float v) { asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(a), "v"(v), "n"(OFF)); }
+template <int OFF>
+NF_DEV void lw128_from_agpr(uint32_t a, const f4v& v) { asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(a), "a"(v), "n"(OFF)); }
+template <int OFF>
+NF_DEV void gload128_to_agpr(f4v& v, uint32_t voff, const void* sbase) {
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=a"(v) : "v"(voff), "s"(sbase), "n"(OFF));
+}
+template <int CNT>
+NF_DEV void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(CNT)); }
+NF_DEV void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)"); }
+
+// ---- twiddles: w = e^{i*pi*m/64} = wr + i*wi with wr = (nr ? -1 : 1) * T[c].{hr}, wi = (ni ? -1 : 1) * T[c].{hi} ----
+struct Tw {
+  int c, hr, hi, nr, ni;
+};
+NF_DEV constexpr Tw tw(int m) {
+  m = ((m % 128) + 128) % 128;
+  const int a = m / 32, b = m % 32;
+  const bool sw = b > 16;
+  const int c = sw ? 32 - b : b;
+  const int h0 = sw ? 1 : 0, h1 = sw ? 0 : 1;  // halves holding cos / sin of the reduced angle
+  switch (a) {
+    case 0: return Tw{c, h0, h1, 0, 0};
+    case 1: return Tw{c, h1, h0, 1, 0};
+    case 2: return Tw{c, h0, h1, 1, 1};
+    default: return Tw{c, h1, h0, 0, 1};
+  }
+}
+template <bool SCALED, int C>
+NF_DEV cf tconst() {
+  if constexpr (SCALED) return cf{NFFT_T17P_C[C], NFFT_T17P_S[C]};
+  else return cf{NFFT_T17_C[C], NFFT_T17_S[C]};
+}
+
+// operand-select strings with the Tw fields as immediate operands  R=hr I=hi NR=nr NI=ni (operand numbers given)
+#define NF2_SUB "neg_lo:[0,1] neg_hi:[0,1]"
+#define NF2_ADDI_P "op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" /* a + i b */
+#define NF2_ADDI_M "op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" /* a - i b */
+#define NF2_TWOA_MINUS "op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]"
+// u = a + wr*b:            v_pk_fma u, b, T, a   with T broadcast from half R, sign NR
+#define NF2_RE(R, NR) "op_sel:[0," R ",0] op_sel_hi:[1," R ",1] neg_lo:[0," NR ",0] neg_hi:[0," NR ",0]"
+// A = u + wi*(-b.y, b.x):  v_pk_fma A, b, T, u   with b swapped (lo negated), T broadcast from half I, sign NI
+#define NF2_IM(I, NI) "op_sel:[1," I ",0] op_sel_hi:[0," I ",1] neg_lo:[1," NI ",0] neg_hi:[0," NI ",0]"
+
+// kind of the butterfly twiddle index M (units pi/64, mod 128): 0: w = 1, 1: w = i, 2: w = -i, 3: general
+NF_DEV constexpr int kind(int M) { return M == 0 ? 0 : (M == 32 ? 1 : (M == 96 ? 2 : 3)); }
+
+// MODE 0: a' = a + w b, b' = a - w b;  1: a' only;  2: b is zero: b' = a' = a;  3: nothing
+template <int M, int MODE>
+NF_DEV void bfly1(cf& a, cf& b) {
+  constexpr int kd = kind(M);
+  constexpr Tw t = tw(M);
+  if constexpr (MODE == 2) {
+    b = a;
+  } else if constexpr (MODE == 1) {
+    cf A;
+    if constexpr (kd == 0) asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(A) : "v"(a), "v"(b));
+    else if constexpr (kd == 1) asm volatile("v_pk_add_f32 %0, %1, %2 " NF2_ADDI_P : "=v"(A) : "v"(a), "v"(b));
+    else if constexpr (kd == 2) asm volatile("v_pk_add_f32 %0, %1, %2 " NF2_ADDI_M : "=v"(A) : "v"(a), "v"(b));
+    else {
+      const cf T = tconst<false, t.c>();
+      asm volatile("v_pk_fma_f32 %0, %1, %3, %2 " NF2_RE("%4", "%6") "\n\tv_pk_fma_f32 %0, %1, %3, %0 " NF2_IM("%5", "%7")
+                   : "=&v"(A) : "v"(b), "v"(a), "s"(T), "n"(t.hr), "n"(t.hi), "n"(t.nr), "n"(t.ni));
+    }
+    a = A;
+  } else if constexpr (MODE == 0) {
+    cf A;
+    if constexpr (kd == 0) {
+      asm volatile("v_pk_add_f32 %0, %2, %1\n\tv_pk_add_f32 %1, %2, %1 " NF2_SUB : "=&v"(A), "+v"(b) : "v"(a));
+    } else if constexpr (kd == 1) {
+      asm volatile("v_pk_add_f32 %0, %2, %1 " NF2_ADDI_P "\n\tv_pk_add_f32 %1, %2, %1 " NF2_ADDI_M : "=&v"(A), "+v"(b) : "v"(a));
+    } else if constexpr (kd == 2) {
+      asm volatile("v_pk_add_f32 %0, %2, %1 " NF2_ADDI_M "\n\tv_pk_add_f32 %1, %2, %1 " NF2_ADDI_P : "=&v"(A), "+v"(b) : "v"(a));
+    } else {
+      const cf T = tconst<false, t.c>();
+      asm volatile("v_pk_fma_f32 %0, %1, %3, %2 " NF2_RE("%4", "%6") "\n\tv_pk_fma_f32 %0, %1, %3, %0 " NF2_IM("%5", "%7")
+                   "\n\tv_pk_fma_f32 %1, %2, 2.0, %0 " NF2_TWOA_MINUS
+                   : "=&v"(A), "+v"(b) : "v"(a), "s"(T), "n"(t.hr), "n"(t.hi), "n"(t.nr), "n"(t.ni));
+    }
+    a = A;
+  }
+}
+
+// two independent full butterflies of the same kind, interleaved (dependent packed ops are never adjacent)
+template <int M0, int M1, int MODE0, int MODE1>
+NF_DEV void bfly2(cf& a0, cf& b0, cf& a1, cf& b1) {
+  constexpr int kd = kind(M0);
+  if constexpr (MODE0 == 0 && MODE1 == 0 && kind(M0) == kind(M1)) {
+    cf A0, A1;
+    if constexpr (kd == 0) {
+      asm volatile("v_pk_add_f32 %0, %4, %2\n\tv_pk_add_f32 %1, %5, %3\n\t"
+                   "v_pk_add_f32 %2, %4, %2 " NF2_SUB "\n\tv_pk_add_f32 %3, %5, %3 " NF2_SUB
+                   : "=&v"(A0), "=&v"(A1), "+v"(b0), "+v"(b1) : "v"(a0), "v"(a1));
+    } else if constexpr (kd == 1) {
+      asm volatile("v_pk_add_f32 %0, %4, %2 " NF2_ADDI_P "\n\tv_pk_add_f32 %1, %5, %3 " NF2_ADDI_P "\n\t"
+                   "v_pk_add_f32 %2, %4, %2 " NF2_ADDI_M "\n\tv_pk_add_f32 %3, %5, %3 " NF2_ADDI_M
+                   : "=&v"(A0), "=&v"(A1), "+v"(b0), "+v"(b1) : "v"(a0), "v"(a1));
+    } else if constexpr (kd == 2) {
+      asm volatile("v_pk_add_f32 %0, %4, %2 " NF2_ADDI_M "\n\tv_pk_add_f32 %1, %5, %3 " NF2_ADDI_M "\n\t"
+                   "v_pk_add_f32 %2, %4, %2 " NF2_ADDI_P "\n\tv_pk_add_f32 %3, %5, %3 " NF2_ADDI_P
+                   : "=&v"(A0), "=&v"(A1), "+v"(b0), "+v"(b1) : "v"(a0), "v"(a1));
+    } else {
+      constexpr Tw t0 = tw(M0), t1 = tw(M1);
+      const cf T0 = tconst<false, t0.c>(), T1 = tconst<false, t1.c>();
+      asm volatile("v_pk_fma_f32 %0, %2, %6, %4 " NF2_RE("%8", "%10") "\n\tv_pk_fma_f32 %1, %3, %7, %5 " NF2_RE("%12", "%14") "\n\t"
+                   "v_pk_fma_f32 %0, %2, %6, %0 " NF2_IM("%9", "%11") "\n\tv_pk_fma_f32 %1, %3, %7, %1 " NF2_IM("%13", "%15") "\n\t"
+                   "v_pk_fma_f32 %2, %4, 2.0, %0 " NF2_TWOA_MINUS "\n\tv_pk_fma_f32 %3, %5, 2.0, %1 " NF2_TWOA_MINUS
+                   : "=&v"(A0), "=&v"(A1), "+v"(b0), "+v"(b1)
+                   : "v"(a0), "v"(a1), "s"(T0), "s"(T1), "n"(t0.hr), "n"(t0.hi), "n"(t0.nr), "n"(t0.ni), "n"(t1.hr), "n"(t1.hi),
+                     "n"(t1.nr), "n"(t1.ni));
+    }
+    a0 = A0;
+    a1 = A1;
+  } else {
+    bfly1<M0, MODE0>(a0, b0);
+    bfly1<M1, MODE1>(a1, b1);
+  }
+}
+
+template <int LOGN, int NZ, int NOUT>
+NF_DEV constexpr int bfly_mode(int s, int x, int h) {
+  if (s == 0 && bitrev(x + 1, LOGN) >= NZ) return 2;
+  if (s == LOGN - 1) {
+    if (x >= NOUT) return 3;
+    if (x + h >= NOUT) return 1;
+  }
+  return 0;
+}
+
+// In-register radix-2 DIT FFT of 2^LOGN points, direction SIGN.  Entry: v[p] = input bitrev(p) (inputs >= NZ are zero
+// and need not be stored); exit: v[f] = bin f for f < NOUT.
+template <int LOGN, int SIGN, int NZ, int NOUT>
+NF_DEV void fft(cf (&v)[1 << LOGN]) {
+  constexpr int n = 1 << LOGN;
+  sfor<0, LOGN>([&](auto S) NF2_LAMBDA {
+    constexpr int s = decltype(S)::value, h = 1 << s, G = n / (2 * h);
+    sfor<0, n / 4>([&](auto Q) NF2_LAMBDA {
+      constexpr int t0 = 2 * decltype(Q)::value, t1 = t0 + 1;
+      constexpr int j0 = t0 / G, g0 = t0 % G, j1 = t1 / G, g1 = t1 % G;  // same twiddle across groups first
+      constexpr int x0 = g0 * 2 * h + j0, x1 = g1 * 2 * h + j1;
+      constexpr int e0 = j0 * (32 >> s), e1 = j1 * (32 >> s);              // units of 2*pi/64
+      constexpr int M0 = (SIGN > 0 ? 2 * e0 : 128 - 2 * e0) % 128, M1 = (SIGN > 0 ? 2 * e1 : 128 - 2 * e1) % 128;
+      constexpr int m0 = bfly_mode<LOGN, NZ, NOUT>(s, x0, h), m1 = bfly_mode<LOGN, NZ, NOUT>(s, x1, h);
+      bfly2<M0, M1, m0, m1>(v[x0], v[x0 + h], v[x1], v[x1 + h]);
+    });
+  });
+}
+
+// (a + i b) * e^{i*pi*M/64} for the samples in the lo halves (M0) and hi halves (M1) of A (plane A) and B (plane B):
+//   m = a * (wr, wi);  r = b * (-wi, wr) + m
+template <int M0, int M1, bool BOTH>
+NF_DEV void twiddle_in2(cf A, cf B, cf& lo, cf& hi) {
+  constexpr Tw t0 = tw(M0), t1 = tw(M1);
+  const cf T0 = tconst<false, t0.c>(), T1 = tconst<false, t1.c>();
+  // v_pk_mul m, A, T : src0 both lanes = A.sel; src1 lanes = (hr, hi) with signs (nr, ni)
+  // v_pk_fma r, B, T, m : src0 both lanes = B.sel; src1 lanes = (hi, hr) with signs (!ni, nr)
+  if constexpr (BOTH)
+    asm volatile("v_pk_mul_f32 %0, %2, %4 op_sel:[0,%6] op_sel_hi:[0,%7] neg_lo:[0,%8] neg_hi:[0,%9]\n\t"
+                 "v_pk_mul_f32 %1, %2, %5 op_sel:[1,%11] op_sel_hi:[1,%12] neg_lo:[0,%13] neg_hi:[0,%14]\n\t"
+                 "v_pk_fma_f32 %0, %3, %4, %0 op_sel:[0,%7,0] op_sel_hi:[0,%6,1] neg_lo:[0,%10,0] neg_hi:[0,%8,0]\n\t"
+                 "v_pk_fma_f32 %1, %3, %5, %1 op_sel:[1,%12,0] op_sel_hi:[1,%11,1] neg_lo:[0,%15,0] neg_hi:[0,%13,0]"
+                 : "=&v"(lo), "=&v"(hi)
+                 : "v"(A), "v"(B), "s"(T0), "s"(T1), "n"(t0.hr), "n"(t0.hi), "n"(t0.nr), "n"(t0.ni), "n"(1 - t0.ni), "n"(t1.hr),
+                   "n"(t1.hi), "n"(t1.nr), "n"(t1.ni), "n"(1 - t1.ni));
+  else
+    asm volatile("v_pk_mul_f32 %0, %1, %3 op_sel:[0,%4] op_sel_hi:[0,%5] neg_lo:[0,%6] neg_hi:[0,%7]\n\t"
+                 "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[0,%5,0] op_sel_hi:[0,%4,1] neg_lo:[0,%8,0] neg_hi:[0,%6,0]"
+                 : "=&v"(lo) : "v"(A), "v"(B), "s"(T0), "n"(t0.hr), "n"(t0.hi), "n"(t0.nr), "n"(t0.ni), "n"(1 - t0.ni));
+}
+
+// c * e^{i*pi*M/64}, c a packed complex:  m = c * (wr, wr);  r = (c.y, c.x) * (-wi, wi) + m
+template <int M, bool SCALED>
+NF_DEV cf cmul_tw(cf c) {
+  constexpr Tw t = tw(M);
+  const cf T = tconst<SCALED, t.c>();
+  cf m, r;
+  asm volatile("v_pk_mul_f32 %0, %2, %3 op_sel:[0,%4] op_sel_hi:[1,%4] neg_lo:[0,%6] neg_hi:[0,%6]\n\t"
+               "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[1,%5,0] op_sel_hi:[0,%5,1] neg_lo:[0,%8,0] neg_hi:[0,%7,0]"
+               : "=&v"(m), "=&v"(r) : "v"(c), "s"(T), "n"(t.hr), "n"(t.hi), "n"(t.nr), "n"(t.ni), "n"(1 - t.ni));
+  return r;
+}
+
+}  // namespace nf2
+
+// Grid: `nmain` persistent workgroups for the npairs interior pairs, plus (when planes needs it) ONE extra workgroup
+// that runs the general v1 path on the remaining pair(s) meanwhile.
+__global__ __launch_bounds__(64) void xcorr_north_fft2_kernel(const float* __restrict__ x, const float* __restrict__ k,
+                                                              float* __restrict__ out, int npairs, int nmain, int planes,
+                                                              const nfft::cf* __restrict__ tab) {
+  using namespace nf2;
+  extern __shared__ __align__(16) float smem[];
+  if ((int)blockIdx.x >= nmain) {
+    north_fft_v1_body(smem, x, k, out, planes, npairs, 0, 1, tab);
+    return;
+  }
+  const int lane = threadIdx.x;
+  const uint32_t sb = lds_addr(smem);
+
+  const int fc = lane & 31;
+  const float sgn = lane < 32 ? 1.f : -1.f;
+  const cf sg = {sgn, sgn};
+  // LDS byte addresses that do not depend on the pair
+  const uint32_t a_stash = sb + lane * 16;                     // linear 16-byte chunks
+  const uint32_t a_row = sb + lane * (RS * 8);                 // spectrum row `lane`
+  const uint32_t a_col = sb + lane * 8;                        // spectrum column `lane` / linear 8-byte words
+  const uint32_t a_colp = sb + fc * 8, a_colq = sb + (63 - fc) * 8;
+  const uint32_t a_rowo = sb + (lane < HO ? lane : HO - 1) * (RS * 8);
+  const uint32_t a_out = sb + lane * (HO * 4);
+  const uint32_t voff = lane * 16;
+
+  f4v Rx[XQ], Rk[KQ];  // the next pair's global data: AGPRs
+
+  auto fetch_x = [&](int p) NF2_LAMBDA {
+    const long long first = ((long long)p * (2 * XPL)) & ~3LL;
+    sfor<0, XQ>([&](auto Qi) NF2_LAMBDA {
+      constexpr int q = decltype(Qi)::value;
+      gload128_to_agpr<(q & 3) * 1024>(Rx[q], voff, reinterpret_cast<const char*>(x + first) + (q >> 2) * 4096);
+    });
+  };
+  auto fetch_k = [&](int p) NF2_LAMBDA {
+    const long long first = ((long long)p * (2 * KPL)) & ~3LL;
+    sfor<0, KQ>([&](auto Qi) NF2_LAMBDA {
+      constexpr int q = decltype(Qi)::value;
+      gload128_to_agpr<(q & 3) * 1024>(Rk[q], voff, reinterpret_cast<const char*>(k + first) + (q >> 2) * 4096);
+    });
+  };
+
+  int p = blockIdx.x;
+  if (p >= npairs) return;
+  fetch_x(p);
+  fetch_k(p);
+
+  for (; p < npairs; p += nmain) {
+    const int offx = (int)(((long long)p * (2 * XPL)) & 3), offk = (int)(((long long)p * (2 * KPL)) & 3);
+    const int pn = min(p + nmain, npairs - 1);  // (the last iteration re-fetches its own pair: harmless)
+
+    // ---- search pair: AGPRs -> LDS; refill the AGPRs with the next pair
+    wait_vm0();
+    sfor<0, XQ>([&](auto Qi) NF2_LAMBDA { constexpr int q = decltype(Qi)::value; lw128_from_agpr<q * 1024>(a_stash, Rx[q]); });
+    fetch_x(pn);
+
+    // ---- row pass: lane = row; half-bin twiddle e^{-i*pi*j/64}, FFT, real/imaginary split, store
+    {
+      const uint32_t aA = sb + (offx + (lane < HX ? lane : HX - 1) * HX) * 4, aB = aA + XPL * 4;
+      cf ra[31], rb[31];
+      sfor<0, 31>([&](auto Mi) NF2_LAMBDA {
+        constexpr int m = decltype(Mi)::value;
+        ra[m] = lr2x32<2 * m, 2 * m + 1>(aA);
+        rb[m] = lr2x32<2 * m, 2 * m + 1>(aB);
+      });
+      wait_lgkm<0>();
+      cf v[64];
+      sfor<0, 31>([&](auto Mi) NF2_LAMBDA {
+        constexpr int j = 2 * decltype(Mi)::value;
+        cf lo, hi;
+        const cf A = ra[j / 2], B = rb[j / 2];
+        twiddle_in2<-j, -(j + 1), (j + 1 < HX)>(A, B, lo, hi);
+        v[bitrev(j, 6)] = lo;
+        if constexpr (j + 1 < HX) v[bitrev(j + 1, 6)] = hi;
+      });
+      fft<6, -1, HX, 64>(v);
+      if (lane < HX) {
+        sfor<0, 32>([&](auto F) NF2_LAMBDA {
+          constexpr int f = decltype(F)::value;
+          cf sa, sb2;  // C(f) + conj C(63-f),  C(f) - conj C(63-f)
+          const cf cp = v[f], cq = v[63 - f];
+          asm volatile("v_pk_add_f32 %0, %2, %3 neg_hi:[0,1]\n\tv_pk_add_f32 %1, %2, %3 neg_lo:[0,1]"
+                       : "=&v"(sa), "=&v"(sb2) : "v"(cp), "v"(cq));
+          lw2x64<f, 32 + f>(a_row, sa, sb2);
+        });
+      }
+    }
+
+    // ---- column pass: lane = (plane, half-bin column); straight into X
+    cf X[64];
+    sfor<0, HX>([&](auto R) NF2_LAMBDA { constexpr int r = decltype(R)::value; X[bitrev(r, 6)] = lr64<r * RS * 8>(a_col); });
+    wait_lgkm<0>();
+    // kernel pair: AGPRs -> LDS (beyond spectrum rows 0..30) and its row-pass inputs: in flight under the column FFT
+    sfor<0, KQ>([&](auto Qi) NF2_LAMBDA { constexpr int q = decltype(Qi)::value; lw128_from_agpr<KSTAGE * 4 + q * 1024>(a_stash, Rk[q]); });
+    fetch_k(pn);
+    const uint32_t akA = sb + (KSTAGE + offk + (lane < HK ? lane : HK - 1) * HK) * 4, akB = akA + KPL * 4;
+    cf ka[16], kb[16];
+    sfor<0, 16>([&](auto Mi) NF2_LAMBDA {
+      constexpr int m = decltype(Mi)::value;
+      ka[m] = lr2x32<2 * m, 2 * m + 1>(akA);
+      kb[m] = lr2x32<2 * m, 2 * m + 1>(akB);
+    });
+    fft<6, -1, HX, 64>(X);
+
+    // ---- kernel row pass, pruned: even bins = FFT32(c * e^{-i*pi*j/64}), odd bins = FFT32(c * e^{-3i*pi*j/64});
+    //      raw spectra to LDS (the split needs an even and an odd bin: the column lanes do it)
+    sfor<0, 2>([&](auto Hf) NF2_LAMBDA {
+      constexpr int half = decltype(Hf)::value;
+      wait_lgkm<0>();
+      cf v[32];
+      sfor<0, 16>([&](auto Mi) NF2_LAMBDA {
+        constexpr int j = 2 * decltype(Mi)::value;
+        constexpr int mul = half ? 3 : 1;
+        cf lo, hi;
+        const cf A = ka[j / 2], B = kb[j / 2];
+        twiddle_in2<-mul * j, -mul * (j + 1), (j + 1 < HK)>(A, B, lo, hi);
+        v[bitrev(j, 5)] = lo;
+        if constexpr (j + 1 < HK) v[bitrev(j + 1, 5)] = hi;
+      });
+      fft<5, -1, HK, 32>(v);
+      if constexpr (half == 0) {  // the same inputs again for the odd bins (holding them would not fit next to X)
+        sfor<0, 16>([&](auto Mi) NF2_LAMBDA {
+          constexpr int m = decltype(Mi)::value;
+          ka[m] = lr2x32<2 * m, 2 * m + 1>(akA);
+          kb[m] = lr2x32<2 * m, 2 * m + 1>(akB);
+        });
+      }
+      if (lane < HK) {
+        sfor<0, 16>([&](auto Gi) NF2_LAMBDA {
+          constexpr int g = 2 * decltype(Gi)::value;
+          lw2x64<2 * g + half, 2 * g + 2 + half>(a_row, v[g], v[g + 1]);
+        });
+      }
+    });
+
+    // ---- kernel column pass (pruned halves; split by a per-lane sign while reading) and product X * conj(K)
+    sfor<0, 2>([&](auto Hf) NF2_LAMBDA {
+      constexpr int half = decltype(Hf)::value;
+      cf K[32];
+      constexpr int CH = 5, NCH = (HK + CH - 1) / CH;  // rows in chunks of 5, two chunks in flight
+      cf pp[2][CH], qq[2][CH];
+      auto issue = [&](auto Ci) NF2_LAMBDA {
+        constexpr int c = decltype(Ci)::value;
+        sfor<0, CH>([&](auto Ri) NF2_LAMBDA {
+          constexpr int r = c * CH + decltype(Ri)::value;
+          if constexpr (r < HK) {
+            pp[c & 1][r - c * CH] = lr64<r * RS * 8>(a_colp);
+            qq[c & 1][r - c * CH] = lr64<r * RS * 8>(a_colq);
+          }
+        });
+      };
+      issue(std::integral_constant<int, 0>{});
+      sfor<0, NCH>([&](auto Ci) NF2_LAMBDA {
+        constexpr int c = decltype(Ci)::value;
+        constexpr int next_rows = (c + 1 < NCH) ? ((c + 2) * CH <= HK ? CH : HK - (c + 1) * CH) : 0;
+        if constexpr (c + 1 < NCH) issue(std::integral_constant<int, c + 1>{});
+        wait_lgkm<2 * next_rows>();
+        sfor<0, CH>([&](auto Ri) NF2_LAMBDA {
+          constexpr int r = c * CH + decltype(Ri)::value;
+          if constexpr (r < HK) {
+            cf s;
+            const cf pv = pp[c & 1][r - c * CH], qv = qq[c & 1][r - c * CH], sgl = sg;
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 neg_hi:[1,0,0]" : "=v"(s) : "v"(qv), "v"(sgl), "v"(pv));  // p +- conj q
+            if constexpr (half == 1 && r > 0) s = cmul_tw<-2 * r, false>(s);                                       // times w64^r
+            K[bitrev(r, 5)] = s;
+          }
+        });
+      });
+      fft<5, -1, HK, 32>(K);
+      sfor<0, 16>([&](auto Gi) NF2_LAMBDA {
+        constexpr int g0 = 2 * decltype(Gi)::value, g1 = g0 + 1;
+        cf m0, m1;
+        cf x0 = X[2 * g0 + half], x1 = X[2 * g1 + half];
+        const cf k0 = K[g0], k1 = K[g1];
+        asm volatile("v_pk_mul_f32 %0, %2, %4 op_sel_hi:[1,0]\n\tv_pk_mul_f32 %1, %3, %5 op_sel_hi:[1,0]\n\t"
+                     "v_pk_fma_f32 %2, %2, %4, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]\n\t"
+                     "v_pk_fma_f32 %3, %3, %5, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+                     : "=&v"(m0), "=&v"(m1), "+v"(x0), "+v"(x1) : "v"(k0), "v"(k1));
+        X[2 * g0 + half] = x0;
+        X[2 * g1 + half] = x1;
+      });
+    });
+
+    // ---- inverse column pass (rows 0..30 needed), to LDS
+    {
+      cf V[64];
+      sfor<0, 64>([&](auto F) NF2_LAMBDA { constexpr int f = decltype(F)::value; V[bitrev(f, 6)] = X[f]; });
+      fft<6, +1, 64, HO>(V);
+      sfor<0, HO>([&](auto R) NF2_LAMBDA { constexpr int r = decltype(R)::value; lw64<r * RS * 8>(a_col, V[r]); });
+    }
+
+    // ---- inverse row pass: lane = output row; Hermitian re-packing of the pair, FFT, un-shift e^{+i*pi*j/64} / 16384
+    {
+      cf y[64];
+      sfor<0, 32>([&](auto C) NF2_LAMBDA { constexpr int c = 2 * decltype(C)::value; lr2x64<c, c + 1>(a_rowo, y[c], y[c + 1]); });
+      wait_lgkm<0>();
+      cf v[64];
+      sfor<0, 32>([&](auto F) NF2_LAMBDA {
+        constexpr int f = decltype(F)::value;
+        cf c0, c1;
+        const cf ya = y[f], yb = y[32 + f];
+        asm volatile("v_pk_add_f32 %0, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"   // ya + i yb
+                     "v_pk_add_f32 %1, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]"       // conj ya + i conj yb
+                     : "=&v"(c0), "=&v"(c1) : "v"(ya), "v"(yb));
+        v[bitrev(f, 6)] = c0;
+        v[bitrev(63 - f, 6)] = c1;
+      });
+      fft<6, +1, 64, HO>(v);
+      if (lane < HO) {
+        sfor<0, 16>([&](auto Ji) NF2_LAMBDA {
+          constexpr int j = 2 * decltype(Ji)::value;
+          const cf o0 = cmul_tw<j, true>(v[j]);
+          if constexpr (j + 1 < HO) {
+            const cf o1 = cmul_tw<j + 1, true>(v[j + 1]);
+            lw2x32<j, j + 1>(a_out, o0.x, o1.x);
+            lw2x32<j, j + 1>(a_out + OPL * 4, o0.y, o1.y);
+          } else {
+            lw32<j * 4>(a_out, o0.x);
+            lw32<(OPL + j) * 4>(a_out, o0.y);
+          }
+        });
+      }
+    }
+
+    // ---- results: one contiguous 8-byte-aligned range per pair (both planes exist for every pair given to this kernel)
+    {
+      cf* o2 = reinterpret_cast<cf*>(out + (long long)p * (2 * OPL));
+      cf w[16];
+      sfor<0, 16>([&](auto Qi) NF2_LAMBDA { constexpr int q = decltype(Qi)::value; w[q] = lr64<q * 512>(a_col); });
+      wait_lgkm<0>();
+      sfor<0, 16>([&](auto Qi) NF2_LAMBDA {
+        constexpr int q = decltype(Qi)::value;
+        cf wq = w[q];
+        asm volatile("" : "+v"(wq));  // consumed only after the wait
+        if (lane + 64 * q < OPL) o2[lane + 64 * q] = wq;
+      });
+    }
+  }
+}
+
+// Pairs whose load windows stay inside the tensors and whose two planes exist: those go to the v2 kernel.
+static int north_fft_full_pairs(int planes) {
+  const long long xtotal = (long long)planes * nfft::XPL, ktotal = (long long)planes * nfft::KPL;
+  int n = planes / 2;
+  while (n > 0) {
+    const long long xf = ((long long)(n - 1) * 2 * nfft::XPL) & ~3LL, kf = ((long long)(n - 1) * 2 * nfft::KPL) & ~3LL;
+    if (xf + nfft::XQ * 256 <= xtotal && kf + nfft::KQ * 256 <= ktotal) break;
+    --n;
+  }
+  return n;
+}
+
+int launch_north_fft2(const float* x, const float* k, float* out, int planes, int max_blocks, hipStream_t stream) {
+  const int npairs = (planes + 1) / 2, nfull = north_fft_full_pairs(planes);
+  if (nfull == 0) return launch_north_fft(x, k, out, planes, max_blocks, stream, 0);
+  const nfft::cf* tab = north_fft_table();
+  if (!tab) return -(1000 + (int)hipErrorInvalidSymbol);
+  const int nmain = nfull < max_blocks ? nfull : max_blocks;
+  const int grid = nmain + (nfull < npairs ? 1 : 0);
+  hipLaunchKernelGGL(xcorr_north_fft2_kernel, dim3(grid), dim3(64), nfft::LDS_BYTES, stream, x, k, out, nfull, nmain, planes, tab);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? HDN_OK : -(1000 + (int)e);
+}
+
+}  // namespace hdn

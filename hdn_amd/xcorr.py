@@ -130,3 +130,33 @@ def xcorr_slow(x: torch.Tensor, kernel: torch.Tensor) -> torch.Tensor:
 def last_variant() -> str:
     """Name of the kernel the last correlation call dispatched to (tests / profiles)."""
     return _lib.load().hdn_last_xcorr_variant().decode()
+
+
+NORTH_VARIANTS = {"fft": 0, "direct": 1, "dense": 2, "mfma": 3}  # HDN_NORTH_* in include/hdn_hip.h
+
+
+class north_variant:
+    """Select the kernel used for the 31x31 (x) 61x61 shape, process-wide; usable as a context manager.
+
+        with north_variant("direct"): y = xcorr_depthwise(x, k)
+    """
+
+    def __init__(self, name: str):
+        if name not in NORTH_VARIANTS:
+            raise ValueError(f"north variant must be one of {sorted(NORTH_VARIANTS)}")
+        rc = _lib.load().hdn_xcorr_north_variant(NORTH_VARIANTS[name])
+        if rc < 0:
+            _lib.check(rc, "hdn_xcorr_north_variant")
+        self.prev = rc
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        _lib.load().hdn_xcorr_north_variant(self.prev)
+        return False
+
+
+def current_north_variant() -> str:
+    v = _lib.load().hdn_xcorr_north_variant(-1)
+    return next(k for k, n in NORTH_VARIANTS.items() if n == v)

@@ -38,6 +38,20 @@ int hdn_abi_version(void);
 const char* hdn_last_xcorr_variant(void);
 
 /*
+ * Kernel used for the 31x31 (x) 61x61 shape (BASELINE north-star shape).  v >= 0 selects it for the whole process,
+ * v < 0 only queries; returns the previous value (or HDN_E_LIMIT).  HDN_NORTH_FFT needs 16-byte aligned x / k and
+ * 8-byte aligned out and otherwise falls back to HDN_NORTH_DIRECT.  All variants meet the same parity bar; they
+ * differ in rounding: the direct kernels accumulate each output in one fixed fp32 chain (planes independent), the
+ * FFT kernel has a smaller error against float64 but transforms planes in pairs, so a plane's rounding depends on
+ * its neighbour's magnitude.  For tests, benchmarks and A/B runs.
+ */
+#define HDN_NORTH_FFT 0          /* 64x64 fp32 FFT per pair of planes (default)        */
+#define HDN_NORTH_DIRECT 1       /* packed-FMA direct sum, zero taps skipped            */
+#define HDN_NORTH_DIRECT_DENSE 2 /* packed-FMA direct sum, every tap                    */
+#define HDN_NORTH_MFMA 3         /* split-bf16 matrix-core direct sum                   */
+int hdn_xcorr_north_variant(int v);
+
+/*
  * Depthwise (per batch, per channel) valid cross-correlation, stride 1, no flip:
  *   out[b,c,i,j] = sum_{u,v} x[b,c,i+u,j+v] * k[b,c,u,v]
  *   x[B,C,Hx,Wx], k[B,C,Hk,Wk] -> out[B,C,Hx-Hk+1,Wx-Wk+1]

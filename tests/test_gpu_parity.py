@@ -56,13 +56,18 @@ def check_xcorr(got, x, k, ref, circular, name):
 def test_xcorr_depthwise_golden(dev):
     g = load_golden("xcorr_depthwise")
     seen = set()
-    for n in cases(g):
-        x, k = g[n + "__x"], g[n + "__k"]
-        y = hdn_amd.xcorr_depthwise(T(x).to(dev), T(k).to(dev))
-        seen.add(X.last_variant())
-        check_xcorr(y, x, k, g[n + "__y"], False, n)
-    # the fixtures exercise the three specialised kernels and the generic one
-    assert {"prod_29x29_5x5", "f1_35x35_5x5", "north_61x61_31x31", "generic_lds"} <= seen, seen
+    for variant in ("fft", "direct", "dense"):  # only the 31x31 (x) 61x61 fixtures depend on it
+        with X.north_variant(variant):
+            for n in cases(g):
+                x, k = g[n + "__x"], g[n + "__k"]
+                if variant != "fft" and x.shape[-1] != 61:
+                    continue
+                y = hdn_amd.xcorr_depthwise(T(x).to(dev), T(k).to(dev))
+                seen.add(X.last_variant())
+                check_xcorr(y, x, k, g[n + "__y"], False, n + "/" + variant)
+    assert X.current_north_variant() == "fft"
+    # the fixtures exercise the specialised kernels (both families for the north-star shape) and the generic one
+    assert {"prod_29x29_5x5", "f1_35x35_5x5", "north_61x61_31x31", "north_fft_61x61_31x31", "generic_lds"} <= seen, seen
 
 
 def test_xcorr_depthwise_sampled_full_channel(dev):
@@ -98,6 +103,43 @@ def test_xcorr_ragged_plane_counts_vs_oracle(dev, shape):
     x, k = relu_normal(r, (B, C, Hx, Wx)), relu_normal(r, (B, C, Hk, Wk))
     y = hdn_amd.xcorr_depthwise(T(x).to(dev), T(k).to(dev))
     check_xcorr(y, x, k, O.xcorr_depthwise(T(x), T(k)).numpy(), False, str(shape))
+
+
+@pytest.mark.parametrize("planes", [(1, 1), (1, 2), (1, 3), (1, 4), (3, 5), (2, 8), (1, 33), (5, 205), (8, 256)])
+@pytest.mark.parametrize("variant", ["fft", "direct"])
+def test_xcorr_north_plane_counts(dev, planes, variant):
+    """31x31 (x) 61x61 for odd / even / tiny plane counts (the FFT kernel works on PAIRS of planes, its last pair(s)
+    take a guarded path in an extra workgroup) up to several persistent passes; signed and post-ReLU data."""
+    B, C = planes
+    r = np.random.default_rng(1000 * B + C)
+    for signed in (False, True):
+        x = r.standard_normal((B, C, 61, 61), dtype=np.float32)
+        k = r.standard_normal((B, C, 31, 31), dtype=np.float32)
+        if not signed:
+            x, k = np.maximum(x, 0), np.maximum(k, 0)
+        with X.north_variant(variant):
+            y = hdn_amd.xcorr_depthwise(T(x).to(dev), T(k).to(dev))
+            assert X.last_variant() == ("north_fft_61x61_31x31" if variant == "fft" else "north_61x61_31x31")
+            assert torch.equal(y, hdn_amd.xcorr_depthwise(T(x).to(dev), T(k).to(dev)))  # deterministic
+        check_xcorr(y, x, k, O.xcorr_depthwise(T(x), T(k)).numpy(), False, f"{planes} {variant} signed={signed}")
+
+
+def test_xcorr_north_fft_pair_crosstalk_is_rounding_only(dev):
+    """The FFT kernel packs planes (2p, 2p+1) into one complex transform.  A plane next to a 1000x larger one must
+    still meet the bound relative to the PAIR's magnitude, and an all-zero kernel plane gives |out| at rounding level
+    of the partner (the direct kernels give exact zeros: test_xcorr_multi_eight_problems_and_limits)."""
+    r = np.random.default_rng(77)
+    x, k = relu_normal(r, (1, 6, 61, 61)), relu_normal(r, (1, 6, 31, 31))
+    x[0, 1] *= 1000.0
+    k[0, 2] = 0
+    with X.north_variant("fft"):
+        y = hdn_amd.xcorr_depthwise(T(x).to(dev), T(k).to(dev)).cpu().numpy()
+    truth = O.xcorr_depthwise_f64(x, k)
+    mag = O.xcorr_depthwise_f64(np.abs(x), np.abs(k))
+    pair_mag = np.maximum(mag[:, 0::2], mag[:, 1::2]).repeat(2, axis=1)  # per pair of planes
+    assert np.all(np.abs(y - truth) <= 1e-4 + 2e-6 * pair_mag.max(axis=(2, 3), keepdims=True))
+    assert np.abs(y[0, 2]).max() <= 2e-6 * mag[0, 3].max()
+    assert np.abs(y[0, 0] - truth[0, 0]).max() <= 2e-6 * mag[0, 1].max()  # small plane beside the large one
 
 
 @pytest.mark.parametrize("shape", [(3, 7, 13, 13, 13, 13), (1, 1, 13, 13, 13, 13), (2, 3, 9, 12, 4, 6), (1, 2, 5, 5, 9, 9)])
@@ -175,7 +217,9 @@ def test_xcorr_multi_eight_problems_and_limits(dev):
     k = T(relu_normal(r, (1, 4, 31, 31))).to(dev)
     k[0, 1] = 0
     k[0, 2, 3, 4] = -0.0
-    y = hdn_amd.xcorr_depthwise(x, k)
+    with X.north_variant("direct"):
+        y = hdn_amd.xcorr_depthwise(x, k)
+    assert X.last_variant() == "north_61x61_31x31"
     assert bool((y[0, 1] == 0).all())
     check_xcorr(y, x.cpu().numpy(), k.cpu().numpy(), O.xcorr_depthwise(x.cpu(), k.cpu()).numpy(), False, "zero taps")
 
@@ -211,7 +255,7 @@ def test_xcorr_multi_launch_equals_single(dev):
         assert torch.equal(o, hdn_amd.xcorr_depthwise_circular(x, k))
 
 
-def _full_size_properties(dev, fn, ofn, shape_x, shape_k, signed):
+def _full_size_properties(dev, fn, ofn, shape_x, shape_k, signed, paired=False):
     """BASELINE full sizes (B=64, C=256): size-independent properties + oracle on a few sampled planes."""
     gen = torch.Generator(device="cpu").manual_seed(20260928)
     mk = (lambda s: torch.randn(s, generator=gen)) if signed else (lambda s: torch.randn(s, generator=gen).clamp_min(0))
@@ -238,9 +282,15 @@ def _full_size_properties(dev, fn, ofn, shape_x, shape_k, signed):
     kz = kd.clone()
     kz[5, 17] = 0
     yz = fn(xd, kz)
-    assert bool((yz[5, 17] == 0).all())
-    yz[5, 17] = y[5, 17]
-    assert torch.equal(yz, y)
+    if not paired:
+        assert bool((yz[5, 17] == 0).all())
+        yz[5, 17] = y[5, 17]
+        assert torch.equal(yz, y)
+    else:  # planes (5,16) and (5,17) share one complex transform: they move by rounding, everything else not at all
+        assert float(yz[5, 17].abs().max()) <= 2e-6 * float(mag[5, 16].max())
+        assert float((yz[5, 16] - y[5, 16]).abs().max()) <= 1e-4 + 2e-6 * float(mag[5, 16].max())
+        yz[5, 16:18] = y[5, 16:18]
+        assert torch.equal(yz, y)
 
 
 def test_xcorr_full_size_production(dev):
@@ -248,9 +298,12 @@ def test_xcorr_full_size_production(dev):
     assert X.last_variant() == "prod_29x29_5x5"
 
 
-def test_xcorr_full_size_north_star(dev):
-    _full_size_properties(dev, hdn_amd.xcorr_depthwise, O.xcorr_depthwise, (64, 256, 61, 61), (64, 256, 31, 31), False)
-    assert X.last_variant() == "north_61x61_31x31"
+@pytest.mark.parametrize("variant", ["fft", "direct"])
+def test_xcorr_full_size_north_star(dev, variant):
+    with X.north_variant(variant):
+        _full_size_properties(dev, hdn_amd.xcorr_depthwise, O.xcorr_depthwise, (64, 256, 61, 61), (64, 256, 31, 31), False,
+                              paired=(variant == "fft"))
+        assert X.last_variant() == ("north_fft_61x61_31x31" if variant == "fft" else "north_61x61_31x31")
 
 
 def test_xcorr_north_matrix_core_variant(dev):
