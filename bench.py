@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle timing (profiling runs)")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the per-kernel breakdown after the timed region")
     ap.add_argument("--only-north", action="store_true", help="step = the north-star correlation only (profiling aid)")
+    ap.add_argument("--north", choices=["fft", "direct", "dense", "mfma"], default=None,
+                    help="kernel for the 31x31 (x) 61x61 correlation (default: the library's default, fft); A/B runs")
     ap.add_argument("--workload", choices=["kernels", "full"], default="kernels",
                     help="kernels = BASELINE configs[1] (default); full = configs[2]: the whole HomoModelBuilder head "
                          "incl. the PyTorch-ROCm ResNet-34 trunk on 64 pairs per GPU, then the offsets all-gather")
@@ -110,6 +112,8 @@ def main():
     from hdn_amd import share_feature as SF
     from hdn_amd import xcorr as X
 
+    if args.north:
+        X.north_variant(args.north)  # process-wide
     d = make_inputs(dev, rank)
     torch.manual_seed(SEED)
     sf = hdn_amd.PreShareFeature().eval()
@@ -201,14 +205,17 @@ def main():
 
     # HBM traffic of the dominant kernel: measured with rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs,
     # gfx950 x2 correction on the 16 B/lane stream) and committed under profiles/; bench.py cannot collect PMCs itself.
-    traffic, traffic_note = None, "no committed PMC measurement found"
+    X.xcorr_depthwise(d["north_x"], d["north_k"])
+    north_variant = X.last_variant()
+    north_kernel = {"north_fft_61x61_31x31": "xcorr_north_fft2_kernel", "north_61x61_31x31": "xcorr_north_kernel",
+                    "north_mfma_61x61_31x31": "xcorr_north_mfma_kernel"}[north_variant]
+    traffic, traffic_note = None, "no committed PMC measurement found for " + north_kernel
     try:
         with open(os.path.join(ROOT, "profiles", "round1_pmc_hbm_traffic.json")) as f:
             for name, rec in json.load(f).items():
-                if "xcorr_north_kernel" in name and "traffic_calibrated_bytes" in rec:
+                if north_kernel in name and "traffic_calibrated_bytes" in rec:
                     traffic = rec["traffic_calibrated_bytes"]
-                    traffic_note = ("profiles/round1_pmc_hbm_traffic.txt: 2*(FETCH_SIZE - scalar tap bytes) + scalar tap bytes + WRITE_SIZE, "
-                                    "bytes per launch; FETCH_SIZE x2 on the whole counter would give %.0f" % (rec["fetch_x2_bytes"] + rec["write_counter_bytes"]))
+                    traffic_note = rec.get("how", "profiles/round1_pmc_hbm_traffic.txt")
     except (OSError, ValueError):
         pass
 
@@ -235,7 +242,7 @@ def main():
             "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective except the offsets all-gather",
         },
         "roofline": {
-            "kernel": "hdn::xcorr_north_kernel (hdn_xcorr_depthwise_f32, 31x31 (x) 61x61)",
+            "kernel": "hdn::%s (hdn_xcorr_depthwise_f32, 31x31 (x) 61x61, variant %s)" % (north_kernel, north_variant),
             "bound": "hbm",
             "achieved": north_gbps,
             "peak": HBM_PEAK_GBPS,
@@ -245,13 +252,18 @@ def main():
             "traffic_source": traffic_note,
             "algorithmic_bytes_per_launch": NORTH_BYTES_PER_PAIR * PAIRS,
             "avg_launch_ms": north_ms,
-            "note": ("exact-fp32 depthwise correlation at 81.8 FLOP/B is fp32-FMA-bound (ridge 19.7 FLOP/B), and the packed-FMA pipe "
-                     "is saturated at the clock the power budget allows (profiles/round1_pmc_sq_north.txt): see valu_*"),
-            "valu_achieved_tflops": north_tflops,
-            "valu_peak_tflops": FP32_VALU_PEAK_TFLOPS,
-            "valu_frac": north_tflops / FP32_VALU_PEAK_TFLOPS,
         },
     }
+    if north_variant == "north_fft_61x61_31x31":
+        result["roofline"]["note"] = (
+            "64x64 fp32 FFT per pair of planes in registers + LDS (~1,650 packed VALU ops per plane instead of the direct "
+            "sum's 7,688); one wave per SIMD (33 KB of LDS per wave), issue-bound: DESIGN.md section 4/6")
+    else:
+        result["roofline"].update({
+            "note": ("direct fp32 sum at 81.8 FLOP/B is fp32-FMA-bound (ridge 19.7 FLOP/B), and the packed-FMA pipe is "
+                     "saturated at the clock the power budget allows (profiles/round1_pmc_sq_north.txt): see valu_*"),
+            "valu_achieved_tflops": north_tflops, "valu_peak_tflops": FP32_VALU_PEAK_TFLOPS,
+            "valu_frac": north_tflops / FP32_VALU_PEAK_TFLOPS})
 
     if rank == 0 and not args.no_breakdown and not args.only_north:
         result["kernels"] = breakdown(d, imgs2, tmpl, folded, X, SF, G)

@@ -39,7 +39,7 @@ constexpr int HX = 61, HK = 31, HO = 31;
 constexpr int XPL = HX * HX, KPL = HK * HK, OPL = HO * HO;   // 3721, 961, 961
 constexpr int XQ = 30, KQ = 8;                 // 16-byte chunks per lane for the x / k window of a pair
 constexpr int KSTAGE = 4096;                   // float offset of the k staging area (beyond spectrum rows 0..30)
-constexpr int LDS_BYTES = N * RS * 8;          // 33,280
+constexpr int LDS_BYTES = HX * RS * 8;         // 31,720: spectrum rows 61..63 are never stored -> 5 waves per CU
 
 NF_DEV constexpr int bitrev(int p, int bits) {
   int r = 0;
