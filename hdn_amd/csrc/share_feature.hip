@@ -10,6 +10,8 @@
 // the image are forced to 0 (they are not "what the conv would give on an extended image").
 // The 396 weights + 26 BN scale/shift values are wave-uniform: they are read through the
 // scalar cache (layout: even/odd input-channel pairs adjacent, see include/hdn_hip.h).
+#include <cstdlib>
+
 #include "hdn_common.h"
 
 namespace hdn {
@@ -138,20 +140,23 @@ __device__ __forceinline__ const cfloat2v* opaque_const(const float2v* p) {
   return (const cfloat2v*)a;
 }
 
-namespace sfw {
-constexpr int R = 4, CS = 130;                 // output rows per workgroup; LDS row stride (cols -1..128)
-constexpr int IN_H = R + 6, A_H = R + 4, B_H = R + 2;
-constexpr int IN_N = IN_H * CS, A_N = A_H * CS, B_N = B_H * CS;
-constexpr int W_N = 424;                       // parameter block staged in LDS (422 floats, padded)
-constexpr int LDS_FLOATS = IN_N + 2 * (2 * A_N) + 2 * (4 * B_N) + W_N;
-}  // namespace sfw
+template <int R_>
+struct Sfw {
+  static constexpr int R = R_, CS = 130;       // output rows per workgroup (even); LDS row stride (cols -1..128)
+  static constexpr int IN_H = R + 6, A_H = R + 4, B_H = R + 2;
+  static constexpr int IN_N = IN_H * CS, A_N = A_H * CS, B_N = B_H * CS;
+  static constexpr int W_N = 424;              // parameter block staged in LDS (422 floats, padded)
+  static constexpr int LDS_FLOATS = IN_N + 2 * (2 * A_N) + 2 * (4 * B_N) + W_N;
+  static constexpr int LDS_BYTES = LDS_FLOATS * 4;
+};
 
-__device__ __forceinline__ void sfw_fetch(float (&pin)[sfw::IN_H / 2], const float* __restrict__ img, int tile,
+template <class S>
+__device__ __forceinline__ void sfw_fetch(float (&pin)[S::IN_H / 2], const float* __restrict__ img, int tile,
                                           int tiles_per_img, int H, int W, int c, int rr) {
-  const int b = tile / tiles_per_img, r0 = (tile - b * tiles_per_img) * sfw::R;
+  const int b = tile / tiles_per_img, r0 = (tile - b * tiles_per_img) * S::R;
   const float* __restrict__ src = img + size_t(b) * H * W;
 #pragma unroll
-  for (int q = 0; q < sfw::IN_H / 2; ++q) {
+  for (int q = 0; q < S::IN_H / 2; ++q) {
     const int gr = r0 - 3 + 2 * q + rr;
     const bool ok = gr >= 0 && gr < H && c < W;
     pin[q] = src[ok ? gr * W + c : 0];
@@ -159,14 +164,17 @@ __device__ __forceinline__ void sfw_fetch(float (&pin)[sfw::IN_H / 2], const flo
   }
 }
 
-// Persistent: a workgroup walks tiles (image b, 4-row block); the next tile's 10 input rows are in flight in registers
-// while the current tile runs its three layers out of LDS.
+// Persistent: a workgroup walks tiles (image b, R-row block); the next tile's R+6 input rows are in flight in registers
+// while the current tile runs its three layers out of LDS.  R = 8 (76 KB of LDS, 2 workgroups per CU) recomputes
+// 1.25x the layer-2 rows and 1.5x the layer-1 rows; R = 4 (48 KB, 3 per CU) 1.5x and 2x.
+template <int R_>
 __global__ __launch_bounds__(HDN_BLOCK) void share_feature_w128_kernel(const float* __restrict__ img,
                                                                        const float* __restrict__ prm,
                                                                        float* __restrict__ out, int H, int W,
                                                                        int tiles_per_img, int total_tiles) {
-  using namespace sfw;
-  __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
+  using S = Sfw<R_>;
+  constexpr int R = S::R, CS = S::CS, IN_H = S::IN_H, A_H = S::A_H, B_H = S::B_H, IN_N = S::IN_N, A_N = S::A_N, B_N = S::B_N;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_in = smem;
   float2v* s_a = reinterpret_cast<float2v*>(smem + IN_N);            // [2][A_H][CS]
   float2v* s_b = reinterpret_cast<float2v*>(smem + IN_N + 4 * A_N);  // [4][B_H][CS]
@@ -186,7 +194,7 @@ __global__ __launch_bounds__(HDN_BLOCK) void share_feature_w128_kernel(const flo
   }
   float pin[IN_H / 2];
   int tile = blockIdx.x;
-  if (tile < total_tiles) sfw_fetch(pin, img, tile, tiles_per_img, H, W, c, rr);
+  if (tile < total_tiles) sfw_fetch<S>(pin, img, tile, tiles_per_img, H, W, c, rr);
 
 #pragma unroll 1
   for (; tile < total_tiles; tile += gridDim.x) {
@@ -196,7 +204,7 @@ __global__ __launch_bounds__(HDN_BLOCK) void share_feature_w128_kernel(const flo
   // input rows r0-3 .. r0+R+2 (columns 0..127 -> LDS columns 1..128; zero outside the image)
 #pragma unroll
   for (int q = 0; q < IN_H / 2; ++q) s_in[(2 * q + rr) * CS + c + 1] = pin[q];
-  if (tile + (int)gridDim.x < total_tiles) sfw_fetch(pin, img, tile + gridDim.x, tiles_per_img, H, W, c, rr);
+  if (tile + (int)gridDim.x < total_tiles) sfw_fetch<S>(pin, img, tile + gridDim.x, tiles_per_img, H, W, c, rr);
   __syncthreads();
 
   // ---- layer 1: 1 -> 4 at rows r0-2 .. r0+R+1 -------------------------------------------
@@ -297,6 +305,27 @@ __global__ __launch_bounds__(HDN_BLOCK) void share_feature_w128_kernel(const flo
   }  // tile loop (the next iteration's first barrier orders this tile's LDS reads before the next tile's writes)
 }
 
+template <int R_>
+static int launch_sf_w128(const float* img, const float* folded, float* out, int B, int H, int W, hipStream_t stream) {
+  using S = Sfw<R_>;
+  static bool attr_done = false;  // dynamic LDS above 64 KiB needs the opt-in once per kernel
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&share_feature_w128_kernel<R_>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS_BYTES);
+    if (e != hipSuccess) return -(1000 + (int)e);
+    attr_done = true;
+  }
+  const int tiles_per_img = cdiv(H, S::R);
+  const long long total = (long long)tiles_per_img * B;
+  if (total > 0x7fffffffLL) return HDN_E_LIMIT;
+  const int per_cu = 163840 / S::LDS_BYTES;  // persistent: as many workgroups as fit a CU's LDS x 256 CUs
+  const int cap = 256 * (per_cu < 1 ? 1 : per_cu);
+  const int grid = (int)(total < cap ? total : cap);
+  hipLaunchKernelGGL(share_feature_w128_kernel<R_>, dim3(grid), dim3(HDN_BLOCK), S::LDS_BYTES, stream, img, folded, out, H, W,
+                     tiles_per_img, (int)total);
+  return launch_status();
+}
+
 }  // namespace hdn
 
 extern "C" int hdn_share_feature_f32(const float* img, const float* folded, float* out, int B, int H, int W,
@@ -306,13 +335,9 @@ extern "C" int hdn_share_feature_f32(const float* img, const float* folded, floa
   if (B > 65535 || (long long)H * W > 0x7fffffffLL / 4) return HDN_E_LIMIT;
   if (out == img) return HDN_E_ALIAS;
   if (W <= 128) {
-    const int tiles_per_img = hdn::cdiv(H, hdn::sfw::R);
-    const long long total = (long long)tiles_per_img * B;
-    if (total > 0x7fffffffLL) return HDN_E_LIMIT;
-    const int grid = (int)(total < 768 ? total : 768);  // persistent: 3 workgroups per CU x 256 CUs
-    hipLaunchKernelGGL(hdn::share_feature_w128_kernel, dim3(grid), dim3(HDN_BLOCK), 0, static_cast<hipStream_t>(stream),
-                       img, folded, out, H, W, tiles_per_img, (int)total);
-    return hdn::launch_status();
+    static const int rows = [] { const char* e = getenv("HDN_SF_ROWS"); return (e && e[0] == '8') ? 8 : 4; }();  // A/B switch: 8 rows measured 5 % slower (2 workgroups per CU)
+    if (rows == 8 && H > 8) return hdn::launch_sf_w128<8>(img, folded, out, B, H, W, static_cast<hipStream_t>(stream));
+    return hdn::launch_sf_w128<4>(img, folded, out, B, H, W, static_cast<hipStream_t>(stream));
   }
   dim3 grid(hdn::cdiv(W, hdn::SF_COLS), hdn::cdiv(H, hdn::SF_ROWS), B);
   if (grid.y > 65535) return HDN_E_LIMIT;

@@ -124,6 +124,19 @@ def test_xcorr_north_plane_counts(dev, planes, variant):
         check_xcorr(y, x, k, O.xcorr_depthwise(T(x), T(k)).numpy(), False, f"{planes} {variant} signed={signed}")
 
 
+def test_xcorr_north_multi_problem_launch(dev):
+    """Several 31x31 (x) 61x61 problems through the multi entry point (the FFT kernel runs them back to back)."""
+    r = np.random.default_rng(404)
+    xs = [T(relu_normal(r, (2, 9, 61, 61))).to(dev) for _ in range(3)]
+    ks = [T(relu_normal(r, (2, 9, 31, 31))).to(dev) for _ in range(3)]
+    for variant in ("fft", "direct"):
+        with X.north_variant(variant):
+            outs = hdn_amd.xcorr_depthwise_multi(xs, ks)
+            for x, k, o in zip(xs, ks, outs):
+                assert torch.equal(o, hdn_amd.xcorr_depthwise(x, k))
+                check_xcorr(o, x.cpu().numpy(), k.cpu().numpy(), O.xcorr_depthwise(x.cpu(), k.cpu()).numpy(), False, variant)
+
+
 def test_xcorr_north_fft_pair_crosstalk_is_rounding_only(dev):
     """The FFT kernel packs planes (2p, 2p+1) into one complex transform.  A plane next to a 1000x larger one must
     still meet the bound relative to the PAIR's magnitude, and an all-zero kernel plane gives |out| at rounding level
