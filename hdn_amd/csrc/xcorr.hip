@@ -850,6 +850,115 @@ __global__ __launch_bounds__(HDN_BLOCK) void xcorr_circ13_kernel(XcorrPtrs P, in
   else copy_l2g(so, og, np * PL, tid);
 }
 
+// Same arithmetic, different work split: a workgroup owns 256 consecutive OUTPUT ROWS of the [planes*13, 13] result
+// (one per lane: every lane busy, where 4 planes of 13 rows per wave leave 12 of 64 idle) and stages the 20-21 planes
+// those rows belong to.  Its outputs are one contiguous 16-byte-aligned range; planes cut by a workgroup border are
+// staged by both neighbours (+5 % reads, mostly L2 hits).
+namespace circ13r {
+constexpr int N = 13, PL = N * N, ROWS = HDN_BLOCK;
+constexpr int MAXP = (ROWS + N - 2) / N + 1;          // 21 planes can be touched by 256 consecutive rows
+constexpr int WIN = ((MAXP * PL + 3) / 4 + 1) * 4;    // 16-byte aligned window incl. up to 3 floats of head slack: 3556
+constexpr int WIN4 = WIN / 4, WITER = (WIN4 + HDN_BLOCK - 1) / HDN_BLOCK;
+}  // namespace circ13r
+
+__global__ __launch_bounds__(HDN_BLOCK, 3) void xcorr_circ13r_kernel(XcorrPtrs P, int planes) {
+  using namespace circ13r;
+  __shared__ __attribute__((aligned(16))) float smem[2 * WIN];
+  float* sx = smem;
+  float* sk = smem + WIN;
+
+  const int tid = threadIdx.x;
+  const int prob = blockIdx.y;
+  const long long total_rows = (long long)planes * N, total = (long long)planes * PL;
+  const long long row0 = (long long)blockIdx.x * ROWS;
+  const int nrows = (int)min((long long)ROWS, total_rows - row0);
+  const int p0 = (int)(row0 / N), p1 = (int)min((row0 + ROWS - 1) / N, (long long)planes - 1);
+  const int np = p1 - p0 + 1;
+  const float* xg = P.x[prob];
+  const float* kg = P.k[prob];
+  const long long base = (long long)p0 * PL;
+  const int head = (int)(base & 3);
+  const long long first = base - head;
+
+  if (aligned16(xg) && aligned16(kg) && first + WIN <= total) {  // all 16-byte loads of both windows in flight at once
+    const float4* x4 = reinterpret_cast<const float4*>(xg + first);
+    const float4* k4 = reinterpret_cast<const float4*>(kg + first);
+    float4 rx[WITER], rk[WITER];
+#pragma unroll
+    for (int q = 0; q < WITER; ++q) {
+      const int i = min(tid + q * HDN_BLOCK, WIN4 - 1);
+      rx[q] = x4[i];
+      rk[q] = k4[i];
+    }
+#pragma unroll
+    for (int q = 0; q < WITER; ++q) {
+      const int i = tid + q * HDN_BLOCK;
+      if (i < WIN4) {
+        reinterpret_cast<float4*>(sx)[i] = rx[q];
+        reinterpret_cast<float4*>(sk)[i] = rk[q];
+      }
+    }
+  } else {
+    for (int i = tid; i < np * PL; i += HDN_BLOCK) {
+      sx[head + i] = xg[base + i];
+      sk[head + i] = kg[base + i];
+    }
+  }
+  __syncthreads();
+
+  const bool live = tid < nrows;
+  const long long g = row0 + min(tid, nrows - 1);
+  const int plane = (int)(g / N);
+  const int i = (int)(g - (long long)plane * N);  // output row
+  const float* xs = sx + head + (plane - p0) * PL;
+  const float* ks = sk + head + (plane - p0) * PL;
+  float2v accE[7], accO[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) accE[j] = accO[j] = float2v{0.f, 0.f};
+  int r = i + 7;  // source row of padded row i + u, u = 0
+  r = r >= N ? r - N : r;
+#pragma unroll 1
+  for (int u = 0; u < N; ++u) {
+    const float* xr = xs + r * N;
+    const float* kr = ks + u * N;
+    float2v X[7], K[7];  // (x[2m], x[2m+1]) and (k[2m], k[2m+1]); the 14th element of each is never used
+#pragma unroll
+    for (int m = 0; m < 7; ++m) {
+      X[m] = float2v{xr[2 * m], xr[2 * m + 1]};
+      K[m] = float2v{kr[2 * m], kr[2 * m + 1]};
+    }
+    const float2v lo = X[0].xx, hi = X[6].xx;  // replicated columns: (x0,x0) and (x12,x12)
+    auto R = [&](int n) -> float2v { return n < 3 ? lo : (n < 9 ? X[n - 3] : hi); };
+#pragma unroll
+    for (int w = 0; w < 7; ++w) {
+      {
+        const float2v kk = K[w].xx;  // tap 2w
+#pragma unroll
+        for (int j = 0; j < 7; ++j) accE[j] = __builtin_elementwise_fma(R(j + w), kk, accE[j]);
+      }
+      if (w < 6) {
+        const float2v kk = K[w].yy;  // tap 2w+1
+#pragma unroll
+        for (int j = 0; j < 7; ++j) accO[j] = __builtin_elementwise_fma(R(j + w), kk, accO[j]);
+      }
+    }
+    r = (r + 1 == N) ? 0 : r + 1;
+  }
+  __syncthreads();  // every lane is done with sx: the output rows are staged over it
+  if (live) {
+    float* os = sx + tid * N;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      os[2 * j] = accE[j].x + accO[j].y;
+      if (j < 6) os[2 * j + 1] = accE[j].y + accO[j + 1].x;
+    }
+  }
+  __syncthreads();
+  float* og = P.out[prob] + row0 * N;
+  if (nrows == ROWS && aligned16(og)) copy_l2g_full<ROWS * N>(sx, og, tid);
+  else copy_l2g(sx, og, nrows * N, tid);
+}
+
 // ---------------------------------------------------------------------------------------
 // generic runtime-shape kernel: one workgroup per plane
 // ---------------------------------------------------------------------------------------
@@ -1009,6 +1118,13 @@ static int launch_prod29(const XcorrPtrs& P, int n, int planes, hipStream_t stre
 }
 
 static int launch_circ13(const XcorrPtrs& P, int n, int planes, hipStream_t stream) {
+  static const bool old = [] { const char* e = getenv("HDN_CIRC13_PLANES"); return e && e[0] == '1'; }();  // A/B switch
+  if (!old) {
+    const long long blocks = ((long long)planes * circ13r::N + circ13r::ROWS - 1) / circ13r::ROWS;
+    hipLaunchKernelGGL(xcorr_circ13r_kernel, dim3((unsigned)blocks, n), dim3(HDN_BLOCK), 0, stream, P, planes);
+    g_last_variant = "circ13";
+    return launch_status();
+  }
   hipLaunchKernelGGL(xcorr_circ13_kernel, dim3(cdiv(planes, circ13::PPB), n), dim3(HDN_BLOCK), 0, stream, P, planes);
   g_last_variant = "circ13";
   return launch_status();
