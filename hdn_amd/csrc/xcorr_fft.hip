@@ -23,6 +23,8 @@
 // Waves are autonomous (workgroup = 1 wave, 33 KB LDS, 4 per CU) and persistent.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "../../include/hdn_hip.h"
 #include "fft_twiddles.h"
 #include "hdn_common.h"
@@ -611,7 +613,7 @@ NF_DEV cf cmul_tw(cf c) {
 // that runs the general v1 path on the remaining pair(s) meanwhile.
 __global__ __launch_bounds__(64) void xcorr_north_fft2_kernel(const float* __restrict__ x, const float* __restrict__ k,
                                                               float* __restrict__ out, int npairs, int nmain, int planes,
-                                                              const nfft::cf* __restrict__ tab) {
+                                                              int clamp_from, const nfft::cf* __restrict__ tab) {
   using namespace nf2;
   extern __shared__ __align__(16) float smem[];
   if ((int)blockIdx.x >= nmain) {
@@ -635,32 +637,53 @@ __global__ __launch_bounds__(64) void xcorr_north_fft2_kernel(const float* __res
 
   f4v Rx[XQ], Rk[KQ];  // the next pair's global data: AGPRs
 
+  // Pairs >= clamp_from have a load window that leaves the tensor; the launcher only sends them here when the tensor
+  // ends on a 16-byte boundary, so redirecting the chunks beyond the end to the last chunk inside is all it takes
+  // (what they deliver is never read).
+  const long long xlast = ((long long)planes * XPL - 4) * 4, klast = ((long long)planes * KPL - 4) * 4;  // byte offsets
   auto fetch_x = [&](int p) NF2_LAMBDA {
     const long long first = ((long long)p * (2 * XPL)) & ~3LL;
-    sfor<0, XQ>([&](auto Qi) NF2_LAMBDA {
-      constexpr int q = decltype(Qi)::value;
-      gload128_to_agpr<(q & 3) * 1024>(Rx[q], voff, reinterpret_cast<const char*>(x + first) + (q >> 2) * 4096);
-    });
+    if (p < clamp_from) {
+      sfor<0, XQ>([&](auto Qi) NF2_LAMBDA {
+        constexpr int q = decltype(Qi)::value;
+        gload128_to_agpr<(q & 3) * 1024>(Rx[q], voff, reinterpret_cast<const char*>(x + first) + (q >> 2) * 4096);
+      });
+    } else {
+      const uint32_t lim = (uint32_t)(xlast - first * 4);
+      sfor<0, XQ>([&](auto Qi) NF2_LAMBDA {
+        constexpr int q = decltype(Qi)::value;
+        gload128_to_agpr<0>(Rx[q], min(voff + q * 1024, lim), reinterpret_cast<const char*>(x + first));
+      });
+    }
   };
   auto fetch_k = [&](int p) NF2_LAMBDA {
     const long long first = ((long long)p * (2 * KPL)) & ~3LL;
-    sfor<0, KQ>([&](auto Qi) NF2_LAMBDA {
-      constexpr int q = decltype(Qi)::value;
-      gload128_to_agpr<(q & 3) * 1024>(Rk[q], voff, reinterpret_cast<const char*>(k + first) + (q >> 2) * 4096);
-    });
+    if (p < clamp_from) {
+      sfor<0, KQ>([&](auto Qi) NF2_LAMBDA {
+        constexpr int q = decltype(Qi)::value;
+        gload128_to_agpr<(q & 3) * 1024>(Rk[q], voff, reinterpret_cast<const char*>(k + first) + (q >> 2) * 4096);
+      });
+    } else {
+      const uint32_t lim = (uint32_t)(klast - first * 4);
+      sfor<0, KQ>([&](auto Qi) NF2_LAMBDA {
+        constexpr int q = decltype(Qi)::value;
+        gload128_to_agpr<0>(Rk[q], min(voff + q * 1024, lim), reinterpret_cast<const char*>(k + first));
+      });
+    }
   };
 
   int p = blockIdx.x;
   if (p >= npairs) return;
   fetch_x(p);
   fetch_k(p);
+  wait_vm0();
 
   for (; p < npairs; p += nmain) {
     const int offx = (int)(((long long)p * (2 * XPL)) & 3), offk = (int)(((long long)p * (2 * KPL)) & 3);
     const int pn = min(p + nmain, npairs - 1);  // (the last iteration re-fetches its own pair: harmless)
 
-    // ---- search pair: AGPRs -> LDS; refill the AGPRs with the next pair
-    wait_vm0();
+    // ---- search pair: AGPRs -> LDS; refill the AGPRs with the next pair.  (The loads were waited for before the
+    //      previous pair's stores were issued, see the end of the loop: nobody ever waits for a store.)
     sfor<0, XQ>([&](auto Qi) NF2_LAMBDA { constexpr int q = decltype(Qi)::value; lw128_from_agpr<q * 1024>(a_stash, Rx[q]); });
     fetch_x(pn);
 
@@ -685,13 +708,18 @@ __global__ __launch_bounds__(64) void xcorr_north_fft2_kernel(const float* __res
       });
       fft<6, -1, HX, 64>(v);
       if (lane < HX) {
-        sfor<0, 32>([&](auto F) NF2_LAMBDA {
+        cf sa[32], sb2[32];  // C(f) + conj C(63-f),  C(f) - conj C(63-f); each write trails its split by one element
+        sfor<0, 33>([&](auto F) NF2_LAMBDA {
           constexpr int f = decltype(F)::value;
-          cf sa, sb2;  // C(f) + conj C(63-f),  C(f) - conj C(63-f)
-          const cf cp = v[f], cq = v[63 - f];
-          asm volatile("v_pk_add_f32 %0, %2, %3 neg_hi:[0,1]\n\tv_pk_add_f32 %1, %2, %3 neg_lo:[0,1]"
-                       : "=&v"(sa), "=&v"(sb2) : "v"(cp), "v"(cq));
-          lw2x64<f, 32 + f>(a_row, sa, sb2);
+          if constexpr (f < 32) {
+            const cf cp = v[f], cq = v[63 - f];
+            cf a, b;
+            asm volatile("v_pk_add_f32 %0, %2, %3 neg_hi:[0,1]\n\tv_pk_add_f32 %1, %2, %3 neg_lo:[0,1]"
+                         : "=&v"(a), "=&v"(b) : "v"(cp), "v"(cq));
+            sa[f] = a;
+            sb2[f] = b;
+          }
+          if constexpr (f > 0) lw2x64<f - 1, 32 + f - 1>(a_row, sa[f - 1], sb2[f - 1]);
         });
       }
     }
@@ -838,6 +866,7 @@ __global__ __launch_bounds__(64) void xcorr_north_fft2_kernel(const float* __res
       cf w[16];
       sfor<0, 16>([&](auto Qi) NF2_LAMBDA { constexpr int q = decltype(Qi)::value; w[q] = lr64<q * 512>(a_col); });
       wait_lgkm<0>();
+      wait_vm0();  // the next pair's loads (issued most of an iteration ago) have landed; the stores below stay in flight
       sfor<0, 16>([&](auto Qi) NF2_LAMBDA {
         constexpr int q = decltype(Qi)::value;
         cf wq = w[q];
@@ -862,12 +891,17 @@ static int north_fft_full_pairs(int planes) {
 
 int launch_north_fft2(const float* x, const float* k, float* out, int planes, int max_blocks, hipStream_t stream) {
   const int npairs = (planes + 1) / 2, nfull = north_fft_full_pairs(planes);
-  if (nfull == 0) return launch_north_fft(x, k, out, planes, max_blocks, stream, 0);
   const nfft::cf* tab = north_fft_table();
   if (!tab) return -(1000 + (int)hipErrorInvalidSymbol);
-  const int nmain = nfull < max_blocks ? nfull : max_blocks;
-  const int grid = nmain + (nfull < npairs ? 1 : 0);
-  hipLaunchKernelGGL(xcorr_north_fft2_kernel, dim3(grid), dim3(64), nfft::LDS_BYTES, stream, x, k, out, nfull, nmain, planes, tab);
+  // planes % 4 == 0: both tensors end on a 16-byte boundary and every plane has a partner: the fast kernel takes every
+  // pair (the last windows are clamped).  Otherwise the pairs from `nfull` on go to one extra, guarded workgroup.
+  const bool all = (planes % 4 == 0) && planes >= 4;
+  const int nfast = all ? npairs : nfull;
+  if (nfast == 0) return launch_north_fft(x, k, out, planes, max_blocks, stream, 0);
+  const int nmain = nfast < max_blocks ? nfast : max_blocks;
+  const int grid = nmain + (nfast < npairs ? 1 : 0);
+  hipLaunchKernelGGL(xcorr_north_fft2_kernel, dim3(grid), dim3(64), nfft::LDS_BYTES, stream, x, k, out, nfast, nmain, planes,
+                     all ? nfull : 0x7fffffff, tab);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? HDN_OK : -(1000 + (int)e);
 }
