@@ -14,6 +14,8 @@ region starts):
     PreShareFeature(template,search) -> fused DLT+warp (offsets ~ N(0, 8^2) px) -> PreShareFeature(warped) -> 2 scores
     N > 1: one RCCL all-gather of the [64,8] corner offsets per rank (the path's only exchange step)
 Pairs are independent, so ranks hold disjoint batches (weak scaling) and `value` = N*64*K / max-over-ranks time.
+Before the W warm-up steps the GPU is kept busy for --prewarm-ms (150 ms, untimed, rank-local): from idle an MI355X needs
+~40 ms of sustained load to reach steady clocks, and the first ~80 steps would otherwise be timed on the ramp.
 
 The JSON line also carries
     "roofline"      for the dominant kernel (the 31x31 (x) 61x61 correlation), measured with events on the launch stream
@@ -52,8 +54,11 @@ WARP_BYTES_PER_PAIR = 2 * 4 * 127 * 127 + 64 + 36                 # 129,132
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--prewarm-ms", type=float, default=150.0,
+                    help="before the W warm-up steps, keep the GPU busy with untimed steps for this long: an idle MI355X "
+                         "needs ~40 ms of sustained load to reach its steady clocks (tools/exp_warmup.py: 0.48 -> 0.38 ms/step)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle timing (profiling runs)")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the per-kernel breakdown after the timed region")
     ap.add_argument("--only-north", action="store_true", help="step = the north-star correlation only (profiling aid)")
@@ -139,14 +144,14 @@ def main():
         full_data = {"org_imgs": d["imgs"], "input_tensors": d["imgs"], "h4p": d["h4p"],
                      "patch_indices": torch.arange(127 * 127, dtype=torch.float32, device=dev).repeat(PAIRS, 1)}
 
-    def step_full(record):
+    def step_full(record, collective):
         st = homo_stages(full_net, full_data)
-        if world > 1:
+        if world > 1 and collective:
             hdist.all_gather_offsets(st["x"], PAIRS * world)
 
-    def step(record):
+    def step(record, collective=True):
         if args.workload == "full":
-            return step_full(record)
+            return step_full(record, collective)
         if record:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -163,7 +168,7 @@ def main():
         pf = SF.share_feature(warped, folded)
         G.l1_score(feats[0, 1], pf[0, 0], 1.0 / (127 * 127))
         G.l1_score(feats[0, 1], feats[0, 0], 1.0 / (127 * 127))
-        if world > 1:
+        if world > 1 and collective:
             hdist.all_gather_offsets(d["off"], PAIRS * world)
 
     def fence():
@@ -172,6 +177,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    t_pre = time.perf_counter()
+    while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:  # clock / power ramp from idle, untimed
+        for _ in range(5):
+            step(False, collective=False)  # wall-clock bounded, so rank-local: no collective in here
+        torch.cuda.synchronize()
     for _ in range(args.warmup + (5 if args.workload == "full" else 0)):
         step(False)
     fence()
@@ -226,6 +236,7 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
+        "prewarm_ms": args.prewarm_ms,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
         "scaling": "weak",
