@@ -166,8 +166,7 @@ def main():
         feats = SF.share_feature(imgs2, folded).reshape(PAIRS, 2, 127, 127)
         Hm, warped = G.dlt_warp(d["h4p"], d["off"], tmpl)
         pf = SF.share_feature(warped, folded)
-        G.l1_score(feats[0, 1], pf[0, 0], 1.0 / (127 * 127))
-        G.l1_score(feats[0, 1], feats[0, 0], 1.0 / (127 * 127))
+        G.l1_score2(feats[0, 1], pf[0, 0], feats[0, 0], 1.0 / (127 * 127))
         if world > 1 and collective:
             hdist.all_gather_offsets(d["off"], PAIRS * world)
 
@@ -247,7 +246,7 @@ def main():
             "workload": ("north-star correlation only" if args.only_north else
                          "BASELINE configs[1]: batch=64 synthetic 127/255 pairs per GPU, 256-ch features; HIP kernels only: "
                          "1x xcorr 31x31(x)61x61 + 6x xcorr 5x5(x)29x29 + 6x circular xcorr 13x13(x)13x13 + "
-                         "3x PreShareFeature 127x127 + fused DLT/warp + 2 L1 scores" + (" + RCCL all-gather of [64,8] offsets" if world > 1 else "")),
+                         "3x PreShareFeature 127x127 + fused DLT/warp + the 2 L1 scores (one launch)" + (" + RCCL all-gather of [64,8] offsets" if world > 1 else "")),
             "pairs_per_gpu": PAIRS,
             "channels": C,
             "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective except the offsets all-gather",

@@ -211,9 +211,12 @@ __global__ __launch_bounds__(HDN_BLOCK) void dlt_warp_kernel(const float* __rest
 // two scores are 16 elements per thread: every load is issued before the first add, so the kernel costs one
 // L2 round trip instead of a chain of them.
 constexpr int L1_THREADS = 1024, L1_PER_THREAD = 16;
-__global__ __launch_bounds__(L1_THREADS) void l1_score_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                              float* __restrict__ out, int n, float scale) {
+// Workgroup j scores a against (j ? b1 : b0) into out[j]: the two scores of a frame are one launch.
+__global__ __launch_bounds__(L1_THREADS) void l1_score_kernel(const float* __restrict__ a, const float* __restrict__ b0,
+                                                              const float* __restrict__ b1, float* __restrict__ out, int n,
+                                                              float scale) {
   __shared__ float part[L1_THREADS / HDN_WAVE];
+  const float* __restrict__ b = blockIdx.x ? b1 : b0;
   float s = 0.f;
   for (int base = 0; base < n; base += L1_THREADS * L1_PER_THREAD) {
     float av[L1_PER_THREAD], bv[L1_PER_THREAD];
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(L1_THREADS) void l1_score_kernel(const float* __res
     float t = threadIdx.x < L1_THREADS / HDN_WAVE ? part[threadIdx.x] : 0.f;
 #pragma unroll
     for (int m = 8; m >= 1; m >>= 1) t += __shfl_xor(t, m, HDN_WAVE);
-    if (threadIdx.x == 0) out[0] = t * scale;
+    if (threadIdx.x == 0) out[blockIdx.x] = t * scale;
   }
 }
 
@@ -281,7 +284,15 @@ int hdn_dlt_warp_f32(const float* h4p, const float* off, const float* img, float
 int hdn_l1_score_f32(const float* a, const float* b, float* out, int n, float scale, void* stream) {
   if (!a || !b || !out) return HDN_E_NULL;
   if (n <= 0) return HDN_E_SHAPE;
-  hipLaunchKernelGGL(hdn::l1_score_kernel, dim3(1), dim3(hdn::L1_THREADS), 0, static_cast<hipStream_t>(stream), a, b, out,
+  hipLaunchKernelGGL(hdn::l1_score_kernel, dim3(1), dim3(hdn::L1_THREADS), 0, static_cast<hipStream_t>(stream), a, b, b, out,
+                     n, scale);
+  return hdn::launch_status();
+}
+
+int hdn_l1_score2_f32(const float* a, const float* b0, const float* b1, float* out2, int n, float scale, void* stream) {
+  if (!a || !b0 || !b1 || !out2) return HDN_E_NULL;
+  if (n <= 0) return HDN_E_SHAPE;
+  hipLaunchKernelGGL(hdn::l1_score_kernel, dim3(2), dim3(hdn::L1_THREADS), 0, static_cast<hipStream_t>(stream), a, b0, b1, out2,
                      n, scale);
   return hdn::launch_status();
 }

@@ -89,8 +89,7 @@ def track_proj(net, data, tmp_mask=None, cached_patch_1=None):
     st = homo_stages(net, data, cached_patch_1)
     # model_builder…:213-216 — sample 0 / channel 0 only, divided by the literal 127*127
     inv = 1.0 / (127 * 127)
-    score = G.l1_score(st["patch_2"][0, 0], st["pred_feat"][0, 0], inv)
-    score_simi = G.l1_score(st["patch_2"][0, 0], st["patch_1"][0, 0], inv)
+    score, score_simi = G.l1_score2(st["patch_2"][0, 0], st["pred_feat"][0, 0], st["patch_1"][0, 0], inv)
     return st["H_mat"], score, score_simi
 
 

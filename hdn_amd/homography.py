@@ -117,3 +117,18 @@ def l1_score(a: torch.Tensor, b: torch.Tensor, scale: float) -> torch.Tensor:
         rc = _lib.load().hdn_l1_score_f32(_lib.ptr(ac), _lib.ptr(bc), _lib.ptr(out), ac.numel(), float(scale), _lib.stream_ptr(dev))
     _lib.check(rc, "l1_score")
     return out[0]
+
+
+def l1_score2(a: torch.Tensor, b0: torch.Tensor, b1: torch.Tensor, scale: float):
+    """(sum |a - b0|, sum |a - b1|) * scale as two 0-dim device tensors from ONE launch: track_proj's two scores share
+    their first operand (model_builder_e2e_unconstrained_v2.py:213-216).  Bit-identical to two l1_score calls."""
+    dev = _lib.require_device(a, b0, b1)
+    if a.numel() != b0.numel() or a.numel() != b1.numel() or a.numel() == 0:
+        raise ValueError("l1_score2 needs three non-empty tensors of equal size")
+    ac, b0c, b1c = a.detach().contiguous(), b0.detach().contiguous(), b1.detach().contiguous()
+    out = torch.empty((2,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.load().hdn_l1_score2_f32(_lib.ptr(ac), _lib.ptr(b0c), _lib.ptr(b1c), _lib.ptr(out), ac.numel(), float(scale),
+                                           _lib.stream_ptr(dev))
+    _lib.check(rc, "l1_score2")
+    return out[0], out[1]

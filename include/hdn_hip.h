@@ -139,6 +139,10 @@ int hdn_dlt_warp_f32(const float* h4p, const float* off, const float* img, float
  */
 int hdn_l1_score_f32(const float* a, const float* b, float* out, int n, float scale, void* stream);
 
+/* Both scores of a frame in one launch: out2[j] = sum_i |a[i] - b_j[i]| * scale, j = 0, 1 (bit-identical to two calls
+ * of hdn_l1_score_f32). */
+int hdn_l1_score2_f32(const float* a, const float* b0, const float* b1, float* out2, int n, float scale, void* stream);
+
 /*
  * Log-polar resample of the search crop: out[b,c,a,r] = bilinear(img[b,c], p(a,r)) with
  *   g = (rho[r]*cos_theta[a] + polar[b,0], rho[r]*sin_theta[a] + polar[b,1]) / (size//2)   (the reference's grid)

@@ -586,6 +586,18 @@ def _cfg1_data(B, seed):
     return {"org_imgs": st("org_imgs"), "input_tensors": st("input_tensors"), "patch_indices": st("patch_indices"), "h4p": st("four_points")}
 
 
+def test_l1_score_pair_equals_two_single_launches(dev):
+    r = np.random.default_rng(9)
+    for n in (1, 63, 1024, 16129, 40000):
+        a, b0, b1 = (T(r.standard_normal(n, dtype=np.float32)).to(dev) for _ in range(3))
+        s0, s1 = G.l1_score2(a, b0, b1, 1.0 / 16129)
+        assert torch.equal(s0, G.l1_score(a, b0, 1.0 / 16129)) and torch.equal(s1, G.l1_score(a, b1, 1.0 / 16129))
+        ref = (a.double() - b0.double()).abs().sum().item() / 16129
+        assert abs(float(s0) - ref) <= 1e-5 * max(1.0, ref)
+    with pytest.raises(ValueError):
+        G.l1_score2(a, b0, b1[:5], 1.0)
+
+
 def test_homo_forward_golden_post_trunk(dev):
     """HomoModelBuilder.forward with the reference trunk's output injected: every HIP stage against the fixture."""
     g = load_golden("homo_forward")
