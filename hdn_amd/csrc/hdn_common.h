@@ -13,6 +13,19 @@ namespace hdn {
 constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 constexpr int round_up(int a, int b) { return cdiv(a, b) * b; }
 
+// One-time-per-device bookkeeping (hipFuncSetAttribute, device symbol addresses): the library assumes one process per
+// GPU but stays correct when a process drives several devices.
+struct PerDeviceOnce {
+  unsigned long long mask = 0;
+  static int device() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return d & 63;
+  }
+  bool done(int d) const { return (mask >> d) & 1ull; }
+  void set(int d) { mask |= 1ull << d; }
+};
+
 inline int launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? HDN_OK : -(1000 + (int)e);

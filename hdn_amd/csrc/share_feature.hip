@@ -325,12 +325,13 @@ __global__ __launch_bounds__(HDN_BLOCK) void share_feature_w128_kernel(const flo
 template <int R_>
 static int launch_sf_w128(const float* img, const float* folded, float* out, int B, int H, int W, hipStream_t stream) {
   using S = Sfw<R_>;
-  static bool attr_done = false;  // dynamic LDS above 64 KiB needs the opt-in once per kernel
-  if (!attr_done) {
+  static PerDeviceOnce attr;  // dynamic LDS above 64 KiB needs the opt-in once per kernel and device
+  const int dev_ = PerDeviceOnce::device();
+  if (!attr.done(dev_)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&share_feature_w128_kernel<R_>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS_BYTES);
     if (e != hipSuccess) return -(1000 + (int)e);
-    attr_done = true;
+    attr.set(dev_);
   }
   const int tiles_per_img = cdiv(H, S::R);
   const long long total = (long long)tiles_per_img * B;

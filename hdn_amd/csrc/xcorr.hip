@@ -226,13 +226,11 @@ __global__ __launch_bounds__(HDN_BLOCK) void xcorr_prod29_kernel(XcorrPtrs P, in
       const int i4 = tid + q * HDN_BLOCK;
       if (i4 < N4) {
         const float v[4] = {r[q].x, r[q].y, r[q].z, r[q].w};
+        // element e of the group lives at e + (SX - WX) * (e / WX): the planes of a group are consecutive rows and
+        // LPLANE = HX * SX, so one division per 16-byte chunk and a carry per element do the whole re-striding
+        const int e0 = 4 * i4, row0 = e0 / WX, c0 = e0 - row0 * WX;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int e = 4 * i4 + t;
-          const int p = e / XPLANE, rem = e - p * XPLANE;
-          const int rr = rem / WX, c = rem - rr * WX;
-          sx[p * LPLANE + rr * SX + c] = v[t];
-        }
+        for (int t = 0; t < 4; ++t) sx[e0 + t + (SX - WX) * (row0 + (c0 + t >= WX ? 1 : 0))] = v[t];
       }
     }
   } else {
@@ -1025,14 +1023,15 @@ static thread_local const char* g_last_variant = "none";
 
 template <class Cfg>
 static int launch_f1(const XcorrPtrs& P, int n, int planes, hipStream_t stream, const char* name) {
-  static bool attr_done = false;  // dynamic LDS above 64 KiB needs the opt-in once per kernel
-  if (!attr_done) {
+  static PerDeviceOnce attr;  // dynamic LDS above 64 KiB needs the opt-in once per kernel and device
+  const int dev_ = PerDeviceOnce::device();
+  if (!attr.done(dev_)) {
     if (Cfg::LDS_BYTES > 64 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xcorr_f1_kernel<Cfg>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
       if (e != hipSuccess) return -(1000 + (int)e);
     }
-    attr_done = true;
+    attr.set(dev_);
   }
   dim3 grid(cdiv(planes, Cfg::PPB), n);
   hipLaunchKernelGGL(xcorr_f1_kernel<Cfg>, grid, dim3(HDN_BLOCK), Cfg::LDS_BYTES, stream, P, planes);
@@ -1065,12 +1064,13 @@ static int north_variant() {
 static int launch_north(const XcorrPtrs& P, int n, int planes, hipStream_t stream, int mode) {
   // mode 1: zero taps skipped (default), 0: dense: see xcorr_north_kernel
   void (*kern)(XcorrPtrs, int) = mode == 0 ? &xcorr_north_kernel<0> : &xcorr_north_kernel<1>;
-  static bool attr_done[2] = {false, false};  // dynamic LDS above 64 KiB needs the opt-in once per kernel
-  if (!attr_done[mode]) {
+  static PerDeviceOnce attr[2];  // dynamic LDS above 64 KiB needs the opt-in once per kernel and device
+  const int dev_ = PerDeviceOnce::device();
+  if (!attr[mode].done(dev_)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)north::LDS_BYTES);
     if (e != hipSuccess) return -(1000 + (int)e);
-    attr_done[mode] = true;
+    attr[mode].set(dev_);
   }
   // persistent: 2 workgroups per CU x 256 CUs (fewer if there are fewer planes); n problems share the grid.
   // HDN_NORTH_BLOCKS caps the grid (e.g. 256 = one workgroup per CU, leaving LDS for kernels on other streams).
@@ -1097,12 +1097,13 @@ static int launch_north_fft_all(const XcorrPtrs& P, int n, int planes, hipStream
 }
 
 static int launch_north_mfma(const XcorrPtrs& P, int n, int planes, hipStream_t stream) {
-  static bool attr_done = false;
-  if (!attr_done) {
+  static PerDeviceOnce attr;
+  const int dev_ = PerDeviceOnce::device();
+  if (!attr.done(dev_)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xcorr_north_mfma_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)nmf::LDS_BYTES);
     if (e != hipSuccess) return -(1000 + (int)e);
-    attr_done = true;
+    attr.set(dev_);
   }
   // persistent: 2 workgroups per CU x 256 CUs (fewer if there are fewer planes); n problems share the grid
   const int per_problem = max(1, min(cdiv(planes, nmf::PPB), 512 / n));

@@ -329,13 +329,14 @@ __global__ __launch_bounds__(64) void xcorr_north_fft_kernel(const float* __rest
 __device__ __attribute__((used)) nfft::cf g_nfft_tab[NFFT_TAB_LEN] = NFFT_TAB_INIT;
 
 static const nfft::cf* north_fft_table() {
-  static const nfft::cf* tab = nullptr;
-  if (!tab) {
+  static const nfft::cf* tab[64] = {};  // per device
+  const int d = PerDeviceOnce::device();
+  if (!tab[d]) {
     void* p = nullptr;
     if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_nfft_tab)) != hipSuccess) return nullptr;
-    tab = static_cast<const nfft::cf*>(p);
+    tab[d] = static_cast<const nfft::cf*>(p);
   }
-  return tab;
+  return tab[d];
 }
 
 // x, k 16-byte aligned, out 8-byte aligned (the dispatcher checks); planes = B*C; pairs pair0.. only.
