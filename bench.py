@@ -62,7 +62,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle timing (profiling runs)")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the per-kernel breakdown after the timed region")
     ap.add_argument("--only-north", action="store_true", help="step = the north-star correlation only (profiling aid)")
-    ap.add_argument("--north", choices=["fft", "direct", "dense", "mfma"], default=None,
+    ap.add_argument("--north", choices=["fft", "fft2w", "direct", "dense", "mfma"], default=None,
                     help="kernel for the 31x31 (x) 61x61 correlation (default: the library's default, fft); A/B runs")
     ap.add_argument("--workload", choices=["kernels", "full"], default="kernels",
                     help="kernels = BASELINE configs[1] (default); full = configs[2]: the whole HomoModelBuilder head "

@@ -1053,6 +1053,7 @@ static int north_variant() {
   if (e && e[0] == 'd' && e[1] == 'i') v = HDN_NORTH_DIRECT;
   else if (e && e[0] == 'd') v = HDN_NORTH_DIRECT_DENSE;
   else if (e && e[0] == 'm') v = HDN_NORTH_MFMA;
+  else if (e && e[0] == 'f' && e[1] == 'f' && e[2] == 't' && e[3] == '2') v = HDN_NORTH_FFT_2W;
   else if (e && e[0] == 'f') v = HDN_NORTH_FFT;
   else if (m && m[0] == '1') v = HDN_NORTH_MFMA;
   else if (t && t[0] == 'd') v = HDN_NORTH_DIRECT_DENSE;
@@ -1084,12 +1085,14 @@ static int launch_north(const XcorrPtrs& P, int n, int planes, hipStream_t strea
 // xcorr_fft.hip
 int launch_north_fft(const float* x, const float* k, float* out, int planes, int max_blocks, hipStream_t stream, int pair0);
 int launch_north_fft2(const float* x, const float* k, float* out, int planes, int max_blocks, hipStream_t stream);
+int launch_north_fft3(const float* x, const float* k, float* out, int planes, int max_blocks, hipStream_t stream);
 
-static int launch_north_fft_all(const XcorrPtrs& P, int n, int planes, hipStream_t stream) {
+static int launch_north_fft_all(const XcorrPtrs& P, int n, int planes, hipStream_t stream, bool two_waves = false) {
   // persistent: 4 one-wave workgroups per CU x 256 CUs (LDS-limited); n problems run back to back
   static const int cap = [] { const char* e = getenv("HDN_NORTH_BLOCKS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
   for (int i = 0; i < n; ++i) {
-    const int rc = launch_north_fft2(P.x[i], P.k[i], P.out[i], planes, cap, stream);
+    const int rc = (two_waves && planes % 4 == 0) ? launch_north_fft3(P.x[i], P.k[i], P.out[i], planes, 2 * cap, stream)
+                                                  : launch_north_fft2(P.x[i], P.k[i], P.out[i], planes, cap, stream);
     if (rc) return rc;
   }
   g_last_variant = "north_fft_61x61_31x31";
@@ -1154,11 +1157,11 @@ static int xcorr_dispatch(const XcorrPtrs& P, int n, int circular, int B, int C,
       // out; otherwise, or on request (hdn_xcorr_north_variant / environment), one of the direct kernels runs:
       // packed-FMA with zero-tap skipping (~255 us on post-ReLU data), the same without skipping, or split-bf16 MFMA.
       const int v = north_variant();
-      if (v == HDN_NORTH_FFT) {
+      if (v == HDN_NORTH_FFT || v == HDN_NORTH_FFT_2W) {
         bool ok = true;
         for (int i = 0; i < n; ++i)
           ok = ok && aligned16(P.x[i]) && aligned16(P.k[i]) && (reinterpret_cast<uintptr_t>(P.out[i]) & 7u) == 0;
-        if (ok) return launch_north_fft_all(P, n, planes, stream);
+        if (ok) return launch_north_fft_all(P, n, planes, stream, v == HDN_NORTH_FFT_2W);
       }
       if (v == HDN_NORTH_MFMA) return launch_north_mfma(P, n, planes, stream);
       return launch_north(P, n, planes, stream, v == HDN_NORTH_DIRECT_DENSE ? 0 : 1);
@@ -1195,7 +1198,7 @@ const char* hdn_last_xcorr_variant(void) { return hdn::g_last_variant; }
 int hdn_xcorr_north_variant(int v) {
   const int prev = hdn::north_variant();
   if (v >= 0) {
-    if (v > HDN_NORTH_MFMA) return HDN_E_LIMIT;
+    if (v > HDN_NORTH_FFT_2W) return HDN_E_LIMIT;
     hdn::g_north_variant.store(v, std::memory_order_relaxed);
   }
   return prev;

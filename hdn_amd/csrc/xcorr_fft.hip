@@ -878,6 +878,377 @@ __global__ __launch_bounds__(64) void xcorr_north_fft2_kernel(const float* __res
   }
 }
 
+// =======================================================================================
+// v3: the same transform with HALF the LDS image, so that two waves fit a SIMD (one wave alone cannot issue a packed op
+// every 4 clocks and exposes every LDS turn-around: profiles/round1_ubench_issue_rate.txt).  The pair of planes is
+// still packed into one complex signal for the ROW passes, but the column passes run one PLANE at a time: 64 lanes =
+// 32 half-bin columns x the two halves of a column's 64 bins (DIF split: lane (c, h) transforms
+// (a_r + s_h a_{r+32}) * tw_h(r), tw_0 = 1, tw_1 = w64^r, with a 32-point FFT and ends with bins 2g + h).  The LDS image
+// is 61 x 32 complex (16 KB), a lane holds 32 bins per plane (64 registers), nothing is prefetched in registers (the
+// second wave of the SIMD hides the loads), the whole kernel stays under 256 registers.  The inverse column pass is the
+// mirror image (DIT: each lane inverts its 32 bins; the ROW lanes combine E'[r] + w64^r O'[r] while they read).
+// Requires planes % 4 == 0 (aligned tensor ends); everything else goes to v2.
+// =======================================================================================
+namespace nf3 {
+using namespace nf2;
+typedef float f3v __attribute__((ext_vector_type(3)));
+constexpr int RSX = 33, RSK = 65;            // row strides (complex): x spectrum of ONE plane; raw kernel spectrum / inverse rows
+constexpr int T_BYTES = 16128;               // >= 61*33*8, 31*65*8, 15*1024 (one staged plane)
+constexpr int LDS_BYTES = T_BYTES;
+constexpr int PQ = 15;                       // 16-byte chunks per lane of one staged x plane
+
+template <int OFF>
+NF_DEV void gload128(f4v& v, uint32_t voff, const void* sbase) {
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(v) : "v"(voff), "s"(sbase), "n"(OFF));
+}
+template <int OFF>
+NF_DEV void gload96(f3v& v, uint32_t voff, const void* sbase) {
+  asm volatile("global_load_dwordx3 %0, %1, %2 offset:%3" : "=v"(v) : "v"(voff), "s"(sbase), "n"(OFF));
+}
+template <int OFF>
+NF_DEV void lw128(uint32_t a, const f4v& v) { asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(a), "v"(v), "n"(OFF)); }
+template <int CNT>
+NF_DEV void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT)); }
+
+// c * t, both per lane
+NF_DEV cf cmul_vv(cf c, cf t) {
+  cf m, r;
+  asm volatile("v_pk_mul_f32 %0, %2, %3 op_sel_hi:[1,0]\n\t"
+               "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+               : "=&v"(m), "=&v"(r) : "v"(c), "v"(t));
+  return r;
+}
+// e + w * o, w per lane
+NF_DEV cf axpy_c(cf e, cf o, cf w) {
+  cf r;
+  asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]\n\t"
+               "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+               : "=&v"(r) : "v"(o), "v"(w), "v"(e));
+  return r;
+}
+
+// t * (h ? w64^R : 1) without a per-lane table: t + hm * (t * (w64^R - 1)) with the lane mask hm = (h, h) and the
+// wave-uniform constant (w64^R - 1) from the twiddle table (one more packed op instead of one more LDS read).
+template <int R>
+NF_DEV cf dif_twiddle(cf t, cf hm) {
+  constexpr Tw w = tw(-2 * R);
+  const cf T = tconst<false, w.c>();
+  // d = t * w  (as cmul_tw), then r = t + hm * (d - t) = fma(hm, d, fma(-hm, t, t))
+  cf m, d, r;
+  asm volatile("v_pk_mul_f32 %0, %3, %4 op_sel:[0,%5] op_sel_hi:[1,%5] neg_lo:[0,%7] neg_hi:[0,%7]\n\t"
+               "v_pk_fma_f32 %1, %3, %4, %0 op_sel:[1,%6,0] op_sel_hi:[0,%6,1] neg_lo:[0,%9,0] neg_hi:[0,%8,0]\n\t"
+               "v_pk_fma_f32 %2, %10, %3, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+               "v_pk_fma_f32 %2, %10, %1, %2"
+               : "=&v"(m), "=&v"(d), "=&v"(r)
+               : "v"(t), "s"(T), "n"(w.hr), "n"(w.hi), "n"(w.nr), "n"(w.ni), "n"(1 - w.ni), "v"(hm));
+  return r;
+}
+
+// Forward column pass of one plane: reads T[r][c] (stride RSX) for r < NR, optional split p +- conj q (kernel: SPLIT = +1/-1
+// on the raw spectrum with stride RSK, q from the mirrored column), DIF fold, per-lane twiddle, 32-point FFT.
+// X[g] = bin 2g + h on exit.
+template <int NR, int SPLIT>
+NF_DEV void column_pass(cf (&X)[32], uint32_t a_p, uint32_t a_q, cf hm, cf sg) {
+  constexpr int STRIDE = (SPLIT == 0 ? RSX : RSK) * 8;
+  constexpr int CH = 8, NCH = 32 / CH;     // rows r and r + 32 (or p, q) in chunks of 8, two chunks in flight (<= 15 reads each)
+  cf lo[2][CH], hi[2][CH];
+  auto second = [](int r) constexpr -> bool { return SPLIT == 0 ? (r + 32 < NR) : (r < NR); };
+  auto issue = [&](auto Ci) NF2_LAMBDA {
+    constexpr int c = decltype(Ci)::value;
+    sfor<0, CH>([&](auto Ri) NF2_LAMBDA {
+      constexpr int r = c * CH + decltype(Ri)::value;
+      if constexpr (r < NR) lo[c & 1][r - c * CH] = lr64<r * STRIDE>(a_p);
+      if constexpr (SPLIT == 0) {
+        if constexpr (r + 32 < NR) hi[c & 1][r - c * CH] = lr64<(r + 32) * STRIDE>(a_p);
+      } else {
+        if constexpr (r < NR) hi[c & 1][r - c * CH] = lr64<r * STRIDE>(a_q);
+      }
+    });
+  };
+  auto reads_in = [second](int c) constexpr -> int {  // LDS reads issued for chunk c
+    int n = 0;
+    for (int i = 0; i < CH; ++i) {
+      const int r = c * CH + i;
+      if (r < NR) ++n;
+      if (second(r)) ++n;
+    }
+    return n;
+  };
+  issue(std::integral_constant<int, 0>{});
+  sfor<0, NCH>([&](auto Ci) NF2_LAMBDA {
+    constexpr int c = decltype(Ci)::value;
+    constexpr int nxt = (c + 1 < NCH) ? reads_in(c + 1) : 0;
+    if constexpr (c + 1 < NCH) issue(std::integral_constant<int, c + 1>{});
+    wait_lgkm<(nxt < 15 ? nxt : 15)>();   // (16 reads in flight: the counter saturates at 15, one read early is harmless
+    if constexpr (nxt > 15) wait_lgkm<15>();  //  because the chunk being waited for is older)
+    sfor<0, CH>([&](auto Ri) NF2_LAMBDA {
+      constexpr int r = c * CH + decltype(Ri)::value;
+      if constexpr (r < NR) {
+        cf t = lo[c & 1][r - c * CH];
+        if constexpr (SPLIT == 0) {
+          if constexpr (r + 32 < NR) {
+            const cf b2 = hi[c & 1][r - c * CH], sgl = sg;
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(t) : "v"(b2), "v"(sgl));  // a_r +- a_{r+32}
+          }
+        } else {
+          const cf q = hi[c & 1][r - c * CH];
+          if constexpr (SPLIT > 0) asm volatile("v_pk_add_f32 %0, %0, %1 neg_hi:[0,1]" : "+v"(t) : "v"(q));   // p + conj q
+          else asm volatile("v_pk_add_f32 %0, %0, %1 neg_lo:[0,1]" : "+v"(t) : "v"(q));                        // p - conj q
+        }
+        if constexpr (r > 0) t = dif_twiddle<r>(t, hm);
+        X[bitrev(r, 5)] = t;
+      } else {
+        X[bitrev(r, 5)] = cf{0.f, 0.f};  // (only r = 31 of the kernel; the pruned FFT does not read it)
+      }
+    });
+  });
+  fft<5, -1, (NR < 32 ? NR : 32), 32>(X);
+}
+
+}  // namespace nf3
+
+__global__ __launch_bounds__(64, 2) void xcorr_north_fft3_kernel(const float* __restrict__ x, const float* __restrict__ k,
+                                                                 float* __restrict__ out, int npairs, int planes,
+                                                                 const nfft::cf* __restrict__ tab) {
+  using namespace nf3;
+  extern __shared__ __align__(16) float smem[];
+  const int lane = threadIdx.x;
+  const uint32_t sb = lds_addr(smem);
+  const int c = lane & 31, h = lane >> 5;
+  const float sgn = h ? -1.f : 1.f;
+  const cf sg = {sgn, sgn};
+  const cf hm = {(float)h, (float)h};  // lane mask of the odd-bin half
+  const int rrow = lane < HO ? lane : HO - 1;
+  const cf wrow = tab[NFFT_TAB_TAU + 2 * rrow];  // w64^{-r} = e^{+2*pi*i*r/64}: the inverse column combine of row r
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+  const uint32_t a_stash = sb + lane * 16;
+  const uint32_t a_rowx = sb + lane * (RSX * 8);           // x spectrum row `lane`, one plane
+  const uint32_t a_rowk = sb + lane * (RSK * 8);           // raw kernel spectrum row / inverse row `lane`
+  const uint32_t a_colx = sb + c * 8;                      // x spectrum column c
+  const uint32_t a_kp = sb + c * 8, a_kq = sb + (63 - c) * 8;
+  const uint32_t a_lane = sb + lane * 8;                   // column `lane` of a 64-wide image / linear 8-byte words
+  const uint32_t a_rowo = sb + rrow * (RSK * 8);
+  const uint32_t a_out = sb + lane * (HO * 4);
+  const long long xlast = ((long long)planes * XPL - 4) * 4;
+
+  for (int p = blockIdx.x; p < npairs; p += gridDim.x) {
+    // ---- the two search planes: coalesced 16-byte chunks of each plane's aligned window (clamped at the tensor end)
+    f4v RA[PQ], RB[PQ];
+    const long long baseA = (long long)(2 * p) * XPL, baseB = baseA + XPL;
+    const long long firstA = baseA & ~3LL, firstB = baseB & ~3LL;
+    const int offA = (int)(baseA - firstA), offB = (int)(baseB - firstB);
+    {
+      const long long cap32 = 0xffffff00LL;  // (voff is 32-bit; a window that far from the end is never clamped)
+      const uint32_t limA = (uint32_t)min(xlast - firstA * 4, cap32), limB = (uint32_t)min(xlast - firstB * 4, cap32);
+      sfor<0, PQ>([&](auto Qi) NF2_LAMBDA {
+        constexpr int q = decltype(Qi)::value;
+        gload128<0>(RA[q], min((uint32_t)(lane * 16 + q * 1024), limA), x + firstA);
+      });
+      sfor<0, PQ>([&](auto Qi) NF2_LAMBDA {
+        constexpr int q = decltype(Qi)::value;
+        gload128<0>(RB[q], min((uint32_t)(lane * 16 + q * 1024), limB), x + firstB);
+      });
+    }
+    cf X[2][32];  // spectra of the two planes: [plane][g] = bin 2g + h of column c
+    {
+      // ---- row pass: lane = row of the PAIR (plane A real part, plane B imaginary part), as in v2
+      const int rr = lane < HX ? lane : HX - 1;
+      cf ra[31], rb[31];
+      wait_vm<PQ>();  // plane A has landed (loads return in order)
+      sfor<0, PQ>([&](auto Qi) NF2_LAMBDA { constexpr int q = decltype(Qi)::value; lw128<q * 1024>(a_stash, RA[q]); });
+      {
+        const uint32_t aA = sb + (offA + rr * HX) * 4;
+        sfor<0, 31>([&](auto Mi) NF2_LAMBDA { constexpr int m = decltype(Mi)::value; ra[m] = lr2x32<2 * m, 2 * m + 1>(aA); });
+      }
+      wait_vm<0>();
+      sfor<0, PQ>([&](auto Qi) NF2_LAMBDA { constexpr int q = decltype(Qi)::value; lw128<q * 1024>(a_stash, RB[q]); });
+      {
+        const uint32_t aB = sb + (offB + rr * HX) * 4;
+        sfor<0, 31>([&](auto Mi) NF2_LAMBDA { constexpr int m = decltype(Mi)::value; rb[m] = lr2x32<2 * m, 2 * m + 1>(aB); });
+      }
+      wait_lgkm<0>();
+      cf v[64];
+      sfor<0, 31>([&](auto Mi) NF2_LAMBDA {
+        constexpr int j = 2 * decltype(Mi)::value;
+        cf lo, hi;
+        const cf A = ra[j / 2], B = rb[j / 2];
+        twiddle_in2<-j, -(j + 1), (j + 1 < HX)>(A, B, lo, hi);
+        v[bitrev(j, 6)] = lo;
+        if constexpr (j + 1 < HX) v[bitrev(j + 1, 6)] = hi;
+      });
+      fft<6, -1, HX, 64>(v);
+      cf sbp[32];  // plane B's half waits in registers while plane A's goes through the column pass
+      sfor<0, 16>([&](auto F) NF2_LAMBDA {
+        constexpr int f = 2 * decltype(F)::value;
+        cf sa0, sa1, sb0, sb1;
+        const cf p0 = v[f], q0 = v[63 - f], p1 = v[f + 1], q1 = v[62 - f];
+        asm volatile("v_pk_add_f32 %0, %4, %5 neg_hi:[0,1]\n\tv_pk_add_f32 %1, %6, %7 neg_hi:[0,1]\n\t"
+                     "v_pk_add_f32 %2, %4, %5 neg_lo:[0,1]\n\tv_pk_add_f32 %3, %6, %7 neg_lo:[0,1]"
+                     : "=&v"(sa0), "=&v"(sa1), "=&v"(sb0), "=&v"(sb1) : "v"(p0), "v"(q0), "v"(p1), "v"(q1));
+        sbp[f] = sb0;
+        sbp[f + 1] = sb1;
+        if (lane < HX) lw2x64<f, f + 1>(a_rowx, sa0, sa1);
+      });
+      column_pass<HX, 0>(X[0], a_colx, 0, hm, sg);
+      if (lane < HX) {
+        sfor<0, 16>([&](auto F) NF2_LAMBDA { constexpr int f = 2 * decltype(F)::value; lw2x64<f, f + 1>(a_rowx, sbp[f], sbp[f + 1]); });
+      }
+    }
+    column_pass<HX, 0>(X[1], a_colx, 0, hm, sg);
+
+    // ---- kernel row pass: lane = row of the pair, rows straight from global memory (31 floats, dword aligned),
+    //      pruned halves (even / odd bins), raw spectrum to LDS
+    {
+      const int rk = lane < HK ? lane : HK - 1;
+      const float* kpair = k + (long long)(2 * p) * KPL;
+      const uint32_t vA = rk * (HK * 4), vB = vA + KPL * 4;
+      sfor<0, 2>([&](auto Hf) NF2_LAMBDA {
+        constexpr int half = decltype(Hf)::value;
+        constexpr int mul = half ? 3 : 1;
+        cf v[32];
+        f4v a0, a1, a2, a3, b0, b1, b2, b3;
+        gload128<0>(a0, vA, kpair); gload128<16>(a1, vA, kpair); gload128<32>(a2, vA, kpair); gload128<48>(a3, vA, kpair);
+        gload128<0>(b0, vB, kpair); gload128<16>(b1, vB, kpair); gload128<32>(b2, vB, kpair); gload128<48>(b3, vB, kpair);
+        f4v a4, a5, a6, b4, b5, b6;
+        f3v a7, b7;
+        gload128<64>(a4, vA, kpair); gload128<80>(a5, vA, kpair); gload128<96>(a6, vA, kpair); gload96<112>(a7, vA, kpair);
+        gload128<64>(b4, vB, kpair); gload128<80>(b5, vB, kpair); gload128<96>(b6, vB, kpair); gload96<112>(b7, vB, kpair);
+        wait_vm<8>();
+        auto tw4 = [&](auto J, const f4v& fa, const f4v& fb) NF2_LAMBDA {
+          constexpr int j = decltype(J)::value;
+          cf l0, h0, l1, h1;
+          twiddle_in2<-mul * j, -mul * (j + 1), true>(cf{fa.x, fa.y}, cf{fb.x, fb.y}, l0, h0);
+          twiddle_in2<-mul * (j + 2), -mul * (j + 3), true>(cf{fa.z, fa.w}, cf{fb.z, fb.w}, l1, h1);
+          v[bitrev(j, 5)] = l0; v[bitrev(j + 1, 5)] = h0; v[bitrev(j + 2, 5)] = l1; v[bitrev(j + 3, 5)] = h1;
+        };
+        tw4(std::integral_constant<int, 0>{}, a0, b0);
+        tw4(std::integral_constant<int, 4>{}, a1, b1);
+        tw4(std::integral_constant<int, 8>{}, a2, b2);
+        tw4(std::integral_constant<int, 12>{}, a3, b3);
+        wait_vm<0>();
+        tw4(std::integral_constant<int, 16>{}, a4, b4);
+        tw4(std::integral_constant<int, 20>{}, a5, b5);
+        tw4(std::integral_constant<int, 24>{}, a6, b6);
+        {
+          cf l0, h0, l1, h1;
+          twiddle_in2<-mul * 28, -mul * 29, true>(cf{a7.x, a7.y}, cf{b7.x, b7.y}, l0, h0);
+          twiddle_in2<-mul * 30, -mul * 31, false>(cf{a7.z, a7.z}, cf{b7.z, b7.z}, l1, h1);
+          v[bitrev(28, 5)] = l0; v[bitrev(29, 5)] = h0; v[bitrev(30, 5)] = l1;
+        }
+        fft<5, -1, HK, 32>(v);
+        if (lane < HK) {
+          sfor<0, 16>([&](auto Gi) NF2_LAMBDA {
+            constexpr int g = 2 * decltype(Gi)::value;
+            lw2x64<2 * g + half, 2 * g + 2 + half>(a_rowk, v[g], v[g + 1]);
+          });
+        }
+      });
+    }
+
+    // ---- kernel column passes (split while reading) and products, one plane at a time from the same raw spectrum
+    {
+      cf K[32];
+      column_pass<HK, +1>(K, a_kp, a_kq, hm, sg);
+      sfor<0, 16>([&](auto Gi) NF2_LAMBDA {
+        constexpr int g0 = 2 * decltype(Gi)::value, g1 = g0 + 1;
+        cf m0, m1;
+        cf x0 = X[0][g0], x1 = X[0][g1];
+        const cf k0 = K[g0], k1 = K[g1];
+        asm volatile("v_pk_mul_f32 %0, %2, %4 op_sel_hi:[1,0]\n\tv_pk_mul_f32 %1, %3, %5 op_sel_hi:[1,0]\n\t"
+                     "v_pk_fma_f32 %2, %2, %4, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]\n\t"
+                     "v_pk_fma_f32 %3, %3, %5, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+                     : "=&v"(m0), "=&v"(m1), "+v"(x0), "+v"(x1) : "v"(k0), "v"(k1));
+        X[0][g0] = x0; X[0][g1] = x1;
+      });
+      column_pass<HK, -1>(K, a_kp, a_kq, hm, sg);
+      sfor<0, 16>([&](auto Gi) NF2_LAMBDA {
+        constexpr int g0 = 2 * decltype(Gi)::value, g1 = g0 + 1;
+        cf m0, m1;
+        cf x0 = X[1][g0], x1 = X[1][g1];
+        const cf k0 = K[g0], k1 = K[g1];
+        asm volatile("v_pk_mul_f32 %0, %2, %4 op_sel_hi:[1,0]\n\tv_pk_mul_f32 %1, %3, %5 op_sel_hi:[1,0]\n\t"
+                     "v_pk_fma_f32 %2, %2, %4, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]\n\t"
+                     "v_pk_fma_f32 %3, %3, %5, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+                     : "=&v"(m0), "=&v"(m1), "+v"(x0), "+v"(x1) : "v"(k0), "v"(k1));
+        X[1][g0] = x0; X[1][g1] = x1;
+      });
+    }
+
+    // ---- inverse column passes: each lane inverts its 32 bins (DIT halves E', O'); the row lanes combine while reading
+    cf Y[2][32];
+    sfor<0, 2>([&](auto Pl) NF2_LAMBDA {
+      constexpr int pl = decltype(Pl)::value;
+      {
+        cf V[32];
+        sfor<0, 32>([&](auto G) NF2_LAMBDA { constexpr int g = decltype(G)::value; V[bitrev(g, 5)] = X[pl][g]; });
+        fft<5, +1, 32, HO>(V);
+        sfor<0, HO>([&](auto R) NF2_LAMBDA { constexpr int r = decltype(R)::value; lw64<r * RSK * 8>(a_lane, V[r]); });
+      }
+      // row lane r: Y(r, c) = E'[r][c] + w64^{-r} O'[r][c], columns in chunks of 8
+      sfor<0, 4>([&](auto Cc) NF2_LAMBDA {
+        constexpr int c0 = 8 * decltype(Cc)::value;
+        cf e[8], o[8];
+        sfor<0, 8>([&](auto I) NF2_LAMBDA { constexpr int i = decltype(I)::value; lr2x64<c0 + i, 32 + c0 + i>(a_rowo, e[i], o[i]); });
+        wait_lgkm<0>();
+        sfor<0, 8>([&](auto I) NF2_LAMBDA { constexpr int i = decltype(I)::value; Y[pl][c0 + i] = axpy_c(e[i], o[i], wrow); });
+      });
+    });
+
+    // ---- inverse row pass (as v2): Hermitian re-packing of the pair, FFT, un-shift e^{+i*pi*j/64} / 16384
+    {
+      cf v[64];
+      sfor<0, 32>([&](auto F) NF2_LAMBDA {
+        constexpr int f = decltype(F)::value;
+        cf c0, c1;
+        const cf ya = Y[0][f], yb = Y[1][f];
+        asm volatile("v_pk_add_f32 %0, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+                     "v_pk_add_f32 %1, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]"
+                     : "=&v"(c0), "=&v"(c1) : "v"(ya), "v"(yb));
+        v[bitrev(f, 6)] = c0;
+        v[bitrev(63 - f, 6)] = c1;
+      });
+      fft<6, +1, 64, HO>(v);
+      if (lane < HO) {
+        sfor<0, 16>([&](auto Ji) NF2_LAMBDA {
+          constexpr int j = 2 * decltype(Ji)::value;
+          const cf o0 = cmul_tw<j, true>(v[j]);
+          if constexpr (j + 1 < HO) {
+            const cf o1 = cmul_tw<j + 1, true>(v[j + 1]);
+            lw2x32<j, j + 1>(a_out, o0.x, o1.x);
+            lw2x32<j, j + 1>(a_out + OPL * 4, o0.y, o1.y);
+          } else {
+            lw32<j * 4>(a_out, o0.x);
+            lw32<(OPL + j) * 4>(a_out, o0.y);
+          }
+        });
+      }
+    }
+    {
+      cf* o2 = reinterpret_cast<cf*>(out + (long long)p * (2 * OPL));
+      cf w[16];
+      sfor<0, 16>([&](auto Qi) NF2_LAMBDA { constexpr int q = decltype(Qi)::value; w[q] = lr64<q * 512>(a_lane); });
+      wait_lgkm<0>();
+      sfor<0, 16>([&](auto Qi) NF2_LAMBDA {
+        constexpr int q = decltype(Qi)::value;
+        cf wq = w[q];
+        asm volatile("" : "+v"(wq));
+        if (lane + 64 * q < OPL) o2[lane + 64 * q] = wq;
+      });
+    }
+  }
+}
+
+int launch_north_fft3(const float* x, const float* k, float* out, int planes, int max_blocks, hipStream_t stream) {
+  const nfft::cf* tab = north_fft_table();
+  if (!tab) return -(1000 + (int)hipErrorInvalidSymbol);
+  const int npairs = planes / 2;
+  const int grid = npairs < max_blocks ? npairs : max_blocks;
+  hipLaunchKernelGGL(xcorr_north_fft3_kernel, dim3(grid), dim3(64), nf3::LDS_BYTES, stream, x, k, out, npairs, planes, tab);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? HDN_OK : -(1000 + (int)e);
+}
+
 // Pairs whose load windows stay inside the tensors and whose two planes exist: those go to the v2 kernel.
 static int north_fft_full_pairs(int planes) {
   const long long xtotal = (long long)planes * nfft::XPL, ktotal = (long long)planes * nfft::KPL;

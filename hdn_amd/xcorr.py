@@ -132,7 +132,7 @@ def last_variant() -> str:
     return _lib.load().hdn_last_xcorr_variant().decode()
 
 
-NORTH_VARIANTS = {"fft": 0, "direct": 1, "dense": 2, "mfma": 3}  # HDN_NORTH_* in include/hdn_hip.h
+NORTH_VARIANTS = {"fft": 0, "direct": 1, "dense": 2, "mfma": 3, "fft2w": 4}  # HDN_NORTH_* in include/hdn_hip.h
 
 
 class north_variant:

@@ -49,6 +49,7 @@ const char* hdn_last_xcorr_variant(void);
 #define HDN_NORTH_DIRECT 1       /* packed-FMA direct sum, zero taps skipped            */
 #define HDN_NORTH_DIRECT_DENSE 2 /* packed-FMA direct sum, every tap                    */
 #define HDN_NORTH_MFMA 3         /* split-bf16 matrix-core direct sum                   */
+#define HDN_NORTH_FFT_2W 4       /* FFT, 16 KB LDS image, two waves per SIMD (planes % 4 == 0, else as HDN_NORTH_FFT) */
 int hdn_xcorr_north_variant(int v);
 
 /*

@@ -124,6 +124,20 @@ def test_xcorr_north_plane_counts(dev, planes, variant):
         check_xcorr(y, x, k, O.xcorr_depthwise(T(x), T(k)).numpy(), False, f"{planes} {variant} signed={signed}")
 
 
+@pytest.mark.parametrize("planes", [(1, 4), (2, 8), (3, 12), (5, 204), (1, 6)])
+def test_xcorr_north_two_wave_fft_variant(dev, planes):
+    """HDN_NORTH=fft2w: the 16 KB-LDS layout (column passes one plane at a time on lane pairs), two waves per SIMD.
+    Plane counts that are not multiples of 4 fall back to the default FFT kernel."""
+    B, C = planes
+    r = np.random.default_rng(31 * B + C)
+    x, k = relu_normal(r, (B, C, 61, 61)), relu_normal(r, (B, C, 31, 31))
+    with X.north_variant("fft2w"):
+        y = hdn_amd.xcorr_depthwise(T(x).to(dev), T(k).to(dev))
+        assert X.last_variant() == "north_fft_61x61_31x31"
+        assert torch.equal(y, hdn_amd.xcorr_depthwise(T(x).to(dev), T(k).to(dev)))
+    check_xcorr(y, x, k, O.xcorr_depthwise(T(x), T(k)).numpy(), False, f"{planes} fft2w")
+
+
 def test_xcorr_north_multi_problem_launch(dev):
     """Several 31x31 (x) 61x61 problems through the multi entry point (the FFT kernel runs them back to back)."""
     r = np.random.default_rng(404)
