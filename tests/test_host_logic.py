@@ -277,3 +277,27 @@ print("INSTALL_OK")
 ''' % (ROOT, ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert "INSTALL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_committed_bench_line_follows_the_contract():
+    """profiles/round1_bench_line.json is one output line of bench.py: the driver's fields, the roofline block of the
+    dominant kernel and the CPU baseline must all be there and be self-consistent."""
+    import json
+    with open(os.path.join(ROOT, "profiles", "round1_bench_line.json")) as f:
+        d = json.load(f)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 64 * d["n_gpus"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) <= 1e-6 * r["achieved"]
+    assert r["traffic"] is None or 0.9 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.5
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["value"] > 0
