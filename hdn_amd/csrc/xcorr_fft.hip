@@ -629,11 +629,13 @@ __global__ __launch_bounds__(64) void xcorr_north_fft2_kernel(const float* __res
   const cf sg = {sgn, sgn};
   // LDS byte addresses that do not depend on the pair
   const uint32_t a_stash = sb + lane * 16;                     // linear 16-byte chunks
-  const uint32_t a_row = sb + lane * (RS * 8);                 // spectrum row `lane`
+  // lanes past the last row redo that row and rewrite it with identical values: no exec branches around the writes
+  const uint32_t a_row = sb + (lane < HX ? lane : HX - 1) * (RS * 8);    // search spectrum row
+  const uint32_t a_rowk = sb + (lane < HK ? lane : HK - 1) * (RS * 8);   // kernel spectrum row
   const uint32_t a_col = sb + lane * 8;                        // spectrum column `lane` / linear 8-byte words
   const uint32_t a_colp = sb + fc * 8, a_colq = sb + (63 - fc) * 8;
   const uint32_t a_rowo = sb + (lane < HO ? lane : HO - 1) * (RS * 8);
-  const uint32_t a_out = sb + lane * (HO * 4);
+  const uint32_t a_out = sb + (lane < HO ? lane : HO - 1) * (HO * 4);
   const uint32_t voff = lane * 16;
 
   f4v Rx[XQ], Rk[KQ];  // the next pair's global data: AGPRs
@@ -708,7 +710,7 @@ __global__ __launch_bounds__(64) void xcorr_north_fft2_kernel(const float* __res
         if constexpr (j + 1 < HX) v[bitrev(j + 1, 6)] = hi;
       });
       fft<6, -1, HX, 64>(v);
-      if (lane < HX) {
+      {
         cf sa[32], sb2[32];  // C(f) + conj C(63-f),  C(f) - conj C(63-f); each write trails its split by one element
         sfor<0, 33>([&](auto F) NF2_LAMBDA {
           constexpr int f = decltype(F)::value;
@@ -764,12 +766,10 @@ __global__ __launch_bounds__(64) void xcorr_north_fft2_kernel(const float* __res
           kb[m] = lr2x32<2 * m, 2 * m + 1>(akB);
         });
       }
-      if (lane < HK) {
-        sfor<0, 16>([&](auto Gi) NF2_LAMBDA {
-          constexpr int g = 2 * decltype(Gi)::value;
-          lw2x64<2 * g + half, 2 * g + 2 + half>(a_row, v[g], v[g + 1]);
-        });
-      }
+      sfor<0, 16>([&](auto Gi) NF2_LAMBDA {
+        constexpr int g = 2 * decltype(Gi)::value;
+        lw2x64<2 * g + half, 2 * g + 2 + half>(a_rowk, v[g], v[g + 1]);
+      });
     });
 
     // ---- kernel column pass (pruned halves; split by a per-lane sign while reading) and product X * conj(K)
@@ -794,14 +794,21 @@ __global__ __launch_bounds__(64) void xcorr_north_fft2_kernel(const float* __res
         constexpr int next_rows = (c + 1 < NCH) ? ((c + 2) * CH <= HK ? CH : HK - (c + 1) * CH) : 0;
         if constexpr (c + 1 < NCH) issue(std::integral_constant<int, c + 1>{});
         wait_lgkm<2 * next_rows>();
+        cf sp[CH];
         sfor<0, CH>([&](auto Ri) NF2_LAMBDA {
           constexpr int r = c * CH + decltype(Ri)::value;
           if constexpr (r < HK) {
-            cf s;
+            cf s2;
             const cf pv = pp[c & 1][r - c * CH], qv = qq[c & 1][r - c * CH], sgl = sg;
-            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 neg_hi:[1,0,0]" : "=v"(s) : "v"(qv), "v"(sgl), "v"(pv));  // p +- conj q
-            if constexpr (half == 1 && r > 0) s = cmul_tw<-2 * r, false>(s);                                       // times w64^r
-            K[bitrev(r, 5)] = s;
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 neg_hi:[1,0,0]" : "=v"(s2) : "v"(qv), "v"(sgl), "v"(pv));  // p +- conj q
+            sp[r - c * CH] = s2;
+          }
+        });
+        sfor<0, CH>([&](auto Ri) NF2_LAMBDA {  // odd bins: times w64^r, after all splits of the chunk (no dependent neighbours)
+          constexpr int r = c * CH + decltype(Ri)::value;
+          if constexpr (r < HK) {
+            if constexpr (half == 1 && r > 0) K[bitrev(r, 5)] = cmul_tw<-2 * r, false>(sp[r - c * CH]);
+            else K[bitrev(r, 5)] = sp[r - c * CH];
           }
         });
       });
@@ -845,7 +852,7 @@ __global__ __launch_bounds__(64) void xcorr_north_fft2_kernel(const float* __res
         v[bitrev(63 - f, 6)] = c1;
       });
       fft<6, +1, 64, HO>(v);
-      if (lane < HO) {
+      {
         sfor<0, 16>([&](auto Ji) NF2_LAMBDA {
           constexpr int j = 2 * decltype(Ji)::value;
           const cf o0 = cmul_tw<j, true>(v[j]);
