@@ -283,8 +283,10 @@ __global__ __launch_bounds__(HDN_BLOCK) void share_feature_w128_kernel(const flo
       const bool inside = gr >= 0 && gr < H && c < W;
       float y[8];
 #pragma unroll
-      for (int co = 0; co < 8; ++co)
-        y[co] = inside ? fmaxf(__builtin_fmaf(acc[q][co].x + acc[q][co].y, prm[SF_ALPHA + 4 + co], prm[SF_BETA + 4 + co]), 0.f) : 0.f;
+      for (int co = 0; co < 8; ++co) {  // BN constants from the LDS copy, unconditional: no scalar load + exec branch per channel
+        const float t = fmaxf(__builtin_fmaf(acc[q][co].x + acc[q][co].y, s_w[SF_ALPHA + 4 + co], s_w[SF_BETA + 4 + co]), 0.f);
+        y[co] = inside ? t : 0.f;
+      }
 #pragma unroll
       for (int p = 0; p < 4; ++p) s_b[(p * B_H + r) * CS + c + 1] = float2v{y[2 * p], y[2 * p + 1]};
     }
@@ -315,8 +317,8 @@ __global__ __launch_bounds__(HDN_BLOCK) void share_feature_w128_kernel(const flo
 #pragma unroll
     for (int q = 0; q < NPX; ++q) {
       const int gr = r0 + 2 * q + rr;
-      if (gr < H && c < W)
-        out[plane + size_t(gr) * W + c] = fmaxf(__builtin_fmaf(acc[q].x + acc[q].y, prm[SF_ALPHA + 12], prm[SF_BETA + 12]), 0.f);
+      const float t = fmaxf(__builtin_fmaf(acc[q].x + acc[q].y, s_w[SF_ALPHA + 12], s_w[SF_BETA + 12]), 0.f);
+      if (gr < H && c < W) out[plane + size_t(gr) * W + c] = t;
     }
   }
   }  // tile loop (the next iteration's first barrier orders this tile's LDS reads before the next tile's writes)
