@@ -43,7 +43,8 @@ const char* hdn_last_xcorr_variant(void);
  * 8-byte aligned out and otherwise falls back to HDN_NORTH_DIRECT.  All variants meet the same parity bar; they
  * differ in rounding: the direct kernels accumulate each output in one fixed fp32 chain (planes independent), the
  * FFT kernel has a smaller error against float64 but transforms planes in pairs, so a plane's rounding depends on
- * its neighbour's magnitude.  For tests, benchmarks and A/B runs.
+ * its neighbour's magnitude, and a NaN / Inf anywhere in a plane reaches every output of that plane and of its partner
+ * (the direct kernels keep it to the windows that contain it, as the reference does).  For tests, benchmarks and A/B runs.
  */
 #define HDN_NORTH_FFT 0          /* 64x64 fp32 FFT per pair of planes (default)        */
 #define HDN_NORTH_DIRECT 1       /* packed-FMA direct sum, zero taps skipped            */
