@@ -12,14 +12,19 @@ region starts):
     6 x xcorr_depthwise           [64,256,29,29] (x) [64,256,5,5]       MultiBAN: 3 levels x {cls,loc}  (one launch)
     6 x xcorr_depthwise_circular  [64,256,13,13] (x) [64,256,13,13]     MultiCircBAN                    (one launch)
     PreShareFeature(template,search) -> fused DLT+warp (offsets ~ N(0, 8^2) px) -> PreShareFeature(warped) -> 2 scores
-    N > 1: one RCCL all-gather of the [64,8] corner offsets per rank (the path's only exchange step)
+    N > 1: one RCCL all-gather of the [64,8] corner offsets per rank (the path's only exchange step), issued through the
+           C ABI (hdn_allgather_offsets on a communicator bootstrapped over torch.distributed's nccl group)
 Pairs are independent, so ranks hold disjoint batches (weak scaling) and `value` = N*64*K / max-over-ranks time.
 Before the W warm-up steps the GPU is kept busy for --prewarm-ms (150 ms, untimed, rank-local): from idle an MI355X needs
 ~40 ms of sustained load to reach steady clocks, and the first ~80 steps would otherwise be timed on the ramp.
 
 The JSON line also carries
     "roofline"      for the dominant kernel (the 31x31 (x) 61x61 correlation), measured with events on the launch stream
-    "cpu_baseline"  the CPU oracle (PyTorch-CPU restatement of the reference path) timed on this box's host cores
+    "cpu_baseline"  the CPU oracle (PyTorch-CPU restatement of the reference path) timed on this box's host cores:
+                    all 64 pairs, warm-up 3, best of 5, headline = 1 thread pinned to one core (the reference's own
+                    setting, tools/test.py:51), all-cores figure beside it
+    "full_head"     BASELINE configs[2] per GPU, timed after the headline region: the whole HomoModelBuilder head incl. the
+                    PyTorch-ROCm ResNet-34 trunk on the same 64 pairs (the trunk is >90 % of it), with its own CPU figure
 """
 from __future__ import annotations
 
@@ -61,6 +66,10 @@ def parse():
                          "needs ~40 ms of sustained load to reach its steady clocks (tools/exp_warmup.py: 0.48 -> 0.38 ms/step)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle timing (profiling runs)")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the per-kernel breakdown after the timed region")
+    ap.add_argument("--no-full-head", action="store_true", help="skip the full_head block (configs[2] per-GPU workload)")
+    ap.add_argument("--full-head-steps", type=int, default=30)
+    ap.add_argument("--collective", choices=["c_abi", "torch"], default="c_abi",
+                    help="N > 1: hdn_allgather_offsets of the C ABI (default) or torch.distributed.all_gather_into_tensor")
     ap.add_argument("--only-north", action="store_true", help="step = the north-star correlation only (profiling aid)")
     ap.add_argument("--north", choices=["fft", "fft2w", "direct", "dense", "mfma"], default=None,
                     help="kernel for the 31x31 (x) 61x61 correlation (default: the library's default, fft); A/B runs")
@@ -113,6 +122,9 @@ def main():
 
     import hdn_amd
     from hdn_amd import dist as hdist
+    comm = None
+    if world > 1 and not one_device and args.collective == "c_abi":
+        comm = hdist.RcclComm.from_process_group(dev)
     from hdn_amd import homography as G
     from hdn_amd import share_feature as SF
     from hdn_amd import xcorr as X
@@ -134,20 +146,26 @@ def main():
 
     north_ev = []
     full_net = full_data = None
-    if args.workload == "full":
-        from hdn_amd.homo_model import homo_stages
+
+    def build_full():
         torch.manual_seed(SEED + 7)
-        full_net = hdn_amd.HomoModelBuilder().eval()
-        full_net.fc.weight.data.mul_(0.01)
+        net = hdn_amd.HomoModelBuilder().eval()
+        net.fc.weight.data.mul_(0.01)
+        cpu_sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
         torch.backends.cudnn.benchmark = True  # MIOpen find mode for the trunk's fixed shapes (searched during warm-up)
-        full_net = full_net.to(dev).optimize_for_inference(channels_last=True)
-        full_data = {"org_imgs": d["imgs"], "input_tensors": d["imgs"], "h4p": d["h4p"],
-                     "patch_indices": torch.arange(127 * 127, dtype=torch.float32, device=dev).repeat(PAIRS, 1)}
+        net = net.to(dev).optimize_for_inference(channels_last=True)
+        data = {"org_imgs": d["imgs"], "input_tensors": d["imgs"], "h4p": d["h4p"],
+                "patch_indices": torch.arange(127 * 127, dtype=torch.float32, device=dev).repeat(PAIRS, 1)}
+        return net, data, cpu_sd
+
+    from hdn_amd.homo_model import homo_stages
+    if args.workload == "full":
+        full_net, full_data, _ = build_full()
 
     def step_full(record, collective):
         st = homo_stages(full_net, full_data)
         if world > 1 and collective:
-            hdist.all_gather_offsets(st["x"], PAIRS * world)
+            hdist.all_gather_offsets(st["x"], PAIRS * world, comm=comm)
 
     def step(record, collective=True):
         if args.workload == "full":
@@ -168,7 +186,7 @@ def main():
         pf = SF.share_feature(warped, folded)
         G.l1_score2(feats[0, 1], pf[0, 0], feats[0, 0], 1.0 / (127 * 127))
         if world > 1 and collective:
-            hdist.all_gather_offsets(d["off"], PAIRS * world)
+            hdist.all_gather_offsets(d["off"], PAIRS * world, comm=comm)
 
     def fence():
         torch.cuda.synchronize()
@@ -216,15 +234,19 @@ def main():
     # gfx950 x2 correction on the 16 B/lane stream) and committed under profiles/; bench.py cannot collect PMCs itself.
     X.xcorr_depthwise(d["north_x"], d["north_k"])
     north_variant = X.last_variant()
-    north_kernel = {"north_fft_61x61_31x31": "xcorr_north_fft2_kernel", "north_61x61_31x31": "xcorr_north_kernel",
-                    "north_mfma_61x61_31x31": "xcorr_north_mfma_kernel"}[north_variant]
+    north_kernel = {"north_fft_61x61_31x31": "xcorr_north_fft2_kernel", "north_fft2w_61x61_31x31": "xcorr_north_fft3_kernel",
+                    "north_61x61_31x31": "xcorr_north_kernel", "north_mfma_61x61_31x31": "xcorr_north_mfma_kernel"}[north_variant]
     traffic, traffic_note = None, "no committed PMC measurement found for " + north_kernel
     try:
-        with open(os.path.join(ROOT, "profiles", "round1_pmc_hbm_traffic.json")) as f:
-            for name, rec in json.load(f).items():
-                if north_kernel in name and "traffic_calibrated_bytes" in rec:
-                    traffic = rec["traffic_calibrated_bytes"]
-                    traffic_note = rec.get("how", "profiles/round1_pmc_hbm_traffic.txt")
+        for rnd in ("round2", "round1"):  # the newest committed PMC measurement of this kernel
+            path = os.path.join(ROOT, "profiles", rnd + "_pmc_hbm_traffic.json")
+            if not os.path.exists(path):
+                continue
+            with open(path) as f:
+                for name, rec in json.load(f).items():
+                    if north_kernel in name and "traffic_calibrated_bytes" in rec and traffic is None:
+                        traffic = rec["traffic_calibrated_bytes"]
+                        traffic_note = rec.get("how", "profiles/%s_pmc_hbm_traffic.txt" % rnd)
     except (OSError, ValueError):
         pass
 
@@ -264,7 +286,7 @@ def main():
             "avg_launch_ms": north_ms,
         },
     }
-    if north_variant == "north_fft_61x61_31x31":
+    if north_variant.startswith("north_fft"):
         result["roofline"]["note"] = (
             "64x64 fp32 FFT per pair of planes in registers + LDS (~1,650 packed VALU ops per plane instead of the direct "
             "sum's 7,688); one wave per SIMD (33 KB of LDS per wave), issue-bound: DESIGN.md section 4/6")
@@ -277,6 +299,32 @@ def main():
 
     if rank == 0 and not args.no_breakdown and not args.only_north:
         result["kernels"] = breakdown(d, imgs2, tmpl, folded, X, SF, G)
+    if not args.no_full_head and not args.only_north:
+        # BASELINE configs[2] per GPU, outside the headline region: every rank runs it (same max-over-ranks rule)
+        full_net, full_data, full_cpu_sd = build_full()
+        for _ in range(8):  # MIOpen find + clocks
+            homo_stages(full_net, full_data)
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.full_head_steps):
+            st = homo_stages(full_net, full_data)
+            if world > 1:
+                hdist.all_gather_offsets(st["x"], PAIRS * world, comm=comm)
+        fence()
+        el = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        result["full_head"] = {
+            "workload": "BASELINE configs[2] per GPU: full HomoModelBuilder head (PreShareFeature x2 -> PyTorch-ROCm ResNet-34 "
+                        "trunk, BN-folded NHWC under MIOpen find mode -> fused DLT+warp -> PreShareFeature) on 64 pairs"
+                        + (", offsets all-gathered" if world > 1 else ""),
+            "value": PAIRS * world * args.full_head_steps / el, "unit": "frames/s", "steps": args.full_head_steps,
+            "ms_per_step": el / args.full_head_steps * 1e3, "n_gpus": world,
+        }
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            result["full_head"]["cpu_baseline"] = cpu_full_head(d, full_cpu_sd)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(d, sf_cpu_sd)
         result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
@@ -319,11 +367,55 @@ def breakdown(d, imgs2, tmpl, folded, X, SF, G, iters=20):
     return out
 
 
+def _host_cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return ""
+
+
+def _timed_cpu(one_pass, units, warm=3, reps=5):
+    """warm-up 3, best of 5, time.perf_counter; measured twice:
+    (a) torch.set_num_threads(1) with the process pinned to ONE core — the reference's own setting (tools/test.py:51) and
+        the headline, because it does not depend on how oneDNN's grouped-conv threading behaves on a given box;
+    (b) all cores (capped at 64 threads), affinity restored.
+    Returns (units/s at 1 thread, units/s at all cores, threads used for (b), relative spread of the 1-thread repeats)."""
+    have_aff = hasattr(os, "sched_getaffinity")
+    cpus = sorted(os.sched_getaffinity(0)) if have_aff else list(range(os.cpu_count() or 1))
+
+    def run(threads):
+        torch.set_num_threads(threads)
+        for _ in range(warm):
+            one_pass()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            one_pass()
+            ts.append(time.perf_counter() - t0)
+        return ts
+
+    if have_aff:
+        os.sched_setaffinity(0, {cpus[len(cpus) // 2]})  # one core, away from core 0's interrupt load
+    try:
+        t1 = run(1)
+    finally:
+        if have_aff:
+            os.sched_setaffinity(0, set(cpus))
+    all_threads = min(len(cpus), 64)
+    tall = run(all_threads) if all_threads > 1 else t1
+    torch.set_num_threads(all_threads)
+    return units / min(t1), units / min(tall), all_threads, (max(t1) - min(t1)) / min(t1)
+
+
 def cpu_baseline(d, sf_sd):
-    """The CPU oracle on a bounded sample of the same workload: 8 of the 64 pairs, all kernels of the step."""
+    """The CPU oracle on the SAME workload as the GPU step: all 64 pairs, every kernel of the step."""
     from oracle import hdn_oracle as O
 
-    n = 8
+    n = PAIRS
     c = lambda t: t[:n].detach().cpu()
     nx, nk = c(d["north_x"]), c(d["north_k"])
     px, pk = [c(t) for t in d["prod_x"]], [c(t) for t in d["prod_k"]]
@@ -344,40 +436,45 @@ def cpu_baseline(d, sf_sd):
             (p2 - pf).abs()[0][0].sum() / (127 * 127)
             (p2 - p1).abs()[0][0].sum() / (127 * 127)
 
-    def best(threads):
-        torch.set_num_threads(threads)
-        one_pass()
-        ts = []
-        for _ in range(3):
-            t0 = time.perf_counter()
-            one_pass()
-            ts.append(time.perf_counter() - t0)
-        return n / min(ts)
-
-    ncpu = os.cpu_count() or 1
-    all_threads = min(ncpu, 64)
-    v1 = best(1)
-    vall = best(all_threads)
-    model = ""
-    try:
-        with open("/proc/cpuinfo") as f:
-            for line in f:
-                if line.startswith("model name"):
-                    model = line.split(":", 1)[1].strip()
-                    break
-    except OSError:
-        pass
+    v1, vall, all_threads, spread = _timed_cpu(one_pass, n)
     return {
-        "value": max(v1, vall),
+        "value": v1,
         "unit": "frames/s",
-        "cores": all_threads if vall >= v1 else 1,
+        "cores": 1,
         "kind": "port",
-        "sample": f"{n} of the 64 pairs, every kernel of the step, best of 3 passes (oracle/hdn_oracle.py, PyTorch-CPU fp32)",
+        "sample": f"all {n} pairs of the step, every kernel of the step; warm-up 3, best of 5 passes; 1 thread pinned to one core "
+                  "(the reference's torch.set_num_threads(1), tools/test.py:51); oracle/hdn_oracle.py, PyTorch-CPU fp32",
         "frames_per_s_1_thread": v1,
-        f"frames_per_s_{all_threads}_threads": vall,
-        "host_cpu": model,
-        "host_logical_cpus": ncpu,
+        "frames_per_s_all_cores": vall,
+        "all_cores_threads": all_threads,
+        "repeat_spread_1_thread": spread,
+        "host_cpu": _host_cpu_model(),
+        "host_logical_cpus": os.cpu_count() or 1,
     }
+
+
+def cpu_full_head(d, net_sd):
+    """configs[2] on the host: the oracle's track_proj stages around a PyTorch-CPU ResNet-34 with the same weights,
+    on 16 of the 64 pairs (the trunk is ~36 ms per pair on one core)."""
+    import hdn_amd
+    from oracle import hdn_oracle as O
+
+    n = 16
+    net = hdn_amd.HomoModelBuilder().eval()
+    net.load_state_dict(net_sd)
+    sf_sd = {k: v for k, v in net.ShareFeature.state_dict().items()}
+    imgs = d["imgs"][:n].detach().cpu()
+    data = {"org_imgs": imgs, "input_tensors": imgs, "h4p": d["h4p"][:n].detach().cpu()}
+    regress = lambda f: net.fc(net.avgpool(net.backbone(f)).flatten(1))
+
+    def one_pass():
+        with torch.no_grad():
+            O.track_proj(data, sf_sd, regress)
+
+    v1, vall, all_threads, spread = _timed_cpu(one_pass, n, warm=1, reps=3)
+    return {"value": v1, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{n} of the 64 pairs, whole head incl. the ResNet-34 trunk on PyTorch-CPU; warm-up 1, best of 3; 1 pinned thread",
+            "frames_per_s_all_cores": vall, "all_cores_threads": all_threads, "repeat_spread_1_thread": spread}
 
 
 if __name__ == "__main__":

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libhdn_hip.so"
 LIB_PATH = os.environ.get("HDN_LIB_PATH", os.path.join(_HERE, LIB_NAME))  # override: A/B builds of the kernels
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _c_float_p = ctypes.c_void_p  # device pointers travel as integers
 _i = ctypes.c_int
@@ -34,9 +34,15 @@ SIGNATURES = {
     "hdn_share_feature_f32": (_i, [_c_float_p] * 3 + [_i] * 3 + [ctypes.c_void_p]),
     "hdn_dlt_solve_f32": (_i, [_c_float_p] * 3 + [_i, ctypes.c_void_p]),
     "hdn_warp_f32": (_i, [_c_float_p] * 3 + [_i] * 4 + [ctypes.c_void_p]),
+    "hdn_warp_count_f32": (_i, [_c_float_p] * 4 + [_i] * 4 + [ctypes.c_void_p]),
     "hdn_dlt_warp_f32": (_i, [_c_float_p] * 5 + [_i] * 3 + [ctypes.c_void_p]),
     "hdn_l1_score_f32": (_i, [_c_float_p] * 3 + [_i, ctypes.c_float, ctypes.c_void_p]),
     "hdn_l1_score2_f32": (_i, [_c_float_p] * 4 + [_i, ctypes.c_float, ctypes.c_void_p]),
+    "hdn_allgather_offsets": (_i, [_c_float_p] * 2 + [_i, ctypes.c_void_p, ctypes.c_void_p]),
+    "hdn_rccl_available": (_i, []),
+    "hdn_rccl_unique_id": (_i, [ctypes.c_void_p]),
+    "hdn_rccl_comm_create": (_i, [ctypes.POINTER(ctypes.c_void_p), _i, _i, ctypes.c_void_p]),
+    "hdn_rccl_comm_destroy": (_i, [ctypes.c_void_p]),
     "hdn_logpolar_sample_f32": (_i, [_c_float_p] * 7 + [_i] * 5 + [ctypes.c_void_p]),
 }
 
@@ -45,6 +51,7 @@ ERRORS = {
     -2: "HDN_E_SHAPE: non-positive size, or correlation kernel larger than the search plane",
     -3: "HDN_E_LIMIT: size exceeds what the kernels support",
     -4: "HDN_E_ALIAS: output aliases an input",
+    -5: "HDN_E_NORCCL: librccl.so.1 could not be loaded",
 }
 
 _lock = threading.Lock()
@@ -87,6 +94,8 @@ def check(rc: int, what: str) -> None:
         return
     if rc in ERRORS:
         raise ValueError(f"{what}: {ERRORS[rc]}")
+    if rc <= -2000:
+        raise HdnHipError(f"{what}: RCCL call failed with ncclResult_t {-rc - 2000}")
     if rc <= -1000:
         raise HdnHipError(f"{what}: HIP launch failed with hipError_t {-rc - 1000}")
     raise HdnHipError(f"{what}: unknown error code {rc}")

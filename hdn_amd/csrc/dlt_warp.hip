@@ -115,7 +115,8 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 
 // One output pixel (row i, column j) of image `img` (C planes of H x W, plane stride H*W) written to
 // out[(i*W + j)*C + c].
-__device__ __forceinline__ void warp_pixel(const float* __restrict__ img, const float* th, float* __restrict__ out,
+// Returns the pixel's term of the reference's `condition` count: |t| > 1e-7 after the nudge (utils.py:241).
+__device__ __forceinline__ bool warp_pixel(const float* __restrict__ img, const float* th, float* __restrict__ out,
                                            int i, int j, int C, int H, int W) {
   const float gx = grid_coord(j, W), gy = grid_coord(i, H);
   // T = theta @ [gx, gy, 1]: fma(t1, gy, t0*gx) + t2   (the reference's sgemm order; utils.py:230)
@@ -145,6 +146,7 @@ __device__ __forceinline__ void warp_pixel(const float* __restrict__ img, const 
     // utils.py:185: wa*Ia + wb*Ib + wc*Ic + wd*Id, left to right, no fusion
     o[c] = rn_add(rn_add(rn_add(rn_mul(wa, Ia), rn_mul(wb, Ib)), rn_mul(wc, Ic)), rn_mul(wd, Id));
   }
+  return fabsf(t) > 1e-7f;
 }
 
 __global__ __launch_bounds__(HDN_BLOCK) void dlt_solve_kernel(const float* __restrict__ src,
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(HDN_BLOCK) void dlt_solve_kernel(const float* __res
 
 __global__ __launch_bounds__(HDN_BLOCK) void warp_kernel(const float* __restrict__ img,
                                                          const float* __restrict__ theta, float* __restrict__ out,
-                                                         int C, int H, int W) {
+                                                         unsigned int* __restrict__ count, int C, int H, int W) {
   const int b = blockIdx.y;
   const size_t HW = size_t(H) * W;
   float th[9];
@@ -172,10 +174,16 @@ __global__ __launch_bounds__(HDN_BLOCK) void warp_kernel(const float* __restrict
   const float* im = img + size_t(b) * C * HW;
   float* ob = out + size_t(b) * C * HW;
   const int base = blockIdx.x * WARP_PX_PER_BLOCK + threadIdx.x;
+  unsigned int ok = 0;
 #pragma unroll
   for (int q = 0; q < WARP_PX_PER_THREAD; ++q) {
     const int pix = base + q * HDN_BLOCK;
-    if (pix < H * W) warp_pixel(im, th, ob, pix / W, pix - (pix / W) * W, C, H, W);
+    if (pix < H * W) ok += warp_pixel(im, th, ob, pix / W, pix - (pix / W) * W, C, H, W) ? 1u : 0u;
+  }
+  if (count) {  // kernel-uniform branch: one atomic per wave
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) ok += __shfl_xor(ok, m, HDN_WAVE);
+    if ((threadIdx.x & (HDN_WAVE - 1)) == 0 && ok) atomicAdd(count, ok);
   }
 }
 
@@ -258,15 +266,24 @@ int hdn_dlt_solve_f32(const float* src, const float* off, float* H_out, int B, v
   return hdn::launch_status();
 }
 
-int hdn_warp_f32(const float* img, const float* theta, float* out, int B, int C, int H, int W, void* stream) {
+int hdn_warp_count_f32(const float* img, const float* theta, float* out, unsigned int* count_or_null, int B, int C, int H,
+                       int W, void* stream) {
   if (!img || !theta || !out) return HDN_E_NULL;
   if (B <= 0 || C <= 0 || H <= 1 || W <= 1) return HDN_E_SHAPE;  // linspace(-1,1,1) has no step
   if (B > 65535 || (long long)H * W > (1LL << 30) || (long long)C * H * W > 0x7fffffffLL) return HDN_E_LIMIT;
   if (out == img) return HDN_E_ALIAS;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (count_or_null) {
+    hipError_t e = hipMemsetAsync(count_or_null, 0, sizeof(unsigned int), st);
+    if (e != hipSuccess) return -(1000 + (int)e);
+  }
   dim3 grid(hdn::cdiv(H * W, hdn::WARP_PX_PER_BLOCK), B);
-  hipLaunchKernelGGL(hdn::warp_kernel, grid, dim3(HDN_BLOCK), 0, static_cast<hipStream_t>(stream), img, theta, out, C,
-                     H, W);
+  hipLaunchKernelGGL(hdn::warp_kernel, grid, dim3(HDN_BLOCK), 0, st, img, theta, out, count_or_null, C, H, W);
   return hdn::launch_status();
+}
+
+int hdn_warp_f32(const float* img, const float* theta, float* out, int B, int C, int H, int W, void* stream) {
+  return hdn_warp_count_f32(img, theta, out, nullptr, B, C, H, W, stream);
 }
 
 int hdn_dlt_warp_f32(const float* h4p, const float* off, const float* img, float* H_out, float* warped, int B, int H,

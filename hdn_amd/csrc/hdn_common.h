@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/hdn_hip.h"
 
 #define HDN_WAVE 64
@@ -15,15 +17,20 @@ constexpr int round_up(int a, int b) { return cdiv(a, b) * b; }
 
 // One-time-per-device bookkeeping (hipFuncSetAttribute, device symbol addresses): the library assumes one process per
 // GPU but stays correct when a process drives several devices.
+// The entry points are reached through ctypes (GIL released), so two host threads can make their first call at the same
+// time: the mask is atomic (a duplicated one-time call is harmless, a lost bit is not).  Device ids beyond 63 are never
+// marked done and simply repeat the (cheap, idempotent) setup on every call.
 struct PerDeviceOnce {
-  unsigned long long mask = 0;
+  std::atomic<unsigned long long> mask{0};
   static int device() {
     int d = 0;
     (void)hipGetDevice(&d);
-    return d & 63;
+    return d;
   }
-  bool done(int d) const { return (mask >> d) & 1ull; }
-  void set(int d) { mask |= 1ull << d; }
+  bool done(int d) const { return d >= 0 && d < 64 && ((mask.load(std::memory_order_acquire) >> d) & 1ull); }
+  void set(int d) {
+    if (d >= 0 && d < 64) mask.fetch_or(1ull << d, std::memory_order_release);
+  }
 };
 
 inline int launch_status() {

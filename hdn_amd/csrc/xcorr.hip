@@ -1095,7 +1095,7 @@ static int launch_north_fft_all(const XcorrPtrs& P, int n, int planes, hipStream
                                                   : launch_north_fft2(P.x[i], P.k[i], P.out[i], planes, cap, stream);
     if (rc) return rc;
   }
-  g_last_variant = "north_fft_61x61_31x31";
+  g_last_variant = (two_waves && planes % 4 == 0) ? "north_fft2w_61x61_31x31" : "north_fft_61x61_31x31";
   return HDN_OK;
 }
 

@@ -331,9 +331,11 @@ __device__ __attribute__((used)) nfft::cf g_nfft_tab[NFFT_TAB_LEN] = NFFT_TAB_IN
 static const nfft::cf* north_fft_table() {
   static const nfft::cf* tab[64] = {};  // per device
   const int d = PerDeviceOnce::device();
-  if (!tab[d]) {
+  const bool cacheable = d >= 0 && d < 64;  // (a pointer-sized store: racing first calls write the same value)
+  if (!cacheable || !tab[d]) {
     void* p = nullptr;
     if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_nfft_tab)) != hipSuccess) return nullptr;
+    if (!cacheable) return static_cast<const nfft::cf*>(p);
     tab[d] = static_cast<const nfft::cf*>(p);
   }
   return tab[d];

@@ -65,25 +65,69 @@ class DepthwiseCircBAN(DepthwiseBAN):
     _loc_out = 4
 
 
-def _template_key(z_fs):
-    return tuple((id(z), z.data_ptr(), z._version) for z in z_fs)
+class _TemplateCache:
+    """conv_kernel(z_f) of every (level, branch) for ONE template.
+
+    Holds strong references to the template tensors it was computed from: identity (`is`) and the in-place version
+    counter then identify the template for as long as the entry lives (a freed tensor's id / address / version 0
+    can all be reused by the next template: that is how a key of plain integers goes stale).  The version counters of
+    the conv_kernel parameters and BN buffers are part of the key, so load_state_dict() / .to() / optimiser steps
+    after a forward invalidate the entry as well."""
+
+    __slots__ = ("z_fs", "z_versions", "param_versions", "training", "kern")
+
+    def __init__(self, z_fs, branches, training, kern):
+        self.z_fs = tuple(z_fs)
+        self.z_versions = tuple(z._version for z in z_fs)
+        self.param_versions = _param_versions(branches)
+        self.training = training
+        self.kern = kern
+
+    def matches(self, z_fs, branches, training):
+        return (len(z_fs) == len(self.z_fs) and all(a is b for a, b in zip(z_fs, self.z_fs))
+                and tuple(z._version for z in z_fs) == self.z_versions and training == self.training
+                and _param_versions(branches) == self.param_versions)
+
+
+def _param_versions(branches):
+    out = []
+    for br in branches:
+        for t in list(br.conv_kernel.parameters()) + list(br.conv_kernel.buffers()):
+            out.append((id(t), t.data_ptr(), t._version))
+    return tuple(out)
+
+
+def invalidate_template_cache(head):
+    """Drop the cached template-branch features of a MultiBAN / MultiCircBAN (hooked by install() into
+    ModelBuilder.template(); call it yourself after mutating weights through .data)."""
+    object.__setattr__(head, "_hdn_template_cache", None)
 
 
 def fused_forward(self, z_fs, x_fs, circular=None):
     """MultiBAN.forward / MultiCircBAN.forward (ban.py:102-127, ban_lp.py:66-92) with one correlation launch and
-    cached template-branch features.  `self` needs box2.., (cls|loc)_weight, loc_scale, weighted."""
+    cached template-branch features.  `self` needs box2.., (cls|loc)_weight, loc_scale, weighted.
+
+    Inference only (runs under no_grad, BN in eval mode): in training mode it defers to the class's original forward
+    when install() saved one (`_hdn_orig_forward`), and raises otherwise, rather than silently dropping gradients."""
+    if self.training:
+        orig = getattr(type(self), "_hdn_orig_forward", None)
+        if orig is not None:
+            return orig(self, z_fs, x_fs)
+        raise RuntimeError("hdn_amd heads are inference-only (fused forward under no_grad): call .eval(), or train with "
+                           "the reference's own modules (hdn_amd.install.uninstall() restores them)")
+    z_fs, x_fs = list(z_fs), list(x_fs)
     n = len(z_fs)
     boxes = [getattr(self, "box" + str(i + 2)) for i in range(n)]
+    branches = [br for box in boxes for br in (box.cls, box.loc)]
     if circular is None:
         circular = bool(getattr(boxes[0].cls, "_circular", False)) or type(boxes[0].cls).__name__.endswith("Circ")
     with torch.no_grad():
-        key = _template_key(z_fs) + (bool(self.training),)
         cache = getattr(self, "_hdn_template_cache", None)
-        if cache is None or cache[0] != key:
+        if cache is None or not cache.matches(z_fs, branches, False):
             kern = [br.conv_kernel(z) for box, z in zip(boxes, z_fs) for br in (box.cls, box.loc)]
-            cache = (key, kern)
+            cache = _TemplateCache(z_fs, branches, False, kern)
             object.__setattr__(self, "_hdn_template_cache", cache)
-        kern = cache[1]
+        kern = cache.kern
         srch = [br.conv_search(x) for box, x in zip(boxes, x_fs) for br in (box.cls, box.loc)]
         same = all(k.shape == kern[0].shape for k in kern) and all(s.shape == srch[0].shape for s in srch)
         if same and len(kern) <= 8:

@@ -34,11 +34,11 @@ def DLT_solve(src_p: torch.Tensor, off_set: torch.Tensor) -> torch.Tensor:
     return H.view(B, 1, 3, 3)
 
 
-def transformer(U: torch.Tensor, theta: torch.Tensor, out_size, **kwargs):
+def transformer(U: torch.Tensor, theta: torch.Tensor, out_size, want_condition: bool = True, **kwargs):
     """Projective spatial transformer: U [B,C,H,W], theta [B,3,3] (or [B,9]) -> ([B,H,W,C], condition).
 
-    `condition` (the count of |t| > 1e-7, utils.py:241) is unused by every caller in the reference; it is
-    returned as None here rather than paying a reduction for it.
+    `condition` (the count of |t| > 1e-7 after the nudge, utils.py:241; unused by every caller in the reference)
+    is returned as a 0-dim fp32 device tensor like the reference's; it costs one atomic per wave.
     """
     if U.dim() != 4:
         raise ValueError(f"U must be [B,C,H,W], got {tuple(U.shape)}")
@@ -52,10 +52,12 @@ def transformer(U: torch.Tensor, theta: torch.Tensor, out_size, **kwargs):
         raise ValueError(f"theta batch {th.shape[0]} != image batch {B}")
     img = U.detach().contiguous()
     out = torch.empty((B, H, W, C), dtype=torch.float32, device=dev)
+    count = torch.empty((1,), dtype=torch.int32, device=dev) if want_condition else None  # zeroed by the call
     with torch.cuda.device(dev):
-        rc = _lib.load().hdn_warp_f32(_lib.ptr(img), _lib.ptr(th), _lib.ptr(out), B, C, H, W, _lib.stream_ptr(dev))
+        rc = _lib.load().hdn_warp_count_f32(_lib.ptr(img), _lib.ptr(th), _lib.ptr(out),
+                                            _lib.ptr(count) if want_condition else None, B, C, H, W, _lib.stream_ptr(dev))
     _lib.check(rc, "transformer")
-    return out, None
+    return out, (count[0].to(torch.float32) if want_condition else None)
 
 
 def _is_full_patch(patch_indices: torch.Tensor, B: int, ph: int, pw: int, H: int, W: int) -> bool:
@@ -73,7 +75,7 @@ def transform(patch_size_h, patch_size_w, M_tile_inv, H_mat, M_tile, I1, patch_i
     B, C, H, W = I1.shape
     dev = _lib.require_device(I1, H_mat)
     Hn = torch.matmul(torch.matmul(M_tile_inv.to(dev), H_mat), M_tile.to(dev))
-    warped, _ = transformer(I1, Hn, (H, W))
+    warped, _ = transformer(I1, Hn, (H, W), want_condition=False)
     if assume_identity_patch and _is_full_patch(patch_indices, B, patch_size_h, patch_size_w, H, W):
         return warped.permute(0, 3, 1, 2)
     flat = warped.reshape(-1, C)

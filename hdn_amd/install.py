@@ -52,10 +52,45 @@ def _track_proj_method(self, data, tmp_mask):
     return homo_model.track_proj(self.hm_net, data, tmp_mask)
 
 
+_MISSING = object()
+_saved = []  # (owner, attribute or dict key, original value, is_dict_item) in application order; undone by uninstall()
+
+
+def _rebind(owner, attr, value, item=False):
+    if item:
+        _saved.append((owner, attr, owner.get(attr, _MISSING), True))
+        owner[attr] = value
+    else:
+        _saved.append((owner, attr, owner.__dict__.get(attr, _MISSING) if isinstance(owner, type) else getattr(owner, attr, _MISSING), False))
+        setattr(owner, attr, value)
+
+
+def uninstall() -> int:
+    """Undo every rebinding install() made (most recent first): the reference runs on its own PyTorch ops again, e.g.
+    for training, which the HIP drop-ins (inference only, no autograd) do not support.  Returns the number undone."""
+    n = 0
+    while _saved:
+        owner, attr, orig, item = _saved.pop()
+        if item:
+            if orig is _MISSING:
+                owner.pop(attr, None)
+            else:
+                owner[attr] = orig
+        elif orig is _MISSING:
+            try:
+                delattr(owner, attr)
+            except AttributeError:
+                pass
+        else:
+            setattr(owner, attr, orig)
+        n += 1
+    return n
+
+
 def install(strict: bool = False, modules: dict = None) -> list:
     """Apply the rebindings.  `modules` (name -> module) lets tests supply stand-in modules; by default the
     real reference modules are imported.  Returns the list of (module, attribute) pairs that were rebound;
-    with strict=True a site that cannot be imported raises instead of being skipped."""
+    with strict=True a site that cannot be imported raises instead of being skipped.  uninstall() reverses it."""
     done = []
 
     def get(name):
@@ -74,23 +109,26 @@ def install(strict: bool = False, modules: dict = None) -> list:
             continue
         if not hasattr(m, attr) and strict:
             raise AttributeError(f"{mod_name}.{attr} not found: reference layout changed?")
-        setattr(m, attr, fn)
+        _rebind(m, attr, fn)
         done.append((mod_name, attr))
 
     pre = get(_DLT + ".preprocess")
     if pre is not None and isinstance(getattr(pre, "head", None), dict):
-        pre.head["PreShareFeature"] = share_feature.PreShareFeature
+        _rebind(pre.head, "PreShareFeature", share_feature.PreShareFeature, item=True)
         done.append((_DLT + ".preprocess", "head['PreShareFeature']"))
 
     # heads: keep the reference's classes (and their weights), swap the schedule of forward()
     for mod_name, cls_name, circ in (("hdn.models.head.ban", "MultiBAN", False), ("hdn.models.head.ban_lp", "MultiCircBAN", True)):
         m = get(mod_name)
         if m is not None and hasattr(m, cls_name):
-            getattr(m, cls_name).forward = (lambda c: lambda self, z_fs, x_fs: heads.fused_forward(self, z_fs, x_fs, c))(circ)
+            klass = getattr(m, cls_name)
+            if "_hdn_orig_forward" not in klass.__dict__ and "forward" in klass.__dict__:
+                _rebind(klass, "_hdn_orig_forward", klass.__dict__["forward"])  # training-mode calls are deferred to it
+            _rebind(klass, "forward", (lambda c: lambda self, z_fs, x_fs: heads.fused_forward(self, z_fs, x_fs, c))(circ))
             done.append((mod_name, cls_name + ".forward"))
 
     mb = get("hdn.models.model_builder_e2e_unconstrained_v2")
     if mb is not None and hasattr(mb, "ModelBuilder"):
-        mb.ModelBuilder.track_proj = _track_proj_method
+        _rebind(mb.ModelBuilder, "track_proj", _track_proj_method)
         done.append(("hdn.models.model_builder_e2e_unconstrained_v2", "ModelBuilder.track_proj"))
     return done

@@ -63,7 +63,9 @@ class STN_Polar(nn.Module):
         return self._tabs[key]
 
     def forward(self, x, polar, delta=[0, 0]):
-        if self._orignal_sz[0] != x.shape[-1] // 2 or x.shape[-1] != x.shape[-2]:
-            raise ValueError(f"STN_Polar({2 * self._orignal_sz[0]}) applied to a {tuple(x.shape[-2:])} crop")
+        # like the reference, the S x S grid (S = image_sz // 2) is sampled from whatever H x W crop arrives
+        # (ModelBuilder.update_template passes the 127 x 127 template through STN_Polar(255), model_builder…:98-107)
+        if x.dim() != 4 or x.shape[-1] < 2 or x.shape[-2] < 2:
+            raise ValueError(f"STN_Polar needs a [B,C,H,W] crop with H, W >= 2, got {tuple(x.shape)}")
         rot = float(delta[1])
         return logpolar_sample(x, polar, self._tables(x.device, rot))

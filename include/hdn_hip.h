@@ -28,9 +28,11 @@ extern "C" {
 #define HDN_E_SHAPE (-2) /* non-positive size, or kernel > search */
 #define HDN_E_LIMIT (-3) /* size exceeds what the kernels support */
 #define HDN_E_ALIAS (-4) /* output aliases an input               */
+#define HDN_E_NORCCL (-5) /* librccl.so.1 could not be loaded (collective entry points only) */
+/* RCCL failures are returned as -(2000 + ncclResult_t). */
 
 /* ABI version of this header; hdn_abi_version() of the loaded library must match. */
-#define HDN_ABI_VERSION 1
+#define HDN_ABI_VERSION 2
 int hdn_abi_version(void);
 
 /* Name of the kernel variant the last hdn_xcorr_* call on this thread dispatched to
@@ -124,6 +126,12 @@ int hdn_dlt_solve_f32(const float* src, const float* off, float* H_out, int B, v
  */
 int hdn_warp_f32(const float* img, const float* theta, float* out, int B, int C, int H, int W, void* stream);
 
+/* The same sampler, also returning the second value of the reference's transformer(): `condition` = the number of
+ * output pixels (over the whole batch) whose projective denominator satisfies |t| > 1e-7 after the 1e-6 nudge
+ * (utils.py:236-241).  count_or_null: one device uint32, zeroed by the call on `stream` before the launch. */
+int hdn_warp_count_f32(const float* img, const float* theta, float* out, unsigned int* count_or_null, int B, int C,
+                       int H, int W, void* stream);
+
 /*
  * Fused DLT_solve + transform for the full-patch case: H = DLT(h4p, off);
  * theta = M^-1 H M with M = [[W/2,0,W/2],[0,H/2,H/2],[0,0,1]]; warped = sampler(img, theta).
@@ -158,6 +166,28 @@ int hdn_l1_score2_f32(const float* a, const float* b0, const float* b1, float* o
 int hdn_logpolar_sample_f32(const float* img, const float* polar, const float* rho, const float* cos_theta,
                             const float* sin_theta, float* out, float* grid_or_null, int B, int C, int H, int W,
                             int S, void* stream);
+
+/*
+ * Multi-GPU: template/search pairs are independent, so ranks own disjoint contiguous blocks of pairs
+ * and the path's ONLY exchange is one all-gather of the predicted corner offsets, on RCCL over xGMI.
+ *   local[Bl,8] (this rank's offsets) -> all[world*Bl,8] on every rank, in rank order; Bl must be equal on all
+ *   ranks (pad ragged shards: hdn_amd.dist does); in place iff local == all + rank*Bl*8.
+ * rccl_comm is an ncclComm_t (from hdn_rccl_comm_create below, or any communicator of the process's RCCL);
+ * asynchronous on `stream` like every other entry point.
+ * The reference has no inference-time collective (its multi-GPU evaluation is manual video ranges per
+ * CUDA_VISIBLE_DEVICES, tools/test.py:49,91-103); this replaces the host-side concatenation a batched caller of
+ * HomoModelBuilder.forward (homo_model_builder.py:161-165: x = fc(...)) would do.
+ */
+int hdn_allgather_offsets(const float* local, float* all, int Bl, void* rccl_comm, void* stream);
+
+/* Communicator plumbing for hosts without torch.distributed: rank 0 fills a 128-byte id, ships it to the other ranks
+ * by any means (file, socket, MPI, torch's store), every rank creates its communicator on its current device.
+ * RCCL is loaded on first use (dlopen "librccl.so.1", or $HDN_RCCL_LIB); hdn_rccl_available() reports whether it was. */
+#define HDN_RCCL_UNIQUE_ID_BYTES 128
+int hdn_rccl_available(void);
+int hdn_rccl_unique_id(void* id128);
+int hdn_rccl_comm_create(void** comm_out, int world, int rank, const void* id128);
+int hdn_rccl_comm_destroy(void* comm);
 
 #ifdef __cplusplus
 }

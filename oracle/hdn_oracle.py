@@ -342,13 +342,14 @@ def logpolar_tables(size: int, rot: float = 0.0):
     return rho, torch.cos(theta), torch.sin(theta)
 
 
-def logpolar_sample(x: torch.Tensor, polar: torch.Tensor, delta=(0, 0)):
-    """STN_Polar(image_sz=x.shape[-1]).forward(x, polar, delta) -> (x_lp [B,C,S,S], grid [B,S,S,2]), S = image_sz//2.
+def logpolar_sample(x: torch.Tensor, polar: torch.Tensor, delta=(0, 0), image_sz: int = None):
+    """STN_Polar(image_sz).forward(x, polar, delta) -> (x_lp [B,C,S,S], grid [B,S,S,2]), S = image_sz//2; image_sz
+    defaults to the crop's width (the reference also applies STN_Polar(255) to 127-px crops: update_template).
 
     Reference: hdn/models/logpolar.py:100-124: grid = (rho*cos(theta) + polar_x, rho*sin(theta) + polar_y) / (size//2),
     then F.grid_sample(bilinear, padding_mode='border', align_corners=False)."""
     B, C, H, W = x.shape
-    S = W // 2
+    S = (W if image_sz is None else image_sz) // 2
     rho, c, s = logpolar_tables(S, float(delta[1]))
     ix = rho.unsqueeze(0) * c.unsqueeze(1)   # [a][b] = rho[b] * cos(theta[a])
     iy = rho.unsqueeze(0) * s.unsqueeze(1)

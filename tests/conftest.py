@@ -31,3 +31,32 @@ def relu_normal(g, shape):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+def seeded_bn_(bn, g):
+    """Same as tests/golden/make_golden.py:seeded_bn_ (non-trivial eval-mode BN statistics)."""
+    import torch
+    n = bn.num_features
+    for name, lo, hi in (("weight", 0.5, 1.5), ("bias", -0.3, 0.3), ("running_mean", -0.5, 0.5), ("running_var", 0.5, 2.0)):
+        getattr(bn, name).data = torch.from_numpy(g.uniform(lo, hi, n).astype(np.float32))
+
+
+def seeded_head256(tag):
+    """The 256-channel MultiBAN / MultiCircBAN of tests/golden/heads256.npz, re-created from the seed exactly as
+    make_golden.py:gen_heads creates the reference's (same constructor order => same torch init stream; the
+    fixture's `param_sum` detects a drift).  Returns (module, z_fs, x_fs)."""
+    import torch
+    from hdn_amd import heads
+    cls, zsz, xsz = (heads.MultiBAN, 7, 31) if tag == "ban" else (heads.MultiCircBAN, 15, 15)
+    torch.manual_seed(SEED + (13 if tag == "ban" else 14))
+    m = cls([256, 256, 256], 2, weighted=True).eval()
+    g = golden_rng(810 if tag == "ban" else 811)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            seeded_bn_(mod, g)
+    m.cls_weight.data = torch.from_numpy(g.standard_normal(3).astype(np.float32))
+    m.loc_weight.data = torch.from_numpy(g.standard_normal(3).astype(np.float32))
+    m.loc_scale.data = torch.from_numpy(g.uniform(0.5, 1.5, 3).astype(np.float32))
+    zfs = [torch.from_numpy(g.standard_normal((1, 256, zsz, zsz), dtype=np.float32)) for _ in range(3)]
+    xfs = [torch.from_numpy(g.standard_normal((1, 256, xsz, xsz), dtype=np.float32)) for _ in range(3)]
+    return m, zfs, xfs

@@ -341,6 +341,30 @@ def gen_homo_model(ref_hmb, ref_gi):
     return m, data
 
 
+def gen_track_proj(ref_mb, hm_seeded, data):
+    """ModelBuilder.track_proj (model_builder_e2e_unconstrained_v2.py:161-217) of the REAL ModelBuilder (83.6 M parameters,
+    built under the production YAML) whose hm_net carries the seeded weights of gen_homo_model; same data as
+    homo_forward.npz, so only the outputs are stored: (H_mat, similarity_norm, similarity_norm_simi) and the trunk
+    output x that the tests inject (the 85 MB trunk is not committed)."""
+    torch.manual_seed(SEED + 2)
+    mb = ref_mb.ModelBuilder().eval()
+    mb.hm_net.load_state_dict(hm_seeded.state_dict(), strict=True)
+    mb.hm_net.eval()
+    with torch.no_grad():
+        H_mat, s, ss = mb.track_proj(data, None)
+        # the trunk output the tuple was computed from (same ops as track_proj :181-194)
+        p1 = mb.hm_net.ShareFeature(data["input_tensors"][:, :1])
+        p2 = mb.hm_net.ShareFeature(data["input_tensors"][:, 1:])
+        x = mb.hm_net.fc(mb.hm_net.avgpool(mb.hm_net.backbone(torch.cat((p1, p2), 1))).flatten(1))
+        # second tuple with the pair order swapped: sample 0 of the batch is what the scores read ([0][0], :213-216)
+        data_sw = {k: v.flip(0).contiguous() for k, v in data.items()}
+        H_sw, s_sw, ss_sw = mb.track_proj(data_sw, None)
+    save("track_proj", x=x.numpy(), H_mat=H_mat.numpy(), similarity_norm=np.array(float(s), np.float32),
+         similarity_norm_simi=np.array(float(ss), np.float32), H_mat_swapped=H_sw.numpy(),
+         similarity_norm_swapped=np.array(float(s_sw), np.float32),
+         similarity_norm_simi_swapped=np.array(float(ss_sw), np.float32))
+
+
 def gen_logpolar(ref_lp):
     """STN_Polar.forward (hdn/models/logpolar.py:50-134) = the log-polar resample of track_new_lp."""
     out = {}
@@ -362,6 +386,15 @@ def gen_logpolar(ref_lp):
     idx = rng(702).choice(y.numel(), size=4096, replace=False)
     out.update(prod_polar=polar, prod_idx=idx.astype(np.int64), prod_val=y.numpy().reshape(-1)[idx],
                prod_sum=np.array(y.double().sum().item()), prod_grid=grid.numpy()[:, ::9, ::9, :])
+    # STN_Polar(255) applied to a 127 x 127 crop, as ModelBuilder.update_template does (model_builder…:98-107): the
+    # 127 x 127 grid is still built for image_sz 255, only the normalisation uses the crop's own size
+    g = rng(703)
+    img = (255.0 * g.random((1, 3, 127, 127))).astype(np.float32)
+    polar = np.array([[0.0, 0.0]], np.float32)
+    y, grid = st(t(img), t(polar), [0, 0.2])
+    idx = rng(704).choice(y.numel(), size=2048, replace=False)
+    out.update(tmpl_idx=idx.astype(np.int64), tmpl_val=y.numpy().reshape(-1)[idx], tmpl_sum=np.array(y.double().sum().item()),
+               tmpl_grid=grid.numpy()[:, ::9, ::9, :])
     save("logpolar", **out)
 
 
@@ -391,6 +424,31 @@ def gen_heads(ref_ban, ref_ban_lp):
             out[f"{tag}__sd__" + k.replace(".", "__")] = v.numpy()
     save("heads", **out)
 
+    # production width (256 channels, the path fused_forward runs in the tracker): the weights (3.6 M per head) do not
+    # fit a fixture, so the modules are re-created from the seed in the test (torch.manual_seed + the same constructor
+    # calls = the same init stream; BN statistics / level weights from the numpy generator) and the outputs are stored
+    # in full (they are only [1,2,25,25] + [1,2,25,25] and [1,2,13,13] + [1,4,13,13]).
+    out = {}
+    for tag, cls, zsz, xsz in (("ban", ref_ban.MultiBAN, 7, 31), ("circ", ref_ban_lp.MultiCircBAN, 15, 15)):
+        torch.manual_seed(SEED + (13 if tag == "ban" else 14))
+        m = cls([256, 256, 256], 2, weighted=True).eval()
+        g = rng(810 if tag == "ban" else 811)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                seeded_bn_(mod, g)
+        m.cls_weight.data = t(g.standard_normal(3).astype(np.float32))
+        m.loc_weight.data = t(g.standard_normal(3).astype(np.float32))
+        m.loc_scale.data = t(g.uniform(0.5, 1.5, 3).astype(np.float32))
+        zfs = [t(g.standard_normal((1, 256, zsz, zsz), dtype=np.float32)) for _ in range(3)]
+        xfs = [t(g.standard_normal((1, 256, xsz, xsz), dtype=np.float32)) for _ in range(3)]
+        with torch.no_grad():
+            c, l = m(zfs, xfs)
+        out[f"{tag}__cls"] = c.numpy()
+        out[f"{tag}__loc"] = l.numpy()
+        # a checksum of the seeded parameters, so that a drift of torch's init stream is reported as such
+        out[f"{tag}__param_sum"] = np.array(sum(float(v.double().sum()) for v in m.state_dict().values()))
+    save("heads256", **out)
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -416,7 +474,9 @@ def main():
     gen_share_feature(ref_pre)
     gen_dlt(ref_utils)
     gen_transform(ref_utils)
-    gen_homo_model(ref_hmb, ref_gi)
+    hm_seeded, hm_data = gen_homo_model(ref_hmb, ref_gi)
+    import hdn.models.model_builder_e2e_unconstrained_v2 as ref_mb
+    gen_track_proj(ref_mb, hm_seeded, hm_data)
     import hdn.models.logpolar as ref_lp
     gen_logpolar(ref_lp)
     import hdn.models.head.ban as ref_ban

@@ -46,6 +46,21 @@ def _worker(rank, world, port, n_pairs, q):
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         ok = ok and lo.item() == hi.item()
+        # hdn_amd.dist.sharded_offsets itself (slicing of the global batch + the gather), with the head's stages
+        # replaced by the stand-in: the real stages need a GPU (tests/test_gpu_dist.py runs them)
+        import hdn_amd.homo_model as hm
+        seen = {}
+
+        def fake_stages(net, data, cached_patch_1=None):
+            seen["keys"], seen["n"] = sorted(data), data["org_imgs"].shape[0]
+            return {"x": _fake_offsets(data["org_imgs"])}
+
+        hm.homo_stages = fake_stages
+        data = {"org_imgs": pairs, "input_tensors": pairs, "h4p": torch.zeros(n_pairs, 8), "patch_indices": torch.zeros(n_pairs, 16),
+                "not_sharded": torch.zeros(3)}
+        full2 = hdist.sharded_offsets(None, data)
+        ok = ok and torch.equal(full2, ref) and seen["n"] == e - s
+        ok = ok and seen["keys"] == ["h4p", "input_tensors", "org_imgs", "patch_indices"]
         # a wrong local size is rejected rather than silently mis-ordered
         if n_pairs >= world and e - s >= 1:
             try:

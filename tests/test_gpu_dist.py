@@ -1,0 +1,146 @@
+"""GPU tests of the multi-GPU path on a ONE-GPU box (-m gpu): RCCL really runs (world of one), and the N > 1 code path
+(shard -> head -> all-gather) runs with two processes sharing GPU 0 (gloo staging, since RCCL refuses two ranks on one
+device).  The scaling curve itself is the driver's job (bench.py --gpus N on an 8-GPU node)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_rccl_all_gather_through_the_c_abi(dev):
+    """hdn_allgather_offsets (include/hdn_hip.h) on a world-of-one RCCL communicator created through the C ABI."""
+    from hdn_amd import _lib
+    from hdn_amd import dist as hdist
+    assert _lib.load().hdn_rccl_available() == 1
+    comm = hdist.RcclComm(1, 0, hdist.RcclComm.unique_id(), dev)
+    try:
+        x = torch.randn(64, 8, device=dev)
+        y = comm.all_gather(x)
+        torch.cuda.synchronize()
+        assert y.data_ptr() != x.data_ptr() and torch.equal(y, x)
+        # the ragged-shard wrapper on top of it (a world of one has nothing to pad, but runs the same code)
+        z = hdist.all_gather_offsets(x, 64, comm=comm, always_collective=True)
+        assert torch.equal(z, x)
+        # in place (local == all + rank*Bl*8) is legal, partial overlap is not
+        import ctypes
+        buf = torch.randn(16, 8, device=dev)
+        keep = buf.clone()
+        rc = _lib.load().hdn_allgather_offsets(_lib.ptr(buf), _lib.ptr(buf), 16, comm._h, _lib.stream_ptr(dev))
+        torch.cuda.synchronize()
+        assert rc == 0 and torch.equal(buf, keep)
+        rc = _lib.load().hdn_allgather_offsets(ctypes.c_void_p(buf.data_ptr() + 32), _lib.ptr(buf), 8, comm._h, _lib.stream_ptr(dev))
+        assert rc == -4
+        with pytest.raises(ValueError):
+            comm.all_gather(torch.zeros(4, 9, device=dev))
+    finally:
+        comm.destroy()
+    with pytest.raises(_lib.HdnHipError):
+        comm.all_gather(torch.zeros(4, 8, device=dev))
+
+
+_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np, torch, torch.distributed as dist
+rank, world, backend = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), os.environ["HDN_TEST_BACKEND"]
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+kw = {"device_id": dev} if backend == "nccl" else {}
+dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+import hdn_amd
+from hdn_amd import dist as hdist
+from hdn_amd.homo_model import homo_stages
+from test_gpu_parity import _seeded_net, _cfg1_data
+net = _seeded_net().to(dev)
+B = int(os.environ["HDN_TEST_PAIRS"])
+data = {k: v.to(dev) for k, v in _cfg1_data(B, 4242).items()}          # every rank holds the same global batch
+want = homo_stages(net, data)["x"]                                      # unsharded, same device
+res = {}
+got = hdist.sharded_offsets(net, data, always_collective=True)           # torch.distributed collective (nccl = RCCL)
+res["torch"] = bool(got.shape == (B, 8) and float((got - want).abs().max()) <= 5e-5)
+if backend == "nccl":
+    comm = hdist.RcclComm.from_process_group(dev)                       # the C-ABI collective on its own communicator
+    got2 = hdist.sharded_offsets(net, data, comm=comm, always_collective=True)
+    res["c_abi"] = bool(torch.equal(got2, got))
+    comm.destroy()
+cs = torch.tensor([got.double().sum().item()], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+lo, hi = cs.clone(), cs.clone()
+dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+res["checksum_equal"] = bool(lo.item() == hi.item())
+torch.cuda.synchronize()
+print("RESULT", rank, json.dumps(res), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def _run_ranks(world, backend, pairs):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HDN_TEST_BACKEND=backend, HDN_TEST_PAIRS=str(pairs), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", _WORKER % {"root": ROOT}], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+            o += "\nTIMEOUT"
+        outs.append(o)
+    return outs
+
+
+def _results(outs):
+    import json
+    res = {}
+    for o in outs:
+        for line in o.splitlines():
+            if line.startswith("RESULT "):
+                _, r, js = line.split(" ", 2)
+                res[int(r)] = json.loads(js)
+    return res
+
+
+def test_sharded_offsets_over_rccl_world_of_one(dev):
+    """init_process_group("nccl") + hdn_amd.dist.sharded_offsets with the collective forced: all_gather_into_tensor on
+    device memory through RCCL, then the same through hdn_allgather_offsets on a communicator bootstrapped from the group."""
+    outs = _run_ranks(1, "nccl", 6)
+    res = _results(outs)
+    assert res == {0: {"torch": True, "c_abi": True, "checksum_equal": True}}, outs[0][-3000:]
+
+
+@pytest.mark.parametrize("pairs", [8, 7])
+def test_sharded_offsets_two_ranks_on_one_gpu(dev, pairs):
+    """The N > 1 path end to end with the real head: 2 processes share GPU 0 (gloo, host-staged gather), even and ragged
+    shards; every rank ends with the unsharded result and equal checksums (SURVEY §8d cfg 3)."""
+    outs = _run_ranks(2, "gloo", pairs)
+    res = _results(outs)
+    ok = {"torch": True, "checksum_equal": True}
+    assert res == {0: ok, 1: ok}, "\n----\n".join(o[-2000:] for o in outs)

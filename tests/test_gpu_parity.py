@@ -133,7 +133,7 @@ def test_xcorr_north_two_wave_fft_variant(dev, planes):
     x, k = relu_normal(r, (B, C, 61, 61)), relu_normal(r, (B, C, 31, 31))
     with X.north_variant("fft2w"):
         y = hdn_amd.xcorr_depthwise(T(x).to(dev), T(k).to(dev))
-        assert X.last_variant() == "north_fft_61x61_31x31"
+        assert X.last_variant() == ("north_fft2w_61x61_31x31" if (B * C) % 4 == 0 else "north_fft_61x61_31x31")
         assert torch.equal(y, hdn_amd.xcorr_depthwise(T(x).to(dev), T(k).to(dev)))
     check_xcorr(y, x, k, O.xcorr_depthwise(T(x), T(k)).numpy(), False, f"{planes} fft2w")
 
@@ -455,8 +455,10 @@ def test_transformer_golden_including_nudge_branch(dev):
     y, cond = hdn_amd.transformer(T(g["img"]).to(dev), T(g["theta"]).to(dev), (20, 33))
     np.testing.assert_allclose(y.cpu().numpy(), g["y"], rtol=0, atol=1e-4)
     assert np.abs(y.cpu().numpy() - g["y"]).max() < 1e-5
-    y3, _ = hdn_amd.transformer(T(g["img3"]).to(dev), T(g["theta3"]).to(dev), (15, 17))
+    assert cond.dim() == 0 and cond.dtype == torch.float32 and float(cond) == float(g["cond"])  # utils.py:241
+    y3, cond3 = hdn_amd.transformer(T(g["img3"]).to(dev), T(g["theta3"]).to(dev), (15, 17))
     np.testing.assert_allclose(y3.cpu().numpy(), g["y3"], rtol=0, atol=1e-4)
+    assert float(cond3) == float(g["cond3"])
     with pytest.raises(ValueError):
         hdn_amd.transformer(T(g["img"]).to(dev), T(g["theta"]).to(dev), (10, 10))
 
@@ -538,6 +540,60 @@ def test_multi_ban_fused_forward_golden(dev, tag, circular):
     assert float((ref_c - c).abs().max()) < 1e-5
 
 
+@pytest.mark.parametrize("tag,circular", [("ban", False), ("circ", True)])
+def test_multi_ban_fused_forward_production_width(dev, tag, circular):
+    """The 256-channel heads the tracker runs (prod29 / circ13 kernels, 6 problems in one launch) end to end against
+    the reference's outputs; the modules are re-created from the seed (conftest.seeded_head256)."""
+    from conftest import seeded_head256
+    g = load_golden("heads256")
+    m, zfs, xfs = seeded_head256(tag)
+    psum = sum(float(v.double().sum()) for v in m.state_dict().values())
+    assert abs(psum - float(g[tag + "__param_sum"])) <= 1e-6 * abs(psum), "torch's init stream drifted: regenerate heads256.npz"
+    m = m.to(dev)
+    c, l = m([z.to(dev) for z in zfs], [x.to(dev) for x in xfs])
+    assert X.last_variant() == ("circ13" if circular else "prod_29x29_5x5")
+    # 3x3 convs over 256 channels + BN + 1x1 heads on MIOpen around the HIP correlation: 2e-4 abs on O(1) outputs
+    np.testing.assert_allclose(c.cpu().numpy(), g[tag + "__cls"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(l.cpu().numpy(), g[tag + "__loc"], rtol=0, atol=2e-4)
+
+
+def test_fused_forward_new_template_after_old_one_is_freed(dev):
+    """Two template() calls with no forward in between, the first template freed (end of one video, init of the next):
+    the cache must not hand the old template's conv_kernel features to the new one, whatever ids / addresses get reused;
+    nor survive a load_state_dict()."""
+    import gc
+    from hdn_amd import heads as HD
+    torch.manual_seed(5)
+    m = HD.MultiBAN([16, 16, 16], 2, weighted=True).to(dev).eval()
+    gen = torch.Generator().manual_seed(6)
+    mk = lambda s: [torch.randn(1, 16, s, s, generator=gen).to(dev) for _ in range(3)]
+    xs = mk(31)
+    z1 = mk(7)
+    c1, _ = m(z1, xs)
+    ids1 = [(id(z), z.data_ptr()) for z in z1]
+    for trial in range(8):
+        del z1
+        gc.collect()
+        z1 = mk(7)  # the caching allocator is free to reuse the addresses, Python the ids
+        fresh = HD.MultiBAN([16, 16, 16], 2, weighted=True).to(dev).eval()
+        fresh.load_state_dict(m.state_dict())
+        want, _ = fresh(z1, xs)
+        got, _ = m(z1, xs)
+        assert torch.equal(got, want), trial
+    # in-place change of the template and reloaded weights both invalidate
+    z1[0].mul_(2.0)
+    fresh = HD.MultiBAN([16, 16, 16], 2, weighted=True).to(dev).eval()
+    fresh.load_state_dict(m.state_dict())
+    assert torch.equal(m(z1, xs)[0], fresh(z1, xs)[0])
+    sd = {k: (v * 1.5 if k.endswith("conv_kernel.0.weight") else v.clone()) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    fresh.load_state_dict(sd)
+    assert torch.equal(m(z1, xs)[0], fresh(z1, xs)[0])
+    m.train()
+    with pytest.raises(RuntimeError):
+        m(z1, xs)
+
+
 # --------------------------------------------------------------------------- log-polar sampler (§8f rank 2)
 def test_logpolar_golden(dev):
     """Crops are raw 0..255 images, so the 1e-4 bound is relative to that amplitude (2.55e-2 abs); observed <= 2e-3
@@ -561,6 +617,14 @@ def test_logpolar_golden(dev):
     assert np.abs(yv - g["prod_val"]).max() < 1e-4 * 255  # white-noise 0..255 crop x ~1e-5 px table difference
     np.testing.assert_allclose(grid.cpu().numpy()[:, ::9, ::9, :], g["prod_grid"], rtol=0, atol=1e-6)
     assert abs(y.double().sum().item() - float(g["prod_sum"])) < 1e-6 * float(g["prod_sum"])
+    # STN_Polar(255) on the 127-px template crop, rotation 0.2 (ModelBuilder.update_template)
+    r = golden_rng(703)
+    tm = (255.0 * r.random((1, 3, 127, 127))).astype(np.float32)
+    y, grid = hdn_amd.STN_Polar(255)(T(tm).to(dev), torch.zeros(1, 2, device=dev), [0, 0.2])
+    assert y.shape == (1, 3, 127, 127)
+    assert np.abs(y.cpu().numpy().reshape(-1)[g["tmpl_idx"]] - g["tmpl_val"]).max() < 1e-4 * 255
+    np.testing.assert_allclose(grid.cpu().numpy()[:, ::9, ::9, :], g["tmpl_grid"], rtol=0, atol=1e-6)
+    assert abs(y.double().sum().item() - float(g["tmpl_sum"])) < 1e-6 * float(g["tmpl_sum"])
 
 
 def test_logpolar_vs_oracle_offsets_and_border(dev):
@@ -636,6 +700,32 @@ def test_homo_forward_golden_post_trunk(dev):
     np.testing.assert_allclose(out["pred_I2_CnnFeature_d"].cpu().numpy(), g["pred_I2_CnnFeature_d"], atol=5e-4)
     np.testing.assert_allclose(out["feature_loss"].cpu().numpy(), g["feature_loss"], rtol=1e-3, atol=1e-8)
     assert float(out["homo_neg_loss"]) == 0.0
+
+
+def test_track_proj_golden_tuple(dev):
+    """(H_mat, similarity_norm, similarity_norm_simi) against the tuple the reference's ModelBuilder.track_proj returned
+    (tests/golden/track_proj.npz; trunk output injected), in both batch orders: the scores read sample 0 only."""
+    g, tp = load_golden("homo_forward"), load_golden("track_proj")
+    net = hdn_amd.HomoModelBuilder().eval()
+    net.ShareFeature.load_state_dict(share_sd(g, "sf__"))
+    net = net.to(dev)
+    net.fc = torch.nn.Identity()
+    net.avgpool = torch.nn.Identity()
+    data = {k: T(g[k]) for k in ("org_imgs", "input_tensors", "h4p", "patch_indices")}
+    for flip, sfx in ((False, ""), (True, "_swapped")):
+        xfix = (T(tp["x"]).flip(0).contiguous() if flip else T(tp["x"])).to(dev)
+
+        class Inject(torch.nn.Module):
+            def forward(self, feats):
+                return xfix
+
+        net.backbone = Inject()
+        d = {k: (v.flip(0).contiguous() if flip else v).to(dev) for k, v in data.items()}
+        Hm, s, ss = net.track_proj(d, None)
+        np.testing.assert_allclose(Hm.cpu().numpy(), tp["H_mat" + sfx], rtol=0, atol=1e-5)
+        # scores: means of |feature differences| over 127^2 pixels, warped features within 5e-4 (white-noise crops)
+        assert abs(float(s) - float(tp["similarity_norm" + sfx])) <= 1e-4, (float(s), float(tp["similarity_norm" + sfx]))
+        assert abs(float(ss) - float(tp["similarity_norm_simi" + sfx])) <= 1e-5
 
 
 def test_track_proj_end_to_end_corner_offsets(dev):

@@ -187,7 +187,8 @@ def test_install_rebinds_the_reference_sites():
     mods[names[6]].ModelBuilder = ModelBuilder
 
     class MultiBAN:
-        pass
+        def forward(self, z_fs, x_fs):
+            return sentinel
 
     class MultiCircBAN:
         pass
@@ -203,6 +204,44 @@ def test_install_rebinds_the_reference_sites():
     assert mods[names[5]].head["PreShareFeature"] is hdn_amd.PreShareFeature
     assert ModelBuilder.track_proj is hinstall._track_proj_method
     assert mods["hdn.models.logpolar"].STN_Polar is hdn_amd.STN_Polar and mods[names[6]].STN_Polar is hdn_amd.STN_Polar
+    # training-mode calls are deferred to the class's own forward (the fused one is inference-only) ...
+    mb = MultiBAN()
+    mb.training = True
+    assert mb.forward([], []) is sentinel
+    mc = MultiCircBAN()
+    mc.training = True
+    with pytest.raises(RuntimeError):
+        mc.forward([], [])
+    # ... and uninstall() puts every site back
+    assert hinstall.uninstall() >= len(done)
+    assert mods["hdn.models.head.ban"].xcorr_depthwise is sentinel and mods[names[6]].Homo_STN is sentinel
+    assert mods[names[5]].head["PreShareFeature"] is sentinel
+    assert MultiBAN().forward([], []) is sentinel and "forward" not in MultiCircBAN.__dict__
+    assert "_hdn_orig_forward" not in MultiBAN.__dict__
+    assert ModelBuilder().track_proj(None, None) is sentinel
+    assert hinstall.uninstall() == 0
+
+
+def test_template_cache_identity_rules():
+    """The template-branch cache of fused_forward is keyed on the template tensors THEMSELVES (strong references),
+    their in-place version and the conv_kernel parameter versions — not on ids / addresses, which a freed template
+    hands to the next one."""
+    from hdn_amd import heads
+    torch.manual_seed(0)
+    box = heads.DepthwiseBAN(4, 4, 2)
+    branches = [box.cls, box.loc]
+    z = [torch.zeros(1, 4, 7, 7)]
+    c = heads._TemplateCache(z, branches, False, kern=["k"])
+    assert c.matches(z, branches, False)
+    assert not c.matches([torch.zeros(1, 4, 7, 7)], branches, False)      # a different tensor, equal in every integer
+    z[0].add_(1.0)
+    assert not c.matches(z, branches, False)                                # same tensor, modified in place
+    c = heads._TemplateCache(z, branches, False, kern=["k"])
+    box.load_state_dict({k: v.clone() for k, v in box.state_dict().items()})
+    assert not c.matches(z, branches, False)                                # weights reloaded after the forward
+    c = heads._TemplateCache(z, branches, False, kern=["k"])
+    assert c.matches(z, branches, False) and not c.matches(z + [z[0]], branches, False)
+    assert c.z_fs[0] is z[0]                                                # the entry pins the template it belongs to
 
 
 def test_logpolar_tables_match_oracle_and_module_signature():
@@ -213,9 +252,12 @@ def test_logpolar_tables_match_oracle_and_module_signature():
     m = hdn_amd.STN_Polar(255)
     assert m._orignal_sz == [127, 127]
     with pytest.raises(ValueError):
-        m(torch.zeros(1, 3, 31, 31), torch.zeros(1, 2))
-    with pytest.raises(_lib.HdnHipError):
-        m(torch.zeros(1, 3, 255, 255), torch.zeros(1, 2))
+        m(torch.zeros(1, 3, 31, 1), torch.zeros(1, 2))
+    # any H x W crop is accepted, as in the reference (update_template feeds the 127-px template to STN_Polar(255));
+    # on the CPU both reach the device check: no fallback
+    for side in (127, 255):
+        with pytest.raises(_lib.HdnHipError):
+            m(torch.zeros(1, 3, side, side), torch.zeros(1, 2))
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference tree only exists in the build container")

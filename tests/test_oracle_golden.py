@@ -149,6 +149,24 @@ def test_homo_forward_post_trunk():
     assert float(out["homo_neg_loss"]) == float(g["homo_neg_loss"]) == 0.0
 
 
+def test_track_proj_tuple():
+    """(H_mat, similarity_norm, similarity_norm_simi) of the reference's ModelBuilder.track_proj
+    (model_builder_e2e_unconstrained_v2.py:161-217), trunk output injected; both batch orders, because the two scores
+    read sample 0 / channel 0 only (:213-216)."""
+    g, tp = load_golden("homo_forward"), load_golden("track_proj")
+    sf = share_sd(g, "sf__")
+    np.testing.assert_array_equal(tp["x"], g["x"])  # same weights, same data: track_proj and forward() share the trunk output
+    data = {k: T(g[k]) for k in ("org_imgs", "input_tensors", "h4p", "patch_indices")}
+    for flip, sfx in ((False, ""), (True, "_swapped")):
+        d = {k: v.flip(0).contiguous() for k, v in data.items()} if flip else data
+        x = T(tp["x"]).flip(0).contiguous() if flip else T(tp["x"])
+        Hm, s, ss, _ = O.track_proj(d, sf, regress=lambda feats: x)
+        np.testing.assert_allclose(Hm.numpy(), tp["H_mat" + sfx], rtol=0, atol=2e-6)
+        assert abs(float(s) - float(tp["similarity_norm" + sfx])) <= 2e-6
+        assert abs(float(ss) - float(tp["similarity_norm_simi" + sfx])) <= 2e-6
+    assert float(tp["similarity_norm"]) != float(tp["similarity_norm_swapped"])  # the fixture does distinguish sample 0
+
+
 def test_host_prep_matches_reference_layout():
     g = load_golden("homo_forward")
     r = np.random.default_rng(1)
@@ -184,6 +202,13 @@ def test_logpolar_sample():
     assert y.shape == (2, 3, 127, 127) and grid.shape == (2, 127, 127, 2)
     np.testing.assert_allclose(y.numpy().reshape(-1)[g["prod_idx"]], g["prod_val"], rtol=0, atol=1e-3)
     np.testing.assert_allclose(grid.numpy()[:, ::9, ::9, :], g["prod_grid"], rtol=0, atol=1e-6)
+    # STN_Polar(255) on the 127-px template crop (update_template)
+    r = golden_rng(703)
+    tm = (255.0 * r.random((1, 3, 127, 127))).astype(np.float32)
+    y, grid = O.logpolar_sample(T(tm), torch.zeros(1, 2), [0, 0.2], image_sz=255)
+    assert y.shape == (1, 3, 127, 127)
+    np.testing.assert_allclose(y.numpy().reshape(-1)[g["tmpl_idx"]], g["tmpl_val"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(grid.numpy()[:, ::9, ::9, :], g["tmpl_grid"], rtol=0, atol=1e-6)
 
 
 def heads_fixture(tag):
@@ -202,6 +227,19 @@ def test_multi_ban_heads(tag, circular):
     assert c.shape == cls.shape and l.shape == loc.shape
     np.testing.assert_allclose(c.numpy(), cls, rtol=0, atol=1e-5)
     np.testing.assert_allclose(l.numpy(), loc, rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag,circular", [("ban", False), ("circ", True)])
+def test_multi_ban_heads_production_width(tag, circular):
+    """256-channel heads (the width the tracker runs): modules re-created from the seed, outputs from the reference."""
+    from conftest import seeded_head256
+    g = load_golden("heads256")
+    m, zfs, xfs = seeded_head256(tag)
+    psum = sum(float(v.double().sum()) for v in m.state_dict().values())
+    assert abs(psum - float(g[tag + "__param_sum"])) <= 1e-6 * abs(psum), "torch's init stream drifted: regenerate heads256.npz"
+    c, l = O.multi_ban(zfs, xfs, m.state_dict(), circular)
+    np.testing.assert_allclose(c.numpy(), g[tag + "__cls"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(l.numpy(), g[tag + "__loc"], rtol=0, atol=2e-5)
 
 
 def test_xcorr_fast_and_slow():
