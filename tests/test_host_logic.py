@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_library_loads_and_reports_abi():
     lib = _lib.load()
-    assert lib.hdn_abi_version() == _lib.ABI_VERSION == 1
+    assert lib.hdn_abi_version() == _lib.ABI_VERSION == 2
     assert lib.hdn_last_xcorr_variant() == b"none"
 
 
@@ -49,6 +49,11 @@ def test_c_abi_argument_errors_need_no_gpu():
     assert lib.hdn_dlt_solve_f32(one, one, None, 1, None) == -1
     assert lib.hdn_warp_f32(one, one, ctypes.c_void_p(32), 1, 1, 1, 5, None) == -2  # linspace(-1,1,1)
     assert lib.hdn_dlt_warp_f32(one, one, one, one, ctypes.c_void_p(32), 70000, 5, 5, None) == -3
+    assert lib.hdn_allgather_offsets(one, one, 4, None, None) == -1 and lib.hdn_allgather_offsets(one, one, 0, one, None) == -2
+    assert lib.hdn_rccl_comm_create(ctypes.byref(ctypes.c_void_p()), 2, 2, ctypes.c_char_p(b"\0" * 128)) == -2
+    assert lib.hdn_rccl_unique_id(None) == -1 and lib.hdn_rccl_available() in (0, 1)
+    with pytest.raises(_lib.HdnHipError, match="ncclResult_t 3"):
+        _lib.check(-2003, "x")
     with pytest.raises(ValueError):
         _lib.check(-2, "x")
     with pytest.raises(_lib.HdnHipError):
