@@ -84,7 +84,10 @@ res["torch"] = bool(got.shape == (B, 8) and float((got - want).abs().max()) <= 5
 if backend == "nccl":
     comm = hdist.RcclComm.from_process_group(dev)                       # the C-ABI collective on its own communicator
     got2 = hdist.sharded_offsets(net, data, comm=comm, always_collective=True)
-    res["c_abi"] = bool(torch.equal(got2, got))
+    # (two runs of the MIOpen trunk are not bit-identical, so this is a tolerance against the unsharded result as well)
+    res["c_abi"] = bool(got2.shape == (B, 8) and float((got2 - want).abs().max()) <= 5e-5)
+    x8 = torch.randn(B, 8, device=dev)
+    res["c_abi_exact"] = bool(torch.equal(hdist.all_gather_offsets(x8, B, comm=comm, always_collective=True), x8))
     comm.destroy()
 cs = torch.tensor([got.double().sum().item()], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
 lo, hi = cs.clone(), cs.clone()
@@ -133,7 +136,7 @@ def test_sharded_offsets_over_rccl_world_of_one(dev):
     device memory through RCCL, then the same through hdn_allgather_offsets on a communicator bootstrapped from the group."""
     outs = _run_ranks(1, "nccl", 6)
     res = _results(outs)
-    assert res == {0: {"torch": True, "c_abi": True, "checksum_equal": True}}, outs[0][-3000:]
+    assert res == {0: {"torch": True, "c_abi": True, "c_abi_exact": True, "checksum_equal": True}}, outs[0][-3000:]
 
 
 @pytest.mark.parametrize("pairs", [8, 7])
