@@ -63,7 +63,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--prewarm-ms", type=float, default=150.0,
                     help="before the W warm-up steps, keep the GPU busy with untimed steps for this long: an idle MI355X "
-                         "needs ~40 ms of sustained load to reach its steady clocks (tools/exp_warmup.py: 0.48 -> 0.38 ms/step)")
+                         "needs ~40 ms of sustained load to reach its steady clocks (tools/experiments/exp_warmup.py: 0.48 -> 0.38 ms/step)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle timing (profiling runs)")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the per-kernel breakdown after the timed region")
     ap.add_argument("--no-full-head", action="store_true", help="skip the full_head block (configs[2] per-GPU workload)")

@@ -182,11 +182,10 @@ NF_DEV void fetch(f4v (&R)[Q], const float* __restrict__ src, long long first, l
 // Pairs pair0 + first, pair0 + first + stride, ... of the tensor; any plane count, any window position.
 __device__ __forceinline__ void north_fft_v1_body(float* smem, const float* __restrict__ x, const float* __restrict__ k,
                                                   float* __restrict__ out, int planes, int pair0, int first, int stride,
-                                                  const nfft::cf* __restrict__ tab) {
+                                                  const nfft::cf* __restrict__ tab, int lane) {
   using namespace nfft;
   cf* const T = reinterpret_cast<cf*>(smem);
   f4v* const S4 = reinterpret_cast<f4v*>(smem);
-  const int lane = threadIdx.x;
   const int npairs = (planes + 1) >> 1;
   const long long xtotal = (long long)planes * XPL, ktotal = (long long)planes * KPL;
 
@@ -323,10 +322,40 @@ __global__ __launch_bounds__(64) void xcorr_north_fft_kernel(const float* __rest
                                                              float* __restrict__ out, int planes, int pair0,
                                                              const nfft::cf* __restrict__ tab) {
   extern __shared__ __align__(16) float smem[];
-  north_fft_v1_body(smem, x, k, out, planes, pair0, blockIdx.x, gridDim.x, tab);
+  north_fft_v1_body(smem, x, k, out, planes, pair0, blockIdx.x, gridDim.x, tab, threadIdx.x);
 }
 
 __device__ __attribute__((used)) nfft::cf g_nfft_tab[NFFT_TAB_LEN] = NFFT_TAB_INIT;
+
+#ifdef HDN_FFT_DEBUG_CLOCKS
+// Instrumented build only (tools/experiments/exp_wave_clocks.sh): every worker of the v2 / v3 kernels records its
+// s_memtime (shader clocks) and s_memrealtime (100 MHz) at entry and exit.
+__device__ unsigned long long g_nfft_dbg[8 * 4096];
+extern "C" int hdn_debug_read_clocks(unsigned long long* host_dst) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_nfft_dbg), sizeof(unsigned long long) * 8 * 4096);
+}
+#define NFFT_DBG_BEGIN(worker) const unsigned long long dbg_t0 = __builtin_readcyclecounter(), dbg_r0 = wall_clock64(); const int dbg_w = (worker);
+#define NFFT_DBG_END() if (lane == 0 && dbg_w < 4096) { unsigned xcc, hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); \
+  g_nfft_dbg[8 * dbg_w] = dbg_t0; g_nfft_dbg[8 * dbg_w + 1] = __builtin_readcyclecounter(); g_nfft_dbg[8 * dbg_w + 2] = dbg_r0; g_nfft_dbg[8 * dbg_w + 3] = wall_clock64(); g_nfft_dbg[8 * dbg_w + 4] = xcc; g_nfft_dbg[8 * dbg_w + 5] = hw; }
+// phase marks of the v2 kernel: raw s_memtime of mark i of iteration `it` for the first 16 workers
+__device__ unsigned long long g_nfft_phase[16 * 16 * 16];
+extern "C" int hdn_debug_read_phases(unsigned long long* host_dst) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_nfft_phase), sizeof(g_nfft_phase));
+}
+#define NFFT_DBG_MARK(i) { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0 && dbg_w < 16 && dbg_it < 16) g_nfft_phase[(dbg_w * 16 + dbg_it) * 16 + (i)] = t_; }
+__device__ float g_nfft_kimg[8192];
+extern "C" int hdn_debug_read_kimg(float* host_dst) { return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_nfft_kimg), sizeof(g_nfft_kimg)); }
+#define NFFT_DBG_DUMP_KIMG() if (dbg_w == 0 && dbg_it == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); for (int i_ = lane; i_ < 31 * 65 * 2; i_ += 64) g_nfft_kimg[i_] = smem[i_]; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+#define NFFT_DBG_ITER() ++dbg_it;
+#define NFFT_DBG_ITER_DECL() int dbg_it = 0;
+#else
+#define NFFT_DBG_BEGIN(worker)
+#define NFFT_DBG_END()
+#define NFFT_DBG_MARK(i)
+#define NFFT_DBG_ITER()
+#define NFFT_DBG_ITER_DECL()
+#define NFFT_DBG_DUMP_KIMG()
+#endif
 
 static const nfft::cf* north_fft_table() {
   static const nfft::cf* tab[64] = {};  // per device
@@ -612,18 +641,29 @@ NF_DEV cf cmul_tw(cf c) {
 
 }  // namespace nf2
 
-// Grid: `nmain` persistent workgroups for the npairs interior pairs, plus (when planes needs it) ONE extra workgroup
-// that runs the general v1 path on the remaining pair(s) meanwhile.
-__global__ __launch_bounds__(64) void xcorr_north_fft2_kernel(const float* __restrict__ x, const float* __restrict__ k,
-                                                              float* __restrict__ out, int npairs, int nmain, int planes,
-                                                              int clamp_from, const nfft::cf* __restrict__ tab) {
+// `nmain` persistent, autonomous WAVES ("workers") for the npairs interior pairs, plus (when planes needs it) ONE extra
+// worker that runs the general v1 path on the remaining pair(s) meanwhile.  A workgroup is WPG workers with one LDS image
+// each and no barrier between them.  WPG = 4 is the shipping form: the hardware places the 4 waves of a workgroup on the
+// 4 SIMDs of a CU, one each, whereas single-wave workgroups (WPG = 1) land on SIMDs unevenly — with 31.7 KB per image
+// five of them fit a CU, and a SIMD that receives two runs both at half speed while the kernel waits for it
+// (tools/experiments/ubench_clock.hip: 2048 one-wave workgroups at "2 per SIMD" live between 2.19 and 2.98 ms).
+constexpr int NF2_TW_OFF = 31744;    // nfft::LDS_BYTES rounded up to 256 B: the worker's image ends here
+constexpr int NF2_WAVE_LDS = 32768;  // image + the per-lane twiddle table of the kernel row pass
+template <int WPG>
+__global__ __launch_bounds__(64 * WPG) void xcorr_north_fft2_kernel(const float* __restrict__ x, const float* __restrict__ k,
+                                                                    float* __restrict__ out, int npairs, int nmain, int planes,
+                                                                    int clamp_from, int tail_worker,
+                                                                    const nfft::cf* __restrict__ tab) {
   using namespace nf2;
-  extern __shared__ __align__(16) float smem[];
-  if ((int)blockIdx.x >= nmain) {
-    north_fft_v1_body(smem, x, k, out, planes, npairs, 0, 1, tab);
-    return;
+  extern __shared__ __align__(16) float smem_wg[];
+  const int wave = WPG == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: an SGPR
+  float* const smem = smem_wg + wave * (NF2_WAVE_LDS / 4);
+  const int worker = (int)blockIdx.x * WPG + wave;
+  const int lane = threadIdx.x & 63;
+  if (worker >= nmain) {
+    if (worker == tail_worker) north_fft_v1_body(smem, x, k, out, planes, npairs, 0, 1, tab, lane);
+    return;  // (a surplus wave of the last workgroup)
   }
-  const int lane = threadIdx.x;
   const uint32_t sb = lds_addr(smem);
 
   const int fc = lane & 31;
@@ -633,7 +673,18 @@ __global__ __launch_bounds__(64) void xcorr_north_fft2_kernel(const float* __res
   const uint32_t a_stash = sb + lane * 16;                     // linear 16-byte chunks
   // lanes past the last row redo that row and rewrite it with identical values: no exec branches around the writes
   const uint32_t a_row = sb + (lane < HX ? lane : HX - 1) * (RS * 8);    // search spectrum row
-  const uint32_t a_rowk = sb + (lane < HK ? lane : HK - 1) * (RS * 8);   // kernel spectrum row
+  // kernel row pass: lanes 0..30 transform the rows' EVEN half-bins, lanes 32..62 the same rows' ODD half-bins (two
+  // pruned 32-point FFTs that differ only in the input twiddle e^{-i*pi*(1 + 2*hl)*j/64}, which is therefore per lane:
+  // a 2 x 32 table behind the wave's image, read through LDS broadcasts); lanes 31 / 63 redo row 30
+  const int hl = lane >> 5, krow = (lane & 31) < HK ? (lane & 31) : HK - 1;
+  const uint32_t a_rowk = sb + krow * (RS * 8) + hl * 8;       // kernel spectrum row, bins of this lane's parity
+  const uint32_t a_tw = sb + NF2_TW_OFF + hl * 256;
+  if (lane < 32) {
+    cf* const tw = reinterpret_cast<cf*>(smem + NF2_TW_OFF / 4);
+    tw[lane] = tab[NFFT_TAB_TAU + lane];
+    tw[32 + lane] = tab[NFFT_TAB_TAU3 + lane];
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   const uint32_t a_col = sb + lane * 8;                        // spectrum column `lane` / linear 8-byte words
   const uint32_t a_colp = sb + fc * 8, a_colq = sb + (63 - fc) * 8;
   const uint32_t a_rowo = sb + (lane < HO ? lane : HO - 1) * (RS * 8);
@@ -677,21 +728,25 @@ __global__ __launch_bounds__(64) void xcorr_north_fft2_kernel(const float* __res
     }
   };
 
-  int p = blockIdx.x;
+  int p = worker;
   if (p >= npairs) return;
+  NFFT_DBG_BEGIN(worker)
   fetch_x(p);
   fetch_k(p);
   wait_vm0();
 
+  NFFT_DBG_ITER_DECL()
   for (; p < npairs; p += nmain) {
     const int offx = (int)(((long long)p * (2 * XPL)) & 3), offk = (int)(((long long)p * (2 * KPL)) & 3);
     const int pn = min(p + nmain, npairs - 1);  // (the last iteration re-fetches its own pair: harmless)
 
+    NFFT_DBG_MARK(0)
     // ---- search pair: AGPRs -> LDS; refill the AGPRs with the next pair.  (The loads were waited for before the
     //      previous pair's stores were issued, see the end of the loop: nobody ever waits for a store.)
     sfor<0, XQ>([&](auto Qi) NF2_LAMBDA { constexpr int q = decltype(Qi)::value; lw128_from_agpr<q * 1024>(a_stash, Rx[q]); });
     fetch_x(pn);
 
+    NFFT_DBG_MARK(1)
     // ---- row pass: lane = row; half-bin twiddle e^{-i*pi*j/64}, FFT, real/imaginary split, store
     {
       const uint32_t aA = sb + (offx + (lane < HX ? lane : HX - 1) * HX) * 4, aB = aA + XPL * 4;
@@ -702,6 +757,7 @@ __global__ __launch_bounds__(64) void xcorr_north_fft2_kernel(const float* __res
         rb[m] = lr2x32<2 * m, 2 * m + 1>(aB);
       });
       wait_lgkm<0>();
+      NFFT_DBG_MARK(2)
       cf v[64];
       sfor<0, 31>([&](auto Mi) NF2_LAMBDA {
         constexpr int j = 2 * decltype(Mi)::value;
@@ -712,6 +768,7 @@ __global__ __launch_bounds__(64) void xcorr_north_fft2_kernel(const float* __res
         if constexpr (j + 1 < HX) v[bitrev(j + 1, 6)] = hi;
       });
       fft<6, -1, HX, 64>(v);
+      NFFT_DBG_MARK(3)
       {
         cf sa[32], sb2[32];  // C(f) + conj C(63-f),  C(f) - conj C(63-f); each write trails its split by one element
         sfor<0, 33>([&](auto F) NF2_LAMBDA {
@@ -729,14 +786,16 @@ __global__ __launch_bounds__(64) void xcorr_north_fft2_kernel(const float* __res
       }
     }
 
+    NFFT_DBG_MARK(4)
     // ---- column pass: lane = (plane, half-bin column); straight into X
     cf X[64];
     sfor<0, HX>([&](auto R) NF2_LAMBDA { constexpr int r = decltype(R)::value; X[bitrev(r, 6)] = lr64<r * RS * 8>(a_col); });
     wait_lgkm<0>();
+    NFFT_DBG_MARK(5)
     // kernel pair: AGPRs -> LDS (beyond spectrum rows 0..30) and its row-pass inputs: in flight under the column FFT
     sfor<0, KQ>([&](auto Qi) NF2_LAMBDA { constexpr int q = decltype(Qi)::value; lw128_from_agpr<KSTAGE * 4 + q * 1024>(a_stash, Rk[q]); });
     fetch_k(pn);
-    const uint32_t akA = sb + (KSTAGE + offk + (lane < HK ? lane : HK - 1) * HK) * 4, akB = akA + KPL * 4;
+    const uint32_t akA = sb + (KSTAGE + offk + krow * HK) * 4, akB = akA + KPL * 4;
     cf ka[16], kb[16];
     sfor<0, 16>([&](auto Mi) NF2_LAMBDA {
       constexpr int m = decltype(Mi)::value;
@@ -744,36 +803,61 @@ __global__ __launch_bounds__(64) void xcorr_north_fft2_kernel(const float* __res
       kb[m] = lr2x32<2 * m, 2 * m + 1>(akB);
     });
     fft<6, -1, HX, 64>(X);
+    NFFT_DBG_MARK(6)
 
-    // ---- kernel row pass, pruned: even bins = FFT32(c * e^{-i*pi*j/64}), odd bins = FFT32(c * e^{-3i*pi*j/64});
-    //      raw spectra to LDS (the split needs an even and an odd bin: the column lanes do it)
-    sfor<0, 2>([&](auto Hf) NF2_LAMBDA {
-      constexpr int half = decltype(Hf)::value;
+    // ---- kernel row pass, pruned: even bins = FFT32(c * e^{-i*pi*j/64}) on lanes 0..30, odd bins =
+    //      FFT32(c * e^{-3i*pi*j/64}) on lanes 32..62, in ONE pass; raw spectra to LDS (the real/imaginary split needs an
+    //      even and an odd bin: the column lanes do it)
+    {
       wait_lgkm<0>();
       cf v[32];
-      sfor<0, 16>([&](auto Mi) NF2_LAMBDA {
-        constexpr int j = 2 * decltype(Mi)::value;
-        constexpr int mul = half ? 3 : 1;
-        cf lo, hi;
-        const cf A = ka[j / 2], B = kb[j / 2];
-        twiddle_in2<-mul * j, -mul * (j + 1), (j + 1 < HK)>(A, B, lo, hi);
-        v[bitrev(j, 5)] = lo;
-        if constexpr (j + 1 < HK) v[bitrev(j + 1, 5)] = hi;
+      constexpr int TCH = 4;  // twiddles arrive in chunks of 4 (two ds_read2_b64), one chunk ahead of their use
+      cf tq[2][TCH];
+      auto tw_issue = [&](auto Ci) NF2_LAMBDA {
+        constexpr int c = decltype(Ci)::value;
+        lr2x64<TCH * c, TCH * c + 1>(a_tw, tq[c & 1][0], tq[c & 1][1]);
+        // entry 31 has no consumer: loading it would leave an in-flight write to a register the compiler considers dead
+        // (and hands to the next packed op) - these loads are invisible to its liveness / wait-count tracking
+        if constexpr (TCH * c + 3 < HK) lr2x64<TCH * c + 2, TCH * c + 3>(a_tw, tq[c & 1][2], tq[c & 1][3]);
+        else tq[c & 1][2] = lr64<(TCH * c + 2) * 8>(a_tw);
+      };
+      tw_issue(std::integral_constant<int, 0>{});
+      sfor<0, 8>([&](auto Ci) NF2_LAMBDA {
+        constexpr int c = decltype(Ci)::value;
+        if constexpr (c + 1 < 8) {
+          tw_issue(std::integral_constant<int, c + 1>{});
+          wait_lgkm<2>();
+        } else {
+          wait_lgkm<0>();
+        }
+        sfor<0, 2>([&](auto Ui) NF2_LAMBDA {
+          constexpr int m = 2 * c + decltype(Ui)::value, j = 2 * m;
+          cf lo, hi;
+          const cf A = ka[m], B = kb[m], T0 = tq[c & 1][j % TCH], T1 = tq[c & 1][j % TCH + 1];
+          // (a + i b) * conj(t), t = (cos, sin):  m = a * (c, -s);  r = b * (s, c) + m   (samples j: lo halves, j + 1: hi halves)
+          if constexpr (j + 1 < HK)
+            asm volatile("v_pk_mul_f32 %0, %2, %4 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
+                         "v_pk_mul_f32 %1, %2, %5 op_sel:[1,0] op_sel_hi:[1,1] neg_hi:[0,1]\n\t"
+                         "v_pk_fma_f32 %0, %3, %4, %0 op_sel:[0,1,0] op_sel_hi:[0,0,1]\n\t"
+                         "v_pk_fma_f32 %1, %3, %5, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1]"
+                         : "=&v"(lo), "=&v"(hi) : "v"(A), "v"(B), "v"(T0), "v"(T1));
+          else
+            asm volatile("v_pk_mul_f32 %0, %1, %3 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
+                         "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[0,1,0] op_sel_hi:[0,0,1]"
+                         : "=&v"(lo) : "v"(A), "v"(B), "v"(T0));
+          v[bitrev(j, 5)] = lo;
+          if constexpr (j + 1 < HK) v[bitrev(j + 1, 5)] = hi;
+        });
       });
       fft<5, -1, HK, 32>(v);
-      if constexpr (half == 0) {  // the same inputs again for the odd bins (holding them would not fit next to X)
-        sfor<0, 16>([&](auto Mi) NF2_LAMBDA {
-          constexpr int m = decltype(Mi)::value;
-          ka[m] = lr2x32<2 * m, 2 * m + 1>(akA);
-          kb[m] = lr2x32<2 * m, 2 * m + 1>(akB);
-        });
-      }
       sfor<0, 16>([&](auto Gi) NF2_LAMBDA {
         constexpr int g = 2 * decltype(Gi)::value;
-        lw2x64<2 * g + half, 2 * g + 2 + half>(a_rowk, v[g], v[g + 1]);
+        lw2x64<2 * g, 2 * g + 2>(a_rowk, v[g], v[g + 1]);  // bins 2g + hl, 2(g + 1) + hl
       });
-    });
+      NFFT_DBG_DUMP_KIMG()
+    }
 
+    NFFT_DBG_MARK(7)
     // ---- kernel column pass (pruned halves; split by a per-lane sign while reading) and product X * conj(K)
     sfor<0, 2>([&](auto Hf) NF2_LAMBDA {
       constexpr int half = decltype(Hf)::value;
@@ -829,6 +913,7 @@ __global__ __launch_bounds__(64) void xcorr_north_fft2_kernel(const float* __res
       });
     });
 
+    NFFT_DBG_MARK(8)
     // ---- inverse column pass (rows 0..30 needed), to LDS
     {
       cf V[64];
@@ -837,11 +922,13 @@ __global__ __launch_bounds__(64) void xcorr_north_fft2_kernel(const float* __res
       sfor<0, HO>([&](auto R) NF2_LAMBDA { constexpr int r = decltype(R)::value; lw64<r * RS * 8>(a_col, V[r]); });
     }
 
+    NFFT_DBG_MARK(9)
     // ---- inverse row pass: lane = output row; Hermitian re-packing of the pair, FFT, un-shift e^{+i*pi*j/64} / 16384
     {
       cf y[64];
       sfor<0, 32>([&](auto C) NF2_LAMBDA { constexpr int c = 2 * decltype(C)::value; lr2x64<c, c + 1>(a_rowo, y[c], y[c + 1]); });
       wait_lgkm<0>();
+      NFFT_DBG_MARK(10)
       cf v[64];
       sfor<0, 32>([&](auto F) NF2_LAMBDA {
         constexpr int f = decltype(F)::value;
@@ -870,12 +957,14 @@ __global__ __launch_bounds__(64) void xcorr_north_fft2_kernel(const float* __res
       }
     }
 
+    NFFT_DBG_MARK(11)
     // ---- results: one contiguous 8-byte-aligned range per pair (both planes exist for every pair given to this kernel)
     {
       cf* o2 = reinterpret_cast<cf*>(out + (long long)p * (2 * OPL));
       cf w[16];
       sfor<0, 16>([&](auto Qi) NF2_LAMBDA { constexpr int q = decltype(Qi)::value; w[q] = lr64<q * 512>(a_col); });
       wait_lgkm<0>();
+      NFFT_DBG_MARK(12)
       wait_vm0();  // the next pair's loads (issued most of an iteration ago) have landed; the stores below stay in flight
       sfor<0, 16>([&](auto Qi) NF2_LAMBDA {
         constexpr int q = decltype(Qi)::value;
@@ -883,8 +972,11 @@ __global__ __launch_bounds__(64) void xcorr_north_fft2_kernel(const float* __res
         asm volatile("" : "+v"(wq));  // consumed only after the wait
         if (lane + 64 * q < OPL) o2[lane + 64 * q] = wq;
       });
+      NFFT_DBG_MARK(13)
+      NFFT_DBG_ITER()
     }
   }
+  NFFT_DBG_END()
 }
 
 // =======================================================================================
@@ -904,6 +996,7 @@ typedef float f3v __attribute__((ext_vector_type(3)));
 constexpr int RSX = 33, RSK = 65;            // row strides (complex): x spectrum of ONE plane; raw kernel spectrum / inverse rows
 constexpr int T_BYTES = 16128;               // >= 61*33*8, 31*65*8, 15*1024 (one staged plane)
 constexpr int LDS_BYTES = T_BYTES;
+constexpr int NF3_WAVE_LDS = (T_BYTES + 255) / 256 * 256;  // one worker's image inside a multi-wave workgroup
 constexpr int PQ = 15;                       // 16-byte chunks per lane of one staged x plane
 
 template <int OFF>
@@ -1016,12 +1109,18 @@ NF_DEV void column_pass(cf (&X)[32], uint32_t a_p, uint32_t a_q, cf hm, cf sg) {
 
 }  // namespace nf3
 
-__global__ __launch_bounds__(64, 2) void xcorr_north_fft3_kernel(const float* __restrict__ x, const float* __restrict__ k,
-                                                                 float* __restrict__ out, int npairs, int planes,
-                                                                 const nfft::cf* __restrict__ tab) {
+// WPG autonomous waves per workgroup, as for the v2 kernel: 8 = two per SIMD by construction.
+template <int WPG>
+__global__ __launch_bounds__(64 * WPG, WPG == 1 ? 2 : 1) void xcorr_north_fft3_kernel(const float* __restrict__ x,
+                                                                                      const float* __restrict__ k,
+                                                                                      float* __restrict__ out, int npairs, int planes,
+                                                                                      const nfft::cf* __restrict__ tab) {
   using namespace nf3;
-  extern __shared__ __align__(16) float smem[];
-  const int lane = threadIdx.x;
+  extern __shared__ __align__(16) float smem_wg[];
+  const int wave = WPG == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: an SGPR
+  float* const smem = smem_wg + wave * (NF3_WAVE_LDS / 4);
+  const int worker = (int)blockIdx.x * WPG + wave, nworkers = (int)gridDim.x * WPG;
+  const int lane = threadIdx.x & 63;
   const uint32_t sb = lds_addr(smem);
   const int c = lane & 31, h = lane >> 5;
   const float sgn = h ? -1.f : 1.f;
@@ -1041,7 +1140,8 @@ __global__ __launch_bounds__(64, 2) void xcorr_north_fft3_kernel(const float* __
   const uint32_t a_out = sb + lane * (HO * 4);
   const long long xlast = ((long long)planes * XPL - 4) * 4;
 
-  for (int p = blockIdx.x; p < npairs; p += gridDim.x) {
+  NFFT_DBG_BEGIN(worker)
+  for (int p = worker; p < npairs; p += nworkers) {
     // ---- the two search planes: coalesced 16-byte chunks of each plane's aligned window (clamped at the tensor end)
     f4v RA[PQ], RB[PQ];
     const long long baseA = (long long)(2 * p) * XPL, baseB = baseA + XPL;
@@ -1246,14 +1346,29 @@ __global__ __launch_bounds__(64, 2) void xcorr_north_fft3_kernel(const float* __
       });
     }
   }
+  NFFT_DBG_END()
 }
 
 int launch_north_fft3(const float* x, const float* k, float* out, int planes, int max_blocks, hipStream_t stream) {
   const nfft::cf* tab = north_fft_table();
   if (!tab) return -(1000 + (int)hipErrorInvalidSymbol);
   const int npairs = planes / 2;
-  const int grid = npairs < max_blocks ? npairs : max_blocks;
-  hipLaunchKernelGGL(xcorr_north_fft3_kernel, dim3(grid), dim3(64), nf3::LDS_BYTES, stream, x, k, out, npairs, planes, tab);
+  const int workers = npairs < max_blocks ? npairs : max_blocks;
+  static const int wpg = [] { const char* e = getenv("HDN_FFT_WPG"); return (e && atoi(e) == 1) ? 1 : 8; }();
+  if (wpg == 1) {
+    hipLaunchKernelGGL(xcorr_north_fft3_kernel<1>, dim3(workers), dim3(64), nf3::LDS_BYTES, stream, x, k, out, npairs, planes, tab);
+  } else {
+    static PerDeviceOnce attr;
+    const int dev_ = PerDeviceOnce::device();
+    if (!attr.done(dev_)) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xcorr_north_fft3_kernel<8>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 8 * nf3::NF3_WAVE_LDS);
+      if (e != hipSuccess) return -(1000 + (int)e);
+      attr.set(dev_);
+    }
+    hipLaunchKernelGGL(xcorr_north_fft3_kernel<8>, dim3((workers + 7) / 8), dim3(512), 8 * nf3::NF3_WAVE_LDS, stream, x, k, out,
+                       npairs, planes, tab);
+  }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? HDN_OK : -(1000 + (int)e);
 }
@@ -1280,9 +1395,25 @@ int launch_north_fft2(const float* x, const float* k, float* out, int planes, in
   const int nfast = all ? npairs : nfull;
   if (nfast == 0) return launch_north_fft(x, k, out, planes, max_blocks, stream, 0);
   const int nmain = nfast < max_blocks ? nfast : max_blocks;
-  const int grid = nmain + (nfast < npairs ? 1 : 0);
-  hipLaunchKernelGGL(xcorr_north_fft2_kernel, dim3(grid), dim3(64), nfft::LDS_BYTES, stream, x, k, out, nfast, nmain, planes,
-                     all ? nfull : 0x7fffffff, tab);
+  const int tail_worker = nfast < npairs ? nmain : -1;
+  const int workers = nmain + (tail_worker >= 0 ? 1 : 0);
+  static const int wpg = [] { const char* e = getenv("HDN_FFT_WPG"); return (e && atoi(e) == 1) ? 1 : 4; }();
+  if (wpg == 1) {
+    hipLaunchKernelGGL(xcorr_north_fft2_kernel<1>, dim3(workers), dim3(64), NF2_WAVE_LDS, stream, x, k, out, nfast, nmain,
+                       planes, all ? nfull : 0x7fffffff, tail_worker, tab);
+  } else {
+    static PerDeviceOnce attr;  // 4 x 31 KB of dynamic LDS needs the opt-in once per device
+    const int dev_ = PerDeviceOnce::device();
+    if (!attr.done(dev_)) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xcorr_north_fft2_kernel<4>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 4 * NF2_WAVE_LDS);
+      if (e != hipSuccess) return -(1000 + (int)e);
+      attr.set(dev_);
+    }
+    const int grid = (workers + 3) / 4;
+    hipLaunchKernelGGL(xcorr_north_fft2_kernel<4>, dim3(grid), dim3(256), 4 * NF2_WAVE_LDS, stream, x, k, out, nfast, nmain,
+                       planes, all ? nfull : 0x7fffffff, tail_worker, tab);
+  }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? HDN_OK : -(1000 + (int)e);
 }

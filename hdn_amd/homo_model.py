@@ -30,7 +30,7 @@ def _regress(net, feats):
 def optimize_trunk(net, enable: bool = True, channels_last: bool = False):
     """Attach the BN-folded trunk to any module with a `.backbone` (also the reference's HomoModelBuilder).
 
-    Measured at B=64 on MI355X (tools/exp_trunk.py, fresh process each): as-is 2.92 ms, folded 2.47 ms; with
+    Measured at B=64 on MI355X (tools/experiments/exp_trunk.py, fresh process each): as-is 2.92 ms, folded 2.47 ms; with
     torch.backends.cudnn.benchmark = True (MIOpen find mode, set before the first forward): 2.76 / 2.28 ms, and
     folded + channels_last 2.06 ms.  Without find mode channels_last does not pay (2.96 ms), hence the default."""
     from .trunk import fold_for_inference

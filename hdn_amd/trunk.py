@@ -72,7 +72,7 @@ def fold_for_inference(net: HomoResNet, channels_last: bool = True) -> nn.Module
     """A copy of `net` with every eval-mode BatchNorm folded into the preceding convolution (weights scaled in
     float64, rounded once) and, optionally, NHWC weights for MIOpen's channels-last kernels.  Measured on MI355X at
     B=64: 2.92 ms (as-is) -> 2.47 ms (folded) -> 2.11 ms (folded + NHWC); outputs agree with the un-folded CPU
-    trunk to ~1.5e-6 relative either way (tools/exp_trunk.py).  The copy does not track later weight changes."""
+    trunk to ~1.5e-6 relative either way (tools/experiments/exp_trunk.py).  The copy does not track later weight changes."""
     import copy
 
     import torch

@@ -1,6 +1,6 @@
 """Correctness + timing of the two-waves-per-SIMD FFT kernel (variant fft2w) against fft and the float64 truth."""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np, torch
 import hdn_amd
 from hdn_amd import xcorr as X

@@ -1,6 +1,6 @@
 """Is the FFT north-star kernel power limited?  Same instruction stream on zeros / ones / random data (warm clocks)."""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import torch
 from hdn_amd import xcorr as X
 dev = torch.device("cuda:0")

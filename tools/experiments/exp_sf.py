@@ -1,6 +1,6 @@
 """A/B of PreShareFeature tile heights (HDN_SF_ROWS=4|8): time for 128 and 64 images of 127x127, parity vs the oracle."""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import torch
 import hdn_amd
 from hdn_amd import share_feature as SF

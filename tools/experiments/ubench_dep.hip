@@ -1,5 +1,5 @@
 // Issue rate of (packed) fp32 ops for ONE or TWO waves per SIMD, K independent chains interleaved.
-// hipcc --offload-arch=gfx950 -O3 tools/ubench_dep.hip -o tools/ubench_dep && tools/ubench_dep
+// hipcc --offload-arch=gfx950 -O3 tools/experiments/ubench_dep.hip -o tools/experiments/ubench_dep && tools/experiments/ubench_dep
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f2 __attribute__((ext_vector_type(2)));

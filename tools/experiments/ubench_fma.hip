@@ -1,6 +1,6 @@
 // Micro-benchmark: fp32 FMA issue ceilings on gfx950 (plain v_fma_f32, v_pk_fma_f32, SGPR operand,
 // dependency distance).  Not part of the product; used to set the VALU roofline for the 31x31 (x) 61x61 kernel.
-//   hipcc --offload-arch=gfx950 -O3 tools/ubench_fma.hip -o /tmp/ubench_fma && /tmp/ubench_fma
+//   hipcc --offload-arch=gfx950 -O3 tools/experiments/ubench_fma.hip -o /tmp/ubench_fma && /tmp/ubench_fma
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
