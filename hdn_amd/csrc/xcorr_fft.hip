@@ -639,6 +639,14 @@ NF_DEV cf cmul_tw(cf c) {
   return r;
 }
 
+// lanes 32..63 of a (c) <-> lanes 0..31 of b (d); needs 2 wait states after a VALU write of any operand
+NF_DEV void half_swap2(float& a, float& b, float& c, float& d) {
+  asm volatile("v_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+NF_DEV void add2(float& a, float& c, float b, float d) {
+  asm volatile("v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3" : "+v"(a), "+v"(c) : "v"(b), "v"(d));
+}
+
 }  // namespace nf2
 
 // `nmain` persistent, autonomous WAVES ("workers") for the npairs interior pairs, plus (when planes needs it) ONE extra
@@ -679,10 +687,21 @@ __global__ __launch_bounds__(64 * WPG) void xcorr_north_fft2_kernel(const float*
   const int hl = lane >> 5, krow = (lane & 31) < HK ? (lane & 31) : HK - 1;
   const uint32_t a_rowk = sb + krow * (RS * 8) + hl * 8;       // kernel spectrum row, bins of this lane's parity
   const uint32_t a_tw = sb + NF2_TW_OFF + hl * 256;
+  // inverse row pass, the same way: lanes 0..30 invert the EVEN bins of a row, lanes 32..62 its ODD bins (two 32-point
+  // inverse FFTs), z[j] = E[j] + w64^j O[j] is formed across the two halves of the wave (v_permlane32_swap); the un-shift
+  // e^{+i*pi*j/64} / 16384 (times w64^j on the odd half) is per lane again
+  const int orow = (lane & 31) < HO ? (lane & 31) : HO - 1;
+  const uint32_t a_ro = sb + orow * (RS * 8) + hl * 8;          // entries 2g + hl
+  const uint32_t a_ro2 = sb + orow * (RS * 8) + (1 - hl) * 8;   // entries 63 - 2g - hl = (62 - 2g) + (1 - hl)
+  const uint32_t a_tw2 = sb + NF2_TW_OFF + 512 + hl * 256;
+  const uint32_t a_ow = sb + orow * (HO * 4) + hl * 64, a_owB = a_ow + OPL * 4;   // outputs j (lanes < 32) / j + 16
+  const uint32_t a_o15 = hl ? sb + 8192 + lane * 8 : a_ow, a_o15B = hl ? sb + 8192 + 1024 + lane * 8 : a_owB;  // j = 31 does not exist
   if (lane < 32) {
     cf* const tw = reinterpret_cast<cf*>(smem + NF2_TW_OFF / 4);
     tw[lane] = tab[NFFT_TAB_TAU + lane];
     tw[32 + lane] = tab[NFFT_TAB_TAU3 + lane];
+    tw[64 + lane] = tab[NFFT_TAB_POST + lane];
+    tw[96 + lane] = tab[NFFT_TAB_POST3 + lane];
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   const uint32_t a_col = sb + lane * 8;                        // spectrum column `lane` / linear 8-byte words
@@ -923,38 +942,75 @@ __global__ __launch_bounds__(64 * WPG) void xcorr_north_fft2_kernel(const float*
     }
 
     NFFT_DBG_MARK(9)
-    // ---- inverse row pass: lane = output row; Hermitian re-packing of the pair, FFT, un-shift e^{+i*pi*j/64} / 16384
+    // ---- inverse row pass: lane = (output row, parity of the bins it inverts); Hermitian re-packing of the pair,
+    //      32-point inverse FFT, un-shift, cross-half sum
     {
-      cf y[64];
-      sfor<0, 32>([&](auto C) NF2_LAMBDA { constexpr int c = 2 * decltype(C)::value; lr2x64<c, c + 1>(a_rowo, y[c], y[c + 1]); });
-      wait_lgkm<0>();
+      cf pa[32], pb[32];  // (ya, yb) of bin 2g + hl (g < 16) or of its mirror 63 - 2g - hl (g >= 16)
+      sfor<0, 16>([&](auto G) NF2_LAMBDA { constexpr int g = decltype(G)::value; lr2x64<2 * g, 32 + 2 * g>(a_ro, pa[g], pb[g]); });
+      sfor<16, 32>([&](auto G) NF2_LAMBDA { constexpr int g = decltype(G)::value; lr2x64<62 - 2 * g, 94 - 2 * g>(a_ro2, pa[g], pb[g]); });
+      constexpr int TCH = 4;
+      cf tq[2][TCH];
+      auto tw_issue = [&](auto Ci) NF2_LAMBDA {
+        constexpr int c = decltype(Ci)::value;
+        lr2x64<TCH * c, TCH * c + 1>(a_tw2, tq[c & 1][0], tq[c & 1][1]);
+        lr2x64<TCH * c + 2, TCH * c + 3>(a_tw2, tq[c & 1][2], tq[c & 1][3]);  // (entry 31 is consumed: see o[31] below)
+      };
+      tw_issue(std::integral_constant<int, 0>{});
+      wait_lgkm<2>();
       NFFT_DBG_MARK(10)
-      cf v[64];
-      sfor<0, 32>([&](auto F) NF2_LAMBDA {
-        constexpr int f = decltype(F)::value;
-        cf c0, c1;
-        const cf ya = y[f], yb = y[32 + f];
-        asm volatile("v_pk_add_f32 %0, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"   // ya + i yb
-                     "v_pk_add_f32 %1, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]"       // conj ya + i conj yb
-                     : "=&v"(c0), "=&v"(c1) : "v"(ya), "v"(yb));
-        v[bitrev(f, 6)] = c0;
-        v[bitrev(63 - f, 6)] = c1;
+      cf v[32];
+      sfor<0, 32>([&](auto G) NF2_LAMBDA {
+        constexpr int g = decltype(G)::value;
+        cf c0;
+        const cf ya = pa[g], yb = pb[g];
+        if constexpr (g < 16) asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(c0) : "v"(ya), "v"(yb));  // ya + i yb
+        else asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]" : "=v"(c0) : "v"(ya), "v"(yb));          // conj ya + i conj yb
+        v[bitrev(g, 5)] = c0;
       });
-      fft<6, +1, 64, HO>(v);
-      {
-        sfor<0, 16>([&](auto Ji) NF2_LAMBDA {
-          constexpr int j = 2 * decltype(Ji)::value;
-          const cf o0 = cmul_tw<j, true>(v[j]);
-          if constexpr (j + 1 < HO) {
-            const cf o1 = cmul_tw<j + 1, true>(v[j + 1]);
-            lw2x32<j, j + 1>(a_out, o0.x, o1.x);
-            lw2x32<j, j + 1>(a_out + OPL * 4, o0.y, o1.y);
-          } else {
-            lw32<j * 4>(a_out, o0.x);
-            lw32<(OPL + j) * 4>(a_out, o0.y);
-          }
+      fft<5, +1, 32, 32>(v);
+      // un-shift: o[j] = v[j] * t[j], t per lane (e^{i*pi*j/64} or e^{3i*pi*j/64}, both / 16384);  m = v * (c, c);  r = (v.y, v.x) * (-s, s) + m
+      float ox[32], oy[32];
+      sfor<0, 8>([&](auto Ci) NF2_LAMBDA {
+        constexpr int c = decltype(Ci)::value;
+        if constexpr (c + 1 < 8) {
+          tw_issue(std::integral_constant<int, c + 1>{});
+          wait_lgkm<2>();
+        } else {
+          wait_lgkm<0>();
+        }
+        sfor<0, 2>([&](auto Ui) NF2_LAMBDA {
+          constexpr int j0 = TCH * c + 2 * decltype(Ui)::value, j1 = j0 + 1;
+          cf m0, m1, r0, r1;
+          const cf V0 = v[j0], V1 = v[j1], T0 = tq[c & 1][j0 % TCH], T1 = tq[c & 1][j1 % TCH];
+          asm volatile("v_pk_mul_f32 %0, %4, %6 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+                       "v_pk_mul_f32 %1, %5, %7 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+                       "v_pk_fma_f32 %2, %4, %6, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]\n\t"
+                       "v_pk_fma_f32 %3, %5, %7, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]"
+                       : "=&v"(m0), "=&v"(m1), "=&v"(r0), "=&v"(r1) : "v"(V0), "v"(V1), "v"(T0), "v"(T1));
+          ox[j0] = r0.x; oy[j0] = r0.y;
+          ox[j1] = r1.x; oy[j1] = r1.y;
         });
-      }
+      });
+      // cross-half sum: after the swaps register k holds the even-bin parts of outputs k (lanes < 32) and k + 16 (lanes
+      // >= 32), register k + 16 the odd-bin parts of the same two; j = 31 is a by-product that is never stored.
+      // (v_permlane32_swap needs 2 wait states after a VALU write of its operands: the swaps start with the oldest.)
+      sfor<0, 16>([&](auto Ki) NF2_LAMBDA {
+        constexpr int kk = decltype(Ki)::value;
+        half_swap2(ox[kk], ox[kk + 16], oy[kk], oy[kk + 16]);
+      });
+      sfor<0, 16>([&](auto Ki) NF2_LAMBDA {
+        constexpr int kk = decltype(Ki)::value;
+        add2(ox[kk], oy[kk], ox[kk + 16], oy[kk + 16]);
+      });
+      sfor<0, 7>([&](auto Ki) NF2_LAMBDA {
+        constexpr int kk = 2 * decltype(Ki)::value;
+        lw2x32<kk, kk + 1>(a_ow, ox[kk], ox[kk + 1]);
+        lw2x32<kk, kk + 1>(a_owB, oy[kk], oy[kk + 1]);
+      });
+      lw32<14 * 4>(a_ow, ox[14]);
+      lw32<14 * 4>(a_owB, oy[14]);
+      lw32<15 * 4>(a_o15, ox[15]);
+      lw32<15 * 4>(a_o15B, oy[15]);
     }
 
     NFFT_DBG_MARK(11)
