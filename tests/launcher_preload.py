@@ -1,0 +1,38 @@
+"""--preload hook of tests/test_host_logic.py::test_unchanged_launcher_runs_the_reference_test_script: makes the reference's
+tools/test.py importable in the build container (no cv2 / yacs / GPU there) and stops it right after ModelBuilder() has
+been constructed, reporting what it was built from.  Not part of the product."""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def prepare():
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_golden as mg
+
+    mg.install_stubs()
+    import types
+
+    for name in ("shapely", "shapely.geometry", "tqdm", "glob2"):
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                m = types.ModuleType(name)
+                m.Polygon = m.MultiPoint = m.tqdm = lambda *a, **k: None
+                sys.modules[name] = m
+    import hdn.utils.model_load as ml
+
+    def stop_here(model, path):
+        import hdn_amd
+        from hdn_amd import install as hi
+        import hdn.models.head.ban as ban
+        print("LAUNCHER_REACHED_LOAD_PRETRAIN",
+              isinstance(model.hm_net.ShareFeature, hdn_amd.PreShareFeature),
+              isinstance(model.logpolar_instance, hdn_amd.STN_Polar),
+              type(model).track_proj is hi._track_proj_method,
+              ban.xcorr_depthwise is hdn_amd.xcorr_depthwise, flush=True)
+        raise SystemExit(0)
+
+    ml.load_pretrain = stop_here

@@ -326,6 +326,31 @@ print("INSTALL_OK")
     assert "INSTALL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference tree only exists in the build container")
+def test_unchanged_launcher_runs_the_reference_test_script():
+    """python -m hdn_amd.run /root/reference/tools/test.py ...: the reference's own benchmark script, byte for byte, with the
+    hot path rebound before it starts; driven up to ModelBuilder() (the snapshot and cv2 do not exist in this container)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "tests")]))
+    r = subprocess.run([sys.executable, "-m", "hdn_amd.run", "--no-build", "--preload", "launcher_preload:prepare",
+                        "/root/reference/tools/test.py", "--dataset", "POT210", "--snapshot", "/nonexistent/model.pth",
+                        "--config", "/root/reference/experiments/tracker_homo_config/proj_e2e_GOT_unconstrained_v2.yaml"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd="/tmp")
+    assert "LAUNCHER_REACHED_LOAD_PRETRAIN True True True True" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "hot-path sites rebound" in r.stderr
+    # the script on disk is the reference's own
+    assert r.returncode == 0
+
+
+def test_launcher_argument_errors():
+    from hdn_amd import run
+    for argv in ([], ["--bogus", "x.py"], ["/nonexistent/script.py"], ["--reference-root"]):
+        with pytest.raises(SystemExit) as e:
+            run.main(argv)
+        assert e.value.code == 2
+
+
 def test_committed_bench_line_follows_the_contract():
     """profiles/round1_bench_line.json is one output line of bench.py: the driver's fields, the roofline block of the
     dominant kernel and the CPU baseline must all be there and be self-consistent."""
