@@ -280,6 +280,87 @@ __global__ __launch_bounds__(HDN_BLOCK) void xcorr_prod29_kernel(XcorrPtrs P, in
 }
 
 // ---------------------------------------------------------------------------------------
+// 5x5 (x) 35x35 -> 31x31: the production correlation at TRACK.INSTANCE_SIZE 303 (BASELINE config 5: search features 37x37
+// -> conv_search 35x35, score map 31x31, hdn_tracker_proj_e2e.py:24-25).  HBM-bound like the 29x29 one.
+//
+// Same workgroup structure as xcorr_prod29_kernel (4 planes = one contiguous 16-byte aligned HBM range in and out, one
+// wave per plane, the 25 taps in SGPRs, results staged in LDS).  The output is 31 wide, so a 32-lane LDS bank group is
+// given exactly ONE block of 31 columns (lane 31 of the group repeats column 30: same address, a broadcast): whatever
+// the row stride, the 32 lanes of a group then read 31 consecutive floats, i.e. conflict-free on the LINEAR image, and
+// the re-striding scatter of the 29x29 kernel is not needed.  A lane owns a VERTICAL 8x1 strip: per tap column it reads
+// 12 floats and issues 40 FMAs; 4 row blocks x 31 columns = 124 strips = two rounds of a wave (97 % of the lanes), the
+// 32nd row of the last block is computed and dropped (its taps read one row beyond the plane: the next plane's first
+// row or the pad behind the last plane).
+// ---------------------------------------------------------------------------------------
+namespace cfg5 {
+constexpr int HX = 35, WX = 35, HK = 5, WK = 5, HO = 31, WO = 31;
+constexpr int XPLANE = HX * WX, OPLANE = HO * WO, KPLANE = HK * WK;
+constexpr int PPB = 4, TH = 8;                       // planes per workgroup, strip height
+constexpr int XFLOATS = round_up(PPB * XPLANE + WX + 4, 4);   // + the row the last block's dropped output reads
+constexpr int LDS_FLOATS = XFLOATS + PPB * OPLANE;   // 8,784 floats = 35 KB: 4 workgroups per CU
+}  // namespace cfg5
+
+__global__ __launch_bounds__(HDN_BLOCK) void xcorr_cfg5_kernel(XcorrPtrs P, int planes) {
+  using namespace cfg5;
+  __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
+  float* sx = smem;
+  float* so = smem + XFLOATS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & (HDN_WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int prob = blockIdx.y;
+  const float* __restrict__ x = P.x[prob];
+  const float* __restrict__ k = P.k[prob];
+  float* __restrict__ out = P.out[prob];
+  const int plane0 = blockIdx.x * PPB;
+  const int np = min(PPB, planes - plane0);
+  const float* xg = x + size_t(plane0) * XPLANE;
+
+  if (np == PPB && aligned16(xg)) copy_g2l_full<PPB * XPLANE>(xg, sx, tid);  // all 16-byte loads in flight at once
+  else copy_g2l(xg, sx, np * XPLANE, tid);
+  if (tid < WX + 4) sx[PPB * XPLANE + tid] = 0.f;  // the pad row (read by dropped outputs only; kept finite)
+  __syncthreads();
+
+  if (wave < np) {  // wave-uniform
+    const float* __restrict__ kp = k + size_t(plane0 + wave) * KPLANE;  // wave-uniform -> scalar loads
+    const float* xs = sx + wave * XPLANE;
+    float* os = so + wave * OPLANE;
+    const int j = min(lane & 31, WO - 1);
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+      const int b = 2 * rd + (lane >> 5);  // one row block per 32-lane bank group
+      const float* xc = xs + (TH * b) * WX + j;
+      float acc[TH];
+#pragma unroll
+      for (int t = 0; t < TH; ++t) acc[t] = 0.f;
+#pragma unroll
+      for (int v = 0; v < WK; ++v) {
+        float col[TH + HK - 1];
+#pragma unroll
+        for (int r = 0; r < TH + HK - 1; ++r) col[r] = xc[r * WX + v];
+#pragma unroll
+        for (int u = 0; u < HK; ++u) {
+          const float kv = kp[u * WK + v];
+#pragma unroll
+          for (int t = 0; t < TH; ++t) acc[t] = __builtin_fmaf(col[t + u], kv, acc[t]);
+        }
+      }
+      if ((lane & 31) < WO) {
+#pragma unroll
+        for (int t = 0; t < TH; ++t)
+          if (TH * b + t < HO) os[(TH * b + t) * WO + j] = acc[t];
+      }
+    }
+  }
+  __syncthreads();
+
+  float* og = out + size_t(plane0) * OPLANE;
+  if (np == PPB && aligned16(og)) copy_l2g_full<PPB * OPLANE>(so, og, tid);
+  else copy_l2g(so, og, np * OPLANE, tid);
+}
+
+// ---------------------------------------------------------------------------------------
 // 31x31 (x) 61x61 -> 31x31 (BASELINE.json north-star shape).  fp32-FMA-bound: 1.85 MFLOP per 23 KB plane.
 //
 // gfx950 only reaches its fp32 vector peak through v_pk_fma_f32 (measured 151 TF vs 75 TF for v_fma_f32,
@@ -1151,7 +1232,13 @@ static int xcorr_dispatch(const XcorrPtrs& P, int n, int circular, int B, int C,
       static const bool f1 = [] { const char* e = getenv("HDN_PROD_F1"); return e && e[0] == '1'; }();  // A/B switch
       return f1 ? launch_f1<F1_29_5>(P, n, planes, stream, "f1_29x29_5x5") : launch_prod29(P, n, planes, stream);
     }
-    if (Hx == 35 && Wx == 35 && Hk == 5 && Wk == 5) return launch_f1<F1_35_5>(P, n, planes, stream, "f1_35x35_5x5");
+    if (Hx == 35 && Wx == 35 && Hk == 5 && Wk == 5) {
+      static const bool f1 = [] { const char* e = getenv("HDN_CFG5_F1"); return e && e[0] == '1'; }();  // A/B switch
+      if (f1) return launch_f1<F1_35_5>(P, n, planes, stream, "f1_35x35_5x5");
+      hipLaunchKernelGGL(xcorr_cfg5_kernel, dim3(cdiv(planes, cfg5::PPB), n), dim3(HDN_BLOCK), 0, stream, P, planes);
+      g_last_variant = "cfg5_35x35_5x5";
+      return launch_status();
+    }
     if (Hx == 61 && Wx == 61 && Hk == 31 && Wk == 31) {
       // Default: the FFT kernel (xcorr_fft.hip, ~125 us at B=64).  It needs 16-byte aligned x / k and 8-byte aligned
       // out; otherwise, or on request (hdn_xcorr_north_variant / environment), one of the direct kernels runs:

@@ -67,7 +67,7 @@ def test_xcorr_depthwise_golden(dev):
                 check_xcorr(y, x, k, g[n + "__y"], False, n + "/" + variant)
     assert X.current_north_variant() == "fft"
     # the fixtures exercise the specialised kernels (both families for the north-star shape) and the generic one
-    assert {"prod_29x29_5x5", "f1_35x35_5x5", "north_61x61_31x31", "north_fft_61x61_31x31", "generic_lds"} <= seen, seen
+    assert {"prod_29x29_5x5", "cfg5_35x35_5x5", "north_61x61_31x31", "north_fft_61x61_31x31", "generic_lds"} <= seen, seen
 
 
 def test_xcorr_depthwise_sampled_full_channel(dev):
@@ -323,6 +323,23 @@ def _full_size_properties(dev, fn, ofn, shape_x, shape_k, signed, paired=False):
 def test_xcorr_full_size_production(dev):
     _full_size_properties(dev, hdn_amd.xcorr_depthwise, O.xcorr_depthwise, (64, 256, 29, 29), (64, 256, 5, 5), False)
     assert X.last_variant() == "prod_29x29_5x5"
+
+
+def test_xcorr_full_size_config5(dev):
+    """BASELINE configs[4]: 303-px search window => 5x5 (x) 35x35 -> 31x31 at batch 256 (1.1 GB of search features), through
+    the size-independent properties; plus ragged plane counts (tail workgroups, unaligned groups) against the oracle."""
+    _full_size_properties(dev, hdn_amd.xcorr_depthwise, O.xcorr_depthwise, (256, 256, 35, 35), (256, 256, 5, 5), False)
+    assert X.last_variant() == "cfg5_35x35_5x5"
+    r = np.random.default_rng(35)
+    for B, C in ((1, 1), (1, 3), (3, 5), (2, 9), (5, 51)):
+        x, k = r.standard_normal((B, C, 35, 35), dtype=np.float32), r.standard_normal((B, C, 5, 5), dtype=np.float32)
+        y = hdn_amd.xcorr_depthwise(T(x).to(dev), T(k).to(dev))
+        check_xcorr(y, x, k, O.xcorr_depthwise(T(x), T(k)).numpy(), False, f"cfg5 {B}x{C}")
+        # unaligned plane groups (a view that starts 4 bytes into the allocation)
+        buf = torch.zeros(x.size + 1, device=dev)
+        buf[1:] = T(x).to(dev).reshape(-1)
+        y2 = hdn_amd.xcorr_depthwise(buf[1:].reshape(x.shape), T(k).to(dev))
+        assert torch.equal(y2, y)
 
 
 @pytest.mark.parametrize("variant", ["fft", "direct"])
