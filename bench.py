@@ -73,6 +73,9 @@ def parse():
     ap.add_argument("--only-north", action="store_true", help="step = the north-star correlation only (profiling aid)")
     ap.add_argument("--north", choices=["fft", "fft2w", "direct", "dense", "mfma"], default=None,
                     help="kernel for the 31x31 (x) 61x61 correlation (default: the library's default, fft); A/B runs")
+    ap.add_argument("--config", type=int, choices=[2, 5], default=2,
+                    help="2 = BASELINE configs[1] (default, the headline); 5 = configs[4]: 303-px search window (6x xcorr 5x5 (x) 35x35 "
+                         "-> 31x31) + the 2-iteration refinement loop, 64 pairs per GPU (256 over 4 GPUs); kernels only")
     ap.add_argument("--workload", choices=["kernels", "full"], default="kernels",
                     help="kernels = BASELINE configs[1] (default); full = configs[2]: the whole HomoModelBuilder head "
                          "incl. the PyTorch-ROCm ResNet-34 trunk on 64 pairs per GPU, then the offsets all-gather")
@@ -143,6 +146,9 @@ def main():
     folded = sf.folded(dev)
     imgs2 = d["imgs"].reshape(PAIRS * 2, 1, 127, 127)
     tmpl = d["imgs"][:, :1].contiguous()
+
+    if args.config == 5:
+        return run_config5(args, dev, rank, world, dist, hdist, comm, sf, folded)
 
     north_ev = []
     full_net = full_data = None
@@ -333,6 +339,87 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result), flush=True)
+
+
+def run_config5(args, dev, rank, world, dist, hdist, comm, sf, folded):
+    """BASELINE configs[4], the HIP kernels only: per GPU 64 pairs (= 256 over 4 GPUs), INSTANCE_SIZE 303 => the six
+    correlations are 5x5 (x) 35x35 -> 31x31 (hdn_tracker_proj_e2e.py:24-25), and the refinement loop runs twice
+    (hdn_tracker_proj_e2e.py:242-250 with trip count 2): PreShareFeature(search) -> fused DLT+warp -> PreShareFeature(warped)
+    -> 2 scores -> refine warp (restated cv2.warpPerspective, BORDER_REPLICATE).  Offsets are synthetic (N(0, 8^2) px)."""
+    from hdn_amd import homography as G
+    from hdn_amd import refine as R
+    from hdn_amd import share_feature as SF
+    from hdn_amd import xcorr as X
+    g = torch.Generator().manual_seed(SEED + 50 + rank)
+    relu_n = lambda *s_: torch.randn(*s_, generator=g).clamp_min_(0)
+    xs = [relu_n(PAIRS, C, 35, 35).to(dev) for _ in range(6)]
+    ks = [relu_n(PAIRS, C, 5, 5).to(dev) for _ in range(6)]
+    imgs = torch.randn(PAIRS, 2, 127, 127, generator=g).to(dev)
+    tmpl, srch = imgs[:, :1].contiguous(), imgs[:, 1:].contiguous()
+    h4p = torch.tensor([[0, 0, 0, 127, 127, 127, 127, 0]], dtype=torch.float32).repeat(PAIRS, 1).to(dev)
+    offs = [(8.0 * torch.randn(PAIRS, 8, generator=g)).to(dev) for _ in range(2)]
+    p1 = SF.share_feature(tmpl, folded)
+    Hc = torch.eye(3, dtype=torch.float64, device=dev).repeat(PAIRS, 1, 1).contiguous()
+    ev = []
+
+    def step(record):
+        if record:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        X.xcorr_depthwise_multi(xs, ks)
+        if record:
+            e1.record()
+            ev.append((e0, e1))
+        cur = srch
+        for it in range(2):
+            p2 = SF.share_feature(cur, folded)
+            Hm, warped = G.dlt_warp(h4p, offs[it], tmpl)
+            pf = SF.share_feature(warped, folded)
+            G.l1_score2(p2[0, 0], pf[0, 0], p1[0, 0], 1.0 / (127 * 127))
+            cur = R.refine_warp(Hm, cur, Hc)
+        if world > 1:
+            hdist.all_gather_offsets(offs[1], PAIRS * world, comm=comm)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    t_pre = time.perf_counter()
+    while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
+        for _ in range(5):
+            step(False) if world == 1 else X.xcorr_depthwise_multi(xs, ks)
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    nbytes = 6 * 4 * C * (35 * 35 + 25 + 31 * 31) * PAIRS
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({
+            "metric": "frames/sec on 127/255 template/search pairs", "value": PAIRS * world * args.steps / elapsed, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[4] per GPU (64 pairs = 256 over 4 GPUs), HIP kernels only: 6x xcorr 5x5(x)35x35 "
+                                   "(303-px search window) + 2 refinement iterations x (PreShareFeature, fused DLT/warp, "
+                                   "PreShareFeature, 2 scores, restated cv2.warpPerspective)", "pairs_per_gpu": PAIRS, "channels": C},
+            "roofline": {"kernel": "hdn::xcorr_cfg5_kernel x6 in one launch (" + X.last_variant() + ")", "bound": "hbm",
+                         "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                         "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms}}), flush=True)
 
 
 def breakdown(d, imgs2, tmpl, folded, X, SF, G, iters=20):

@@ -9,5 +9,6 @@ from .share_feature import PreShareFeature, fold_params  # noqa: F401
 from .homo_model import HomoModelBuilder, track_proj  # noqa: F401
 from .logpolar import STN_Polar  # noqa: F401
 from .heads import MultiBAN, MultiCircBAN  # noqa: F401
+from .refine import homo_refine, refine_warp  # noqa: F401
 
 __version__ = "0.1.0"

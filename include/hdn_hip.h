@@ -144,6 +144,19 @@ int hdn_dlt_warp_f32(const float* h4p, const float* off, const float* img, float
                      int B, int H, int W, void* stream);
 
 /*
+ * One step of the tracker's refinement loop (hdn/tracker/hdn_tracker_proj_e2e.py:242-250; trip count 1 in the shipped
+ * tracker, 2 in BASELINE config 5):  H_hm = inv(H) / inv(H)[2,2];  warped = cv2.warpPerspective(search, inv(H_hm),
+ * (W,H), INTER_LINEAR, BORDER_REPLICATE);  H_comp <- H_comp @ H_hm.
+ *   H_mat[B,9] (what hdn_dlt_solve_f32 / hdn_dlt_warp_f32 returned), search[B,1,H,W] -> warped[B,1,H,W];
+ *   H_comp_or_null[B,9] float64, updated in place (start it at the identity).
+ * The sampler restates OpenCV's INTER_LINEAR warpPerspective (1/32-pixel source coordinates rounded half-to-even,
+ * float32 weights, replicate border); OpenCV is not available to this build, so this entry point is PARITY-UNPINNED: it
+ * is held to the oracle's restatement of the same algorithm, not to cv2 output.
+ */
+int hdn_refine_warp_f32(const float* H_mat, const float* search, float* warped, double* H_comp_or_null, int B, int H,
+                        int W, void* stream);
+
+/*
  * sum_i |a[i] - b[i]| * scale over n floats into out[0] (one block, deterministic order).
  * The two feature-distance scores of track_proj, model_builder_e2e_unconstrained_v2.py:213-216.
  */

@@ -323,6 +323,94 @@ def homo_forward(data: dict, sf_sd: dict, regress) -> dict:
     }
 
 
+# --------------------------------------------------------------------------- #
+# the tracker's refinement loop (hdn/tracker/hdn_tracker_proj_e2e.py:242-250) with OpenCV's warp restated
+# --------------------------------------------------------------------------- #
+def warp_perspective_replicate(img: np.ndarray, M: np.ndarray) -> np.ndarray:
+    """cv2.warpPerspective(img, M, (W, H), flags=INTER_LINEAR, borderMode=BORDER_REPLICATE) for one 2-D image.
+
+    PARITY UNPINNED.  cv2 (opencv-python, unpinned in the reference's INSTALL.md) is absent from the reference tree and from
+    this image, so this is a restatement of OpenCV 4.x's published algorithm (modules/imgproc/src/imgwarp.cpp:
+    WarpPerspectiveInvoker and remapBilinear), not something checked against cv2 output:
+      M is inverted in float64 (dst(x, y) = src(M^-1 (x, y, 1))); destination pixels are walked in blocks of
+      bw x bh = 64 x 16 (for 127 x 127); per pixel  W = W0 + M6*x1, W = 32/W (0 if W == 0),
+      X = cvRound((X0 + M0*x1) * W), Y likewise, with X0 = M0*bx + M1*y + M2 etc. evaluated in that order;
+      sx = X >> 5, fx = (X & 31) / 32; weights (1-fy)(1-fx), (1-fy)fx, fy(1-fx), fy*fx as float32 products; taps clamped
+      to the image; sum left to right in the image's type."""
+    img = np.asarray(img)
+    Hh, Ww = img.shape
+    m = _inv3(np.asarray(M, np.float64))
+    bh = min(16, Hh)
+    bw = min(1024 // bh, Ww)
+    bh = min(1024 // bw, Hh)
+    y = np.arange(Hh, dtype=np.float64)[:, None]
+    x = np.arange(Ww)[None, :]
+    bx = ((x // bw) * bw).astype(np.float64)
+    x1 = (x - (x // bw) * bw).astype(np.float64)
+    X0 = m[0, 0] * bx + m[0, 1] * y + m[0, 2]
+    Y0 = m[1, 0] * bx + m[1, 1] * y + m[1, 2]
+    W0 = m[2, 0] * bx + m[2, 1] * y + m[2, 2]
+    Wd = W0 + m[2, 0] * x1
+    with np.errstate(divide="ignore"):
+        Wd = np.where(Wd != 0.0, 32.0 / np.where(Wd != 0.0, Wd, 1.0), 0.0)
+    fX = np.clip((X0 + m[0, 0] * x1) * Wd, -2147483648.0, 2147483647.0)
+    fY = np.clip((Y0 + m[1, 0] * x1) * Wd, -2147483648.0, 2147483647.0)
+    X = np.rint(fX).astype(np.int64)   # cvRound: half to even
+    Y = np.rint(fY).astype(np.int64)
+    sx, sy = X >> 5, Y >> 5
+    fx = ((X & 31).astype(np.float32)) * np.float32(1.0 / 32.0)
+    fy = ((Y & 31).astype(np.float32)) * np.float32(1.0 / 32.0)
+    one = np.float32(1.0)
+    w00, w01, w10, w11 = (one - fy) * (one - fx), (one - fy) * fx, fy * (one - fx), fy * fx
+    x0, x1c = np.clip(sx, 0, Ww - 1), np.clip(sx + 1, 0, Ww - 1)
+    y0, y1c = np.clip(sy, 0, Hh - 1), np.clip(sy + 1, 0, Hh - 1)
+    wt = img.dtype.type
+    return ((img[y0, x0] * w00.astype(wt) + img[y0, x1c] * w01.astype(wt)) + img[y1c, x0] * w10.astype(wt)) + img[y1c, x1c] * w11.astype(wt)
+
+
+def _inv3(m: np.ndarray) -> np.ndarray:
+    """3x3 inverse by adjugate / determinant in float64 (cv::invert's 3x3 case)."""
+    a, b, c, d, e, f, g, h, i = m.reshape(-1)
+    det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g)
+    idet = 1.0 / det if det != 0.0 else 0.0
+    return np.array([[(e * i - f * h), (c * h - b * i), (b * f - c * e)],
+                     [(f * g - d * i), (a * i - c * g), (c * d - a * f)],
+                     [(d * h - e * g), (b * g - a * h), (a * e - b * d)]], np.float64) * idet
+
+
+def refine_step(H: np.ndarray, search: np.ndarray, H_comp: np.ndarray):
+    """hdn_tracker_proj_e2e.py:246-250 for one sample: H [3,3] float32 (track_proj's H_mat), search [127,127] float32,
+    H_comp [3,3] float64 -> (warped search, H_comp @ H_hm).  The float32 inverses follow numpy's dtype rules there
+    (np.linalg.inv of a float32 array is float32); their last-bit rounding depends on LAPACK's sgesv and is not reproduced
+    beyond float32 precision."""
+    t = _inv3(np.asarray(H, np.float32).astype(np.float64)).astype(np.float32)
+    Hhm = ((1.0 / np.float64(t[2, 2])) * t.astype(np.float64)).astype(np.float32)
+    M = _inv3(Hhm.astype(np.float64)).astype(np.float32)
+    warped = warp_perspective_replicate(np.asarray(search, np.float32), M.astype(np.float64))
+    return warped.astype(np.float32), np.asarray(H_comp, np.float64) @ Hhm.astype(np.float64)
+
+
+def homo_refine(template: torch.Tensor, search: torch.Tensor, sf_sd: dict, regress, iterations: int = 2):
+    """The refinement loop of hdnTrackerHomo.track_new (:242-250) with trip count `iterations` for a batch of independent
+    pairs: template / search [B,1,127,127] normalised gray crops.  Returns (H_comp [B,3,3] float64, scores of the last
+    iteration, list of per-iteration H_mat)."""
+    B = template.shape[0]
+    H_comp = np.tile(np.eye(3), (B, 1, 1))
+    cur = search.clone()
+    h4p = torch.tensor([[0, 0, 0, 127, 127, 127, 127, 0]], dtype=torch.float32).repeat(B, 1)
+    Hs, score, score_simi = [], None, None
+    for _ in range(iterations):
+        imgs = torch.cat([template, cur], dim=1)
+        Hm, score, score_simi, _ = track_proj({"org_imgs": imgs, "input_tensors": imgs, "h4p": h4p}, sf_sd, regress)
+        Hs.append(Hm)
+        nxt = []
+        for b in range(B):
+            w, H_comp[b] = refine_step(Hm[b].numpy(), cur[b, 0].numpy(), H_comp[b])
+            nxt.append(torch.from_numpy(w))
+        cur = torch.stack(nxt).unsqueeze(1)
+    return H_comp, score, score_simi, Hs
+
+
 def corner_error(pred_off: np.ndarray, ref_off: np.ndarray) -> np.ndarray:
     """sqrt(sum ||delta||^2 / 4) per sample — toolkit/utils/statistics.py:206-218 (success_4pts_error)."""
     d = (np.asarray(pred_off, np.float64) - np.asarray(ref_off, np.float64)).reshape(-1, 4, 2)

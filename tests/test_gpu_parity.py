@@ -774,6 +774,74 @@ def test_track_proj_end_to_end_corner_offsets(dev):
     assert float((Hm2 - Hm).abs().max()) < 1e-5 and abs(float(s2) - float(s)) < 1e-5
 
 
+def test_refine_warp_vs_oracle_restatement(dev):
+    """hdn_refine_warp_f32 (the restated cv2.warpPerspective + H bookkeeping of hdn_tracker_proj_e2e.py:246-250) against
+    the oracle's numpy restatement of the same algorithm.  PARITY UNPINNED against OpenCV itself (absent here)."""
+    r = np.random.default_rng(21)
+    B = 7
+    img = r.standard_normal((B, 1, 127, 127)).astype(np.float32)
+    src = np.tile(np.array([0, 0, 0, 127, 127, 127, 127, 0], np.float32), (B, 1))
+    off = (r.standard_normal((B, 8)) * np.array([0, 1, 3, 6, 10, 16, 30])[:, None]).astype(np.float32)
+    Hm = hdn_amd.DLT_solve(T(src).to(dev), T(off).to(dev)).squeeze(1)
+    Hc = torch.eye(3, dtype=torch.float64, device=dev).repeat(B, 1, 1).contiguous()
+    Hc[3] *= 2.0
+    Hc0 = Hc.cpu().numpy().copy()
+    w = hdn_amd.refine_warp(Hm, T(img).to(dev), Hc)
+    w2 = hdn_amd.refine_warp(Hm, T(img).to(dev), None)
+    assert torch.equal(w, w2)
+    Hn = Hm.cpu().numpy()
+    n_diff = 0
+    for b in range(B):
+        wr, Hr = O.refine_step(Hn[b], img[b, 0], Hc0[b])
+        np.testing.assert_allclose(Hc[b].cpu().numpy(), Hr, rtol=1e-6, atol=1e-7)
+        d = np.abs(w[b, 0].cpu().numpy() - wr)
+        # identical 1/32-px coordinates => identical taps and weights; a float32 inverse that differs in its last bit can
+        # move a coordinate across a rounding tie for a few pixels, each by 1/32 px of a white-noise image
+        n_diff += int((d > 1e-5).sum())
+        assert d.max() < 0.25, (b, d.max())
+    assert n_diff <= 16, n_diff
+    # identity H leaves the crop untouched; out-of-range samples replicate the border
+    eye = torch.eye(3, device=dev).repeat(B, 1, 1)
+    assert torch.equal(hdn_amd.refine_warp(eye, T(img).to(dev)), T(img).to(dev))
+    sh = eye.clone(); sh[:, 0, 2] = 40.0
+    ws = hdn_amd.refine_warp(sh, T(img).to(dev)).cpu().numpy()
+    np.testing.assert_array_equal(ws[:, 0, :, :40], np.repeat(img[:, 0, :, :1], 40, axis=2))
+    with pytest.raises(ValueError):
+        hdn_amd.refine_warp(eye[:2], T(img).to(dev))
+
+
+def test_homo_refine_two_iterations_config5(dev):
+    """BASELINE configs[4]'s "2-scale coarse-to-fine": the refinement loop with trip count 2, device-resident, against the
+    oracle's loop (same seeded head; the trunk runs on MIOpen vs PyTorch-CPU), then at the config's batch of 256."""
+    net = _seeded_net()
+    B = 3
+    d = _cfg1_data(B, 909)
+    tmpl, srch = d["org_imgs"][:, :1].contiguous(), d["org_imgs"][:, 1:].contiguous()
+    sd = {k: v.clone() for k, v in net.ShareFeature.state_dict().items()}
+    with torch.no_grad():
+        Hc_ref, s_ref, ss_ref, Hs = O.homo_refine(tmpl, srch, sd, lambda f: net.fc(net.avgpool(net.backbone(f)).flatten(1)), 2)
+    netd = net.to(dev)
+    Hc, s, ss = hdn_amd.homo_refine(netd, tmpl.to(dev), srch.to(dev), iterations=2)
+    assert Hc.dtype == torch.float64 and Hc.shape == (B, 3, 3)
+    # H entries: offsets within 1e-4 px (north-star bound) => H within ~1e-5; second iteration sees a crop resampled at
+    # 1/32-px coordinates that may differ at a few ties
+    np.testing.assert_allclose(Hc.cpu().numpy(), Hc_ref, rtol=0, atol=2e-4)
+    assert abs(float(s) - float(s_ref)) <= 2e-4 and abs(float(ss) - float(ss_ref)) <= 1e-5
+    # one iteration == the shipped tracker's loop: H_comp = inv(H)/inv(H)[2,2]
+    Hc1, _, _ = hdn_amd.homo_refine(netd, tmpl.to(dev), srch.to(dev), iterations=1)
+    Hi = np.linalg.inv(Hs[0].numpy().astype(np.float64))
+    np.testing.assert_allclose(Hc1.cpu().numpy(), Hi / Hi[:, 2:3, 2:3], rtol=0, atol=1e-4)
+    # the config's batch: 256 pairs in one call, pairs independent (row b of a batched call == that pair alone)
+    big = _cfg1_data(8, 910)
+    t8, s8 = big["org_imgs"][:, :1].to(dev), big["org_imgs"][:, 1:].to(dev)
+    tt, st = t8.repeat(32, 1, 1, 1), s8.repeat(32, 1, 1, 1)
+    Hb, _, _ = hdn_amd.homo_refine(netd, tt, st, iterations=2)
+    assert Hb.shape == (256, 3, 3) and bool(torch.isfinite(Hb).all())
+    assert float((Hb[:8] - Hb[248:]).abs().max()) <= 1e-4
+    H8, _, _ = hdn_amd.homo_refine(netd, t8, s8, iterations=2)
+    assert float((Hb[:8] - H8).abs().max()) <= 2e-4
+
+
 def test_graphed_track_proj_matches_eager(dev):
     """hipGraph replay of the per-frame head (B=1) gives the eager result on new inputs (static buffers refreshed)."""
     from hdn_amd.graph import GraphedTrackProj

@@ -250,3 +250,42 @@ def test_xcorr_fast_and_slow():
     y = O.xcorr_fast(T(g["slow__x"]), T(g["slow__k"])).numpy()
     np.testing.assert_array_equal(y, g["slow__y_fast"])
     np.testing.assert_allclose(y, g["slow__y"], rtol=0, atol=1e-5)  # the reference's two forms differ by rounding only
+
+
+def test_warp_perspective_restatement_properties():
+    """oracle.warp_perspective_replicate restates OpenCV's INTER_LINEAR / BORDER_REPLICATE warpPerspective (parity
+    unpinned: no cv2 here).  What can be checked without OpenCV: identity, integer shifts with a replicated border, the
+    1/32-pixel quantisation of the source coordinate, half-to-even rounding at the quantisation ties."""
+    r = np.random.default_rng(4)
+    img = r.standard_normal((127, 127)).astype(np.float32)
+    np.testing.assert_array_equal(O.warp_perspective_replicate(img, np.eye(3)), img)
+    # dst(x, y) = src(M^-1 (x, y)): M = translation by (+3, -2) moves the content right by 3 and up by 2
+    M = np.array([[1, 0, 3.0], [0, 1, -2.0], [0, 0, 1]])
+    w = O.warp_perspective_replicate(img, M)
+    np.testing.assert_array_equal(w[:125, 3:], img[2:, :124])
+    np.testing.assert_array_equal(w[:, :3], np.repeat(w[:, 3:4], 3, axis=1))      # replicated left border
+    np.testing.assert_array_equal(w[125:, 3:], np.repeat(img[126:127, :124], 2, axis=0))
+    # a shift of -0.26 px samples at +0.26, which is quantised to 8/32 = 0.25
+    w = O.warp_perspective_replicate(img, np.array([[1, 0, -0.26], [0, 1, 0], [0, 0, 1.0]]))
+    want = img[:, :-1] * np.float32(0.75) + img[:, 1:] * np.float32(0.25)
+    np.testing.assert_allclose(w[:, :-1], want, rtol=0, atol=1e-6)
+    # ties round half to even: +1/64 px -> 0.5/32 -> 0 (even), +3/64 -> 1.5/32 -> 2/32
+    w0 = O.warp_perspective_replicate(img, np.array([[1, 0, -1 / 64], [0, 1, 0], [0, 0, 1.0]]))
+    w1 = O.warp_perspective_replicate(img, np.array([[1, 0, -3 / 64], [0, 1, 0], [0, 0, 1.0]]))
+    np.testing.assert_array_equal(w0[:, :64], img[:, :64])  # (block 0: x1 = x exactly; column 0's X = 0.5 -> 0)
+    np.testing.assert_allclose(w1[:, :-1], img[:, :-1] * np.float32(1 - 2 / 32) + img[:, 1:] * np.float32(2 / 32), atol=1e-6)
+    # a float64 image is summed in float64 (the tracker's crops are float64 numpy arrays)
+    assert O.warp_perspective_replicate(img.astype(np.float64), M).dtype == np.float64
+
+
+def test_refine_step_composes_normalised_inverse():
+    H = np.array([[1.01, 0.02, 1.5], [-0.01, 0.99, -2.0], [1e-4, -2e-4, 1.0]], np.float32)
+    img = np.random.default_rng(5).standard_normal((127, 127)).astype(np.float32)
+    w, Hc = O.refine_step(H, img, np.eye(3))
+    Hi = np.linalg.inv(H.astype(np.float64))
+    np.testing.assert_allclose(Hc, Hi / Hi[2, 2], rtol=0, atol=1e-5)
+    # cv2 receives M = inv(H_hm) and samples at M^-1 = H_hm = inv(H): for H = shift by +4 the content moves RIGHT by 4
+    Hs = np.array([[1, 0, 4.0], [0, 1, 0], [0, 0, 1]], np.float32)
+    w, _ = O.refine_step(Hs, img, np.eye(3))
+    np.testing.assert_allclose(w[:, 4:124], img[:, :120], rtol=0, atol=1e-6)
+    np.testing.assert_array_equal(w[:, :4], np.repeat(img[:, :1], 4, axis=1))
