@@ -1,0 +1,132 @@
+"""Device-resident frame handling for the tracker loop.
+
+The reference handles every frame on the host (numpy + OpenCV) and uploads three crops per frame
+(hdn/tracker/base_tracker.py:134-135,211-212); here the uint8 frame is uploaded ONCE and the crops / warps are kernels:
+
+    upload(img)                                            np.uint8 [H,W,3] (BGR) -> device tensor
+    get_subwindow(frame, pos, model_sz, original_sz, avg)  <- SiameseTracker.get_subwindow, base_tracker.py:61-136
+    get_subwindow_for_homo(...)                            <- base_tracker.py:138-213 (also returns the crop points)
+    get_search_info(frame, pos, original_sz, avg)          <- get_subwindow_for_homo + get_search_info (get_img_info.py:42-70), fused
+    warp_perspective(frame, M)                             <- cv2.warpPerspective(img, M, BORDER_REPLICATE), hdn_tracker_proj_e2e.py:154
+    rot_around_center(frame, cx, cy, rot)                  <- img_rot_around_center, hdn/utils/transform.py:69-100
+
+Same argument meaning and return shapes as the reference's functions; `pos` / `original_sz` / matrices may be host numbers
+(packed into a small device array without synchronising) or float64 device tensors (nothing leaves the device).  The parts
+that are OpenCV in the reference are restatements (parity-unpinned, see include/hdn_hip.h).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def upload(img) -> torch.Tensor:
+    """np.uint8 [H,W,C] (as cv2.imread returns it) -> contiguous uint8 device tensor; the one host->device copy of a frame."""
+    if isinstance(img, torch.Tensor):
+        t = img
+    else:
+        a = np.ascontiguousarray(img)
+        if a.dtype != np.uint8 or a.ndim != 3:
+            raise TypeError(f"expected a uint8 [H,W,C] frame, got {a.dtype} {a.shape}")
+        t = torch.from_numpy(a)
+    if t.dtype != torch.uint8 or t.dim() != 3:
+        raise TypeError("expected a uint8 [H,W,C] frame")
+    if not torch.cuda.is_available():
+        raise _lib.HdnHipError("hdn_amd runs on the GPU only; there is no CPU fallback")
+    return t.contiguous().cuda(non_blocking=True) if not t.is_cuda else t.contiguous()
+
+
+def _check_frame(frame):
+    if not isinstance(frame, torch.Tensor) or frame.dtype != torch.uint8 or frame.dim() != 3 or not frame.is_cuda:
+        raise _lib.HdnHipError("frame must be a uint8 [H,W,C] tensor on the GPU (hdn_amd.frame.upload); there is no CPU fallback")
+    if not frame.is_contiguous():
+        raise ValueError("frame must be contiguous")
+    return frame.shape
+
+
+def _dev_f64(values, dev) -> torch.Tensor:
+    """Host numbers -> a small float64 device array (pinned-free async copy); device tensors pass through."""
+    if isinstance(values, torch.Tensor):
+        if values.dtype != torch.float64 or not values.is_cuda:
+            raise TypeError("device-side parameters must be float64 GPU tensors")
+        return values.contiguous().reshape(-1)
+    return torch.tensor([float(v) for v in values], dtype=torch.float64).to(dev, non_blocking=True)
+
+
+def crop_points(pos, original_sz, im_h, im_w):
+    """(context_xmin, context_ymin, context_xmax + 1, context_ymax + 1) in the padded frame, as
+    get_subwindow_for_homo returns them (base_tracker.py:150-167,213): host arithmetic on host numbers."""
+    sz = float(original_sz)
+    c = (sz - 1) / 2
+    xmin = math.floor(pos[0] - c + 0.5)
+    ymin = math.floor(pos[1] - c + 0.5)
+    xmax, ymax = xmin + sz - 1, ymin + sz - 1
+    left, top = int(max(0., -xmin)), int(max(0., -ymin))
+    return (xmin + left, ymin + top, xmax + left + 1, ymax + top + 1)
+
+
+def _subwindow(frame, pos, model_sz, original_sz, avg_chans, mode, params=None):
+    H, W, C = _check_frame(frame)
+    dev = frame.device
+    if params is None:
+        params = _dev_f64([pos[0], pos[1], original_sz] + [float(a) for a in np.asarray(avg_chans).reshape(-1)], dev)
+    if params.numel() != 3 + C:
+        raise ValueError(f"params must be [cx, cy, original_sz, avg x {C}]")
+    m = int(model_sz)
+    out = torch.empty((1, 1 if mode else C, m, m), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.load().hdn_subwindow_f32(_lib.ptr(frame), _lib.ptr(params), _lib.ptr(out), H, W, C, m, mode, _lib.stream_ptr(dev))
+    _lib.check(rc, "get_subwindow")
+    return out
+
+
+def get_subwindow(frame, pos, model_sz, original_sz, avg_chans, params=None):
+    """-> float32 [1, C, model_sz, model_sz] (uint8-valued), on the device."""
+    return _subwindow(frame, pos, model_sz, original_sz, avg_chans, 0, params)
+
+
+def get_subwindow_for_homo(frame, pos, model_sz, original_sz, avg_chans):
+    H, W, _ = _check_frame(frame)
+    return _subwindow(frame, pos, model_sz, original_sz, avg_chans, 0), crop_points(pos, original_sz, H, W)
+
+
+def get_search_info(frame, pos, original_sz, avg_chans, model_sz: int = 127, params=None):
+    """The normalised gray crop the homography head consumes, [1, 1, 127, 127] float32 on the device: get_subwindow_for_homo
+    followed by get_search_info's (x - mean) / std, channel mean (float64), in one kernel."""
+    return _subwindow(frame, pos, model_sz, original_sz, avg_chans, 1, params)
+
+
+def warp_perspective(frame, M):
+    """cv2.warpPerspective(frame, M, (W, H), borderMode=cv2.BORDER_REPLICATE); M: 3x3 (host array or float64 device tensor)."""
+    H, W, C = _check_frame(frame)
+    m = _dev_f64(np.asarray(M, np.float64).reshape(-1) if not isinstance(M, torch.Tensor) else M, frame.device)
+    if m.numel() != 9:
+        raise ValueError("M must be 3x3")
+    out = torch.empty_like(frame)
+    with torch.cuda.device(frame.device):
+        rc = _lib.load().hdn_frame_warp_perspective_u8(_lib.ptr(frame), _lib.ptr(m), _lib.ptr(out), H, W, C, _lib.stream_ptr(frame.device))
+    _lib.check(rc, "warp_perspective")
+    return out
+
+
+def warp_affine_cubic(frame, M):
+    """cv2.warpAffine(frame, M, (W, H), flags=cv2.INTER_CUBIC, borderMode=cv2.BORDER_REPLICATE); M: 2x3."""
+    H, W, C = _check_frame(frame)
+    m = _dev_f64(np.asarray(M, np.float64).reshape(-1) if not isinstance(M, torch.Tensor) else M, frame.device)
+    if m.numel() != 6:
+        raise ValueError("M must be 2x3")
+    out = torch.empty_like(frame)
+    with torch.cuda.device(frame.device):
+        rc = _lib.load().hdn_frame_warp_affine_cubic_u8(_lib.ptr(frame), _lib.ptr(m), _lib.ptr(out), H, W, C, _lib.stream_ptr(frame.device))
+    _lib.check(rc, "warp_affine_cubic")
+    return out
+
+
+def rot_around_center(frame, cx, cy, rot):
+    """img_rot_around_center(img, cx, cy, w, h, rot) (hdn/utils/transform.py:69-100): rotation about (cx, cy), bicubic."""
+    cc, ss = math.cos(rot), math.sin(rot)
+    return warp_affine_cubic(frame, [cc, -ss, cx - cx * cc + cy * ss, ss, cc, cy - cy * cc - cx * ss])

@@ -181,6 +181,29 @@ int hdn_logpolar_sample_f32(const float* img, const float* polar, const float* r
                             int S, void* stream);
 
 /*
+ * Device-resident frame handling: the uint8 frame [H,W,C] (HWC, BGR as cv2.imread delivers it) is
+ * uploaded once; crops and warps are kernels.  `params` / `M` are DEVICE float64 arrays so that positions and homographies
+ * produced on the device never visit the host.
+ *
+ * hdn_subwindow_f32: params = [cx, cy, original_sz, avg_chans[0..C)]; the P x P patch around (cx, cy) with
+ *   uint8(avg_chans) outside the frame, resized to model_sz x model_sz (restated cv2.resize, INTER_LINEAR) when P != model_sz;
+ *   mode 0: out[C, model_sz, model_sz] float32 (uint8-valued);  mode 1 (C = 3): out[model_sz, model_sz] = mean over channels of
+ *   (x - [118.93,113.97,102.60]) / [69.85,68.81,72.45] in float64, i.e. get_search_info / get_template_info fused in.
+ *   Replaces SiameseTracker.get_subwindow / get_subwindow_for_homo, hdn/tracker/base_tracker.py:61-213, and
+ *   get_search_info, .../Oneline_DLTv1/tools/get_img_info.py:42-70.  Crop / padding / normalisation arithmetic is pinned to
+ *   fixtures from the reference; the resize is a restatement of OpenCV's and parity-unpinned.
+ * hdn_frame_warp_perspective_u8: dst = cv2.warpPerspective(src, M, (W,H), INTER_LINEAR, BORDER_REPLICATE), M[9];
+ *   replaces hdn/tracker/hdn_tracker_proj_e2e.py:154.  Restated OpenCV, parity-unpinned.
+ * hdn_frame_warp_affine_cubic_u8: dst = cv2.warpAffine(src, M, (W,H), INTER_CUBIC, BORDER_REPLICATE), M[6];
+ *   replaces img_rot_around_center, hdn/utils/transform.py:69-100.  Restated OpenCV, parity-unpinned.  (Its first call on
+ *   a device uploads a 32 KB coefficient table synchronously.)
+ */
+int hdn_subwindow_f32(const unsigned char* frame, const double* params, float* out, int H, int W, int C, int model_sz, int mode,
+                      void* stream);
+int hdn_frame_warp_perspective_u8(const unsigned char* src, const double* M, unsigned char* dst, int H, int W, int C, void* stream);
+int hdn_frame_warp_affine_cubic_u8(const unsigned char* src, const double* M, unsigned char* dst, int H, int W, int C, void* stream);
+
+/*
  * Multi-GPU: template/search pairs are independent, so ranks own disjoint contiguous blocks of pairs
  * and the path's ONLY exchange is one all-gather of the predicted corner offsets, on RCCL over xGMI.
  *   local[Bl,8] (this rank's offsets) -> all[world*Bl,8] on every rank, in rank order; Bl must be equal on all

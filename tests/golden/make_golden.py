@@ -450,6 +450,31 @@ def gen_heads(ref_ban, ref_ban_lp):
     save("heads256", **out)
 
 
+def gen_frame(ref_bt, ref_gi):
+    """The pure-arithmetic part of the tracker's per-frame image handling (no cv2 call is reached):
+    SiameseTracker.get_subwindow / get_subwindow_for_homo with original_sz == model_sz (hdn/tracker/base_tracker.py:61-213:
+    crop position arithmetic, uint8 channel-mean padding on every side) and get_search_info / get_template_info on 127-px
+    crops (get_img_info.py:8-70)."""
+    g = rng(900)
+    im = g.integers(0, 256, (97, 133, 3)).astype(np.uint8)
+    avg = np.mean(im, axis=(0, 1))
+    cases = [((66.0, 48.0), 31), ((3.2, 5.7), 31), ((130.4, 95.9), 33), ((66.5, 48.5), 64), ((-4.0, 50.0), 25),
+             ((60.0, 110.0), 40), ((66.0, 48.0), 127), ((12.49, 12.51), 24)]
+    out = {"im": im, "avg": avg, "pos": np.array([c[0] for c in cases]), "sz": np.array([c[1] for c in cases])}
+    for i, (pos, sz) in enumerate(cases):
+        a = ref_bt.SiameseTracker.get_subwindow(None, im, np.array(pos), sz, sz, avg)
+        b, pts = ref_bt.SiameseTracker.get_subwindow_for_homo(None, im, np.array(pos), sz, sz, avg)
+        assert torch.equal(a, b)
+        out[f"crop{i}"] = a.numpy().astype(np.uint8)   # values are uint8-valued floats
+        out[f"pts{i}"] = np.array(pts, np.float64)
+    crop127 = ref_bt.SiameseTracker.get_subwindow(None, im, np.array((66.0, 48.0)), 127, 127, avg)
+    s, ps = ref_gi.get_search_info(crop127)
+    tt, pt = ref_gi.get_template_info(crop127)
+    assert np.array_equal(s, tt)
+    out["search_info"] = s          # float64 [1,127,127]
+    save("frame", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
@@ -482,6 +507,8 @@ def main():
     import hdn.models.head.ban as ref_ban
     import hdn.models.head.ban_lp as ref_ban_lp
     gen_heads(ref_ban, ref_ban_lp)
+    import hdn.tracker.base_tracker as ref_bt
+    gen_frame(ref_bt, ref_gi)
     print("torch", torch.__version__, "numpy", np.__version__)
 
 

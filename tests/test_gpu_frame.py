@@ -1,0 +1,75 @@
+"""GPU tests (-m gpu) of the device-resident frame handling (hdn_amd.frame) through the C ABI: bit-exact against the
+fixtures the reference's own get_subwindow* / get_search_info produced (tests/golden/frame.npz) for the pinned arithmetic,
+and bit-exact against oracle/frame_oracle.py for the restated OpenCV pieces (parity-unpinned vs cv2 itself)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import frame_oracle as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+from hdn_amd import frame as FR  # noqa: E402
+
+
+def test_get_subwindow_golden(dev):
+    g = load_golden("frame")
+    fr = FR.upload(g["im"])
+    for i, (pos, sz) in enumerate(zip(g["pos"], g["sz"])):
+        sz = int(sz)
+        a = FR.get_subwindow(fr, pos, sz, sz, g["avg"])
+        assert a.shape == (1, 3, sz, sz) and a.dtype == torch.float32
+        np.testing.assert_array_equal(a.cpu().numpy()[0].astype(np.uint8), g[f"crop{i}"][0], err_msg=f"case {i}")
+        b, pts = FR.get_subwindow_for_homo(fr, pos, sz, sz, g["avg"])
+        assert torch.equal(a, b)
+        np.testing.assert_array_equal(np.array(pts, np.float64), g[f"pts{i}"])
+    s = FR.get_search_info(fr, [66.0, 48.0], 127, g["avg"])
+    assert s.shape == (1, 1, 127, 127)
+    np.testing.assert_allclose(s.cpu().numpy()[0], g["search_info"].astype(np.float32), rtol=0, atol=1e-6)
+    # parameters that already live on the device
+    p = torch.tensor([66.0, 48.0, 127.0, *g["avg"]], dtype=torch.float64, device=dev)
+    assert torch.equal(FR.get_search_info(fr, None, None, None, params=p), s)
+
+
+def test_subwindow_with_resize_vs_oracle(dev):
+    r = np.random.default_rng(5)
+    im = r.integers(0, 256, (360, 640, 3)).astype(np.uint8)
+    fr = FR.upload(im)
+    avg = np.mean(im, axis=(0, 1))
+    for pos, osz, msz in (((320.0, 180.0), 253.0, 255), ((10.5, 350.2), 311.0, 255), ((600.0, 20.0), 95.0, 127), ((300.3, 200.7), 57.6, 127),
+                          ((100.0, 100.0), 127.0, 127), ((333.0, 111.0), 510.0, 255), ((5.0, 5.0), 30.0, 127)):
+        want = F.get_subwindow(im, pos, msz, osz, avg)
+        got = FR.get_subwindow(fr, pos, msz, osz, avg)
+        np.testing.assert_array_equal(got.cpu().numpy(), want, err_msg=str((pos, osz, msz)))
+        gray = FR.get_search_info(fr, pos, osz, avg, model_sz=msz)
+        np.testing.assert_allclose(gray.cpu().numpy()[0], F.search_info(want[0]).astype(np.float32), rtol=0, atol=1e-6)
+
+
+def test_frame_warps_vs_oracle(dev):
+    r = np.random.default_rng(6)
+    im = r.integers(0, 256, (180, 320, 3)).astype(np.uint8)
+    fr = FR.upload(im)
+    assert torch.equal(FR.warp_perspective(fr, np.eye(3)), fr)
+    assert torch.equal(FR.rot_around_center(fr, 100.0, 80.0, 0.0), fr)
+    Hs = [np.array([[1.02, 0.03, -4.2], [-0.02, 0.97, 6.1], [1e-5, -2e-5, 1.0]]),
+          np.array([[0.9, 0.2, 30.0], [-0.15, 1.1, -12.0], [3e-4, 1e-4, 1.0]]),
+          np.array([[1, 0, 500.0], [0, 1, -400.0], [0, 0, 1.0]])]
+    for M in Hs:
+        got = FR.warp_perspective(fr, M).cpu().numpy()
+        np.testing.assert_array_equal(got, F.warp_perspective_u8(im, M))
+    Md = torch.tensor(Hs[0].reshape(-1), dtype=torch.float64, device=dev)
+    assert torch.equal(FR.warp_perspective(fr, Md), FR.warp_perspective(fr, Hs[0]))
+    for (cx, cy, rot) in ((160.0, 90.0, 0.3), (10.0, 170.0, -1.2), (400.0, -20.0, 3.0)):
+        got = FR.rot_around_center(fr, cx, cy, rot).cpu().numpy()
+        np.testing.assert_array_equal(got, F.warp_affine_cubic_u8(im, F.rot_matrix_2x3(cx, cy, rot)))
+    with pytest.raises(Exception):
+        FR.get_subwindow(torch.zeros(4, 4, 3, dtype=torch.uint8), [1, 1], 3, 3, [0, 0, 0])
