@@ -1,80 +1,99 @@
 #!/usr/bin/env python3
-"""Synthetic sequence stream through the homography head at B=1 (a reduced BASELINE config 4: no POT data, no cv2 here).
+"""BASELINE configs[3] on the synthetic sequence of tools/synth_sequence.py (no POT data, no cv2 here): a 1280x720
+planar-target sequence streamed through the device-resident tracker loop (hdn_amd.tracker.HomoTracker: upload the uint8
+frame once, full-frame warp, crop + normalise, track_proj, 3x3 bookkeeping, ONE host read of the 4 corners per frame).
 
-A band-limited random texture is the template; frame t's search crop is the template warped by a smooth random-walk
-homography (our own warp kernel) plus noise.  Each frame runs track_proj on the GPU (eager and hipGraph replay) and on
-the CPU oracle with the same seeded weights; reported: corner-offset difference GPU vs CPU (success_4pts_error of the
-offset vectors), and per-frame latency.
-    python tools/sequence_bench.py [--frames 100]
+Reported: wall time per frame with the host reading the corners EVERY frame (what tools/test.py's loop sees, :115-174),
+host syncs per frame, the same loop without the per-frame read (pipelined), corner error (success_4pts_error) of the device
+loop against the CPU restatement of the same loop on the first --parity frames, and — for the B=1 head alone — eager vs
+hipGraph replay, each synchronised per frame.
+    python tools/sequence_bench.py [--frames 200] [--parity 12]
 """
-import argparse, json, os, sys, time
+import argparse, copy, json, os, sys, time
 import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import hdn_amd
-from hdn_amd import homography as G
 from hdn_amd.graph import GraphedTrackProj
-from oracle import hdn_oracle as O
+from hdn_amd.tracker import HomoTracker
+from oracle.tracker_oracle import HomoTrackerOracle
+from synth_sequence import make_sequence, success_4pts_error
 
 
-def texture(g, n=127):
-    f = torch.fft.rfft2(torch.randn(n, n, generator=g))
-    ky, kx = torch.meshgrid(torch.fft.fftfreq(n), torch.fft.rfftfreq(n), indexing="ij")
-    return torch.fft.irfft2(f * torch.exp(-((kx ** 2 + ky ** 2) / (2 * 0.06 ** 2))), s=(n, n))
-
-
-def main():
-    ap = argparse.ArgumentParser(); ap.add_argument("--frames", type=int, default=100); args = ap.parse_args()
-    dev = torch.device("cuda:0")
-    g = torch.Generator().manual_seed(20260928)
+def seeded_net():
     torch.manual_seed(1)
     net = hdn_amd.HomoModelBuilder().eval()
     for m in net.modules():
         if isinstance(m, torch.nn.BatchNorm2d):
             m.running_mean.uniform_(-0.2, 0.2); m.running_var.uniform_(0.8, 1.2)
     net.fc.weight.data.mul_(0.01)
-    sd = {k: v.clone() for k, v in net.ShareFeature.state_dict().items()}
-    cpu_regress = lambda f: net_cpu.fc(net_cpu.avgpool(net_cpu.backbone(f)).flatten(1))
-    import copy
-    net_cpu = copy.deepcopy(net)
+    return net
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=200); ap.add_argument("--parity", type=int, default=12)
+    ap.add_argument("--iterations", type=int, default=1)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    frames, corners, init = make_sequence(n_frames=args.frames, frame_hw=(720, 1280), target_wh=(300, 200))
+    net = seeded_net(); net_cpu = copy.deepcopy(net)
+    sd = {k: v.clone() for k, v in net_cpu.ShareFeature.state_dict().items()}
     netd = net.to(dev)
-    tmpl = texture(g); tmpl = (tmpl - tmpl.mean()) / tmpl.std()
-    h4p = torch.tensor([[0, 0, 0, 127, 127, 127, 127, 0]], dtype=torch.float32)
-    pidx = torch.arange(127 * 127, dtype=torch.float32).unsqueeze(0)
-    off = torch.zeros(1, 8)
-    frames = []
-    for t in range(args.frames):
-        off = 0.9 * off + 1.5 * torch.randn(1, 8, generator=g)           # smooth random walk of the 4 corners
-        _, search = G.dlt_warp(h4p.to(dev), off.to(dev), tmpl.reshape(1, 1, 127, 127).to(dev))
-        search = search.cpu() + 0.02 * torch.randn(1, 1, 127, 127, generator=g)
-        pair = torch.cat([tmpl.reshape(1, 1, 127, 127), search], dim=1)
-        frames.append({"org_imgs": pair, "input_tensors": pair.clone(), "h4p": h4p, "patch_indices": pidx})
-    dd = [{k: v.to(dev) for k, v in f.items()} for f in frames]
-    from hdn_amd.homo_model import homo_stages
-    # parity per frame
-    errs = []
-    with torch.no_grad():
-        for f, fd in zip(frames[:min(20, args.frames)], dd):
-            x_gpu = homo_stages(netd, fd)["x"].cpu().numpy()
-            _, _, _, aux = O.track_proj(f, sd, cpu_regress)
-            errs.append(float(O.corner_error(x_gpu, aux["x"].numpy())[0]))
-    def run(fn):
-        for fd in dd[:5]: fn(fd)
+    torch.backends.cudnn.benchmark = True
+    netd.optimize_for_inference(channels_last=True)
+
+    def new_tracker():
+        t = HomoTracker(netd, iterations=args.iterations)
+        t.init(frames[0], init["bbox"], init["poly"], init["gt_points"], init["first_point"])
+        return t
+
+    # parity of the whole per-frame chain, device vs CPU restatement
+    ref = HomoTrackerOracle(sd, lambda f: net_cpu.fc(net_cpu.avgpool(net_cpu.backbone(f)).flatten(1)), args.iterations)
+    ref.init(frames[0], init["bbox"], init["poly"], init["gt_points"], init["first_point"])
+    trk = new_tracker()
+    errs = [success_4pts_error(trk.track_new(t, frames[t])["points"], ref.track_new(t, frames[t])["points"])
+            for t in range(1, min(args.parity, args.frames))]
+
+    def stream(sync):
+        t = new_tracker()
+        for i in range(1, 6): t.track_new(i, frames[i])            # warm-up (MIOpen find, clocks)
+        t = new_tracker(); torch.cuda.synchronize(); s0 = t.host_syncs
+        t0 = time.perf_counter(); per = []
+        for i in range(1, args.frames):
+            a = time.perf_counter(); t.track_new(i, frames[i], sync=sync); per.append(time.perf_counter() - a)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / (args.frames - 1) * 1e3, (t.host_syncs - s0) / (args.frames - 1), np.percentile(per, 99) * 1e3
+
+    ms_sync, syncs, p99 = stream(True)
+    ms_async, _, _ = stream(False)
+
+    # the B=1 head alone (track_proj), eager vs hipGraph, synchronised EVERY frame as the tracker's score read does
+    t = new_tracker()
+    tmpl = t.init_homo_tmp
+    from hdn_amd import frame as FR
+    searches = [FR.get_search_info(FR.upload(frames[i]), t.init_pos, t.init_s_z_sm, t.channel_average) for i in range(1, min(60, args.frames))]
+    h4p = torch.tensor([[0, 0, 0, 127, 127, 127, 127, 0]], dtype=torch.float32, device=dev)
+    pidx = torch.arange(127 * 127, dtype=torch.float32, device=dev).unsqueeze(0)
+    dd = [{"org_imgs": torch.cat((tmpl, s), 1), "input_tensors": torch.cat((tmpl, s), 1), "h4p": h4p, "patch_indices": pidx} for s in searches]
+
+    def head(fn):
+        for fd in dd[:5]: float(fn(fd)[1])
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        for fd in dd: r = fn(fd)
-        float(r[1]); torch.cuda.synchronize()   # the tracker reads the score on the host every frame
+        for fd in dd: float(fn(fd)[1])                                # per-frame sync: latency, not pipelined throughput
         return (time.perf_counter() - t0) / len(dd) * 1e3
-    eager = run(lambda fd: netd.track_proj(fd, None))
-    netd.optimize_for_inference()
-    eager_folded = run(lambda fd: netd.track_proj(fd, None))
+    eager = head(lambda fd: netd.track_proj(fd, None))
     gr = GraphedTrackProj(netd, dd[0], template_constant=True)
-    H0, s0, _ = netd.track_proj(dd[3], None); Hg, sg, _ = gr(dd[3])
-    graph_ok = float((H0 - Hg).abs().max()) < 1e-5
-    graphed = run(gr)
-    print(json.dumps({"frames": args.frames, "corner_error_gpu_vs_cpu_max": max(errs), "ms_per_frame_eager": eager,
-                      "ms_per_frame_eager_folded_trunk": eager_folded, "ms_per_frame_hipgraph": graphed,
-                      "graph_matches_eager": graph_ok}))
+    graphed = head(gr)
+    print(json.dumps({
+        "sequence": f"{args.frames} frames 1280x720, 300x200 target, seed 20260928 (tools/synth_sequence.py)",
+        "refinement_iterations": args.iterations,
+        "ms_per_frame_loop_host_reads_corners_each_frame": ms_sync, "p99_ms": p99, "fps": 1e3 / ms_sync,
+        "host_syncs_per_frame": syncs, "reference_host_syncs_per_frame": 6,
+        "ms_per_frame_loop_no_host_read": ms_async,
+        "corner_error_device_vs_cpu_loop_px": {"first": errs[0], "max": max(errs), "frames": len(errs)},
+        "head_only_ms_per_frame_eager_synced": eager, "head_only_ms_per_frame_hipgraph_synced": graphed}))
 
 
 if __name__ == "__main__":
