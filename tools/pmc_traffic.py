@@ -24,6 +24,7 @@ KERNELS = {
     "xcorr_north_mfma_kernel": (PL * (61 * 61 + 31 * 31) * 4, PL * 31 * 31 * 4, 0),
     "xcorr_prod29_kernel": (6 * PL * (29 * 29 + 25) * 4, 6 * PL * 25 * 25 * 4, 6 * PL * 25 * 4),
     "xcorr_circ13_kernel": (6 * PL * 2 * 169 * 4, 6 * PL * 169 * 4, 0),
+    "xcorr_circ13r_kernel": (6 * PL * 2 * 169 * 4, 6 * PL * 169 * 4, 0),
 }
 
 
