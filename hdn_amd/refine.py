@@ -36,6 +36,22 @@ def refine_warp(H_mat: torch.Tensor, search: torch.Tensor, H_comp: torch.Tensor 
     return out
 
 
+_CONST = {}
+
+
+def _constants(dev, B, H, W):
+    """h4p / patch_indices of the full-patch case (get_img_info.py:88-98), built once per (device, batch, size): a
+    torch.tensor(list, device=...) is a host->device copy, which a hipGraph capture cannot contain."""
+    key = (str(dev), B, H, W)
+    if key not in _CONST:
+        if len(_CONST) > 32:
+            _CONST.clear()
+        h4p = torch.tensor([[0, 0, 0, H, W, H, W, 0]], dtype=torch.float32, device=dev).repeat(B, 1)
+        pidx = torch.arange(H * W, dtype=torch.float32, device=dev).repeat(B, 1)
+        _CONST[key] = (h4p, pidx)
+    return _CONST[key]
+
+
 def homo_refine(net, template: torch.Tensor, search: torch.Tensor, iterations: int = 2, cache_template: bool = True):
     """template / search: [B,1,127,127] normalised gray crops on the device (get_template_info / get_search_info output).
 
@@ -46,8 +62,7 @@ def homo_refine(net, template: torch.Tensor, search: torch.Tensor, iterations: i
         raise ValueError("iterations must be >= 1")
     B, _, H, W = template.shape
     dev = _lib.require_device(template, search)
-    h4p = torch.tensor([[0, 0, 0, H, W, H, W, 0]], dtype=torch.float32, device=dev).repeat(B, 1)
-    pidx = torch.arange(H * W, dtype=torch.float32, device=dev).repeat(B, 1)
+    h4p, pidx = _constants(dev, B, H, W)
     H_comp = torch.eye(3, dtype=torch.float64, device=dev).repeat(B, 1, 1).contiguous()
     cur = search
     p1 = net.ShareFeature(template) if cache_template else None

@@ -45,10 +45,15 @@ def rot_scale_around_center_shift_tran(cx, cy, rot, scale, sx, sy):
 
 
 class HomoTracker:
-    def __init__(self, hm_net, iterations: int = 1, similarity=None, score_gate: float = 2.5):
+    def __init__(self, hm_net, iterations: int = 1, similarity=None, score_gate: float = 2.5, graph: bool = False):
         """hm_net: hdn_amd.HomoModelBuilder (or the reference's, after install()) in eval mode on the GPU.
-        iterations: trip count of the refinement loop (1 in the shipped tracker, :242; 2 in BASELINE config 5)."""
+        iterations: trip count of the refinement loop (1 in the shipped tracker, :242; 2 in BASELINE config 5).
+        graph: replay the whole per-frame body as ONE hipGraph (about 200 launches at B = 1 are launch-latency bound);
+        only without a `similarity` callable, whose host-side decisions cannot be captured."""
         self.net = hm_net
+        self.use_graph = bool(graph)
+        self._graph = None
+        self._capturing = False
         self.iterations = int(iterations)
         self.similarity = similarity
         self.score_gate = float(score_gate)
@@ -74,7 +79,11 @@ class HomoTracker:
         # get_template_info(get_subwindow_for_homo(...)[:, 0:3]) : the normalised gray template, constant for the sequence
         self.init_homo_tmp = FR.get_search_info(frame, self.center_pos, self.init_s_z_sm, self.channel_average)
         self.init_points = torch.tensor(np.asarray(gt_points, np.float64).reshape(-1, 2), dtype=torch.float64, device=self.dev)
+        self._init_points_h = torch.cat([self.init_points, torch.ones_like(self.init_points[:, :1])], dim=1)
         self.H_total = torch.eye(3, dtype=torch.float64, device=self.dev)
+        self._eye = torch.eye(3, dtype=torch.float64, device=self.dev)
+        self._const_params = FR._dev_f64([self.init_pos[0], self.init_pos[1], self.init_s_z_sm] + [float(a) for a in self.channel_average], self.dev)
+        self._graph = None
         # un-scale / un-shift of the residual (:251-258) are constants of the sequence: H_homo = A @ H_hm_comp @ B
         cw = self.z_crop_points_sm[2] - self.z_crop_points_sm[0] + 1
         ch = self.z_crop_points_sm[3] - self.z_crop_points_sm[1] + 1
@@ -83,26 +92,24 @@ class HomoTracker:
         A = np.linalg.inv(Sh).astype(np.float64) @ np.linalg.inv(S).astype(np.float64)           # (float32 inverses, numpy's dtype rule)
         self._A = torch.tensor(A, dtype=torch.float64, device=self.dev)
         self._B = torch.tensor(S.astype(np.float64) @ Sh.astype(np.float64), dtype=torch.float64, device=self.dev)
-        self._params = None
 
     # -------------------------------------------------------------------------------------------------- one frame
-    def track_new(self, fr_idx, img, gt_box=None, gt_poly=None, gt_points=None, sync: bool = True):
-        frame = FR.upload(img)
-        # :150-155  undo the accumulated motion (a singular H_total is reset to the identity, as the reference does)
-        det = torch.linalg.det(self.H_total)
-        Ht = torch.where(det == 0, torch.eye(3, dtype=torch.float64, device=self.dev), self.H_total)
-        frame = FR.warp_perspective(frame, torch.linalg.inv(Ht).reshape(-1))
-        cx0, cy0 = self.init_pos
-        if self.similarity is not None:
-            dcx, dcy, scale_delta, rot_delta, best_score = self.similarity(frame, self.init_pos)
-        else:
-            dcx, dcy, scale_delta, rot_delta, best_score = 0.0, 0.0, 1.0, 0.0, 0.0
-        cx, cy = cx0 + dcx, cy0 + dcy
-        self.center_pos = np.array([cx, cy], np.float64)
-        H_sim = torch.tensor(rot_scale_around_center_shift_tran(cx, cy, rot_delta, scale_delta, dcx, dcy), dtype=torch.float64).to(self.dev, non_blocking=True)
+    @staticmethod
+    def _det3(m):
+        return (m[0, 0] * (m[1, 1] * m[2, 2] - m[1, 2] * m[2, 1]) - m[0, 1] * (m[1, 0] * m[2, 2] - m[1, 2] * m[2, 0])
+                + m[0, 2] * (m[1, 0] * m[2, 1] - m[1, 1] * m[2, 0]))
+
+    def _body(self, frame, params, H_sim, rot_delta=0.0, cx=None, cy=None):
+        """Everything of a frame that runs on the device, from the uploaded frame to the 4 projected corners; no host
+        reads, no allocations that depend on data: capturable in a hipGraph when its inputs are static buffers."""
+        # :150-155  undo the accumulated motion (a singular H_total is reset to the identity, as the reference does).
+        # hdn_frame_warp_perspective_u8 inverts its matrix itself (cv2 semantics), so it is handed inv(H_total) = adj / det.
+        det = self._det3(self.H_total)
+        Ht = torch.where(det == 0, self._eye, self.H_total)
+        frame = FR.warp_perspective(frame, torch.linalg.inv(Ht).reshape(-1) if not self._capturing else self._inv3(Ht).reshape(-1))
         # :223-239  rotate back, cut the homography crop, normalise
         rot_img = FR.rot_around_center(frame, cx, cy, -rot_delta) if rot_delta != 0 else frame  # (rot 0: bicubic identity)
-        search = FR.get_search_info(rot_img, self.center_pos, self.init_s_z_sm * scale_delta, self.channel_average)
+        search = FR.get_search_info(rot_img, None, None, None, params=params)
         # :242-250  refinement loop around track_proj
         H_comp, homo_score, _ = homo_refine(self.net, self.init_homo_tmp, search, iterations=self.iterations)
         # :251-266  un-scale, un-shift, gate, accumulate
@@ -110,10 +117,62 @@ class HomoTracker:
         base = Ht @ H_sim
         H = torch.where(homo_score.to(torch.float64) > self.score_gate, base, base @ H_homo)
         H = H / H[2, 2]
-        self.H_total = H
         # :272  cv2.perspectiveTransform(init_points, H_total)
-        p = torch.cat([self.init_points, torch.ones_like(self.init_points[:, :1])], dim=1) @ H.T
+        p = self._init_points_h @ H.T
         pts = (p[:, :2] / p[:, 2:3]).to(torch.float32)
+        return H, pts, homo_score
+
+    def _inv3(self, m):
+        """Closed-form 3x3 inverse from elementwise ops (graph capture cannot hold the solver call of torch.linalg.inv)."""
+        a, b, c, d, e, f, g, h, i = (m[0, 0], m[0, 1], m[0, 2], m[1, 0], m[1, 1], m[1, 2], m[2, 0], m[2, 1], m[2, 2])
+        adj = torch.stack([torch.stack([e * i - f * h, c * h - b * i, b * f - c * e]),
+                           torch.stack([f * g - d * i, a * i - c * g, c * d - a * f]),
+                           torch.stack([d * h - e * g, b * g - a * h, a * e - b * d])])
+        return adj / self._det3(m)
+
+    def _capture(self, frame_shape):
+        """hipGraph of the whole per-frame body (similarity = identity only: its parameters are constants of the sequence).
+        The frame lands in a static device buffer; H_total is carried in a static tensor updated by the graph itself."""
+        self._static_frame = torch.empty(frame_shape, dtype=torch.uint8, device=self.dev)
+        self._capturing = True
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        H0 = self.H_total.clone()
+        with torch.cuda.stream(side):
+            for _ in range(3):  # warm-up on the side stream (MIOpen find, lazy initialisations) without touching the state
+                self._body(self._static_frame, self._const_params, self._eye)
+        torch.cuda.current_stream().wait_stream(side)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            H, pts, score = self._body(self._static_frame, self._const_params, self._eye)
+            self.H_total.copy_(H)            # the recurrence lives inside the graph
+            self._g_pts, self._g_score = pts, score
+        self.H_total.copy_(H0)
+        self._capturing = False
+
+    def track_new(self, fr_idx, img, gt_box=None, gt_poly=None, gt_points=None, sync: bool = True):
+        best_score = 0.0
+        if self.use_graph and self.similarity is None:
+            t = img if isinstance(img, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(img))
+            if self._graph is None:
+                self._capture(tuple(t.shape))
+            self._static_frame.copy_(t, non_blocking=True)
+            self._graph.replay()
+            pts, homo_score = self._g_pts, self._g_score
+        else:
+            frame = FR.upload(img)
+            cx0, cy0 = self.init_pos
+            if self.similarity is not None:
+                dcx, dcy, scale_delta, rot_delta, best_score = self.similarity(frame, self.init_pos)
+                cx, cy = cx0 + dcx, cy0 + dcy
+                self.center_pos = np.array([cx, cy], np.float64)
+                H_sim = torch.tensor(rot_scale_around_center_shift_tran(cx, cy, rot_delta, scale_delta, dcx, dcy),
+                                     dtype=torch.float64).to(self.dev, non_blocking=True)
+                params = FR._dev_f64([cx, cy, self.init_s_z_sm * scale_delta] + [float(a) for a in self.channel_average], self.dev)
+                H, pts, homo_score = self._body(frame, params, H_sim, rot_delta, cx, cy)
+            else:
+                H, pts, homo_score = self._body(frame, self._const_params, self._eye)
+            self.H_total = H
         self.last_points, self.last_score = pts, homo_score
         if not sync:
             return {"points": pts, "polygon": pts, "best_score": best_score}

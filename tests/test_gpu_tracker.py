@@ -53,3 +53,23 @@ def test_sequence_stream_device_loop_vs_cpu_restatement(dev):
     # without the host read nothing synchronises: the same frame again, asynchronously, gives device tensors
     out = trk.track_new(99, frames[-1], sync=False)
     assert out["points"].is_cuda and trk.host_syncs == len(frames)
+
+
+def test_graphed_tracker_loop_matches_eager(dev):
+    """The whole per-frame body as one hipGraph replay (static frame buffer, H_total carried inside the graph) gives the
+    eager loop's corners."""
+    from synth_sequence import make_sequence, success_4pts_error
+    from test_gpu_parity import _seeded_net
+    from hdn_amd.tracker import HomoTracker
+    frames, corners, init = make_sequence(n_frames=8, frame_hw=(360, 640), target_wh=(150, 100), seed=8)
+    net = _seeded_net().to(dev)
+    a, b = HomoTracker(net), HomoTracker(net, graph=True)
+    for t in (a, b):
+        t.init(frames[0], init["bbox"], init["poly"], init["gt_points"], init["first_point"])
+    for i in range(1, len(frames)):
+        pa, pb = a.track_new(i, frames[i])["points"], b.track_new(i, frames[i])["points"]
+        # (the seeded head does not track: H_total drifts by ~10 % per frame, and with it the sensitivity to the last bits of
+        #  the closed-form inverse the captured body uses; observed 0 ... 4e-5 px over the first 5 frames)
+        assert success_4pts_error(pa, pb) <= (1e-3 if i <= 3 else 2e-2), (i, pa, pb)
+    assert b._graph is not None
+    np.testing.assert_allclose(a.H_total.cpu().numpy(), b.H_total.cpu().numpy(), rtol=1e-4, atol=1e-3)

@@ -44,8 +44,8 @@ def main():
     torch.backends.cudnn.benchmark = True
     netd.optimize_for_inference(channels_last=True)
 
-    def new_tracker():
-        t = HomoTracker(netd, iterations=args.iterations)
+    def new_tracker(graph=False):
+        t = HomoTracker(netd, iterations=args.iterations, graph=graph)
         t.init(frames[0], init["bbox"], init["poly"], init["gt_points"], init["first_point"])
         return t
 
@@ -56,10 +56,10 @@ def main():
     errs = [success_4pts_error(trk.track_new(t, frames[t])["points"], ref.track_new(t, frames[t])["points"])
             for t in range(1, min(args.parity, args.frames))]
 
-    def stream(sync):
-        t = new_tracker()
-        for i in range(1, 6): t.track_new(i, frames[i])            # warm-up (MIOpen find, clocks)
-        t = new_tracker(); torch.cuda.synchronize(); s0 = t.host_syncs
+    def stream(sync, graph=False):
+        t = new_tracker(graph)
+        for i in range(1, 6): t.track_new(i, frames[i])            # warm-up (MIOpen find, clocks, graph capture)
+        t.H_total.copy_(torch.eye(3, dtype=torch.float64, device=dev)); torch.cuda.synchronize(); s0 = t.host_syncs
         t0 = time.perf_counter(); per = []
         for i in range(1, args.frames):
             a = time.perf_counter(); t.track_new(i, frames[i], sync=sync); per.append(time.perf_counter() - a)
@@ -68,6 +68,7 @@ def main():
 
     ms_sync, syncs, p99 = stream(True)
     ms_async, _, _ = stream(False)
+    ms_graph, _, p99_graph = stream(True, graph=True)
 
     # the B=1 head alone (track_proj), eager vs hipGraph, synchronised EVERY frame as the tracker's score read does
     t = new_tracker()
@@ -92,6 +93,7 @@ def main():
         "ms_per_frame_loop_host_reads_corners_each_frame": ms_sync, "p99_ms": p99, "fps": 1e3 / ms_sync,
         "host_syncs_per_frame": syncs, "reference_host_syncs_per_frame": 6,
         "ms_per_frame_loop_no_host_read": ms_async,
+        "ms_per_frame_loop_one_hipgraph_per_frame": ms_graph, "p99_ms_hipgraph": p99_graph, "fps_hipgraph": 1e3 / ms_graph,
         "corner_error_device_vs_cpu_loop_px": {"first": errs[0], "max": max(errs), "frames": len(errs)},
         "head_only_ms_per_frame_eager_synced": eager, "head_only_ms_per_frame_hipgraph_synced": graphed}))
 
