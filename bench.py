@@ -71,8 +71,8 @@ def parse():
     ap.add_argument("--collective", choices=["c_abi", "torch"], default="c_abi",
                     help="N > 1: hdn_allgather_offsets of the C ABI (default) or torch.distributed.all_gather_into_tensor")
     ap.add_argument("--only-north", action="store_true", help="step = the north-star correlation only (profiling aid)")
-    ap.add_argument("--north", choices=["fft", "fft2w", "direct", "dense", "mfma"], default=None,
-                    help="kernel for the 31x31 (x) 61x61 correlation (default: the library's default, fft); A/B runs")
+    ap.add_argument("--north", choices=["fft", "fftr", "fft2w", "direct", "dense", "mfma"], default=None,
+                    help="kernel for the 31x31 (x) 61x61 correlation (default: the library's default, fft = the column-first FFT kernel; fftr = the row-first one); A/B runs")
     ap.add_argument("--config", type=int, choices=[2, 5], default=2,
                     help="2 = BASELINE configs[1] (default, the headline); 5 = configs[4]: 303-px search window (6x xcorr 5x5 (x) 35x35 "
                          "-> 31x31) + the 2-iteration refinement loop, 64 pairs per GPU (256 over 4 GPUs); kernels only")
@@ -240,7 +240,7 @@ def main():
     # gfx950 x2 correction on the 16 B/lane stream) and committed under profiles/; bench.py cannot collect PMCs itself.
     X.xcorr_depthwise(d["north_x"], d["north_k"])
     north_variant = X.last_variant()
-    north_kernel = {"north_fft_61x61_31x31": "xcorr_north_fft2_kernel", "north_fft2w_61x61_31x31": "xcorr_north_fft3_kernel",
+    north_kernel = {"north_fft_61x61_31x31": "xcorr_north_fft2_kernel", "north_fft2w_61x61_31x31": "xcorr_north_fft3_kernel", "north_fftc_61x61_31x31": "xcorr_north_fft4_kernel",
                     "north_61x61_31x31": "xcorr_north_kernel", "north_mfma_61x61_31x31": "xcorr_north_mfma_kernel"}[north_variant]
     traffic, traffic_note = None, "no committed PMC measurement found for " + north_kernel
     try:
@@ -294,8 +294,8 @@ def main():
     }
     if north_variant.startswith("north_fft"):
         result["roofline"]["note"] = (
-            "64x64 fp32 FFT per pair of planes in registers + LDS (~1,650 packed VALU ops per plane instead of the direct "
-            "sum's 7,688); one wave per SIMD (33 KB of LDS per wave), issue-bound: DESIGN.md section 4/6")
+            "64x64 fp32 FFT per pair of planes in registers + LDS (~1,380 packed VALU ops per plane instead of the direct "
+            "sum's 7,688); one wave per SIMD (32 KB of LDS per wave), issue-bound: DESIGN.md section 4/6")
     else:
         result["roofline"].update({
             "note": ("direct fp32 sum at 81.8 FLOP/B is fp32-FMA-bound (ridge 19.7 FLOP/B), and the packed-FMA pipe is "

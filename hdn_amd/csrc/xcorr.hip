@@ -1145,7 +1145,7 @@ static std::atomic<int> g_north_variant{-1};
 static int north_variant() {
   int v = g_north_variant.load(std::memory_order_relaxed);
   if (v >= 0) return v;
-  v = HDN_NORTH_FFT;
+  v = HDN_NORTH_FFT_COL;
   const char* e = getenv("HDN_NORTH");
   const char* m = getenv("HDN_NORTH_MFMA");
   const char* t = getenv("HDN_NORTH_TAPS");
@@ -1154,7 +1154,8 @@ static int north_variant() {
   else if (e && e[0] == 'd') v = HDN_NORTH_DIRECT_DENSE;
   else if (e && e[0] == 'm') v = HDN_NORTH_MFMA;
   else if (e && e[0] == 'f' && e[1] == 'f' && e[2] == 't' && e[3] == '2') v = HDN_NORTH_FFT_2W;
-  else if (e && e[0] == 'f') v = HDN_NORTH_FFT;
+  else if (e && e[0] == 'f' && e[1] == 'f' && e[2] == 't' && e[3] == 'r') v = HDN_NORTH_FFT;   // "fftr": row-first
+  else if (e && e[0] == 'f') v = HDN_NORTH_FFT_COL;
   else if (m && m[0] == '1') v = HDN_NORTH_MFMA;
   else if (t && t[0] == 'd') v = HDN_NORTH_DIRECT_DENSE;
   else if (f && f[0] == '0') v = HDN_NORTH_DIRECT;
@@ -1186,6 +1187,7 @@ static int launch_north(const XcorrPtrs& P, int n, int planes, hipStream_t strea
 int launch_north_fft(const float* x, const float* k, float* out, int planes, int max_blocks, hipStream_t stream, int pair0);
 int launch_north_fft2(const float* x, const float* k, float* out, int planes, int max_blocks, hipStream_t stream);
 int launch_north_fft3(const float* x, const float* k, float* out, int planes, int max_blocks, hipStream_t stream);
+int launch_north_fft4(const float* x, const float* k, float* out, int planes, int max_blocks, hipStream_t stream);
 
 static int launch_north_fft_all(const XcorrPtrs& P, int n, int planes, hipStream_t stream, bool two_waves = false) {
   // persistent: 4 one-wave workgroups per CU x 256 CUs (LDS-limited); n problems run back to back
@@ -1263,6 +1265,15 @@ static int xcorr_dispatch(const XcorrPtrs& P, int n, int circular, int B, int C,
       // out; otherwise, or on request (hdn_xcorr_north_variant / environment), one of the direct kernels runs:
       // packed-FMA with zero-tap skipping (~255 us on post-ReLU data), the same without skipping, or split-bf16 MFMA.
       const int v = north_variant();
+      if (v == HDN_NORTH_FFT_COL) {  // column-first FFT kernel: no alignment requirement
+        static const int cap = [] { const char* e = getenv("HDN_NORTH_BLOCKS"); int c = e ? atoi(e) : 0; return c > 0 ? c : 1024; }();
+        for (int i = 0; i < n; ++i) {
+          const int rc = launch_north_fft4(P.x[i], P.k[i], P.out[i], planes, cap, stream);
+          if (rc != HDN_OK) return rc;
+        }
+        g_last_variant = "north_fftc_61x61_31x31";
+        return HDN_OK;
+      }
       if (v == HDN_NORTH_FFT || v == HDN_NORTH_FFT_2W) {
         bool ok = true;
         for (int i = 0; i < n; ++i)
@@ -1304,7 +1315,7 @@ const char* hdn_last_xcorr_variant(void) { return hdn::g_last_variant; }
 int hdn_xcorr_north_variant(int v) {
   const int prev = hdn::north_variant();
   if (v >= 0) {
-    if (v > HDN_NORTH_FFT_2W) return HDN_E_LIMIT;
+    if (v > HDN_NORTH_FFT_COL) return HDN_E_LIMIT;
     hdn::g_north_variant.store(v, std::memory_order_relaxed);
   }
   return prev;

@@ -381,6 +381,7 @@ int launch_north_fft(const float* x, const float* k, float* out, int planes, int
   return e == hipSuccess ? HDN_OK : -(1000 + (int)e);
 }
 
+
 }  // namespace hdn
 
 // =======================================================================================
@@ -463,6 +464,25 @@ NF_DEV void lw128_from_agpr(uint32_t a, const f4v& v) { asm volatile("ds_write_b
 template <int OFF>
 NF_DEV void gload128_to_agpr(f4v& v, uint32_t voff, const void* sbase) {
   asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=a"(v) : "v"(voff), "s"(sbase), "n"(OFF));
+}
+template <int OFF>
+NF_DEV void gload32_to_agpr(float& v, uint32_t voff, const void* sbase) {
+  asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=a"(v) : "v"(voff), "s"(sbase), "n"(OFF));
+}
+NF_DEV float acc_read(const float& a) {
+  float r;
+  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(r) : "a"(a));
+  return r;
+}
+template <int OFF>
+NF_DEV void gstore32(uint32_t voff, float v, void* sbase) {
+  asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(voff), "v"(v), "s"(sbase), "n"(OFF) : "memory");
+}
+template <int OFF>  // the same from lanes 0..31 only
+NF_DEV void gstore32_low_half(uint32_t voff, float v, void* sbase) {
+  uint64_t keep;
+  asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 0xffffffff\n\tglobal_store_dword %1, %2, %3 offset:%4\n\ts_mov_b64 exec, %0"
+               : "=&s"(keep) : "v"(voff), "v"(v), "s"(sbase), "n"(OFF) : "memory");
 }
 template <int CNT>
 NF_DEV void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(CNT)); }
@@ -1036,6 +1056,325 @@ __global__ __launch_bounds__(64 * WPG) void xcorr_north_fft2_kernel(const float*
 }
 
 // =======================================================================================
+// v4: v2 on the TRANSPOSED problem ("column first"): see the comment at its loads.  Same passes, same arithmetic per plane
+// pair up to the transposition (the summation order inside a plane differs from v2's: row and column transforms swap).
+// =======================================================================================
+template <int WPG>
+__global__ __launch_bounds__(64 * WPG) void xcorr_north_fft4_kernel(const float* __restrict__ x, const float* __restrict__ k,
+                                                                    float* __restrict__ out, int npairs, int nmain, int planes,
+                                                                    int tail_worker,
+                                                                    const nfft::cf* __restrict__ tab) {
+  using namespace nf2;
+  extern __shared__ __align__(16) float smem_wg[];
+  const int wave = WPG == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: an SGPR
+  float* const smem = smem_wg + wave * (NF2_WAVE_LDS / 4);
+  const int worker = (int)blockIdx.x * WPG + wave;
+  const int lane = threadIdx.x & 63;
+  if (worker >= nmain) {
+    if (worker == tail_worker) north_fft_v1_body(smem, x, k, out, planes, npairs, 0, 1, tab, lane);
+    return;  // (a surplus wave of the last workgroup)
+  }
+  const uint32_t sb = lds_addr(smem);
+
+  const int fc = lane & 31;
+  const float sgn = lane < 32 ? 1.f : -1.f;
+  const cf sg = {sgn, sgn};
+  // LDS byte addresses that do not depend on the pair
+  const uint32_t a_stash = sb + lane * 16;                     // linear 16-byte chunks
+  // lanes past the last row redo that row and rewrite it with identical values: no exec branches around the writes
+  const uint32_t a_row = sb + (lane < HX ? lane : HX - 1) * (RS * 8);    // search spectrum row
+  // kernel row pass: lanes 0..30 transform the rows' EVEN half-bins, lanes 32..62 the same rows' ODD half-bins (two
+  // pruned 32-point FFTs that differ only in the input twiddle e^{-i*pi*(1 + 2*hl)*j/64}, which is therefore per lane:
+  // a 2 x 32 table behind the wave's image, read through LDS broadcasts); lanes 31 / 63 redo row 30
+  const int hl = lane >> 5, krow = (lane & 31) < HK ? (lane & 31) : HK - 1;
+  const uint32_t a_rowk = sb + krow * (RS * 8) + hl * 8;       // kernel spectrum row, bins of this lane's parity
+  const uint32_t a_tw = sb + NF2_TW_OFF + hl * 256;
+  // inverse row pass, the same way: lanes 0..30 invert the EVEN bins of a row, lanes 32..62 its ODD bins (two 32-point
+  // inverse FFTs), z[j] = E[j] + w64^j O[j] is formed across the two halves of the wave (v_permlane32_swap); the un-shift
+  // e^{+i*pi*j/64} / 16384 (times w64^j on the odd half) is per lane again
+  const int orow = (lane & 31) < HO ? (lane & 31) : HO - 1;
+  const uint32_t a_ro = sb + orow * (RS * 8) + hl * 8;          // entries 2g + hl
+  const uint32_t a_ro2 = sb + orow * (RS * 8) + (1 - hl) * 8;   // entries 63 - 2g - hl = (62 - 2g) + (1 - hl)
+  const uint32_t a_tw2 = sb + NF2_TW_OFF + 512 + hl * 256;
+  const uint32_t a_ow = sb + orow * (HO * 4) + hl * 64, a_owB = a_ow + OPL * 4;   // outputs j (lanes < 32) / j + 16
+  const uint32_t a_o15 = hl ? sb + 8192 + lane * 8 : a_ow, a_o15B = hl ? sb + 8192 + 1024 + lane * 8 : a_owB;  // j = 31 does not exist
+  if (lane < 32) {
+    cf* const tw = reinterpret_cast<cf*>(smem + NF2_TW_OFF / 4);
+    tw[lane] = tab[NFFT_TAB_TAU + lane];
+    tw[32 + lane] = tab[NFFT_TAB_TAU3 + lane];
+    tw[64 + lane] = tab[NFFT_TAB_POST + lane];
+    tw[96 + lane] = tab[NFFT_TAB_POST3 + lane];
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  const uint32_t a_col = sb + lane * 8;                        // spectrum column `lane` / linear 8-byte words
+  const uint32_t a_colp = sb + fc * 8, a_colq = sb + (63 - fc) * 8;
+  const uint32_t a_rowo = sb + (lane < HO ? lane : HO - 1) * (RS * 8);
+  const uint32_t a_out = sb + (lane < HO ? lane : HO - 1) * (HO * 4);
+  // Loads and stores of this variant: the transposed problem is solved (out^T = corr(x^T, k^T): same operator), so the
+  // first pass has lane = COLUMN j of the planes and its in-register index = row: a plane row is then 244 contiguous bytes
+  // across the lanes and goes from HBM straight into the registers of the first pass (4-byte loads into AGPRs one pair
+  // ahead, v_accvgpr_read when the pass starts) - no 30 KB stash in LDS, no alignment requirement, no clamped windows; the
+  // last pass ends with lane = output column, so a register is one contiguous output row and is stored as it is.
+  const int jl = lane < HX ? lane : HX - 1;
+  const uint32_t vx = jl * 4, vk = krow * 4;
+  const uint32_t vo = (hl * (16 * HO) + orow) * 4;   // lanes < 32: output row k, column orow; lanes >= 32: row k + 16
+  float AX[2][HX], AK[2][HK];  // the next pair's planes: AGPRs
+  auto fetch_x = [&](int p) NF2_LAMBDA {
+    const char* xb = reinterpret_cast<const char*>(x + (long long)p * (2 * XPL));
+    sfor<0, 2 * HX>([&](auto Qi) NF2_LAMBDA {
+      constexpr int q = decltype(Qi)::value, P = q / HX, r = q % HX;   // 16 rows (3,904 B) per scalar base: 13-bit offsets
+      gload32_to_agpr<(r % 16) * (HX * 4)>(AX[P][r], vx, xb + P * (XPL * 4) + (r / 16) * (16 * HX * 4));
+    });
+  };
+  auto fetch_k = [&](int p) NF2_LAMBDA {
+    const char* kb = reinterpret_cast<const char*>(k + (long long)p * (2 * KPL));
+    sfor<0, 2 * HK>([&](auto Qi) NF2_LAMBDA {
+      constexpr int q = decltype(Qi)::value, P = q / HK, r = q % HK;
+      gload32_to_agpr<r * (HK * 4)>(AK[P][r], vk, kb + P * (KPL * 4));
+    });
+  };
+
+  int p = worker;
+  if (p >= npairs) return;
+  fetch_x(p);
+  fetch_k(p);
+  wait_vm0();
+  for (; p < npairs; p += nmain) {
+    const int pn = min(p + nmain, npairs - 1);  // (the last iteration re-fetches its own pair: harmless)
+    // ---- first pass: lane = column of the planes; samples from the AGPRs, which are refilled with the next pair at once.
+    //      (The loads were waited for before the previous pair's stores were issued: nobody ever waits for a store.)
+    {
+      cf ra[31], rb[31];
+      sfor<0, 31>([&](auto Mi) NF2_LAMBDA {
+        constexpr int m = decltype(Mi)::value;
+        ra[m] = cf{acc_read(AX[0][2 * m]), 2 * m + 1 < HX ? acc_read(AX[0][2 * m + 1 < HX ? 2 * m + 1 : 0]) : 0.f};
+        rb[m] = cf{acc_read(AX[1][2 * m]), 2 * m + 1 < HX ? acc_read(AX[1][2 * m + 1 < HX ? 2 * m + 1 : 0]) : 0.f};
+      });
+      fetch_x(pn);
+      cf v[64];
+      sfor<0, 31>([&](auto Mi) NF2_LAMBDA {
+        constexpr int j = 2 * decltype(Mi)::value;
+        cf lo, hi;
+        const cf A = ra[j / 2], B = rb[j / 2];
+        twiddle_in2<-j, -(j + 1), (j + 1 < HX)>(A, B, lo, hi);
+        v[bitrev(j, 6)] = lo;
+        if constexpr (j + 1 < HX) v[bitrev(j + 1, 6)] = hi;
+      });
+      fft<6, -1, HX, 64>(v);
+      {
+        cf sa[32], sb2[32];  // C(f) + conj C(63-f),  C(f) - conj C(63-f); each write trails its split by one element
+        sfor<0, 33>([&](auto F) NF2_LAMBDA {
+          constexpr int f = decltype(F)::value;
+          if constexpr (f < 32) {
+            const cf cp = v[f], cq = v[63 - f];
+            cf a, b;
+            asm volatile("v_pk_add_f32 %0, %2, %3 neg_hi:[0,1]\n\tv_pk_add_f32 %1, %2, %3 neg_lo:[0,1]"
+                         : "=&v"(a), "=&v"(b) : "v"(cp), "v"(cq));
+            sa[f] = a;
+            sb2[f] = b;
+          }
+          if constexpr (f > 0) lw2x64<f - 1, 32 + f - 1>(a_row, sa[f - 1], sb2[f - 1]);
+        });
+      }
+    }
+    // ---- column pass: lane = (plane, half-bin column); straight into X
+    cf X[64];
+    sfor<0, HX>([&](auto R) NF2_LAMBDA { constexpr int r = decltype(R)::value; X[bitrev(r, 6)] = lr64<r * RS * 8>(a_col); });
+    wait_lgkm<0>();
+    fft<6, -1, HX, 64>(X);
+
+    // ---- kernel row pass, pruned: even bins = FFT32(c * e^{-i*pi*j/64}) on lanes 0..30, odd bins =
+    //      FFT32(c * e^{-3i*pi*j/64}) on lanes 32..62, in ONE pass; raw spectra to LDS (the real/imaginary split needs an
+    //      even and an odd bin: the column lanes do it)
+    {
+      cf ka[16], kb[16];  // the kernel pair, column `krow` of both planes, from the AGPRs (refilled at once)
+      sfor<0, 16>([&](auto Mi) NF2_LAMBDA {
+        constexpr int m = decltype(Mi)::value;
+        ka[m] = cf{acc_read(AK[0][2 * m]), 2 * m + 1 < HK ? acc_read(AK[0][2 * m + 1 < HK ? 2 * m + 1 : 0]) : 0.f};
+        kb[m] = cf{acc_read(AK[1][2 * m]), 2 * m + 1 < HK ? acc_read(AK[1][2 * m + 1 < HK ? 2 * m + 1 : 0]) : 0.f};
+      });
+      fetch_k(pn);
+      cf v[32];
+      constexpr int TCH = 4;  // twiddles arrive in chunks of 4 (two ds_read2_b64), one chunk ahead of their use
+      cf tq[2][TCH];
+      auto tw_issue = [&](auto Ci) NF2_LAMBDA {
+        constexpr int c = decltype(Ci)::value;
+        lr2x64<TCH * c, TCH * c + 1>(a_tw, tq[c & 1][0], tq[c & 1][1]);
+        // entry 31 has no consumer: loading it would leave an in-flight write to a register the compiler considers dead
+        // (and hands to the next packed op) - these loads are invisible to its liveness / wait-count tracking
+        if constexpr (TCH * c + 3 < HK) lr2x64<TCH * c + 2, TCH * c + 3>(a_tw, tq[c & 1][2], tq[c & 1][3]);
+        else tq[c & 1][2] = lr64<(TCH * c + 2) * 8>(a_tw);
+      };
+      tw_issue(std::integral_constant<int, 0>{});
+      sfor<0, 8>([&](auto Ci) NF2_LAMBDA {
+        constexpr int c = decltype(Ci)::value;
+        if constexpr (c + 1 < 8) {
+          tw_issue(std::integral_constant<int, c + 1>{});
+          wait_lgkm<2>();
+        } else {
+          wait_lgkm<0>();
+        }
+        sfor<0, 2>([&](auto Ui) NF2_LAMBDA {
+          constexpr int m = 2 * c + decltype(Ui)::value, j = 2 * m;
+          cf lo, hi;
+          const cf A = ka[m], B = kb[m], T0 = tq[c & 1][j % TCH], T1 = tq[c & 1][j % TCH + 1];
+          // (a + i b) * conj(t), t = (cos, sin):  m = a * (c, -s);  r = b * (s, c) + m   (samples j: lo halves, j + 1: hi halves)
+          if constexpr (j + 1 < HK)
+            asm volatile("v_pk_mul_f32 %0, %2, %4 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
+                         "v_pk_mul_f32 %1, %2, %5 op_sel:[1,0] op_sel_hi:[1,1] neg_hi:[0,1]\n\t"
+                         "v_pk_fma_f32 %0, %3, %4, %0 op_sel:[0,1,0] op_sel_hi:[0,0,1]\n\t"
+                         "v_pk_fma_f32 %1, %3, %5, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1]"
+                         : "=&v"(lo), "=&v"(hi) : "v"(A), "v"(B), "v"(T0), "v"(T1));
+          else
+            asm volatile("v_pk_mul_f32 %0, %1, %3 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
+                         "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[0,1,0] op_sel_hi:[0,0,1]"
+                         : "=&v"(lo) : "v"(A), "v"(B), "v"(T0));
+          v[bitrev(j, 5)] = lo;
+          if constexpr (j + 1 < HK) v[bitrev(j + 1, 5)] = hi;
+        });
+      });
+      fft<5, -1, HK, 32>(v);
+      sfor<0, 16>([&](auto Gi) NF2_LAMBDA {
+        constexpr int g = 2 * decltype(Gi)::value;
+        lw2x64<2 * g, 2 * g + 2>(a_rowk, v[g], v[g + 1]);  // bins 2g + hl, 2(g + 1) + hl
+      });
+    }
+    // ---- kernel column pass (pruned halves; split by a per-lane sign while reading) and product X * conj(K)
+    sfor<0, 2>([&](auto Hf) NF2_LAMBDA {
+      constexpr int half = decltype(Hf)::value;
+      cf K[32];
+      constexpr int CH = 5, NCH = (HK + CH - 1) / CH;  // rows in chunks of 5, two chunks in flight
+      cf pp[2][CH], qq[2][CH];
+      auto issue = [&](auto Ci) NF2_LAMBDA {
+        constexpr int c = decltype(Ci)::value;
+        sfor<0, CH>([&](auto Ri) NF2_LAMBDA {
+          constexpr int r = c * CH + decltype(Ri)::value;
+          if constexpr (r < HK) {
+            pp[c & 1][r - c * CH] = lr64<r * RS * 8>(a_colp);
+            qq[c & 1][r - c * CH] = lr64<r * RS * 8>(a_colq);
+          }
+        });
+      };
+      issue(std::integral_constant<int, 0>{});
+      sfor<0, NCH>([&](auto Ci) NF2_LAMBDA {
+        constexpr int c = decltype(Ci)::value;
+        constexpr int next_rows = (c + 1 < NCH) ? ((c + 2) * CH <= HK ? CH : HK - (c + 1) * CH) : 0;
+        if constexpr (c + 1 < NCH) issue(std::integral_constant<int, c + 1>{});
+        wait_lgkm<2 * next_rows>();
+        cf sp[CH];
+        sfor<0, CH>([&](auto Ri) NF2_LAMBDA {
+          constexpr int r = c * CH + decltype(Ri)::value;
+          if constexpr (r < HK) {
+            cf s2;
+            const cf pv = pp[c & 1][r - c * CH], qv = qq[c & 1][r - c * CH], sgl = sg;
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 neg_hi:[1,0,0]" : "=v"(s2) : "v"(qv), "v"(sgl), "v"(pv));  // p +- conj q
+            sp[r - c * CH] = s2;
+          }
+        });
+        sfor<0, CH>([&](auto Ri) NF2_LAMBDA {  // odd bins: times w64^r, after all splits of the chunk (no dependent neighbours)
+          constexpr int r = c * CH + decltype(Ri)::value;
+          if constexpr (r < HK) {
+            if constexpr (half == 1 && r > 0) K[bitrev(r, 5)] = cmul_tw<-2 * r, false>(sp[r - c * CH]);
+            else K[bitrev(r, 5)] = sp[r - c * CH];
+          }
+        });
+      });
+      fft<5, -1, HK, 32>(K);
+      sfor<0, 16>([&](auto Gi) NF2_LAMBDA {
+        constexpr int g0 = 2 * decltype(Gi)::value, g1 = g0 + 1;
+        cf m0, m1;
+        cf x0 = X[2 * g0 + half], x1 = X[2 * g1 + half];
+        const cf k0 = K[g0], k1 = K[g1];
+        asm volatile("v_pk_mul_f32 %0, %2, %4 op_sel_hi:[1,0]\n\tv_pk_mul_f32 %1, %3, %5 op_sel_hi:[1,0]\n\t"
+                     "v_pk_fma_f32 %2, %2, %4, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]\n\t"
+                     "v_pk_fma_f32 %3, %3, %5, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+                     : "=&v"(m0), "=&v"(m1), "+v"(x0), "+v"(x1) : "v"(k0), "v"(k1));
+        X[2 * g0 + half] = x0;
+        X[2 * g1 + half] = x1;
+      });
+    });
+    // ---- inverse column pass (rows 0..30 needed), to LDS
+    {
+      cf V[64];
+      sfor<0, 64>([&](auto F) NF2_LAMBDA { constexpr int f = decltype(F)::value; V[bitrev(f, 6)] = X[f]; });
+      fft<6, +1, 64, HO>(V);
+      sfor<0, HO>([&](auto R) NF2_LAMBDA { constexpr int r = decltype(R)::value; lw64<r * RS * 8>(a_col, V[r]); });
+    }
+    // ---- inverse row pass: lane = (output row, parity of the bins it inverts); Hermitian re-packing of the pair,
+    //      32-point inverse FFT, un-shift, cross-half sum
+    {
+      cf pa[32], pb[32];  // (ya, yb) of bin 2g + hl (g < 16) or of its mirror 63 - 2g - hl (g >= 16)
+      sfor<0, 16>([&](auto G) NF2_LAMBDA { constexpr int g = decltype(G)::value; lr2x64<2 * g, 32 + 2 * g>(a_ro, pa[g], pb[g]); });
+      sfor<16, 32>([&](auto G) NF2_LAMBDA { constexpr int g = decltype(G)::value; lr2x64<62 - 2 * g, 94 - 2 * g>(a_ro2, pa[g], pb[g]); });
+      constexpr int TCH = 4;
+      cf tq[2][TCH];
+      auto tw_issue = [&](auto Ci) NF2_LAMBDA {
+        constexpr int c = decltype(Ci)::value;
+        lr2x64<TCH * c, TCH * c + 1>(a_tw2, tq[c & 1][0], tq[c & 1][1]);
+        lr2x64<TCH * c + 2, TCH * c + 3>(a_tw2, tq[c & 1][2], tq[c & 1][3]);  // (entry 31 is consumed: see o[31] below)
+      };
+      tw_issue(std::integral_constant<int, 0>{});
+      wait_lgkm<2>();
+      cf v[32];
+      sfor<0, 32>([&](auto G) NF2_LAMBDA {
+        constexpr int g = decltype(G)::value;
+        cf c0;
+        const cf ya = pa[g], yb = pb[g];
+        if constexpr (g < 16) asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(c0) : "v"(ya), "v"(yb));  // ya + i yb
+        else asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]" : "=v"(c0) : "v"(ya), "v"(yb));          // conj ya + i conj yb
+        v[bitrev(g, 5)] = c0;
+      });
+      fft<5, +1, 32, 32>(v);
+      // un-shift: o[j] = v[j] * t[j], t per lane (e^{i*pi*j/64} or e^{3i*pi*j/64}, both / 16384);  m = v * (c, c);  r = (v.y, v.x) * (-s, s) + m
+      float ox[32], oy[32];
+      sfor<0, 8>([&](auto Ci) NF2_LAMBDA {
+        constexpr int c = decltype(Ci)::value;
+        if constexpr (c + 1 < 8) {
+          tw_issue(std::integral_constant<int, c + 1>{});
+          wait_lgkm<2>();
+        } else {
+          wait_lgkm<0>();
+        }
+        sfor<0, 2>([&](auto Ui) NF2_LAMBDA {
+          constexpr int j0 = TCH * c + 2 * decltype(Ui)::value, j1 = j0 + 1;
+          cf m0, m1, r0, r1;
+          const cf V0 = v[j0], V1 = v[j1], T0 = tq[c & 1][j0 % TCH], T1 = tq[c & 1][j1 % TCH];
+          asm volatile("v_pk_mul_f32 %0, %4, %6 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+                       "v_pk_mul_f32 %1, %5, %7 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+                       "v_pk_fma_f32 %2, %4, %6, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]\n\t"
+                       "v_pk_fma_f32 %3, %5, %7, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]"
+                       : "=&v"(m0), "=&v"(m1), "=&v"(r0), "=&v"(r1) : "v"(V0), "v"(V1), "v"(T0), "v"(T1));
+          ox[j0] = r0.x; oy[j0] = r0.y;
+          ox[j1] = r1.x; oy[j1] = r1.y;
+        });
+      });
+      // cross-half sum: after the swaps register k holds the even-bin parts of outputs k (lanes < 32) and k + 16 (lanes
+      // >= 32), register k + 16 the odd-bin parts of the same two; j = 31 is a by-product that is never stored.
+      // (v_permlane32_swap needs 2 wait states after a VALU write of its operands: the swaps start with the oldest.)
+      sfor<0, 16>([&](auto Ki) NF2_LAMBDA {
+        constexpr int kk = decltype(Ki)::value;
+        half_swap2(ox[kk], ox[kk + 16], oy[kk], oy[kk + 16]);
+      });
+      sfor<0, 16>([&](auto Ki) NF2_LAMBDA {
+        constexpr int kk = decltype(Ki)::value;
+        add2(ox[kk], oy[kk], ox[kk + 16], oy[kk + 16]);
+      });
+      // register kk = output row kk (lanes < 32) / kk + 16 (lanes >= 32), lane = output column: one contiguous row each.
+      wait_vm0();  // the next pair's loads (issued most of an iteration ago) have landed; the stores below stay in flight
+      char* const ob = reinterpret_cast<char*>(out + (long long)p * (2 * OPL));
+      sfor<0, 15>([&](auto Ki) NF2_LAMBDA {
+        constexpr int kk = decltype(Ki)::value;
+        gstore32<kk * (HO * 4)>(vo, ox[kk], ob);
+        gstore32<kk * (HO * 4)>(vo, oy[kk], ob + OPL * 4);
+      });
+      gstore32_low_half<15 * (HO * 4)>(vo, ox[15], ob);            // row 31 does not exist: lanes 0..31 only
+      gstore32_low_half<15 * (HO * 4)>(vo, oy[15], ob + OPL * 4);
+    }
+  }
+}
+
+
+// =======================================================================================
 // v3: the same transform with HALF the LDS image, so that two waves fit a SIMD (one wave alone cannot issue a packed op
 // every 4 clocks and exposes every LDS turn-around: profiles/round1_ubench_issue_rate.txt).  The pair of planes is
 // still packed into one complex signal for the ROW passes, but the column passes run one PLANE at a time: 64 lanes =
@@ -1470,6 +1809,30 @@ int launch_north_fft2(const float* x, const float* k, float* out, int planes, in
     hipLaunchKernelGGL(xcorr_north_fft2_kernel<4>, dim3(grid), dim3(256), 4 * NF2_WAVE_LDS, stream, x, k, out, nfast, nmain,
                        planes, all ? nfull : 0x7fffffff, tail_worker, tab);
   }
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? HDN_OK : -(1000 + (int)e);
+}
+
+
+// v4 (column first): any pointers, every pair whose two planes exist; an odd last plane goes to the guarded v1 path.
+int launch_north_fft4(const float* x, const float* k, float* out, int planes, int max_blocks, hipStream_t stream) {
+  const nfft::cf* tab = north_fft_table();
+  if (!tab) return -(1000 + (int)hipErrorInvalidSymbol);
+  const int npairs = (planes + 1) / 2, nfast = planes / 2;
+  if (nfast == 0) return launch_north_fft(x, k, out, planes, max_blocks, stream, 0);
+  const int nmain = nfast < max_blocks ? nfast : max_blocks;
+  const int tail_worker = nfast < npairs ? nmain : -1;
+  const int workers = nmain + (tail_worker >= 0 ? 1 : 0);
+  static PerDeviceOnce attr;
+  const int dev_ = PerDeviceOnce::device();
+  if (!attr.done(dev_)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xcorr_north_fft4_kernel<4>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 4 * NF2_WAVE_LDS);
+    if (e != hipSuccess) return -(1000 + (int)e);
+    attr.set(dev_);
+  }
+  hipLaunchKernelGGL(xcorr_north_fft4_kernel<4>, dim3((workers + 3) / 4), dim3(256), 4 * NF2_WAVE_LDS, stream, x, k, out, nfast, nmain,
+                     planes, tail_worker, tab);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? HDN_OK : -(1000 + (int)e);
 }

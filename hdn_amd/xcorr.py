@@ -132,7 +132,7 @@ def last_variant() -> str:
     return _lib.load().hdn_last_xcorr_variant().decode()
 
 
-NORTH_VARIANTS = {"fft": 0, "direct": 1, "dense": 2, "mfma": 3, "fft2w": 4}  # HDN_NORTH_* in include/hdn_hip.h
+NORTH_VARIANTS = {"fftr": 0, "fft": 5, "fftc": 5, "direct": 1, "dense": 2, "mfma": 3, "fft2w": 4}  # HDN_NORTH_* in include/hdn_hip.h
 
 
 class north_variant:
@@ -159,4 +159,4 @@ class north_variant:
 
 def current_north_variant() -> str:
     v = _lib.load().hdn_xcorr_north_variant(-1)
-    return next(k for k, n in NORTH_VARIANTS.items() if n == v)
+    return next(k for k, n in NORTH_VARIANTS.items() if n == v and k != "fftc")

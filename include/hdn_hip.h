@@ -41,8 +41,8 @@ const char* hdn_last_xcorr_variant(void);
 
 /*
  * Kernel used for the 31x31 (x) 61x61 shape (BASELINE north-star shape).  v >= 0 selects it for the whole process,
- * v < 0 only queries; returns the previous value (or HDN_E_LIMIT).  HDN_NORTH_FFT needs 16-byte aligned x / k and
- * 8-byte aligned out and otherwise falls back to HDN_NORTH_DIRECT.  All variants meet the same parity bar; they
+ * v < 0 only queries; returns the previous value (or HDN_E_LIMIT).  HDN_NORTH_FFT / _2W need 16-byte aligned x / k and
+ * 8-byte aligned out and otherwise fall back to HDN_NORTH_DIRECT; HDN_NORTH_FFT_COL (the default) takes any pointers.  All variants meet the same parity bar; they
  * differ in rounding: the direct kernels accumulate each output in one fixed fp32 chain (planes independent), the
  * FFT kernel has a smaller error against float64 but transforms planes in pairs, so a plane's rounding depends on
  * its neighbour's magnitude, and a NaN / Inf anywhere in a plane reaches every output of that plane and of its partner
@@ -52,11 +52,12 @@ const char* hdn_last_xcorr_variant(void);
  * 1.8e-4); the bound it is held to is |hip - ref| <= 1e-4 + 2e-6 * sum|x*k| and an error against float64 of at most twice the
  * reference's.  The 1e-4 abs of BASELINE's north_star is on the predicted corner offsets, which no correlation feeds.
  */
-#define HDN_NORTH_FFT 0          /* 64x64 fp32 FFT per pair of planes (default)        */
+#define HDN_NORTH_FFT 0          /* 64x64 fp32 FFT per pair of planes, rows first through a 30 KB LDS stash (round 1's default) */
 #define HDN_NORTH_DIRECT 1       /* packed-FMA direct sum, zero taps skipped            */
 #define HDN_NORTH_DIRECT_DENSE 2 /* packed-FMA direct sum, every tap                    */
 #define HDN_NORTH_MFMA 3         /* split-bf16 matrix-core direct sum                   */
 #define HDN_NORTH_FFT_2W 4       /* FFT, 16 KB LDS image, two waves per SIMD (planes % 4 == 0, else as HDN_NORTH_FFT) */
+#define HDN_NORTH_FFT_COL 5      /* (default) the same FFT on the transposed problem: planes go HBM -> registers row by row (no LDS stash, any alignment) */
 int hdn_xcorr_north_variant(int v);
 
 /*

@@ -56,7 +56,7 @@ def check_xcorr(got, x, k, ref, circular, name):
 def test_xcorr_depthwise_golden(dev):
     g = load_golden("xcorr_depthwise")
     seen = set()
-    for variant in ("fft", "direct", "dense"):  # only the 31x31 (x) 61x61 fixtures depend on it
+    for variant in ("fft", "fftr", "direct", "dense"):  # only the 31x31 (x) 61x61 fixtures depend on it
         with X.north_variant(variant):
             for n in cases(g):
                 x, k = g[n + "__x"], g[n + "__k"]
@@ -67,7 +67,7 @@ def test_xcorr_depthwise_golden(dev):
                 check_xcorr(y, x, k, g[n + "__y"], False, n + "/" + variant)
     assert X.current_north_variant() == "fft"
     # the fixtures exercise the specialised kernels (both families for the north-star shape) and the generic one
-    assert {"prod_29x29_5x5", "cfg5_35x35_5x5", "north_61x61_31x31", "north_fft_61x61_31x31", "generic_lds"} <= seen, seen
+    assert {"prod_29x29_5x5", "cfg5_35x35_5x5", "north_61x61_31x31", "north_fft_61x61_31x31", "north_fftc_61x61_31x31", "generic_lds"} <= seen, seen
 
 
 def test_xcorr_depthwise_sampled_full_channel(dev):
@@ -105,8 +105,11 @@ def test_xcorr_ragged_plane_counts_vs_oracle(dev, shape):
     check_xcorr(y, x, k, O.xcorr_depthwise(T(x), T(k)).numpy(), False, str(shape))
 
 
+NORTH_NAME = {"fft": "north_fftc_61x61_31x31", "fftr": "north_fft_61x61_31x31", "direct": "north_61x61_31x31"}
+
+
 @pytest.mark.parametrize("planes", [(1, 1), (1, 2), (1, 3), (1, 4), (3, 5), (2, 8), (1, 33), (5, 205), (8, 256)])
-@pytest.mark.parametrize("variant", ["fft", "direct"])
+@pytest.mark.parametrize("variant", ["fft", "fftr", "direct"])
 def test_xcorr_north_plane_counts(dev, planes, variant):
     """31x31 (x) 61x61 for odd / even / tiny plane counts (the FFT kernel works on PAIRS of planes, its last pair(s)
     take a guarded path in an extra workgroup) up to several persistent passes; signed and post-ReLU data."""
@@ -119,7 +122,7 @@ def test_xcorr_north_plane_counts(dev, planes, variant):
             x, k = np.maximum(x, 0), np.maximum(k, 0)
         with X.north_variant(variant):
             y = hdn_amd.xcorr_depthwise(T(x).to(dev), T(k).to(dev))
-            assert X.last_variant() == ("north_fft_61x61_31x31" if variant == "fft" else "north_61x61_31x31")
+            assert X.last_variant() == NORTH_NAME[variant]
             assert torch.equal(y, hdn_amd.xcorr_depthwise(T(x).to(dev), T(k).to(dev)))  # deterministic
         check_xcorr(y, x, k, O.xcorr_depthwise(T(x), T(k)).numpy(), False, f"{planes} {variant} signed={signed}")
 
@@ -143,7 +146,7 @@ def test_xcorr_north_multi_problem_launch(dev):
     r = np.random.default_rng(404)
     xs = [T(relu_normal(r, (2, 9, 61, 61))).to(dev) for _ in range(3)]
     ks = [T(relu_normal(r, (2, 9, 31, 31))).to(dev) for _ in range(3)]
-    for variant in ("fft", "direct"):
+    for variant in ("fft", "fftr", "direct"):
         with X.north_variant(variant):
             outs = hdn_amd.xcorr_depthwise_multi(xs, ks)
             for x, k, o in zip(xs, ks, outs):
@@ -159,14 +162,15 @@ def test_xcorr_north_fft_pair_crosstalk_is_rounding_only(dev):
     x, k = relu_normal(r, (1, 6, 61, 61)), relu_normal(r, (1, 6, 31, 31))
     x[0, 1] *= 1000.0
     k[0, 2] = 0
-    with X.north_variant("fft"):
-        y = hdn_amd.xcorr_depthwise(T(x).to(dev), T(k).to(dev)).cpu().numpy()
     truth = O.xcorr_depthwise_f64(x, k)
     mag = O.xcorr_depthwise_f64(np.abs(x), np.abs(k))
     pair_mag = np.maximum(mag[:, 0::2], mag[:, 1::2]).repeat(2, axis=1)  # per pair of planes
-    assert np.all(np.abs(y - truth) <= 1e-4 + 2e-6 * pair_mag.max(axis=(2, 3), keepdims=True))
-    assert np.abs(y[0, 2]).max() <= 2e-6 * mag[0, 3].max()
-    assert np.abs(y[0, 0] - truth[0, 0]).max() <= 2e-6 * mag[0, 1].max()  # small plane beside the large one
+    for variant in ("fft", "fftr"):
+        with X.north_variant(variant):
+            y = hdn_amd.xcorr_depthwise(T(x).to(dev), T(k).to(dev)).cpu().numpy()
+        assert np.all(np.abs(y - truth) <= 1e-4 + 2e-6 * pair_mag.max(axis=(2, 3), keepdims=True))
+        assert np.abs(y[0, 2]).max() <= 2e-6 * mag[0, 3].max()
+        assert np.abs(y[0, 0] - truth[0, 0]).max() <= 2e-6 * mag[0, 1].max()  # small plane beside the large one
 
 
 @pytest.mark.parametrize("shape", [(3, 7, 13, 13, 13, 13), (1, 1, 13, 13, 13, 13), (2, 3, 9, 12, 4, 6), (1, 2, 5, 5, 9, 9)])
@@ -226,6 +230,8 @@ def test_xcorr_specialised_kernels_on_unaligned_pointers(dev, shape, circ):
     for ox, ok in ((1, 0), (0, 3), (2, 1)):
         y = fn(shifted(xb, ox), shifted(kb, ok))
         check_xcorr(y, xb, kb, ref, circ, f"{shape} offsets {ox},{ok}")
+        if Hx == 61:  # the column-first FFT kernel has no alignment requirement: it serves these pointers itself
+            assert X.last_variant() == "north_fftc_61x61_31x31"
 
 
 def test_xcorr_multi_eight_problems_and_limits(dev):
@@ -342,12 +348,12 @@ def test_xcorr_full_size_config5(dev):
         assert torch.equal(y2, y)
 
 
-@pytest.mark.parametrize("variant", ["fft", "direct"])
+@pytest.mark.parametrize("variant", ["fft", "fftr", "direct"])
 def test_xcorr_full_size_north_star(dev, variant):
     with X.north_variant(variant):
         _full_size_properties(dev, hdn_amd.xcorr_depthwise, O.xcorr_depthwise, (64, 256, 61, 61), (64, 256, 31, 31), False,
-                              paired=(variant == "fft"))
-        assert X.last_variant() == ("north_fft_61x61_31x31" if variant == "fft" else "north_61x61_31x31")
+                              paired=(variant != "direct"))
+        assert X.last_variant() == NORTH_NAME[variant]
 
 
 def test_xcorr_north_matrix_core_variant(dev):
