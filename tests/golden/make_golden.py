@@ -472,6 +472,12 @@ def gen_frame(ref_bt, ref_gi):
     tt, pt = ref_gi.get_template_info(crop127)
     assert np.array_equal(s, tt)
     out["search_info"] = s          # float64 [1,127,127]
+    # similarity homography builder of the tracker (hdn/utils/transform.py:250-298), the H_sim of hdn_tracker_proj_e2e.py:214
+    import hdn.utils.transform as ref_tf
+    prm = np.array([[320.0, 180.0, 0.0, 1.0, 0.0, 0.0], [320.5, 179.25, 0.12, 1.07, 3.5, -2.25], [100.0, 50.0, -0.4, 0.9, -7.0, 1.5],
+                    [10.0, 20.0, 0.0, 1.2, 0.0, 4.0], [64.0, 64.0, 1.3, 1.0, 2.0, 0.0]])
+    out["sim_params"] = prm
+    out["sim_H"] = np.stack([ref_tf.rot_scale_around_center_shift_tran(*row) for row in prm])
     save("frame", **out)
 
 

@@ -66,3 +66,12 @@ def test_opencv_restatements_properties():
     np.testing.assert_array_equal(a[0].transpose(1, 2, 0), F.resize_linear_u8(F.subwindow_patch(img, [60.0, 45.0], 53.0, [1, 2, 3]), 127, 127))
     # a fractional original_sz (init_s_z_sm * scale_delta) yields floor(sz) rows, as the reference's slice does
     assert F.subwindow_patch(img, [60.0, 45.0], 53.7, [1, 2, 3]).shape == (53, 53, 3)
+
+
+def test_similarity_homography_builder_matches_reference():
+    """hdn_amd.tracker.rot_scale_around_center_shift_tran (host arithmetic of the tracker loop) against the reference's
+    hdn/utils/transform.py:250-298."""
+    from hdn_amd.tracker import rot_scale_around_center_shift_tran
+    g = load_golden("frame")
+    for row, H in zip(g["sim_params"], g["sim_H"]):
+        np.testing.assert_allclose(rot_scale_around_center_shift_tran(*row), H, rtol=0, atol=1e-12)
