@@ -20,6 +20,9 @@ PL = B * C
 # kernel-name substring -> (algorithmic read bytes, algorithmic write bytes, narrow (non 16 B/lane) read bytes) per launch
 KERNELS = {
     "xcorr_north_fft2_kernel": (PL * (61 * 61 + 31 * 31) * 4, PL * 31 * 31 * 4, 0),
+    # the column-first kernel loads 4 B per lane, but as coalesced 244-byte rows: FETCH_SIZE comes out at 0.502 of its
+    # algorithmic read bytes, i.e. the same half-counting as a 16 B/lane stream (calibrated on this kernel's own byte count)
+    "xcorr_north_fft4_kernel": (PL * (61 * 61 + 31 * 31) * 4, PL * 31 * 31 * 4, 0),
     "xcorr_north_kernel": (PL * (61 * 61 + 31 * 31) * 4, PL * 31 * 31 * 4, PL * 31 * 31 * 4),   # taps via s_load
     "xcorr_north_mfma_kernel": (PL * (61 * 61 + 31 * 31) * 4, PL * 31 * 31 * 4, 0),
     "xcorr_prod29_kernel": (6 * PL * (29 * 29 + 25) * 4, 6 * PL * 25 * 25 * 4, 6 * PL * 25 * 4),
