@@ -358,6 +358,12 @@ __device__ __forceinline__ void sfr_fetch(float (&pin)[5], const float* __restri
 // One tile (output rows r0 .. r0+3).  INC: the layer-1 rows r0-2 .. r0+1 and the layer-2 rows r0-1, r0 are in the rings
 // already (left there by the tile above); only rows r0+2 .. r0+5 / r0+1 .. r0+4 are computed.  The input window in s_in
 // starts at row r0-3 (full) or r0+1 (INC).
+#ifndef SFR_UNROLL_T
+#define SFR_UNROLL_T 1
+#endif
+#ifndef SFR_UNROLL_H
+#define SFR_UNROLL_H 1
+#endif
 template <bool INC>
 __device__ __forceinline__ void sfr_tile(const float* s_in, float2v* s_a, float2v* s_b, const float* s_w, float* __restrict__ outp,
                                          int r0, int H, int W, int c, int rr) {
@@ -422,7 +428,7 @@ __device__ __forceinline__ void sfr_tile(const float* s_in, float2v* s_a, float2
     for (int q = 0; q < NPX; ++q)
 #pragma unroll
       for (int co = 0; co < 8; ++co) acc[q][co] = float2v{0.f, 0.f};
-#pragma unroll 1
+#pragma unroll SFR_UNROLL_T
     for (int t = 0; t < 6; ++t) {  // t = cp * 3 + ky
       const int cp = t / 3, ky = t - cp * 3;
       const float2v* w = w2p + t * 24;  // [kx][co]
@@ -470,7 +476,7 @@ __device__ __forceinline__ void sfr_tile(const float* s_in, float2v* s_a, float2
     float2v acc[NPX];
 #pragma unroll
     for (int q = 0; q < NPX; ++q) acc[q] = float2v{0.f, 0.f};
-#pragma unroll 1
+#pragma unroll SFR_UNROLL_H
     for (int h = 0; h < 2; ++h) {  // two channel pairs (36 weights) per iteration
       const float2v* w = w3p + h * 18;
 #pragma unroll

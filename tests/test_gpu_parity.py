@@ -780,6 +780,35 @@ def test_track_proj_end_to_end_corner_offsets(dev):
     assert float((Hm2 - Hm).abs().max()) < 1e-5 and abs(float(s2) - float(s)) < 1e-5
 
 
+def test_config3_per_gpu_share_full_forward(dev):
+    """BASELINE configs[2]: B = 512 over 8 GPUs = 64 pairs per GPU through the full HomoModelBuilder.forward (ShareFeature x2 ->
+    ResNet-34 trunk -> DLT -> warp -> ShareFeature), SURVEY 8d cfg 3: parity against the CPU oracle on a 16-pair sample,
+    independence of the pairs (a pair's result does not depend on its batch), and the dict contract at that batch."""
+    net = _seeded_net()
+    data = _cfg1_data(64, 4040)
+    sd = {k: v.clone() for k, v in net.ShareFeature.state_dict().items()}
+    sample = {k: v[:16] for k, v in data.items()}
+    with torch.no_grad():
+        ref = O.homo_forward(sample, sd, lambda f: net.fc(net.avgpool(net.backbone(f)).flatten(1)))
+    netd = net.to(dev)
+    dd = {k: v.to(dev) for k, v in data.items()}
+    out = netd(dd)
+    assert out["x"].shape == (64, 8) and out["H_mat"].shape == (64, 3, 3) and out["pred_I2_d"].shape == (1, 1, 127, 127)
+    x = out["x"].cpu()
+    assert float((x[:16] - ref["x"]).abs().max()) <= 1e-4          # north-star bound on the corner offsets
+    assert O.corner_error(x[:16].numpy(), ref["x"].numpy()).max() <= 1e-4
+    np.testing.assert_allclose(out["H_mat"][:16].cpu().numpy(), ref["H_mat"].numpy(), atol=2e-5)
+    with torch.no_grad():
+        net.cpu()
+        fl = O.homo_forward(data, sd, lambda f: net.fc(net.avgpool(net.backbone(f)).flatten(1)))["feature_loss"].numpy()
+        net.to(dev)
+    np.testing.assert_allclose(out["feature_loss"].cpu().numpy(), fl, rtol=2e-3)
+    # a shard of the batch gives the same offsets as the same pairs inside the full batch (what sharding over ranks relies on)
+    part = netd({k: v[40:56].contiguous() for k, v in dd.items()})
+    assert float((part["x"] - out["x"][40:56]).abs().max()) <= 5e-5
+    assert bool(torch.isfinite(out["x"]).all()) and bool(torch.isfinite(out["H_mat"]).all())
+
+
 def test_refine_warp_vs_oracle_restatement(dev):
     """hdn_refine_warp_f32 (the restated cv2.warpPerspective + H bookkeeping of hdn_tracker_proj_e2e.py:246-250) against
     the oracle's numpy restatement of the same algorithm.  PARITY UNPINNED against OpenCV itself (absent here)."""
