@@ -156,6 +156,8 @@ class HomoTracker:
             t = img if isinstance(img, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(img))
             if self._graph is None:
                 self._capture(tuple(t.shape))
+            if tuple(t.shape) != tuple(self._static_frame.shape) or t.dtype != torch.uint8:
+                raise ValueError(f"graph mode was captured for uint8 frames of shape {tuple(self._static_frame.shape)}, got {t.dtype} {tuple(t.shape)}")
             self._static_frame.copy_(t, non_blocking=True)
             self._graph.replay()
             pts, homo_score = self._g_pts, self._g_score
