@@ -358,6 +358,11 @@ __device__ __forceinline__ void sfr_fetch(float (&pin)[5], const float* __restri
 // One tile (output rows r0 .. r0+3).  INC: the layer-1 rows r0-2 .. r0+1 and the layer-2 rows r0-1, r0 are in the rings
 // already (left there by the tile above); only rows r0+2 .. r0+5 / r0+1 .. r0+4 are computed.  The input window in s_in
 // starts at row r0-3 (full) or r0+1 (INC).
+// layer-2 / layer-3 weights of the rolling-row kernel through the scalar cache into SGPRs (48 per tap row) instead of LDS
+// broadcasts: a tap's LDS reads drop from 8 + NPX to NPX (measured 42.3 -> 39.9 us at 128 images); -DSFR_LDS_WEIGHTS reverts
+#ifndef SFR_LDS_WEIGHTS
+#define SFR_SGPR_WEIGHTS 1
+#endif
 #ifndef SFR_UNROLL_T
 #define SFR_UNROLL_T 1
 #endif
@@ -366,7 +371,7 @@ __device__ __forceinline__ void sfr_fetch(float (&pin)[5], const float* __restri
 #endif
 template <bool INC>
 __device__ __forceinline__ void sfr_tile(const float* s_in, float2v* s_a, float2v* s_b, const float* s_w, float* __restrict__ outp,
-                                         int r0, int H, int W, int c, int rr) {
+                                         int r0, int H, int W, int c, int rr, const float* __restrict__ prm) {
   using namespace sfr;
   const float2v* w2p = reinterpret_cast<const float2v*>(s_w + SF_W2);  // [2][9][8]
   const float2v* w3p = reinterpret_cast<const float2v*>(s_w + SF_W3);  // [4][9]
@@ -431,7 +436,11 @@ __device__ __forceinline__ void sfr_tile(const float* s_in, float2v* s_a, float2
 #pragma unroll SFR_UNROLL_T
     for (int t = 0; t < 6; ++t) {  // t = cp * 3 + ky
       const int cp = t / 3, ky = t - cp * 3;
+#ifdef SFR_SGPR_WEIGHTS
+      const cfloat2v* w = opaque_const(reinterpret_cast<const float2v*>(prm + SF_W2) + t * 24);  // scalar loads: 48 SGPRs per tap row
+#else
       const float2v* w = w2p + t * 24;  // [kx][co]
+#endif
       int rowq[NPX];
 #pragma unroll
       for (int q = 0; q < NPX; ++q) rowq[q] = cp * A_N + (ky == 0 ? arow[q][0] : (ky == 1 ? arow[q][1] : arow[q][2]));
@@ -478,7 +487,11 @@ __device__ __forceinline__ void sfr_tile(const float* s_in, float2v* s_a, float2
     for (int q = 0; q < NPX; ++q) acc[q] = float2v{0.f, 0.f};
 #pragma unroll SFR_UNROLL_H
     for (int h = 0; h < 2; ++h) {  // two channel pairs (36 weights) per iteration
+#ifdef SFR_SGPR_WEIGHTS
+      const cfloat2v* w = opaque_const(reinterpret_cast<const float2v*>(prm + SF_W3) + h * 18);
+#else
       const float2v* w = w3p + h * 18;
+#endif
 #pragma unroll
       for (int cq = 0; cq < 2; ++cq)
 #pragma unroll
@@ -542,8 +555,8 @@ __global__ __launch_bounds__(HDN_BLOCK) void share_feature_ring_kernel(const flo
       }
       if (t + 1 < t_end) sfr_fetch<3>(pin, src, (t + 1) * R + 1, H, W, c, rr);  // the next tile's 6 new-window rows, in flight meanwhile
       __syncthreads();
-      if (inc) sfr_tile<true>(s_in, s_a, s_b, s_w, dst, r0, H, W, c, rr);
-      else sfr_tile<false>(s_in, s_a, s_b, s_w, dst, r0, H, W, c, rr);
+      if (inc) sfr_tile<true>(s_in, s_a, s_b, s_w, dst, r0, H, W, c, rr, prm);
+      else sfr_tile<false>(s_in, s_a, s_b, s_w, dst, r0, H, W, c, rr, prm);
     }
   }
 }
