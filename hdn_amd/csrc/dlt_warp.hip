@@ -81,6 +81,57 @@ __device__ __forceinline__ double dlt_solve_rows(const float* __restrict__ src, 
   return a[8] / diag;
 }
 
+// The same elimination with the 8 x 9 system in LDS and one wave sharing the work (element (r, j) on lane r*9 + j, the last 8
+// on a second round): a pivot step is a handful of LDS round trips instead of ~40 dependent wave shuffles of doubles.  Same
+// operations on the same values in the same order as dlt_solve_rows => bit-identical H.  Called by ONE wave (64 lanes, uniform
+// control flow); A: 72 doubles of LDS owned by that wave.  On return lane r < 8 holds h[r].
+__device__ __forceinline__ double dlt_solve_lds(const float* __restrict__ src, const float* __restrict__ off, double* A, int lane) {
+  if (lane < 8) {
+    const int r = lane, p = dlt_point(r >> 1);
+    const double x = (double)src[2 * p], y = (double)src[2 * p + 1];
+    const double u = (double)rn_add(src[2 * p], off[2 * p]), v = (double)rn_add(src[2 * p + 1], off[2 * p + 1]);
+    double a[9];
+    if ((r & 1) == 0) {
+      a[0] = x; a[1] = y; a[2] = 1.0; a[3] = 0.0; a[4] = 0.0; a[5] = 0.0; a[6] = -u * x; a[7] = -u * y; a[8] = u;
+    } else {
+      a[0] = 0.0; a[1] = 0.0; a[2] = 0.0; a[3] = x; a[4] = y; a[5] = 1.0; a[6] = -v * x; a[7] = -v * y; a[8] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) A[r * 9 + j] = a[j];
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const int e1 = lane, e2 = lane + 64;
+  const int r1 = e1 / 9, j1 = e1 - r1 * 9;
+  const int r2 = e2 < 72 ? e2 / 9 : 7, j2 = e2 < 72 ? e2 - (e2 / 9) * 9 : 8;   // lanes >= 8 redo element (7, 8): same value
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    // partial pivoting over rows >= k, ties to the lowest row (every lane, redundantly: broadcast reads)
+    double best = -1.0;
+    int p = k;
+#pragma unroll
+    for (int r = k; r < 8; ++r) {
+      const double v = fabs(A[r * 9 + k]);
+      if (v > best) { best = v; p = r; }
+    }
+    const double pk = A[p * 9 + k];
+    auto upd = [&](int r, int j) -> double {
+      const int sr = (r == k) ? p : (r == p ? k : r);  // the row this element held before rows k and p were swapped
+      const double arj = A[sr * 9 + j], ark = A[sr * 9 + k], pj = A[p * 9 + j];
+      if (r == k) return pj;                      // the pivot row moves to position k unchanged
+      if (j < k) return arj;
+      const double f = ark / pk;
+      return fma(-f, pj, arj);
+    };
+    const double n1 = upd(r1, j1), n2 = upd(r2, j2);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every lane's reads of this step precede every write of it
+    A[r1 * 9 + j1] = n1;
+    A[r2 * 9 + j2] = n2;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  const int r = lane & 7;
+  return A[r * 9 + 8] / A[r * 9 + r];
+}
+
 // theta = Minv * H * M with M = [[ax,0,ax],[0,ay,ay],[0,0,1]], each 3x3 product accumulated in
 // k order with one fused step per term, which is what the reference's fp32 bmm produces.
 __device__ __forceinline__ void mat3_mul(const float* A, const float* B, float* C) {
@@ -193,10 +244,11 @@ __global__ __launch_bounds__(HDN_BLOCK) void dlt_warp_kernel(const float* __rest
                                                              float* __restrict__ H_out, float* __restrict__ warped,
                                                              int H, int W) {
   __shared__ float sH[9];
+  __shared__ double sA[72];
   const int b = blockIdx.y;
   const int tid = threadIdx.x;
   if (tid < HDN_WAVE) {  // wave 0 solves (wave-uniform branch)
-    const double h = dlt_solve_rows(h4p + size_t(b) * 8, off + size_t(b) * 8, tid);
+    const double h = dlt_solve_lds(h4p + size_t(b) * 8, off + size_t(b) * 8, sA, tid);
     if (tid < 8) sH[tid] = (float)h;
     if (tid == 8) sH[8] = 1.0f;
   }

@@ -473,6 +473,22 @@ def test_dlt_solve_batch_sizes_and_point_order(dev):
         np.testing.assert_allclose(q[..., :2] / q[..., 2:], (src + off).reshape(B, 4, 2), atol=2e-3)
 
 
+def test_fused_solve_is_bit_identical_to_the_standalone_solve(dev):
+    """hdn_dlt_warp_f32 solves the 8x8 system with the matrix in LDS (one wave sharing a pivot step), hdn_dlt_solve_f32 with
+    wave shuffles on 8 lanes: same operations on the same values in the same order => the same bits, also for ill-conditioned
+    quads and huge offsets."""
+    gen = torch.Generator().manual_seed(5)
+    for scale in (0.0, 1.0, 8.0, 30.0, 100.0):
+        B = 256
+        src = torch.tensor([[0, 0, 0, 127, 127, 127, 127, 0]], dtype=torch.float32).repeat(B, 1) + (scale / 4) * torch.randn(B, 8, generator=gen)
+        off = scale * torch.randn(B, 8, generator=gen)
+        img = torch.randn(B, 1, 31, 33, generator=gen)
+        H1 = hdn_amd.DLT_solve(src.to(dev), off.to(dev)).reshape(B, 9)
+        H2, _ = hdn_amd.dlt_warp(src.to(dev), off.to(dev), img.to(dev))
+        same = (H1 == H2.reshape(B, 9)) | (torch.isnan(H1) & torch.isnan(H2.reshape(B, 9)))
+        assert bool(same.all()), scale
+
+
 def test_transformer_golden_including_nudge_branch(dev):
     g = load_golden("transformer")
     y, cond = hdn_amd.transformer(T(g["img"]).to(dev), T(g["theta"]).to(dev), (20, 33))
