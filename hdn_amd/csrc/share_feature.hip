@@ -582,6 +582,332 @@ static int launch_sf_ring(const float* img, const float* folded, float* out, int
   return launch_status();
 }
 
+// ---------------------------------------------------------------------------------------
+// W <= 128, rows in registers ("sfv", default since round 2): one WAVE owns a strip of output rows over the full width and
+// never touches the LDS or a barrier.  Lane l holds columns 2l and 2l+1 as one packed pair, so every layer is
+// v_pk_fma_f32 over the two pixels with the weight as a broadcast SGPR operand.  Rows roll through three-deep register
+// rings (the row loop is unrolled by 3, so ring slots are register names):
+//   input  row i     -> pairs for the three horizontal taps: (col-1, col), (col, col+1) shifted by two DPP wave shifts
+//   layer-1 row i-1  -> 4 channels, same three tap pairs per channel (gather form over ky and kx)
+//   layer-2 row i-2  -> 8 channel pairs, never stored: scattered at once into the 3 x 3 (out row, kx) accumulators of
+//                       layer 3, whose horizontal taps are resolved on the finished row by two DPP shifts of partial sums
+//   output row i-3   -> epilogue, stored.
+// Per output row and wave: 36 + 288 + 72 packed FMAs, ~60 epilogue / shift / mask instructions, 25 scalar weight loads.
+// A strip of n rows costs n + 2 layer-2 rows (the halo is recomputed), n is chosen so that the launch is 2-3 waves per SIMD.
+// Summation order differs from the LDS kernels (no even / odd input-channel partial sums): same 1e-4 bound, not bit-identical.
+// ---------------------------------------------------------------------------------------
+namespace sfv {
+typedef const float __attribute__((address_space(4))) cfloat;
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f8v __attribute__((ext_vector_type(8)));
+typedef float f4v_ __attribute__((ext_vector_type(4)));
+typedef const f16v __attribute__((address_space(4), aligned(4))) c16;
+typedef const f8v __attribute__((address_space(4), aligned(4))) c8;
+typedef const f4v_ __attribute__((address_space(4), aligned(4))) c4;
+typedef const float2v __attribute__((address_space(4), aligned(4))) c2;
+
+// A wave-uniform pointer into the parameter block in the constant address space (scalar loads), opaque to the optimiser so
+// that a layer's weights are loaded where they are used instead of being hoisted and spilled.
+__device__ __forceinline__ const cfloat* opaque(const float* p) {
+  uint64_t a = reinterpret_cast<uint64_t>(p);
+  asm volatile("" : "+s"(a));
+  return (const cfloat*)a;
+}
+__device__ __forceinline__ float from_prev_lane(float v) {  // lane l <- lane l-1, lane 0 <- 0   (wave_shr:1, bound_ctrl)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float from_next_lane(float v) {  // lane l <- lane l+1, lane 63 <- 0  (wave_shl:1, bound_ctrl)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+
+// Packed FMAs with one half of an SGPR pair broadcast to both pixels, written as asm: LLVM copies every odd SGPR to an even
+// one to broadcast it (one s_mov_b32 per second FMA) and pads every asm statement with s_nop, so a tap's FMAs are ONE
+// statement.  Not volatile (the compiler schedules the statements); it does not see them as VALU writes for its DPP
+// hazard check, so a DPP never reads a register straight out of one of these (a v_max / v_cndmask or an s_nop sits between).
+#define SFV_FMA_LO(a, v, w) "v_pk_fma_f32 " a ", " v ", " w ", " a " op_sel_hi:[1,0,1]\n\t"
+#define SFV_FMA_HI(a, v, w) "v_pk_fma_f32 " a ", " v ", " w ", " a " op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+#define SFV_MUL_LO(a, v, w) "v_pk_mul_f32 " a ", " v ", " w " op_sel_hi:[1,0]\n\t"
+#define SFV_MUL_HI(a, v, w) "v_pk_mul_f32 " a ", " v ", " w " op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+#define SFV_PAIR(w, k) __builtin_shufflevector(w, w, 2 * (k), 2 * (k) + 1)
+
+// layer 2, one (ky, input-channel pair, kx) tap over the 8 output channels: acc[co] (+)= ve * w[co].x + vo * w[co].y
+template <bool INIT>
+__device__ __forceinline__ void tap16(float2v (&acc)[8], float2v ve, float2v vo, const cfloat* wp) {
+  const f16v w = *reinterpret_cast<const c16*>(wp);
+  if constexpr (INIT) {
+    asm(SFV_MUL_LO("%0", "%8", "%10") SFV_MUL_LO("%1", "%8", "%11") SFV_MUL_LO("%2", "%8", "%12") SFV_MUL_LO("%3", "%8", "%13")
+        SFV_MUL_LO("%4", "%8", "%14") SFV_MUL_LO("%5", "%8", "%15") SFV_MUL_LO("%6", "%8", "%16") SFV_MUL_LO("%7", "%8", "%17")
+        SFV_FMA_HI("%0", "%9", "%10") SFV_FMA_HI("%1", "%9", "%11") SFV_FMA_HI("%2", "%9", "%12") SFV_FMA_HI("%3", "%9", "%13")
+        SFV_FMA_HI("%4", "%9", "%14") SFV_FMA_HI("%5", "%9", "%15") SFV_FMA_HI("%6", "%9", "%16") SFV_FMA_HI("%7", "%9", "%17")
+        : "=&v"(acc[0]), "=&v"(acc[1]), "=&v"(acc[2]), "=&v"(acc[3]), "=&v"(acc[4]), "=&v"(acc[5]), "=&v"(acc[6]), "=&v"(acc[7])
+        : "v"(ve), "v"(vo), "s"(SFV_PAIR(w, 0)), "s"(SFV_PAIR(w, 1)), "s"(SFV_PAIR(w, 2)), "s"(SFV_PAIR(w, 3)), "s"(SFV_PAIR(w, 4)),
+          "s"(SFV_PAIR(w, 5)), "s"(SFV_PAIR(w, 6)), "s"(SFV_PAIR(w, 7)));
+  } else {
+    asm(SFV_FMA_LO("%0", "%8", "%10") SFV_FMA_LO("%1", "%8", "%11") SFV_FMA_LO("%2", "%8", "%12") SFV_FMA_LO("%3", "%8", "%13")
+        SFV_FMA_LO("%4", "%8", "%14") SFV_FMA_LO("%5", "%8", "%15") SFV_FMA_LO("%6", "%8", "%16") SFV_FMA_LO("%7", "%8", "%17")
+        SFV_FMA_HI("%0", "%9", "%10") SFV_FMA_HI("%1", "%9", "%11") SFV_FMA_HI("%2", "%9", "%12") SFV_FMA_HI("%3", "%9", "%13")
+        SFV_FMA_HI("%4", "%9", "%14") SFV_FMA_HI("%5", "%9", "%15") SFV_FMA_HI("%6", "%9", "%16") SFV_FMA_HI("%7", "%9", "%17")
+        : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
+        : "v"(ve), "v"(vo), "s"(SFV_PAIR(w, 0)), "s"(SFV_PAIR(w, 1)), "s"(SFV_PAIR(w, 2)), "s"(SFV_PAIR(w, 3)), "s"(SFV_PAIR(w, 4)),
+          "s"(SFV_PAIR(w, 5)), "s"(SFV_PAIR(w, 6)), "s"(SFV_PAIR(w, 7)));
+  }
+}
+
+// layer 3, one input-channel pair (be, bo) of a finished layer-2 row into the nine (tap row, kx) partial sums: o0..o2 belong to
+// the output row this layer-2 row is tap row 0 of, o3..o5 tap row 1, o6..o8 tap row 2.  INIT: o0..o2 start here.
+template <bool INIT>
+__device__ __forceinline__ void scatter18(float2v& o0, float2v& o1, float2v& o2, float2v& o3, float2v& o4, float2v& o5, float2v& o6,
+                                          float2v& o7, float2v& o8, float2v be, float2v bo, const cfloat* wp) {
+  const f16v w = *reinterpret_cast<const c16*>(wp);
+  const float2v w8 = *reinterpret_cast<const c2*>(wp + 16);
+  if constexpr (INIT) {
+    asm(SFV_MUL_LO("%0", "%9", "%11") SFV_MUL_LO("%1", "%9", "%12") SFV_MUL_LO("%2", "%9", "%13") SFV_FMA_LO("%3", "%9", "%14")
+        SFV_FMA_LO("%4", "%9", "%15") SFV_FMA_LO("%5", "%9", "%16") SFV_FMA_LO("%6", "%9", "%17") SFV_FMA_LO("%7", "%9", "%18")
+        SFV_FMA_LO("%8", "%9", "%19")
+        SFV_FMA_HI("%0", "%10", "%11") SFV_FMA_HI("%1", "%10", "%12") SFV_FMA_HI("%2", "%10", "%13") SFV_FMA_HI("%3", "%10", "%14")
+        SFV_FMA_HI("%4", "%10", "%15") SFV_FMA_HI("%5", "%10", "%16") SFV_FMA_HI("%6", "%10", "%17") SFV_FMA_HI("%7", "%10", "%18")
+        SFV_FMA_HI("%8", "%10", "%19")
+        : "=&v"(o0), "=&v"(o1), "=&v"(o2), "+v"(o3), "+v"(o4), "+v"(o5), "+v"(o6), "+v"(o7), "+v"(o8)
+        : "v"(be), "v"(bo), "s"(SFV_PAIR(w, 0)), "s"(SFV_PAIR(w, 1)), "s"(SFV_PAIR(w, 2)), "s"(SFV_PAIR(w, 3)), "s"(SFV_PAIR(w, 4)),
+          "s"(SFV_PAIR(w, 5)), "s"(SFV_PAIR(w, 6)), "s"(SFV_PAIR(w, 7)), "s"(w8));
+  } else {
+    asm(SFV_FMA_LO("%0", "%9", "%11") SFV_FMA_LO("%1", "%9", "%12") SFV_FMA_LO("%2", "%9", "%13") SFV_FMA_LO("%3", "%9", "%14")
+        SFV_FMA_LO("%4", "%9", "%15") SFV_FMA_LO("%5", "%9", "%16") SFV_FMA_LO("%6", "%9", "%17") SFV_FMA_LO("%7", "%9", "%18")
+        SFV_FMA_LO("%8", "%9", "%19")
+        SFV_FMA_HI("%0", "%10", "%11") SFV_FMA_HI("%1", "%10", "%12") SFV_FMA_HI("%2", "%10", "%13") SFV_FMA_HI("%3", "%10", "%14")
+        SFV_FMA_HI("%4", "%10", "%15") SFV_FMA_HI("%5", "%10", "%16") SFV_FMA_HI("%6", "%10", "%17") SFV_FMA_HI("%7", "%10", "%18")
+        SFV_FMA_HI("%8", "%10", "%19")
+        : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3), "+v"(o4), "+v"(o5), "+v"(o6), "+v"(o7), "+v"(o8)
+        : "v"(be), "v"(bo), "s"(SFV_PAIR(w, 0)), "s"(SFV_PAIR(w, 1)), "s"(SFV_PAIR(w, 2)), "s"(SFV_PAIR(w, 3)), "s"(SFV_PAIR(w, 4)),
+          "s"(SFV_PAIR(w, 5)), "s"(SFV_PAIR(w, 6)), "s"(SFV_PAIR(w, 7)), "s"(w8));
+  }
+}
+
+// layer 1, one tap row: 3 taps x 4 output channels on the three shifted pairs of an input row; wp -> [kx][co] 12 floats
+template <bool INIT>
+__device__ __forceinline__ void l1row(float2v (&acc)[4], float2v i0, float2v i1, float2v i2, const cfloat* wp) {
+  const f8v w = *reinterpret_cast<const c8*>(wp);
+  const f4v_ u = *reinterpret_cast<const c4*>(wp + 8);
+  if constexpr (INIT) {
+    asm(SFV_MUL_LO("%0", "%4", "%7") SFV_MUL_HI("%1", "%4", "%7") SFV_MUL_LO("%2", "%4", "%8") SFV_MUL_HI("%3", "%4", "%8")
+        SFV_FMA_LO("%0", "%5", "%9") SFV_FMA_HI("%1", "%5", "%9") SFV_FMA_LO("%2", "%5", "%10") SFV_FMA_HI("%3", "%5", "%10")
+        SFV_FMA_LO("%0", "%6", "%11") SFV_FMA_HI("%1", "%6", "%11") SFV_FMA_LO("%2", "%6", "%12") SFV_FMA_HI("%3", "%6", "%12")
+        : "=&v"(acc[0]), "=&v"(acc[1]), "=&v"(acc[2]), "=&v"(acc[3])
+        : "v"(i0), "v"(i1), "v"(i2), "s"(SFV_PAIR(w, 0)), "s"(SFV_PAIR(w, 1)), "s"(SFV_PAIR(w, 2)), "s"(SFV_PAIR(w, 3)),
+          "s"(SFV_PAIR(u, 0)), "s"(SFV_PAIR(u, 1)));
+  } else {
+    asm(SFV_FMA_LO("%0", "%4", "%7") SFV_FMA_HI("%1", "%4", "%7") SFV_FMA_LO("%2", "%4", "%8") SFV_FMA_HI("%3", "%4", "%8")
+        SFV_FMA_LO("%0", "%5", "%9") SFV_FMA_HI("%1", "%5", "%9") SFV_FMA_LO("%2", "%5", "%10") SFV_FMA_HI("%3", "%5", "%10")
+        SFV_FMA_LO("%0", "%6", "%11") SFV_FMA_HI("%1", "%6", "%11") SFV_FMA_LO("%2", "%6", "%12") SFV_FMA_HI("%3", "%6", "%12")
+        : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])
+        : "v"(i0), "v"(i1), "v"(i2), "s"(SFV_PAIR(w, 0)), "s"(SFV_PAIR(w, 1)), "s"(SFV_PAIR(w, 2)), "s"(SFV_PAIR(w, 3)),
+          "s"(SFV_PAIR(u, 0)), "s"(SFV_PAIR(u, 1)));
+  }
+}
+
+// BatchNorm + ReLU on a packed pair: ab = (alpha, beta) of the channel in a VGPR pair (same value in every lane).  The maxima are
+// asm as well: on an asm result fmaxf() costs a second v_max (canonicalisation of a value the compiler knows nothing about).
+__device__ __forceinline__ float2v bn_relu(float2v acc, float2v ab) {
+  asm("v_pk_fma_f32 %0, %0, %1, %1 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(ab));
+  float lo = acc.x, hi = acc.y;
+  asm("v_max_f32 %0, 0, %0" : "+v"(lo));
+  asm("v_max_f32 %0, 0, %0" : "+v"(hi));
+  return float2v{lo, hi};
+}
+
+struct State {
+  float2v in[3][3];     // [slot][kx]: (value at col c0 + kx - 1, value at col c1 + kx - 1)
+  float2v a[3][4][3];   // layer-1 rows: [slot][channel][kx]
+  float2v o[3][3];      // layer-3 partial sums: [out-row slot][kx], at the column the layer-2 value sits at
+  float2v ab[13];       // (alpha, beta) per channel
+};
+
+struct Ctx {
+  const float* __restrict__ src;
+  float* __restrict__ dst;
+  const float* __restrict__ prm;
+  int H, W, ra, rb;       // strip = output rows [ra, rb)
+  int col0, col1;         // this lane's two columns, clamped into the row for the loads
+  bool m0, m1;            // columns 2 * lane, 2 * lane + 1 inside the image
+};
+
+__device__ __forceinline__ float2v load_row(const Ctx& c, int i) {
+  const bool row_ok = i >= 0 && i < c.H;
+  const float* __restrict__ p = c.src + (row_ok ? i : 0) * c.W;
+  const float x0 = p[c.col0], x1 = p[c.col1];
+  return float2v{row_ok && c.m0 ? x0 : 0.f, row_ok && c.m1 ? x1 : 0.f};
+}
+
+// One step of the rolling pipeline: input row i arrives (xin); layer-1 row i-1, layer-2 row i-2 and output row i-3 are produced.
+// PH = ring slot of row i (rows i-1, i-2, i-3 sit in slots PH+2, PH+1, PH modulo 3).  FULL: every row involved exists and is
+// wanted (ra + 3 <= i <= min(rb + 2, H - 1)): no conditions at all.
+template <int PH, bool FULL>
+__device__ __forceinline__ void step(State& st, const Ctx& c, int i, float2v xin) {
+  constexpr int S0 = PH, S1 = (PH + 2) % 3, S2 = (PH + 1) % 3;
+  const cfloat* prm = opaque(c.prm);  // once per step: the weights are (re)loaded inside the step that uses them
+  st.in[S0][1] = xin;
+  st.in[S0][0] = float2v{from_prev_lane(xin.y), xin.x};
+  st.in[S0][2] = float2v{xin.y, from_next_lane(xin.x)};
+
+  // ---- layer 1, row i-1 (slot S1) from input rows i-2 (S2), i-1 (S1), i (S0) ----
+  const int sg = i - 1;
+  if (FULL || sg >= c.ra - 2) {
+    if (FULL || (sg >= 0 && sg < c.H)) {
+      const cfloat* w1 = prm + SF_W1;
+      float2v acc[4];
+      l1row<true>(acc, st.in[S2][0], st.in[S2][1], st.in[S2][2], w1);
+      l1row<false>(acc, st.in[S1][0], st.in[S1][1], st.in[S1][2], w1 + 12);
+      l1row<false>(acc, st.in[S0][0], st.in[S0][1], st.in[S0][2], w1 + 24);
+#pragma unroll
+      for (int co = 0; co < 4; ++co) {
+        float2v y = bn_relu(acc[co], st.ab[co]);
+        y.x = c.m0 ? y.x : 0.f;
+        y.y = c.m1 ? y.y : 0.f;
+        st.a[S1][co][1] = y;
+        st.a[S1][co][0] = float2v{from_prev_lane(y.y), y.x};
+        st.a[S1][co][2] = float2v{y.y, from_next_lane(y.x)};
+      }
+    } else {
+#pragma unroll
+      for (int co = 0; co < 4; ++co)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) st.a[S1][co][kx] = float2v{0.f, 0.f};
+    }
+  }
+
+  // ---- layer 2, row i-2, from layer-1 rows i-3 (S0), i-2 (S2), i-1 (S1); scattered into layer 3 at once: it is tap row 0 of
+  //      output row i-1 (slot S1, which starts here), tap row 1 of row i-2 (S2), tap row 2 of row i-3 (S0) ----
+  const int rho = i - 2;
+  if (FULL || (rho >= c.ra - 1 && rho >= 0 && rho < c.H)) {
+    float2v acc[8];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      constexpr int rs_[3] = {S0, S2, S1};
+      const int rs = rs_[ky];
+#pragma unroll
+      for (int cp = 0; cp < 2; ++cp) {
+        const cfloat* w = prm + SF_W2 + (cp * 3 + ky) * 48;  // [kx][co] pairs (ci even, ci odd)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          if (ky == 0 && cp == 0 && kx == 0) tap16<true>(acc, st.a[rs][2 * cp][kx], st.a[rs][2 * cp + 1][kx], w + kx * 16);
+          else tap16<false>(acc, st.a[rs][2 * cp][kx], st.a[rs][2 * cp + 1][kx], w + kx * 16);
+        }
+      }
+    }
+#pragma unroll
+    for (int co = 0; co < 8; ++co) acc[co] = bn_relu(acc[co], st.ab[4 + co]);
+    const cfloat* w3 = prm + SF_W3;  // [ci >> 1][ky][kx] pairs (ci even, ci odd)
+    scatter18<true>(st.o[S1][0], st.o[S1][1], st.o[S1][2], st.o[S2][0], st.o[S2][1], st.o[S2][2], st.o[S0][0], st.o[S0][1], st.o[S0][2],
+                    acc[0], acc[1], w3);
+#pragma unroll
+    for (int cq = 1; cq < 4; ++cq)
+      scatter18<false>(st.o[S1][0], st.o[S1][1], st.o[S1][2], st.o[S2][0], st.o[S2][1], st.o[S2][2], st.o[S0][0], st.o[S0][1], st.o[S0][2],
+                       acc[2 * cq], acc[2 * cq + 1], w3 + cq * 18);
+  } else {
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) st.o[S1][kx] = float2v{0.f, 0.f};  // a layer-2 row outside the image contributes zeros
+  }
+
+  // ---- output row i-3 (slot S0) ----
+  const int orow = i - 3;
+  if (FULL || (orow >= c.ra && orow < c.rb)) {
+    asm volatile("s_nop 1");  // the partial sums come straight out of asm FMAs the DPP hazard check cannot see
+    const float2v A = st.o[S0][0], B = st.o[S0][1];
+    float2v C = st.o[S0][2];
+    C.x = c.m0 ? C.x : 0.f;  // a layer-2 column outside the image is the next conv's zero padding
+    C.y = c.m1 ? C.y : 0.f;
+    const float2v r = bn_relu(float2v{from_prev_lane(A.y) + B.x + C.y, A.x + B.y + from_next_lane(C.x)}, st.ab[12]);
+    float* __restrict__ q = c.dst + size_t(orow) * c.W;
+    if (c.m0) q[c.col0] = r.x;
+    if (c.m1) q[c.col1] = r.y;
+  }
+}
+
+// three consecutive steps i, i+1, i+2 (slots 0, 1, 2); x = input row i on entry, input row i+3 on exit.  The generic form
+// stops after the step that finishes the strip and says so.
+template <bool FULL>
+__device__ __forceinline__ bool round3(State& st, const Ctx& c, int i, int last, float2v& x) {
+  float2v xn = load_row(c, i + 1);
+  step<0, FULL>(st, c, i, x);
+  if (!FULL && i + 1 > last) return true;
+  x = load_row(c, i + 2);
+  step<1, FULL>(st, c, i + 1, xn);
+  if (!FULL && i + 2 > last) return true;
+  xn = load_row(c, i + 3);
+  step<2, FULL>(st, c, i + 2, x);
+  x = xn;
+  return !FULL && i + 3 > last;
+}
+}  // namespace sfv
+
+__global__ __launch_bounds__(HDN_BLOCK) void share_feature_rows_kernel(const float* __restrict__ img, const float* __restrict__ prm,
+                                                                       float* __restrict__ out, int H, int W, int rows_per_strip,
+                                                                       int strips_per_img, int total_strips) {
+  using namespace sfv;
+  const int lane = threadIdx.x & 63;
+  const int strip = __builtin_amdgcn_readfirstlane(blockIdx.x * (HDN_BLOCK / 64) + (threadIdx.x >> 6));
+  if (strip >= total_strips) return;
+  const int bimg = strip / strips_per_img, k = strip - bimg * strips_per_img;
+  Ctx c;
+  c.src = img + size_t(bimg) * H * W;
+  c.dst = out + size_t(bimg) * H * W;
+  c.prm = prm;
+  c.H = H;
+  c.W = W;
+  c.ra = k * rows_per_strip;
+  c.rb = min(c.ra + rows_per_strip, H);
+  c.m0 = 2 * lane < W;
+  c.m1 = 2 * lane + 1 < W;
+  c.col0 = c.m0 ? 2 * lane : 0;
+  c.col1 = c.m1 ? 2 * lane + 1 : 0;
+  State st;
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      st.in[s][kx] = float2v{0.f, 0.f};
+      st.o[s][kx] = float2v{0.f, 0.f};
+#pragma unroll
+      for (int ch = 0; ch < 4; ++ch) st.a[s][ch][kx] = float2v{0.f, 0.f};
+    }
+#pragma unroll
+  for (int ch = 0; ch < 13; ++ch) {
+    st.ab[ch] = float2v{prm[SF_ALPHA + ch], prm[SF_BETA + ch]};
+    asm volatile("" : "+v"(st.ab[ch]));  // resident in VGPRs (the compiler would keep the uniform values in SGPRs and copy per use)
+  }
+  const int last = c.rb + 2;  // output row rb-1 is finished by step rb+2
+  const int full_lo = c.ra + 3, full_hi = min(c.rb + 2, H - 1);
+  int i = c.ra - 3;
+  float2v x = load_row(c, i);
+#pragma unroll 1
+  for (;;) {  // generic rounds at both ends of the strip (two before row ra+3, up to two after), condition-free rounds between
+    if (round3<false>(st, c, i, last, x)) break;
+    i += 3;
+    if (i >= full_lo) {
+#pragma unroll 1
+      while (i + 2 <= full_hi) {
+        round3<true>(st, c, i, last, x);
+        i += 3;
+      }
+    }
+  }
+}
+
+static int launch_sf_rows(const float* img, const float* folded, float* out, int B, int H, int W, hipStream_t stream) {
+  // strip height: the smallest of 2, 4, 8, 16, ... whose wave count fits the chip at 3 waves per SIMD (3,072)
+  static const int forced = [] { const char* e = getenv("HDN_SF_STRIP"); return e ? atoi(e) : 0; }();  // A/B switch
+  int n = 2;
+  while (n < H && (long long)B * cdiv(H, n) > 3072) n *= 2;
+  if (forced > 0) n = forced;
+  const int strips = cdiv(H, n);
+  const long long total = (long long)strips * B;
+  if (total > 0x7fffffffLL) return HDN_E_LIMIT;
+  const int wpb = HDN_BLOCK / 64;
+  hipLaunchKernelGGL(share_feature_rows_kernel, dim3((unsigned)((total + wpb - 1) / wpb)), dim3(HDN_BLOCK), 0, stream, img, folded, out,
+                     H, W, n, strips, (int)total);
+  return launch_status();
+}
+
 template <int R_>
 static int launch_sf_w128(const float* img, const float* folded, float* out, int B, int H, int W, hipStream_t stream) {
   using S = Sfw<R_>;
@@ -615,6 +941,8 @@ extern "C" int hdn_share_feature_f32(const float* img, const float* folded, floa
   if (W <= 128) {
     static const int rows = [] { const char* e = getenv("HDN_SF_ROWS"); return (e && e[0] == '8') ? 8 : ((e && e[0] == '2') ? 2 : 4); }();  // A/B switch: 8 rows measured 5 % slower (2 workgroups per CU)
     static const bool ring = [] { const char* e = getenv("HDN_SF_RING"); return !(e && e[0] == '0'); }();  // A/B switch
+    static const bool lds = [] { const char* e = getenv("HDN_SF_LDS"); return e && e[0] == '1'; }();        // A/B switch: the LDS kernels
+    if (!lds && !getenv("HDN_SF_ROWS")) return hdn::launch_sf_rows(img, folded, out, B, H, W, static_cast<hipStream_t>(stream));
     if (ring && !getenv("HDN_SF_ROWS")) return hdn::launch_sf_ring(img, folded, out, B, H, W, static_cast<hipStream_t>(stream));
     if (rows == 8 && H > 8) return hdn::launch_sf_w128<8>(img, folded, out, B, H, W, static_cast<hipStream_t>(stream));
     if (rows == 2) return hdn::launch_sf_w128<2>(img, folded, out, B, H, W, static_cast<hipStream_t>(stream));
