@@ -1065,147 +1065,72 @@ __global__ __launch_bounds__(HDN_BLOCK, 3) void xcorr_circ13r_kernel(XcorrPtrs P
 // the 13 x 13 tap sum of every output into 7 independent complex 1-D correlations along the (clamped) column axis:
 //   X_f[s] = sum_r x[r][s] w^(f r),  K_f[j] = sum_u k[u][j] w^(f u),  w = exp(-2 pi i / 13), f = 0..6 (real input)
 //   Z_f[c] = sum_j conj(K_f[j]) X_f[clamp(c + j - 6)]                 (taps that meet a replicated column are summed first)
-//   out[i][c] = sum_f Re(Z_f[c] T_f[i]),  T_f[i] = g_f / 13 w^(-f (i + 7)),  g_0 = 1, g_f = 2
-// 4.3 k real multiply-adds per plane instead of 28.6 k (the direct kernel above executes 24 k).
-// A WAVE owns 9 consecutive planes and never meets a barrier; its LDS slot holds them at a stride of 172 floats (16-byte
-// aligned planes: which (row, column) a register of a 16-byte word holds is a compile-time fact).
-//   stage A  lane = (plane, f), 7 lanes per plane: both forward DFTs (the 7 lanes of a plane read the same LDS addresses:
-//            broadcast), the correlation; Z to LDS over the dead inputs.
-//   stage B  lane = (plane, output row): the 7-term inverse for the 13 columns, 117 rows in two rounds; rows staged in LDS
-//            and written out 16 bytes per lane.
+//   out[i][c] = 1/13 (Z_0[c] + 2 sum_{f>0} Re(Z_f[c] w^(-f (i + 7))))
+// about 3 k real multiply-adds per plane instead of 28.6 k (the direct kernel above executes 24 k).
+// A WAVE owns 9 consecutive planes and never meets a barrier; its LDS slot holds them at a stride of 172 floats.
+//   stage 1  lane = (plane, column): the 13-point DFT of its column of x and of k as 6 sums / differences of rows r, 13 - r
+//            times the 6 base twiddles (SGPR operands), 117 columns in two rounds; spectra to LDS as [plane][f][column]
+//   stage 2  lane = (plane, f), 63 lanes: the clamped correlation along the columns; Z to LDS as [plane][column][f]
+//   stage 3  lane = (plane, column): the inverse for the 13 rows of its column, rows m, 13 - m together; rows staged in LDS and
+//            written out 16 bytes per lane.
 // Accuracy: fp32 throughout; against float64 the result is closer than the direct fp32 sum (tests: same bounds).
 // ---------------------------------------------------------------------------------------
 namespace circ13f {
-constexpr int N = 13, PL = N * N, NF = 7, PPW = 9, WAVES = HDN_BLOCK / 64, PPB = PPW * WAVES;
-constexpr int XS = 172;                    // floats per plane in the LDS input images (43 16-byte words)
-constexpr int ZS = 184;                    // floats per plane in the Z image: 7 x 13 complex, padded to 16 bytes
-constexpr int NCH = XS / 4;                // 43
-constexpr int Z_OFF = 0, O_OFF = PPW * ZS; // Z overlays the inputs once they are dead; output staging behind it
-constexpr int WAVE_FLOATS = O_OFF + PPW * XS;  // 3,204 floats = 12.8 KB per wave: 12 waves per CU
-static_assert(2 * PPW * XS <= WAVE_FLOATS, "inputs fit");
+constexpr int N = 13, PL = N * N, NF = 7, PPW = 9, WAVES = HDN_BLOCK / 64;
+constexpr int XS = 172;                    // floats per plane in the LDS input / output images (43 16-byte words)
+constexpr int TS = 184;                    // floats per plane in the spectra and Z images: 7 x 13 complex, padded
+constexpr int REGION = PPW * TS;           // 1,656 floats: a region holds 9 input planes, or 9 spectra, or Z, or the output rows
+constexpr int WAVE_FLOATS = 2 * REGION;    // 13.2 KB per wave: 12 waves per CU
+static_assert(PPW * XS <= REGION, "inputs fit");
 
 typedef float f4e __attribute__((ext_vector_type(4)));
 typedef f4e f4u __attribute__((aligned(4)));   // a 16-byte access that is only 4-byte aligned (HBM side: plane = 676 bytes)
 
-template <int I, int E, class F>
-__device__ __forceinline__ void sfor(F&& f) {
-  if constexpr (I < E) {
-    f(std::integral_constant<int, I>{});
-    sfor<I + 1, E>(static_cast<F&&>(f));
-  }
-}
 __device__ __forceinline__ float2v cmac_conj(float2v acc, float2v k, float2v x) {  // acc += conj(k) * x
   acc = __builtin_elementwise_fma(x, k.xx, acc);
   return __builtin_elementwise_fma(float2v{x.y, -x.x}, k.yy, acc);
 }
-// One ds_read_b128 the compiler does not track (it would sink every load next to its use and wait on each): the loads of
-// the next batch are issued before the current batch is consumed, and a batch is handed to the arithmetic through wait8().
-template <int OFF>
-__device__ __forceinline__ f4e lds_read128(uint32_t addr) {
-  f4e r;
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
-  return r;
+
+// the 6 base twiddles (cos, sin)(2 pi k / 13) and their conjugates, wave-uniform (SGPRs)
+struct Tw {
+  float2v p[6], m[6];  // p[k-1] = (cos, sin), m[k-1] = (cos, -sin)
+};
+// (cos, -sin)(2 pi n / 13) for any n >= 0: the forward twiddle w^n
+__device__ __forceinline__ float2v tw_fwd(const Tw& t, int n) {
+  const int k = n % N;
+  return k <= 6 ? t.m[k - 1] : t.p[N - k - 1];
 }
-// wait until at most PENDING later LDS loads are outstanding; the batch passes through the statement, so nothing that reads it
-// can be scheduled above the wait
-template <int PENDING>
-__device__ __forceinline__ void wait8(f4e (&b)[8]) {
-  asm volatile("s_waitcnt lgkmcnt(%8)"
-               : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7])
-               : "n"(PENDING));
-}
-template <int PENDING>
-__device__ __forceinline__ void wait3(f4e (&b)[8]) {
-  asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]) : "n"(PENDING));
-}
-// S (+)= (v, v) * tw with v = half HALF of the register pair (asm: for the second half of a pair LLVM moves the value first)
-template <int HALF>
-__device__ __forceinline__ void fma_bcast(float2v& S, float2v pair, float2v tw) {
-  if constexpr (HALF == 0) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(S) : "v"(pair), "v"(tw));
-  else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(S) : "v"(pair), "v"(tw));
-}
-template <int HALF>
-__device__ __forceinline__ float2v mul_bcast(float2v pair, float2v tw) {
-  float2v S;
-  if constexpr (HALF == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(S) : "v"(pair), "v"(tw));
-  else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(S) : "v"(pair), "v"(tw));
-  return S;
+// (cos, sin)(2 pi n / 13)
+__device__ __forceinline__ float2v tw_inv(const Tw& t, int n) {
+  const int k = n % N;
+  return k <= 6 ? t.p[k - 1] : t.m[N - k - 1];
 }
 
-// S[s] = sum_r v[r][s] * tw[r] for the plane at the 16-byte aligned LDS byte address `addr`: 43 words in batches of 8,
-// batch B + 1 in flight while batch B is consumed.
-template <int B>
-__device__ __forceinline__ void dft_batches(float2v (&S)[N], f4e (&cur)[8], uint32_t addr, const float2v (&tw)[N]) {
-  constexpr int NB = (NCH + 7) / 8;
-  constexpr int cur_n = NCH - 8 * B < 8 ? NCH - 8 * B : 8;
-  constexpr int nxt_n = B + 1 < NB ? (NCH - 8 * (B + 1) < 8 ? NCH - 8 * (B + 1) : 8) : 0;
-  static_assert(cur_n == 8 || cur_n == 3, "43 = 5 x 8 + 3");
-  f4e nxt[8];
-  sfor<0, nxt_n>([&](auto Q) {
-    constexpr int q = decltype(Q)::value;
-    nxt[q] = lds_read128<(8 * (B + 1) + q) * 16>(addr);
-  });
-  if constexpr (cur_n == 8) wait8<nxt_n>(cur);
-  else wait3<nxt_n>(cur);
-  sfor<0, cur_n>([&](auto Q) {
-    constexpr int q = decltype(Q)::value, e = 8 * B + q;
-    const float2v lo = __builtin_shufflevector(cur[q], cur[q], 0, 1), hi = __builtin_shufflevector(cur[q], cur[q], 2, 3);
-    sfor<0, 4>([&](auto KK) {
-      constexpr int k = decltype(KK)::value, idx = 4 * e + k;
-      if constexpr (idx < PL) {
-        constexpr int r = idx / N, c = idx - r * N;
-        if constexpr (r == 0) S[c] = mul_bcast<(k & 1)>(k < 2 ? lo : hi, tw[0]);
-        else fma_bcast<(k & 1)>(S[c], k < 2 ? lo : hi, tw[r]);
-      }
-    });
-  });
-  if constexpr (B + 1 < NB) dft_batches<B + 1>(S, nxt, addr, tw);
-}
-__device__ __forceinline__ void dft_rows(float2v (&S)[N], uint32_t addr, const float2v (&tw)[N]) {
-  f4e first[8];
-  sfor<0, 8>([&](auto Q) {
-    constexpr int q = decltype(Q)::value;
-    first[q] = lds_read128<q * 16>(addr);
-  });
-  dft_batches<0>(S, first, addr, tw);
-}
-
-__device__ __forceinline__ void stage_a(float2v (&Z)[N], uint32_t ax, uint32_t ak, const float* __restrict__ twg) {
-  float2v tw[N];
+// stage 1 for one tensor: column s of plane q -> its 7 spectral values S[f] (S[0] = (sum, 0))
+__device__ __forceinline__ void dft_col(float2v (&S)[NF], const float* col, const Tw& t) {
+  float v[N];
 #pragma unroll
-  for (int r = 0; r < N; ++r) tw[r] = float2v{twg[2 * r], twg[2 * r + 1]};
-  float2v X[N], K[N];
-  dft_rows(X, ax, tw);
-  dft_rows(K, ak, tw);
-  // prefix / suffix sums of K over the taps that meet the replicated first / last column
-  float2v PS[7], SS[7];  // PS[m] = K[0] + .. + K[m];  SS[m] = K[12 - m] + .. + K[12]
-  PS[0] = K[0];
-  SS[0] = K[12];
+  for (int r = 0; r < N; ++r) v[r] = col[r * N];
+  float2v sd[7];  // (v[r] + v[13 - r], v[r] - v[13 - r]), r = 1..6
+  float s0 = v[0];
 #pragma unroll
-  for (int m = 1; m < 7; ++m) {
-    PS[m] = PS[m - 1] + K[m];
-    SS[m] = SS[m - 1] + K[12 - m];
+  for (int r = 1; r <= 6; ++r) {
+    sd[r] = float2v{v[r] + v[N - r], v[r] - v[N - r]};
+    s0 += sd[r].x;
   }
+  S[0] = float2v{s0, 0.f};
 #pragma unroll
-  for (int c = 0; c < N; ++c) {
-    float2v z = float2v{0.f, 0.f};
-    if (c <= 6) z = cmac_conj(z, PS[6 - c], X[0]);    // taps j <= 6 - c read column 0
-    if (c >= 6) z = cmac_conj(z, SS[c - 6], X[12]);   // taps j >= 18 - c read column 12
+  for (int f = 1; f < NF; ++f) {
+    float2v a = float2v{v[0], 0.f};
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-      const int s = c + j - 6;
-      if (s >= 1 && s <= 11) z = cmac_conj(z, K[j], X[s]);
-    }
-    Z[c] = z;
+    for (int r = 1; r <= 6; ++r) a = __builtin_elementwise_fma(sd[r], tw_fwd(t, f * r), a);
+    S[f] = a;
   }
 }
 
-// 9 planes between HBM (169 floats per plane, 4-byte aligned) and an LDS image (172 floats per plane): 42 16-byte words
-// and one last float per plane.  Lane tasks t = lane + 64 * round = (plane, word); the offsets are computed once and serve
-// the three moves of a wave (x in, k in, out).
 struct Moves {
-  static constexpr int WPP = 42, ROUNDS = (PPW * WPP + 63) / 64;  // 6 rounds
-  int g[ROUNDS], l[ROUNDS];                                       // float offsets of the word in HBM / in the LDS image; -1: no task
+  static constexpr int WPP = 42, ROUNDS = (PPW * WPP + 63) / 64;  // 42 16-byte words per plane (+ one float): 6 rounds of 64 lanes
+  int g[ROUNDS], l[ROUNDS];                                       // float offsets of the word in HBM (-1: no task) / in the LDS image
 };
 __device__ __forceinline__ Moves make_moves(int np, int lane) {
   Moves m;
@@ -1218,15 +1143,20 @@ __device__ __forceinline__ Moves make_moves(int np, int lane) {
   }
   return m;
 }
-__device__ __forceinline__ void planes_in(float* lds, const float* __restrict__ g, const Moves& m, int np, int lane) {
+struct PlaneRegs {
   f4e v[Moves::ROUNDS];
+  float last;
+};
+__device__ __forceinline__ void planes_load(PlaneRegs& r, const float* __restrict__ g, const Moves& m, int np, int lane) {
 #pragma unroll
-  for (int rd = 0; rd < Moves::ROUNDS; ++rd) v[rd] = *reinterpret_cast<const f4u*>(g + max(m.g[rd], 0));  // all in flight at once
-  const float last = g[min(lane, np - 1) * PL + 168];
+  for (int rd = 0; rd < Moves::ROUNDS; ++rd) r.v[rd] = *reinterpret_cast<const f4u*>(g + max(m.g[rd], 0));  // all in flight at once
+  r.last = g[min(lane, np - 1) * PL + 168];
+}
+__device__ __forceinline__ void planes_store(float* lds, const PlaneRegs& r, const Moves& m, int np, int lane) {
 #pragma unroll
   for (int rd = 0; rd < Moves::ROUNDS; ++rd)
-    if (m.g[rd] >= 0) *reinterpret_cast<f4e*>(lds + m.l[rd]) = v[rd];
-  if (lane < np) lds[lane * XS + 168] = last;
+    if (m.g[rd] >= 0) *reinterpret_cast<f4e*>(lds + m.l[rd]) = r.v[rd];
+  if (lane < np) lds[lane * XS + 168] = r.last;
 }
 __device__ __forceinline__ void planes_out(const float* lds, float* __restrict__ g, const Moves& m, int np, int lane) {
 #pragma unroll
@@ -1236,69 +1166,126 @@ __device__ __forceinline__ void planes_out(const float* lds, float* __restrict__
 }
 }  // namespace circ13f
 
-__global__ __launch_bounds__(HDN_BLOCK, 3) void xcorr_circ13f_kernel(XcorrPtrs P, int planes) {
+__global__ __launch_bounds__(HDN_BLOCK, 3) void xcorr_circ13f_kernel(XcorrPtrs P, int planes, int groups_per_problem, int total_groups) {
   using namespace circ13f;
   __shared__ __attribute__((aligned(16))) float smem[WAVES * WAVE_FLOATS];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int prob = blockIdx.y;
-  const int p0 = (blockIdx.x * WAVES + wave) * PPW;  // this wave's first plane
-  if (p0 >= planes) return;
-  const int np = min(PPW, planes - p0);
-  float* ws = smem + wave * WAVE_FLOATS;
-  float* sx = ws;
-  float* sk = ws + PPW * XS;
+  const int g = blockIdx.x * WAVES + wave;
+  if (g >= total_groups) return;
+  const int prob = g / groups_per_problem, p0 = (g - prob * groups_per_problem) * PPW, np = min(PPW, planes - p0);
+  float* ra = smem + wave * WAVE_FLOATS;  // region A: x image -> x spectra -> Z
+  float* rb = ra + REGION;                // region B: k image -> k spectra -> output rows
   const Moves mv = make_moves(np, lane);
-  planes_in(sx, P.x[prob] + size_t(p0) * PL, mv, np, lane);
-  planes_in(sk, P.k[prob] + size_t(p0) * PL, mv, np, lane);
-
-  // ---- stage A: lane = (plane q, frequency f) ----
-  const int q = lane / NF, f = lane - q * NF;
-  const bool a_live = q < np;         // lane 63 and the planes a short last group lacks redo plane 0: in bounds, unused
-  const int qa = a_live ? q : 0;
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the image is written (same wave: program order is enough)
-  float2v Z[N];
-  stage_a(Z, lds_addr(sx + qa * XS), lds_addr(sk + qa * XS), CIRC13_FWD[f]);
-  float* sz = ws + Z_OFF;
-  if (a_live) {
-    float2v* zp = reinterpret_cast<float2v*>(sz + q * ZS + f * 2 * N);
+  PlaneRegs rx, rk;
+  planes_load(rx, P.x[prob] + size_t(p0) * PL, mv, np, lane);
+  planes_load(rk, P.k[prob] + size_t(p0) * PL, mv, np, lane);
+  Tw tw;
 #pragma unroll
-    for (int c = 0; c < N; ++c) zp[c] = Z[c];
+  for (int k = 0; k < 6; ++k) {
+    tw.p[k] = float2v{CIRC13_CS[2 * k], CIRC13_CS[2 * k + 1]};
+    tw.m[k] = float2v{CIRC13_CS[2 * k], -CIRC13_CS[2 * k + 1]};
   }
+  planes_store(ra, rx, mv, np, lane);
+  planes_store(rb, rk, mv, np, lane);
 
-  // ---- stage B: lane = (plane, output row i), two rounds ----
-  float* so = ws + O_OFF;
-#pragma unroll 1
+  // ---- stage 1: lane = (plane, column), two rounds; both rounds read before the spectra go over the images ----
+  float2v SX[2][NF], SK[2][NF];
+  int sq[2], ss[2];
+#pragma unroll
   for (int rd = 0; rd < 2; ++rd) {
-    const int t = lane + rd * 64;
-    if (t < np * N) {
-      const int bp = t / N, i = t - bp * N;
-      const f4e* tg = reinterpret_cast<const f4e*>(CIRC13_INV[i]);
-      const f4e t0 = tg[0], t1 = tg[1], t2 = tg[2], t3 = tg[3];
-      const float2v T[NF] = {float2v{t0.x, t0.y}, float2v{t0.z, t0.w}, float2v{t1.x, t1.y}, float2v{t1.z, t1.w},
-                             float2v{t2.x, t2.y}, float2v{t2.z, t2.w}, float2v{t3.x, t3.y}};
-      const f4e* z4 = reinterpret_cast<const f4e*>(__builtin_assume_aligned(sz + bp * ZS, 16));
-      float2v acc[N];
+    const int t = min(lane + 64 * rd, np * N - 1);
+    sq[rd] = t / N;
+    ss[rd] = t - sq[rd] * N;
+    dft_col(SX[rd], ra + sq[rd] * XS + ss[rd], tw);
+    dft_col(SK[rd], rb + sq[rd] * XS + ss[rd], tw);
+  }
 #pragma unroll
-      for (int c = 0; c < N; ++c) acc[c] = float2v{0.f, 0.f};
+  for (int rd = 0; rd < 2; ++rd) {
+    if (lane + 64 * rd < np * N) {
+      float2v* xp = reinterpret_cast<float2v*>(ra + sq[rd] * TS) + ss[rd];
+      float2v* kp = reinterpret_cast<float2v*>(rb + sq[rd] * TS) + ss[rd];
 #pragma unroll
-      for (int m = 0; m < (NF * N + 1) / 2; ++m) {  // 46 words of two complex values: flat index n = f * 13 + c
-        const f4e v = z4[m];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int n = 2 * m + h;
-          if (n < NF * N) {
-            const int ff = n / N, c = n - ff * N;
-            acc[c] = __builtin_elementwise_fma(h ? float2v{v.z, v.w} : float2v{v.x, v.y}, T[ff], acc[c]);
-          }
-        }
+      for (int f = 0; f < NF; ++f) {
+        xp[f * N] = SX[rd][f];
+        kp[f * N] = SK[rd][f];
       }
-      float* os = so + bp * XS + i * N;
-#pragma unroll
-      for (int c = 0; c < N; ++c) os[c] = acc[c].x + acc[c].y;
     }
   }
-  planes_out(so, P.out[prob] + size_t(p0) * PL, mv, np, lane);
+
+  // ---- stage 2: lane = (plane q, frequency f) ----
+  {
+    const int q = lane / NF, f = lane - q * NF;
+    const bool live = q < np;  // lane 63 and the planes a short last group lacks redo plane 0: in bounds, unused
+    const int qa = live ? q : 0;
+    const float2v* xp = reinterpret_cast<const float2v*>(ra + qa * TS) + f * N;
+    const float2v* kp = reinterpret_cast<const float2v*>(rb + qa * TS) + f * N;
+    float2v X[N], K[N];
+#pragma unroll
+    for (int s = 0; s < N; ++s) {
+      X[s] = xp[s];
+      K[s] = kp[s];
+    }
+    // prefix / suffix sums of K over the taps that meet the replicated first / last column
+    float2v PS[7], SS[7];  // PS[m] = K[0] + .. + K[m];  SS[m] = K[12 - m] + .. + K[12]
+    PS[0] = K[0];
+    SS[0] = K[12];
+#pragma unroll
+    for (int m = 1; m < 7; ++m) {
+      PS[m] = PS[m - 1] + K[m];
+      SS[m] = SS[m - 1] + K[12 - m];
+    }
+    const float zs = f == 0 ? 1.f / 13.f : 2.f / 13.f;  // the inverse's weights: the conjugate half of the spectrum counts twice
+    float2v Z[N];
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+      float2v z = float2v{0.f, 0.f};
+      if (c <= 6) z = cmac_conj(z, PS[6 - c], X[0]);    // taps j <= 6 - c read column 0
+      if (c >= 6) z = cmac_conj(z, SS[c - 6], X[12]);   // taps j >= 18 - c read column 12
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const int s = c + j - 6;
+        if (s >= 1 && s <= 11) z = cmac_conj(z, K[j], X[s]);
+      }
+      Z[c] = z * float2v{zs, zs};
+    }
+    if (live) {
+      float2v* zp = reinterpret_cast<float2v*>(ra + q * TS) + f;  // [column][f], 7 complex per column
+#pragma unroll
+      for (int c = 0; c < N; ++c) zp[c * NF] = Z[c];
+    }
+  }
+
+  // ---- stage 3: lane = (plane, column c): rows m = (i + 7) mod 13 and 13 - m share their products ----
+  float orow[2][N];
+#pragma unroll
+  for (int rd = 0; rd < 2; ++rd) {
+    const float2v* zp = reinterpret_cast<const float2v*>(ra + sq[rd] * TS) + ss[rd] * NF;
+    float2v Zf[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) Zf[f] = zp[f];
+    float o0 = Zf[0].x;
+#pragma unroll
+    for (int f = 1; f < NF; ++f) o0 += Zf[f].x;
+    orow[rd][6] = o0;  // m = 0 is row i = 6
+#pragma unroll
+    for (int m = 1; m <= 6; ++m) {
+      float2v ab = float2v{0.f, 0.f};  // (sum Zr cos, sum Zi sin)
+#pragma unroll
+      for (int f = 1; f < NF; ++f) ab = __builtin_elementwise_fma(Zf[f], tw_inv(tw, f * m), ab);
+      orow[rd][(m + 6) % N] = Zf[0].x + ab.x - ab.y;
+      orow[rd][(N - m + 6) % N] = Zf[0].x + ab.x + ab.y;
+    }
+  }
+#pragma unroll
+  for (int rd = 0; rd < 2; ++rd) {
+    if (lane + 64 * rd < np * N) {
+      float* os = rb + sq[rd] * XS + ss[rd];
+#pragma unroll
+      for (int i = 0; i < N; ++i) os[i * N] = orow[rd][i];
+    }
+  }
+  planes_out(rb, P.out[prob] + size_t(p0) * PL, mv, np, lane);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1471,7 +1458,11 @@ static int launch_circ13(const XcorrPtrs& P, int n, int planes, hipStream_t stre
   static const bool old = [] { const char* e = getenv("HDN_CIRC13_PLANES"); return e && e[0] == '1'; }();  // A/B switch
   static const bool direct = [] { const char* e = getenv("HDN_CIRC13_DIRECT"); return e && e[0] == '1'; }();  // A/B switch: the direct-sum kernel
   if (!old && !direct) {
-    hipLaunchKernelGGL(xcorr_circ13f_kernel, dim3(cdiv(planes, circ13f::PPB), n), dim3(HDN_BLOCK), 0, stream, P, planes);
+    // a wave owns a group of 9 planes; the groups of all problems of the launch are one flat grid
+    const int gpp = cdiv(planes, circ13f::PPW);
+    const long long total = (long long)gpp * n;
+    if (total > 0x7fffffffLL) return HDN_E_LIMIT;
+    hipLaunchKernelGGL(xcorr_circ13f_kernel, dim3(cdiv((int)total, circ13f::WAVES)), dim3(HDN_BLOCK), 0, stream, P, planes, gpp, (int)total);
     g_last_variant = "circ13";
     return launch_status();
   }
