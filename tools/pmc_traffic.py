@@ -28,6 +28,7 @@ KERNELS = {
     "xcorr_prod29_kernel": (6 * PL * (29 * 29 + 25) * 4, 6 * PL * 25 * 25 * 4, 6 * PL * 25 * 4),
     "xcorr_circ13_kernel": (6 * PL * 2 * 169 * 4, 6 * PL * 169 * 4, 0),
     "xcorr_circ13r_kernel": (6 * PL * 2 * 169 * 4, 6 * PL * 169 * 4, 0),
+    "xcorr_circ13f_kernel": (6 * PL * 2 * 169 * 4, 6 * PL * 169 * 4, 0),  # 16 B/lane words (+ one float per plane)
 }
 
 
