@@ -226,6 +226,30 @@ static int ensure_cubic_tab() {
   return HDN_OK;
 }
 
+// ---- cv2.remap, 8U data, INTER_LINEAR, BORDER_CONSTANT 0, float32 maps (what cv2.logPolar / cv2.linearPolar call) -----------
+// One lane per destination pixel: the map values go to 1/32 px exactly as remap's converter does (cvRound(map * 32), the
+// integer part saturated to short), the four taps are weighted with the 15-bit table values (32 - a)(32 - b) * 32 (exact for
+// 1/32 steps), taps outside the source are the border value 0, dst = (sum + 2^14) >> 15.  The planes are float32 holding
+// uint8 values (what get_subwindow returns); the result is uint8-valued float32 again.
+__global__ __launch_bounds__(HDN_BLOCK) void remap_linear_kernel(const float* __restrict__ src, const float* __restrict__ mapx,
+                                                                 const float* __restrict__ mapy, float* __restrict__ dst, int C, int Hs,
+                                                                 int Ws, int Hd, int Wd) {
+  const size_t n = size_t(Hd) * Wd;
+  for (size_t pix = size_t(blockIdx.x) * HDN_BLOCK + threadIdx.x; pix < n; pix += size_t(gridDim.x) * HDN_BLOCK) {
+    const int X = (int)rintf(mapx[pix] * 32.f), Y = (int)rintf(mapy[pix] * 32.f);   // cvRound(float): round half to even
+    const int sx = min(max(X >> 5, -32768), 32767), sy = min(max(Y >> 5, -32768), 32767), ax = X & 31, ay = Y & 31;
+    const int w00 = (32 - ay) * (32 - ax) * 32, w01 = (32 - ay) * ax * 32, w10 = ay * (32 - ax) * 32, w11 = ay * ax * 32;
+    const bool x0 = sx >= 0 && sx < Ws, x1 = sx + 1 >= 0 && sx + 1 < Ws, y0 = sy >= 0 && sy < Hs, y1 = sy + 1 >= 0 && sy + 1 < Hs;
+    for (int q = 0; q < C; ++q) {
+      const float* pl = src + size_t(q) * Hs * Ws;
+      const int v00 = x0 && y0 ? (int)pl[size_t(sy) * Ws + sx] : 0, v01 = x1 && y0 ? (int)pl[size_t(sy) * Ws + sx + 1] : 0;
+      const int v10 = x0 && y1 ? (int)pl[size_t(sy + 1) * Ws + sx] : 0, v11 = x1 && y1 ? (int)pl[size_t(sy + 1) * Ws + sx + 1] : 0;
+      const int acc = v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11;
+      dst[size_t(q) * n + pix] = (float)min(max((acc + (1 << 14)) >> 15, 0), 255);
+    }
+  }
+}
+
 static int frame_grid(size_t n) {
   const size_t b = (n + HDN_BLOCK - 1) / HDN_BLOCK;
   return (int)(b < 8192 ? b : 8192);
@@ -266,6 +290,17 @@ int hdn_frame_warp_affine_cubic_u8(const unsigned char* src, const double* M, un
   if (rc != HDN_OK) return rc;
   hipLaunchKernelGGL(hdn::frame_warp_affine_cubic_kernel, dim3(hdn::frame_grid((size_t)H * W)), dim3(HDN_BLOCK), 0,
                      static_cast<hipStream_t>(stream), src, M, dst, H, W, C);
+  return hdn::launch_status();
+}
+
+int hdn_remap_linear_f32(const float* src, const float* mapx, const float* mapy, float* dst, int C, int Hs, int Ws, int Hd, int Wd,
+                         void* stream) {
+  if (!src || !mapx || !mapy || !dst) return HDN_E_NULL;
+  if (C <= 0 || Hs <= 0 || Ws <= 0 || Hd <= 0 || Wd <= 0) return HDN_E_SHAPE;
+  if (C > hdn::FR_MAXC || (long long)Hs * Ws > (1LL << 30) || (long long)Hd * Wd > (1LL << 30)) return HDN_E_LIMIT;
+  if (src == dst) return HDN_E_ALIAS;
+  hipLaunchKernelGGL(hdn::remap_linear_kernel, dim3(hdn::frame_grid((size_t)Hd * Wd)), dim3(HDN_BLOCK), 0,
+                     static_cast<hipStream_t>(stream), src, mapx, mapy, dst, C, Hs, Ws, Hd, Wd);
   return hdn::launch_status();
 }
 

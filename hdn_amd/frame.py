@@ -9,6 +9,7 @@ The reference handles every frame on the host (numpy + OpenCV) and uploads three
     get_search_info(frame, pos, original_sz, avg)          <- get_subwindow_for_homo + get_search_info (get_img_info.py:42-70), fused
     warp_perspective(frame, M)                             <- cv2.warpPerspective(img, M, BORDER_REPLICATE), hdn_tracker_proj_e2e.py:154
     rot_around_center(frame, cx, cy, rot)                  <- img_rot_around_center, hdn/utils/transform.py:69-100
+    get_polar_img(patch) / get_subwindow(..., islog=1)     <- getPolarImg (cv2.logPolar), hdn/models/logpolar.py:11-29, base_tracker.py:119-126
 
 Same argument meaning and return shapes as the reference's functions; `pos` / `original_sz` / matrices may be host numbers
 (packed into a small device array without synchronising) or float64 device tensors (nothing leaves the device).  The parts
@@ -84,14 +85,58 @@ def _subwindow(frame, pos, model_sz, original_sz, avg_chans, mode, params=None):
     return out
 
 
-def get_subwindow(frame, pos, model_sz, original_sz, avg_chans, params=None):
-    """-> float32 [1, C, model_sz, model_sz] (uint8-valued), on the device."""
-    return _subwindow(frame, pos, model_sz, original_sz, avg_chans, 0, params)
+def get_subwindow(frame, pos, model_sz, original_sz, avg_chans, params=None, islog: int = 0):
+    """-> float32 [1, C, model_sz, model_sz] (uint8-valued), on the device; islog=1 appends the C log-polar channels
+    (np.concatenate((im_patch, getPolarImg(im_patch)), 2), base_tracker.py:119-126) -> [1, 2C, model_sz, model_sz]."""
+    out = _subwindow(frame, pos, model_sz, original_sz, avg_chans, 0, params)
+    if islog == 1:
+        return torch.cat([out, get_polar_img(out)], dim=1)
+    if islog:
+        raise NotImplementedError("islog=2 (cv2.linearPolar) is not used by the shipped tracker configuration")
+    return out
 
 
-def get_subwindow_for_homo(frame, pos, model_sz, original_sz, avg_chans):
+def log_polar_maps(w: int, h: int, center, M: float):
+    """(mapx, mapy) float32 [h, w] of cv2.logPolar(src, center, M, flags) = cv::warpPolar(src, size(src), center, exp(w / M),
+    flags | WARP_POLAR_LOG) as OpenCV >= 3.4.2 / 4.x builds them (imgwarp.cpp): rho along x, angle along y, all in double,
+    stored as float."""
+    max_radius = math.exp(w / M) if M > 0 else 1.0
+    kangle = 2.0 * math.pi / h
+    kmag = math.log(max_radius) / w
+    rhos = (np.exp(np.arange(w, dtype=np.float64) * kmag) - 1.0).astype(np.float32).astype(np.float64)
+    ang = kangle * np.arange(h, dtype=np.float64)
+    mx = (rhos[None, :] * np.cos(ang)[:, None] + float(center[0])).astype(np.float32)
+    my = (rhos[None, :] * np.sin(ang)[:, None] + float(center[1])).astype(np.float32)
+    return mx, my
+
+
+_polar_maps = {}
+
+
+def get_polar_img(patch: torch.Tensor, original=None) -> torch.Tensor:
+    """getPolarImg (hdn/models/logpolar.py:11-29) on a device crop [1, C, S, S] (uint8-valued float32): cv2.logPolar about
+    (S // 2, S // 2) (or round(original)) with M = S / log(S / 2), INTER_LINEAR, outliers filled with 0.  Restated OpenCV."""
+    if patch.dim() != 4 or patch.shape[0] != 1 or patch.dtype != torch.float32:
+        raise ValueError("get_polar_img takes a float32 [1, C, H, W] crop")
+    dev = _lib.require_device(patch)
+    _, C, H, W = patch.shape
+    center = (float(np.round(original[0])), float(np.round(original[1]))) if original is not None else (float(H // 2), float(W // 2))
+    key = (dev, H, W, center)
+    if key not in _polar_maps:
+        mx, my = log_polar_maps(W, H, center, W / math.log(W / 2))
+        _polar_maps[key] = (torch.from_numpy(mx).to(dev), torch.from_numpy(my).to(dev))
+    mx, my = _polar_maps[key]
+    src = patch.detach().contiguous()
+    out = torch.empty_like(src)
+    with torch.cuda.device(dev):
+        rc = _lib.load().hdn_remap_linear_f32(_lib.ptr(src), _lib.ptr(mx), _lib.ptr(my), _lib.ptr(out), C, H, W, H, W, _lib.stream_ptr(dev))
+    _lib.check(rc, "get_polar_img")
+    return out
+
+
+def get_subwindow_for_homo(frame, pos, model_sz, original_sz, avg_chans, islog: int = 0):
     H, W, _ = _check_frame(frame)
-    return _subwindow(frame, pos, model_sz, original_sz, avg_chans, 0), crop_points(pos, original_sz, H, W)
+    return get_subwindow(frame, pos, model_sz, original_sz, avg_chans, islog=islog), crop_points(pos, original_sz, H, W)
 
 
 def get_search_info(frame, pos, original_sz, avg_chans, model_sz: int = 127, params=None):

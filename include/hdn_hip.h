@@ -205,11 +205,18 @@ int hdn_logpolar_sample_f32(const float* img, const float* polar, const float* r
  * hdn_frame_warp_affine_cubic_u8: dst = cv2.warpAffine(src, M, (W,H), INTER_CUBIC, BORDER_REPLICATE), M[6];
  *   replaces img_rot_around_center, hdn/utils/transform.py:69-100.  Restated OpenCV, parity-unpinned.  (Its first call on
  *   a device uploads a 32 KB coefficient table synchronously.)
+ * hdn_remap_linear_f32: dst[c] = cv2.remap(src[c] as uint8, mapx, mapy, INTER_LINEAR, BORDER_CONSTANT 0) on C planes of
+ *   uint8-valued float32 (what hdn_subwindow_f32 mode 0 returns), float32 maps [Hd, Wd] on the device.  With the maps of
+ *   cv::warpPolar (hdn_amd.frame.log_polar_maps builds them on the host as OpenCV >= 3.4.2 / 4.x does) this is
+ *   cv2.logPolar(img, center, M, WARP_FILL_OUTLIERS + INTER_LINEAR): replaces getPolarImg, hdn/models/logpolar.py:11-29, called on
+ *   every template crop by get_subwindow(islog=1), hdn/tracker/base_tracker.py:119-126.  Restated OpenCV, parity-unpinned.
  */
 int hdn_subwindow_f32(const unsigned char* frame, const double* params, float* out, int H, int W, int C, int model_sz, int mode,
                       void* stream);
 int hdn_frame_warp_perspective_u8(const unsigned char* src, const double* M, unsigned char* dst, int H, int W, int C, void* stream);
 int hdn_frame_warp_affine_cubic_u8(const unsigned char* src, const double* M, unsigned char* dst, int H, int W, int C, void* stream);
+int hdn_remap_linear_f32(const float* src, const float* mapx, const float* mapy, float* dst, int C, int Hs, int Ws, int Hd, int Wd,
+                         void* stream);
 
 /*
  * Multi-GPU: template/search pairs are independent, so ranks own disjoint contiguous blocks of pairs

@@ -13,6 +13,8 @@ only — identity, integer shifts, borders, monotonicity):
 """
 from __future__ import annotations
 
+import math
+
 import numpy as np
 
 MEAN_I = np.array([118.93, 113.97, 102.60])
@@ -100,6 +102,52 @@ def resize_linear_u8(img: np.ndarray, dw: int, dh: int) -> np.ndarray:
     S0, S1 = rows[sy], rows[np.minimum(sy + 1, sh - 1)]
     out = (((b0[:, None, None] * (S0 >> 4)) >> 16) + ((b1[:, None, None] * (S1 >> 4)) >> 16) + 2) >> 2
     return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def log_polar_maps(w: int, h: int, center, M: float):
+    """The float32 maps cv2.logPolar(src, center, M, flags) hands to remap: cv::logPolar -> cv::warpPolar(src, size(src), center,
+    maxRadius = exp(w / M), flags | WARP_POLAR_LOG) (OpenCV >= 3.4.2 / 4.x, imgproc/src/imgwarp.cpp): rho along x with
+    rhos[rho] = float(exp(rho * log(maxRadius) / w) - 1), angle along y with 2 pi / h per row, x = rhos * cos + cx in double."""
+    max_radius = math.exp(w / M) if M > 0 else 1.0
+    kangle, kmag = 2.0 * math.pi / h, math.log(max_radius) / w
+    mx = np.empty((h, w), np.float32)
+    my = np.empty((h, w), np.float32)
+    rhos = [float(np.float32(math.exp(rho * kmag) - 1.0)) for rho in range(w)]
+    for phi in range(h):
+        cp, sp = math.cos(kangle * phi), math.sin(kangle * phi)
+        for rho in range(w):
+            mx[phi, rho] = np.float32(rhos[rho] * cp + center[0])
+            my[phi, rho] = np.float32(rhos[rho] * sp + center[1])
+    return mx, my
+
+
+def remap_linear_u8(img: np.ndarray, mapx: np.ndarray, mapy: np.ndarray) -> np.ndarray:
+    """cv2.remap(img, mapx, mapy, INTER_LINEAR, BORDER_CONSTANT, 0) for a uint8 HxWxC image and float32 maps: coordinates to 1/32 px
+    (cvRound(map * 32), integer part saturated to short), the 15-bit bilinear table (exact for 1/32 steps), taps outside the
+    image = 0, dst = (sum + 2^14) >> 15."""
+    Hh, Ww, C = img.shape
+    X = _cv_round(mapx.astype(np.float32) * np.float32(32.0))
+    Y = _cv_round(mapy.astype(np.float32) * np.float32(32.0))
+    sx, sy, ax, ay = np.clip(X >> 5, -32768, 32767), np.clip(Y >> 5, -32768, 32767), X & 31, Y & 31
+    w = [(32 - ay) * (32 - ax) * 32, (32 - ay) * ax * 32, ay * (32 - ax) * 32, ay * ax * 32]
+    s = img.astype(np.int64)
+    acc = np.zeros(mapx.shape + (C,), np.int64)
+    for (dy, dx), wk in zip(((0, 0), (0, 1), (1, 0), (1, 1)), w):
+        yy, xx = sy + dy, sx + dx
+        ok = (yy >= 0) & (yy < Hh) & (xx >= 0) & (xx < Ww)
+        v = s[np.clip(yy, 0, Hh - 1), np.clip(xx, 0, Ww - 1)] * ok[..., None]
+        acc += v * wk[..., None]
+    return np.clip((acc + (1 << 14)) >> 15, 0, 255).astype(np.uint8)
+
+
+def get_polar_img(img: np.ndarray, original=None) -> np.ndarray:
+    """getPolarImg, hdn/models/logpolar.py:11-29: cv2.logPolar(img, o, m, WARP_FILL_OUTLIERS + INTER_LINEAR) with
+    maxRadius = W / 2, m = W / log(maxRadius), o = round(original) or (H // 2, W // 2)."""
+    sz = img.shape
+    m = sz[1] / math.log(sz[1] / 2)
+    o = tuple(np.round(original)) if original is not None else (sz[0] // 2, sz[1] // 2)
+    mx, my = log_polar_maps(sz[1], sz[0], (float(o[0]), float(o[1])), m)
+    return remap_linear_u8(img, mx, my)
 
 
 def _inv3(m):

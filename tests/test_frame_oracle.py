@@ -75,3 +75,36 @@ def test_similarity_homography_builder_matches_reference():
     g = load_golden("frame")
     for row, H in zip(g["sim_params"], g["sim_H"]):
         np.testing.assert_allclose(rot_scale_around_center_shift_tran(*row), H, rtol=0, atol=1e-12)
+
+
+def test_log_polar_restatement_properties():
+    """cv2.logPolar restated (parity-unpinned: OpenCV is in neither tree): what the algorithm must do whatever the data."""
+    r = np.random.default_rng(3)
+    img = r.integers(0, 256, (127, 127, 3), dtype=np.uint8)
+    mx, my = F.log_polar_maps(127, 127, (63.0, 63.0), 127 / np.log(63.5))
+    assert mx.dtype == my.dtype == np.float32 and mx.shape == my.shape == (127, 127)
+    # rho = 0 is the centre for every angle; the last column is the circle of radius exp(126 log(63.5) / 127) - 1
+    assert np.all(mx[:, 0] == 63.0) and np.all(my[:, 0] == 63.0)
+    rad = np.hypot(mx[:, -1].astype(np.float64) - 63, my[:, -1].astype(np.float64) - 63)
+    np.testing.assert_allclose(rad, np.exp(126 * np.log(63.5) / 127) - 1, rtol=1e-6)
+    # angle runs along y: row h/4 looks straight down (+y), row 0 to the right (+x)
+    assert my[0, -1] == 63.0 and mx[0, -1] > 120 and abs(float(mx[32, -1]) - 63.0) < 2.0 and my[32, -1] > 120
+    lp = F.get_polar_img(img)
+    assert lp.shape == img.shape and lp.dtype == np.uint8
+    assert np.all(lp[:, 0] == img[63, 63])                       # integer coordinates reproduce the pixel exactly
+    # a constant image stays constant wherever all four taps are inside; outliers (taps outside) pull towards the border value 0
+    const = np.full((31, 31, 1), 200, np.uint8)
+    mx2, my2 = F.log_polar_maps(31, 31, (15.0, 15.0), 31 / np.log(15.5))
+    out = F.remap_linear_u8(const, mx2, my2)
+    inside = (mx2 >= 0) & (mx2 <= 30) & (my2 >= 0) & (my2 <= 30)
+    assert np.all(out[inside] == 200)
+    far = F.remap_linear_u8(const, mx2 + 100, my2)
+    assert np.all(far == 0)                                        # WARP_FILL_OUTLIERS: constant border 0
+    # the remap itself: an integer shift map is a plain shift with zero fill
+    yy, xx = np.mgrid[0:31, 0:31].astype(np.float32)
+    rnd = r.integers(0, 256, (31, 31, 2), dtype=np.uint8)
+    sh = F.remap_linear_u8(rnd, xx + 3, yy - 2)
+    assert np.array_equal(sh[2:, :28], rnd[:29, 3:]) and np.all(sh[:2] == 0) and np.all(sh[:, 28:] == 0)
+    # half-pixel map: the rounded mean of the two neighbours (weights 16384 / 16384)
+    hp = F.remap_linear_u8(rnd, xx + 0.5, yy)
+    np.testing.assert_array_equal(hp[:, :30], ((rnd[:, :30].astype(int) + rnd[:, 1:].astype(int)) * 16384 + 16384 >> 15).astype(np.uint8))

@@ -73,3 +73,30 @@ def test_frame_warps_vs_oracle(dev):
         np.testing.assert_array_equal(got, F.warp_affine_cubic_u8(im, F.rot_matrix_2x3(cx, cy, rot)))
     with pytest.raises(Exception):
         FR.get_subwindow(torch.zeros(4, 4, 3, dtype=torch.uint8), [1, 1], 3, 3, [0, 0, 0])
+
+
+def test_log_polar_vs_oracle(dev):
+    """get_polar_img / get_subwindow(islog=1) (restated cv2.logPolar, parity-unpinned) bit-exact against the oracle's restatement."""
+    r = np.random.default_rng(11)
+    for S, C in ((127, 3), (31, 1), (64, 2)):
+        img = r.integers(0, 256, (S, S, C), dtype=np.uint8)
+        patch = torch.from_numpy(np.ascontiguousarray(img.transpose(2, 0, 1))[None].astype(np.float32)).to(dev)
+        got = FR.get_polar_img(patch)
+        assert got.shape == patch.shape and got.dtype == torch.float32
+        np.testing.assert_array_equal(got.cpu().numpy()[0].transpose(1, 2, 0).astype(np.uint8), F.get_polar_img(img), err_msg=f"S={S}")
+        assert torch.equal(got, got.round())                                       # uint8-valued
+    o = (40.2, 71.6)
+    patch = torch.from_numpy(np.ascontiguousarray(img.transpose(2, 0, 1))[None].astype(np.float32)).to(dev)
+    np.testing.assert_array_equal(FR.get_polar_img(patch, original=o).cpu().numpy()[0].transpose(1, 2, 0).astype(np.uint8),
+                                  F.get_polar_img(img, original=o))
+    # the 6-channel template crop of the tracker: np.concatenate((im_patch, getPolarImg(im_patch)), 2)
+    g = load_golden("frame")
+    fr = FR.upload(g["im"])
+    six = FR.get_subwindow(fr, g["pos"][0], 127, int(g["sz"][0]), g["avg"], islog=1)
+    assert six.shape == (1, 6, 127, 127)
+    three = FR.get_subwindow(fr, g["pos"][0], 127, int(g["sz"][0]), g["avg"])
+    assert torch.equal(six[:, :3], three)
+    ref = F.get_polar_img(three.cpu().numpy()[0].transpose(1, 2, 0).astype(np.uint8))
+    np.testing.assert_array_equal(six[0, 3:].cpu().numpy().transpose(1, 2, 0).astype(np.uint8), ref)
+    with pytest.raises(ValueError):
+        FR.get_polar_img(patch[0])
