@@ -123,12 +123,14 @@ __global__ __launch_bounds__(HDN_BLOCK) void share_feature_kernel(const float* _
 }
 
 // ---------------------------------------------------------------------------------------
-// W <= 128 (the 127x127 crops of the tracker): one workgroup = 4 output rows x the full width.
+// W <= 128 (the 127x127 crops of the tracker), LDS form: one workgroup = 4 output rows x the full width.
 //   * no horizontal halo recompute: columns outside the image are the convs' own zero padding;
 //   * all three layers issue v_pk_fma_f32 on natural pairs: the intermediates live in LDS as
 //     (channel 2p, channel 2p+1) float2 per pixel, the weights as (w[2p], w[2p+1]) SGPR pairs, and each
 //     accumulator pair holds the partial sums over even / odd input channels (added once at the end);
-//   * pixel = lane index: 8/6/4 rows x 128 columns = exactly 4/3/2 full rounds of 256 threads.
+//   * pixel = lane index: rows x 128 columns = full rounds of 256 threads.
+// (Round 1's tile kernel - every 4-row tile recomputing its 8 / 6 halo-inclusive rows of layers 1 / 2 - is gone; the rolling-row
+// kernel below does the same arithmetic per pixel with 396 instead of 576 FMAs and stays selectable as HDN_SF_LDS=1.)
 // ---------------------------------------------------------------------------------------
 // A wave-uniform pointer into the (read-only) parameter block, re-typed to the constant address space so its loads
 // are scalar (s_load), and passed through an empty asm so the compiler cannot hoist every weight of the layer out of
@@ -140,199 +142,15 @@ __device__ __forceinline__ const cfloat2v* opaque_const(const float2v* p) {
   return (const cfloat2v*)a;
 }
 
-template <int R_>
-struct Sfw {
-  static constexpr int R = R_, CS = 130;       // output rows per workgroup (even); LDS row stride (cols -1..128)
-  static constexpr int IN_H = R + 6, A_H = R + 4, B_H = R + 2;
-  static constexpr int IN_N = IN_H * CS, A_N = A_H * CS, B_N = B_H * CS;
-  static constexpr int W_N = 424;              // parameter block staged in LDS (422 floats, padded)
-  static constexpr int LDS_FLOATS = IN_N + 2 * (2 * A_N) + 2 * (4 * B_N) + W_N;
-  static constexpr int LDS_BYTES = LDS_FLOATS * 4;
-};
-
-template <class S>
-__device__ __forceinline__ void sfw_fetch(float (&pin)[S::IN_H / 2], const float* __restrict__ img, int tile,
-                                          int tiles_per_img, int H, int W, int c, int rr) {
-  const int b = tile / tiles_per_img, r0 = (tile - b * tiles_per_img) * S::R;
-  const float* __restrict__ src = img + size_t(b) * H * W;
-#pragma unroll
-  for (int q = 0; q < S::IN_H / 2; ++q) {
-    const int gr = r0 - 3 + 2 * q + rr;
-    const bool ok = gr >= 0 && gr < H && c < W;
-    pin[q] = src[ok ? gr * W + c : 0];
-    pin[q] = ok ? pin[q] : 0.f;
-  }
-}
-
-// Persistent: a workgroup walks tiles (image b, R-row block); the next tile's R+6 input rows are in flight in registers
-// while the current tile runs its three layers out of LDS.  R = 8 (76 KB of LDS, 2 workgroups per CU) recomputes
-// 1.25x the layer-2 rows and 1.5x the layer-1 rows; R = 4 (48 KB, 3 per CU) 1.5x and 2x.
-template <int R_>
-__global__ __launch_bounds__(HDN_BLOCK) void share_feature_w128_kernel(const float* __restrict__ img,
-                                                                       const float* __restrict__ prm,
-                                                                       float* __restrict__ out, int H, int W,
-                                                                       int tiles_per_img, int total_tiles) {
-  using S = Sfw<R_>;
-  constexpr int R = S::R, CS = S::CS, IN_H = S::IN_H, A_H = S::A_H, B_H = S::B_H, IN_N = S::IN_N, A_N = S::A_N, B_N = S::B_N;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* s_in = smem;
-  float2v* s_a = reinterpret_cast<float2v*>(smem + IN_N);            // [2][A_H][CS]
-  float2v* s_b = reinterpret_cast<float2v*>(smem + IN_N + 4 * A_N);  // [4][B_H][CS]
-  float* s_w = smem + IN_N + 4 * A_N + 8 * B_N;                      // the 422 parameters, read back as broadcasts
-  const float2v* w2p = reinterpret_cast<const float2v*>(s_w + SF_W2);  // [2][9][8]
-  const float2v* w3p = reinterpret_cast<const float2v*>(s_w + SF_W3);  // [4][9]
-
-  const int tid = threadIdx.x;
-  const int c = tid & 127, rr = tid >> 7;  // pixel column, row parity inside a round
-  for (int idx = tid; idx < HDN_SF_PARAMS; idx += HDN_BLOCK) s_w[idx] = prm[idx];
-  // zero, once, the halo columns (-1 and 128) of the input tile and of both intermediates
-  if (tid < 2 * IN_H) s_in[(tid >> 1) * CS + (tid & 1) * (CS - 1)] = 0.f;
-  if (tid < 2 * (2 * A_H + 4 * B_H)) {
-    const int side = tid & 1, row = tid >> 1;
-    if (row < 2 * A_H) s_a[row * CS + side * (CS - 1)] = float2v{0.f, 0.f};
-    else s_b[(row - 2 * A_H) * CS + side * (CS - 1)] = float2v{0.f, 0.f};
-  }
-  float pin[IN_H / 2];
-  int tile = blockIdx.x;
-  if (tile < total_tiles) sfw_fetch<S>(pin, img, tile, tiles_per_img, H, W, c, rr);
-
-#pragma unroll 1
-  for (; tile < total_tiles; tile += gridDim.x) {
-  const int bimg = tile / tiles_per_img;
-  const int r0 = (tile - bimg * tiles_per_img) * R;
-  const size_t plane = size_t(bimg) * H * W;
-  // input rows r0-3 .. r0+R+2 (columns 0..127 -> LDS columns 1..128; zero outside the image)
-#pragma unroll
-  for (int q = 0; q < IN_H / 2; ++q) s_in[(2 * q + rr) * CS + c + 1] = pin[q];
-  if (tile + (int)gridDim.x < total_tiles) sfw_fetch<S>(pin, img, tile + gridDim.x, tiles_per_img, H, W, c, rr);
-  __syncthreads();
-
-  // ---- layer 1: 1 -> 4 at rows r0-2 .. r0+R+1 -------------------------------------------
-  // The 36 weights and the BN scale/shift of the layer sit in registers for the whole tile (read back from the LDS copy
-  // of the parameter block as broadcasts); the epilogue is branch-free.  (Read through `prm` they became one scalar load,
-  // wait and exec-branch per output channel and row: 3x the instructions of the 36 FMAs they feed.)
-  {
-    float w1[9][4], al[4], be[4];
-#pragma unroll
-    for (int k9 = 0; k9 < 9; ++k9)
-#pragma unroll
-      for (int co = 0; co < 4; ++co) w1[k9][co] = s_w[SF_W1 + k9 * 4 + co];
-#pragma unroll
-    for (int co = 0; co < 4; ++co) {
-      al[co] = s_w[SF_ALPHA + co];
-      be[co] = s_w[SF_BETA + co];
-    }
-#pragma unroll 2
-    for (int q = 0; q < A_H / 2; ++q) {
-      const int r = 2 * q + rr;
-      const int gr = r0 - 2 + r;
-      float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const float v = s_in[(r + ky) * CS + c + kx];
-#pragma unroll
-          for (int co = 0; co < 4; ++co) acc[co] = __builtin_fmaf(v, w1[ky * 3 + kx][co], acc[co]);
-        }
-      const bool inside = gr >= 0 && gr < H && c < W;  // rows / columns outside the image are the next layer's zero padding
-      float y[4];
-#pragma unroll
-      for (int co = 0; co < 4; ++co) {
-        const float t = fmaxf(__builtin_fmaf(acc[co], al[co], be[co]), 0.f);
-        y[co] = inside ? t : 0.f;
-      }
-      s_a[(0 * A_H + r) * CS + c + 1] = float2v{y[0], y[1]};
-      s_a[(1 * A_H + r) * CS + c + 1] = float2v{y[2], y[3]};
-    }
-  }
-  __syncthreads();
-
-  // ---- layer 2: 4 -> 8 at rows r0-1 .. r0+R ----------------------------------------------
-  // A thread owns the pixels (row 2q + rr, column c), q = 0..2, and walks the 6 (channel pair, ky) tap rows with
-  // the 48 weights of one tap row in SGPRs at a time (the pointer is made opaque per iteration so the compiler
-  // neither hoists all 288 weights out of the loop nor spills SGPRs through v_readlane).
-  {
-    constexpr int NPX = B_H / 2;
-    float2v acc[NPX][8];
-#pragma unroll
-    for (int q = 0; q < NPX; ++q)
-#pragma unroll
-      for (int co = 0; co < 8; ++co) acc[q][co] = float2v{0.f, 0.f};
-#pragma unroll 1
-    for (int t = 0; t < 6; ++t) {  // t = cp * 3 + ky
-      const int cp = t / 3, ky = t - cp * 3;
-      const float2v* w = w2p + t * 24;  // [kx][co]
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        float2v v[NPX];
-#pragma unroll
-        for (int q = 0; q < NPX; ++q) v[q] = s_a[(cp * A_H + 2 * q + rr + ky) * CS + c + kx];
-#pragma unroll
-        for (int co = 0; co < 8; ++co) {
-          const float2v wv = w[kx * 8 + co];
-#pragma unroll
-          for (int q = 0; q < NPX; ++q) acc[q][co] = __builtin_elementwise_fma(v[q], wv, acc[q][co]);
-        }
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < NPX; ++q) {
-      const int r = 2 * q + rr;
-      const int gr = r0 - 1 + r;
-      const bool inside = gr >= 0 && gr < H && c < W;
-      float y[8];
-#pragma unroll
-      for (int co = 0; co < 8; ++co) {  // BN constants from the LDS copy, unconditional: no scalar load + exec branch per channel
-        const float t = fmaxf(__builtin_fmaf(acc[q][co].x + acc[q][co].y, s_w[SF_ALPHA + 4 + co], s_w[SF_BETA + 4 + co]), 0.f);
-        y[co] = inside ? t : 0.f;
-      }
-#pragma unroll
-      for (int p = 0; p < 4; ++p) s_b[(p * B_H + r) * CS + c + 1] = float2v{y[2 * p], y[2 * p + 1]};
-    }
-  }
-  __syncthreads();
-
-  // ---- layer 3: 8 -> 1 at rows r0 .. r0+R-1, straight to HBM -------------------------------
-  {
-    constexpr int NPX = R / 2;
-    float2v acc[NPX];
-#pragma unroll
-    for (int q = 0; q < NPX; ++q) acc[q] = float2v{0.f, 0.f};
-#pragma unroll 1
-    for (int h = 0; h < 2; ++h) {  // two channel pairs (36 weights) per iteration
-      const float2v* w = w3p + h * 18;
-#pragma unroll
-      for (int cq = 0; cq < 2; ++cq)
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx) {
-            const float2v wv = w[cq * 9 + ky * 3 + kx];
-#pragma unroll
-            for (int q = 0; q < NPX; ++q)
-              acc[q] = __builtin_elementwise_fma(s_b[((2 * h + cq) * B_H + 2 * q + rr + ky) * CS + c + kx], wv, acc[q]);
-          }
-    }
-#pragma unroll
-    for (int q = 0; q < NPX; ++q) {
-      const int gr = r0 + 2 * q + rr;
-      const float t = fmaxf(__builtin_fmaf(acc[q].x + acc[q].y, s_w[SF_ALPHA + 12], s_w[SF_BETA + 12]), 0.f);
-      if (gr < H && c < W) out[plane + size_t(gr) * W + c] = t;
-    }
-  }
-  }  // tile loop (the next iteration's first barrier orders this tile's LDS reads before the next tile's writes)
-}
-
 // ---------------------------------------------------------------------------------------
-// W <= 128, rolling rows ("ring"): the w128 kernel above recomputes, for every 4-row tile, 8 rows of layer 1 and 6 rows of
-// layer 2 (2x and 1.5x the work: measured, the kernel's time follows its FMA count).  Here a workgroup walks DOWN a strip of
+// W <= 128, rolling rows ("ring"): a tile kernel recomputes, for every 4-row tile, 8 rows of layer 1 and 6 rows of
+// layer 2 (2x and 1.5x the work: measured, its time follows its FMA count).  Here a workgroup walks DOWN a strip of
 // consecutive tiles of one image and keeps the intermediate rows it already has: the 4-channel layer-1 rows live in an 8-row
 // ring, the 8-channel layer-2 rows in a 6-row ring (slot = row mod ring size, wave-uniform, so a row's LDS address is one
 // scalar-offset add and everything else stays an immediate), and every tile after the first of a strip computes only its 4
 // NEW rows per layer: 396 FMAs per pixel instead of 576.  A strip is images' tiles [k*T/n, (k+1)*T/n): n strips per image,
 // n = (workgroups the chip holds) / images, so short batches still fill the chip (one-tile strips = the old kernel's work).
-// Same LDS footprint (48.5 KB, 3 workgroups per CU), same arithmetic per output pixel as the w128 kernel (bit-identical).
+// 48.5 KB of LDS (3 workgroups per CU); same arithmetic per output pixel as round 1's tile kernel (bit-identical).
 // ---------------------------------------------------------------------------------------
 namespace sfr {
 constexpr int R = 4, CS = 130;
@@ -908,28 +726,6 @@ static int launch_sf_rows(const float* img, const float* folded, float* out, int
   return launch_status();
 }
 
-template <int R_>
-static int launch_sf_w128(const float* img, const float* folded, float* out, int B, int H, int W, hipStream_t stream) {
-  using S = Sfw<R_>;
-  static PerDeviceOnce attr;  // dynamic LDS above 64 KiB needs the opt-in once per kernel and device
-  const int dev_ = PerDeviceOnce::device();
-  if (!attr.done(dev_)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&share_feature_w128_kernel<R_>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS_BYTES);
-    if (e != hipSuccess) return -(1000 + (int)e);
-    attr.set(dev_);
-  }
-  const int tiles_per_img = cdiv(H, S::R);
-  const long long total = (long long)tiles_per_img * B;
-  if (total > 0x7fffffffLL) return HDN_E_LIMIT;
-  const int per_cu = 163840 / S::LDS_BYTES;  // persistent: as many workgroups as fit a CU's LDS x 256 CUs
-  const int cap = 256 * (per_cu < 1 ? 1 : per_cu);
-  const int grid = (int)(total < cap ? total : cap);
-  hipLaunchKernelGGL(share_feature_w128_kernel<R_>, dim3(grid), dim3(HDN_BLOCK), S::LDS_BYTES, stream, img, folded, out, H, W,
-                     tiles_per_img, (int)total);
-  return launch_status();
-}
-
 }  // namespace hdn
 
 extern "C" int hdn_share_feature_f32(const float* img, const float* folded, float* out, int B, int H, int W,
@@ -939,14 +735,9 @@ extern "C" int hdn_share_feature_f32(const float* img, const float* folded, floa
   if (B > 65535 || (long long)H * W > 0x7fffffffLL / 4) return HDN_E_LIMIT;
   if (out == img) return HDN_E_ALIAS;
   if (W <= 128) {
-    static const int rows = [] { const char* e = getenv("HDN_SF_ROWS"); return (e && e[0] == '8') ? 8 : ((e && e[0] == '2') ? 2 : 4); }();  // A/B switch: 8 rows measured 5 % slower (2 workgroups per CU)
-    static const bool ring = [] { const char* e = getenv("HDN_SF_RING"); return !(e && e[0] == '0'); }();  // A/B switch
-    static const bool lds = [] { const char* e = getenv("HDN_SF_LDS"); return e && e[0] == '1'; }();        // A/B switch: the LDS kernels
-    if (!lds && !getenv("HDN_SF_ROWS")) return hdn::launch_sf_rows(img, folded, out, B, H, W, static_cast<hipStream_t>(stream));
-    if (ring && !getenv("HDN_SF_ROWS")) return hdn::launch_sf_ring(img, folded, out, B, H, W, static_cast<hipStream_t>(stream));
-    if (rows == 8 && H > 8) return hdn::launch_sf_w128<8>(img, folded, out, B, H, W, static_cast<hipStream_t>(stream));
-    if (rows == 2) return hdn::launch_sf_w128<2>(img, folded, out, B, H, W, static_cast<hipStream_t>(stream));
-    return hdn::launch_sf_w128<4>(img, folded, out, B, H, W, static_cast<hipStream_t>(stream));
+    static const bool lds = [] { const char* e = getenv("HDN_SF_LDS"); return e && e[0] == '1'; }();  // A/B switch: the LDS (rolling rows) kernel
+    if (lds) return hdn::launch_sf_ring(img, folded, out, B, H, W, static_cast<hipStream_t>(stream));
+    return hdn::launch_sf_rows(img, folded, out, B, H, W, static_cast<hipStream_t>(stream));
   }
   dim3 grid(hdn::cdiv(W, hdn::SF_COLS), hdn::cdiv(H, hdn::SF_ROWS), B);
   if (grid.y > 65535) return HDN_E_LIMIT;

@@ -844,96 +844,13 @@ __global__ __launch_bounds__(HDN_BLOCK, 2) void xcorr_north_mfma_kernel(XcorrPtr
 // 16-plane chunks in HBM -> two all-in-flight 16-byte copies), and the wrap / clamp is folded into the operands:
 //   padded row  (i+u)  -> source row (i+u+7) mod 13      (rows = angle, wraps): one add per tap row
 //   padded cols 0..5 / 19..24 replicate x[0] / x[12]:   broadcast pairs (op_sel), no loads at all
-// A lane owns one output row of one plane (13 lanes per plane, 4 planes per wave).  Same even/odd scheme as the
-// 31x31 kernel: operand pairs R[n] = (xp[2n], xp[2n+1]); even taps accumulate (out[2j], out[2j+1]), odd taps
-// (out[2j-1], out[2j]).  Per tap row: 7 + 7 two-dword LDS reads (x row, k row) and 91 packed FMAs.
+// A lane owns one output row of one plane.  Same even/odd scheme as the 31x31 direct kernel: operand pairs
+// R[n] = (xp[2n], xp[2n+1]); even taps accumulate (out[2j], out[2j+1]), odd taps (out[2j-1], out[2j]).
+// Per tap row: 7 + 7 two-dword LDS reads (x row, k row) and 76 packed FMAs + 5 adds.
+// This is the DIRECT sum (HDN_CIRC13_DIRECT=1); the default since round 2 is the DFT form further down.
 // ---------------------------------------------------------------------------------------
-namespace circ13 {
-constexpr int N = 13, PL = N * N;       // 169
-constexpr int PPW = 4, PPB = 16;        // planes per wave / per workgroup
-constexpr int LDS_FLOATS = 3 * PPB * PL + 16;
-}  // namespace circ13
-
-__global__ __launch_bounds__(HDN_BLOCK) void xcorr_circ13_kernel(XcorrPtrs P, int planes) {
-  using namespace circ13;
-  __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
-  float* sx = smem;
-  float* sk = smem + PPB * PL;
-  float* so = smem + 2 * PPB * PL;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & (HDN_WAVE - 1);
-  const int wave = tid >> 6;
-  const int prob = blockIdx.y;
-  const int plane0 = blockIdx.x * PPB;
-  const int np = min(PPB, planes - plane0);
-  const float* xg = P.x[prob] + size_t(plane0) * PL;
-  const float* kg = P.k[prob] + size_t(plane0) * PL;
-  float* og = P.out[prob] + size_t(plane0) * PL;
-
-  if (np == PPB && aligned16(xg) && aligned16(kg)) {
-    copy_g2l_full<PPB * PL>(xg, sx, tid);
-    copy_g2l_full<PPB * PL>(kg, sk, tid);
-  } else {
-    copy_g2l(xg, sx, np * PL, tid);
-    copy_g2l(kg, sk, np * PL, tid);
-  }
-  __syncthreads();
-
-  const int q = min(lane / N, PPW - 1);       // lanes 52..63 shadow plane 3 and do not store
-  const int i = lane - (lane / N) * N;        // output row
-  const int slot = min(wave * PPW + q, np - 1);
-  const bool live = lane < PPW * N && wave * PPW + q < np;
-  const float* xs = sx + slot * PL;
-  const float* ks = sk + slot * PL;
-  float2v accE[7], accO[7];
-#pragma unroll
-  for (int j = 0; j < 7; ++j) accE[j] = accO[j] = float2v{0.f, 0.f};
-  int r = i + 7;  // source row of padded row i + u, u = 0
-  r = r >= N ? r - N : r;
-#pragma unroll
-  for (int u = 0; u < N; ++u) {
-    const float* xr = xs + r * N;
-    const float* kr = ks + u * N;
-    float2v X[7], K[7];  // (x[2m], x[2m+1]) and (k[2m], k[2m+1]); the 14th element of each is never used
-#pragma unroll
-    for (int m = 0; m < 7; ++m) {
-      X[m] = float2v{xr[2 * m], xr[2 * m + 1]};
-      K[m] = float2v{kr[2 * m], kr[2 * m + 1]};
-    }
-    const float2v lo = X[0].xx, hi = X[6].xx;  // replicated columns: (x0,x0) and (x12,x12)
-    // R[n] = (xp[2n], xp[2n+1]) of the clamped padded row, n = 0..12
-    auto R = [&](int n) -> float2v { return n < 3 ? lo : (n < 9 ? X[n - 3] : hi); };
-#pragma unroll
-    for (int w = 0; w < 7; ++w) {
-      {
-        const float2v kk = K[w].xx;  // tap 2w
-#pragma unroll
-        for (int j = 0; j < 7; ++j) accE[j] = __builtin_elementwise_fma(R(j + w), kk, accE[j]);
-      }
-      if (w < 6) {
-        const float2v kk = K[w].yy;  // tap 2w+1
-#pragma unroll
-        for (int j = 0; j < 7; ++j) accO[j] = __builtin_elementwise_fma(R(j + w), kk, accO[j]);
-      }
-    }
-    r = (r + 1 == N) ? 0 : r + 1;
-  }
-  if (live) {
-    float* os = so + slot * PL + i * N;
-#pragma unroll
-    for (int j = 0; j < 7; ++j) {
-      os[2 * j] = accE[j].x + accO[j].y;
-      if (j < 6) os[2 * j + 1] = accE[j].y + accO[j + 1].x;
-    }
-  }
-  __syncthreads();
-  if (np == PPB && aligned16(og)) copy_l2g_full<PPB * PL>(so, og, tid);
-  else copy_l2g(so, og, np * PL, tid);
-}
-
-// Same arithmetic, different work split: a workgroup owns 256 consecutive OUTPUT ROWS of the [planes*13, 13] result
-// (one per lane: every lane busy, where 4 planes of 13 rows per wave leave 12 of 64 idle) and stages the 20-21 planes
+// Work split: a workgroup owns 256 consecutive OUTPUT ROWS of the [planes*13, 13] result
+// (one per lane: every lane busy, where 4 planes of 13 rows per wave would leave 12 of 64 idle) and stages the 20-21 planes
 // those rows belong to.  Its outputs are one contiguous 16-byte-aligned range; planes cut by a workgroup border are
 // staged by both neighbours (+5 % reads, mostly L2 hits).
 namespace circ13r {
@@ -1455,9 +1372,8 @@ static int launch_prod29(const XcorrPtrs& P, int n, int planes, hipStream_t stre
 }
 
 static int launch_circ13(const XcorrPtrs& P, int n, int planes, hipStream_t stream) {
-  static const bool old = [] { const char* e = getenv("HDN_CIRC13_PLANES"); return e && e[0] == '1'; }();  // A/B switch
   static const bool direct = [] { const char* e = getenv("HDN_CIRC13_DIRECT"); return e && e[0] == '1'; }();  // A/B switch: the direct-sum kernel
-  if (!old && !direct) {
+  if (!direct) {
     // a wave owns a group of 9 planes; the groups of all problems of the launch are one flat grid
     const int gpp = cdiv(planes, circ13f::PPW);
     const long long total = (long long)gpp * n;
@@ -1466,13 +1382,8 @@ static int launch_circ13(const XcorrPtrs& P, int n, int planes, hipStream_t stre
     g_last_variant = "circ13";
     return launch_status();
   }
-  if (!old) {
-    const long long blocks = ((long long)planes * circ13r::N + circ13r::ROWS - 1) / circ13r::ROWS;
-    hipLaunchKernelGGL(xcorr_circ13r_kernel, dim3((unsigned)blocks, n), dim3(HDN_BLOCK), 0, stream, P, planes);
-    g_last_variant = "circ13";
-    return launch_status();
-  }
-  hipLaunchKernelGGL(xcorr_circ13_kernel, dim3(cdiv(planes, circ13::PPB), n), dim3(HDN_BLOCK), 0, stream, P, planes);
+  const long long blocks = ((long long)planes * circ13r::N + circ13r::ROWS - 1) / circ13r::ROWS;
+  hipLaunchKernelGGL(xcorr_circ13r_kernel, dim3((unsigned)blocks, n), dim3(HDN_BLOCK), 0, stream, P, planes);
   g_last_variant = "circ13";
   return launch_status();
 }

@@ -1,4 +1,4 @@
-"""A/B of PreShareFeature tile heights (HDN_SF_ROWS=4|8): time for 128 and 64 images of 127x127, parity vs the oracle."""
+"""PreShareFeature: parity vs the oracle on a few shapes, time for 128 and 64 images of 127x127 (HDN_SF_LDS=1: the LDS kernel)."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import torch
