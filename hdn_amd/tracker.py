@@ -12,7 +12,7 @@ loop around ModelBuilder.track_proj (:242-250), un-scale / un-shift the residual
 The similarity branch (translation and log-polar scale / rotation: ResNet-50 backbone, necks, MultiBAN / MultiCircBAN heads,
 :164-214) belongs to PyTorch-ROCm and the reference's own modules (north_star); it enters here through the optional
 `similarity` callable, `similarity(frame_u8_device, center_pos) -> (delta_cx, delta_cy, scale_delta, rot_delta, best_score)`.
-Without one the similarity estimate is the identity: that is the harness configuration of tests/ and tools/sequence_bench.py
+Without one the similarity estimate is the identity: that is the harness configuration of tests/ and tests/tools/sequence_bench.py
 (one planar target per sequence; sequences are independent, so N GPUs run N sequences: replicas only, no collective).
 
 What the reference does on the host per frame — cv2 warps of the full frame, numpy crops, three crop uploads and six

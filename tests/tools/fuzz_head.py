@@ -1,9 +1,9 @@
 """Randomised differential test of PreShareFeature / DLT / warp against the CPU oracle (run on the GPU box).
 
-    python tools/fuzz_head.py [seconds]
+    python tests/tools/fuzz_head.py [seconds]
 """
 import os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np, torch
 import hdn_amd
 from hdn_amd import homography as G, share_feature as SF

@@ -1,11 +1,11 @@
 """Randomised differential test of the correlation entry points against the CPU oracle (run on the GPU box).
 
-    python tools/fuzz_parity.py [seconds]
+    python tests/tools/fuzz_parity.py [seconds]
 Random plane counts / shapes / variants / pointer alignments / data scales; every result is held to the parity bound of
 tests/test_gpu_parity.py::check_xcorr.  Prints a summary line; exits non-zero on the first violation.
 """
 import os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np, torch
 import hdn_amd
 from hdn_amd import xcorr as X

@@ -7,12 +7,12 @@ Reported: wall time per frame with the host reading the corners EVERY frame (wha
 host syncs per frame, the same loop without the per-frame read (pipelined), corner error (success_4pts_error) of the device
 loop against the CPU restatement of the same loop on the first --parity frames, and — for the B=1 head alone — eager vs
 hipGraph replay, each synchronised per frame.
-    python tools/sequence_bench.py [--frames 200] [--parity 12]
+    python tests/tools/sequence_bench.py [--frames 200] [--parity 12]
 """
 import argparse, copy, json, os, sys, time
 import numpy as np
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import hdn_amd
 from hdn_amd.graph import GraphedTrackProj
