@@ -22,7 +22,7 @@ def head(rec):
     pf = SF.share_feature(warped, folded)
     G.l1_score(feats[0, 1], pf[0, 0], 1.0 / 16129); G.l1_score(feats[0, 1], feats[0, 0], 1.0 / 16129)
 parts = {"N": north, "P": prod, "C": circ, "H": head}
-for order in ("NPCH", "PNCH", "NPCH", "HNPC", "NPCH", "PCNH", "NCPH", "NHPC", "NPCH"):
+for order in (sys.argv[1:] or ("NPCH", "PNCH", "NPCH", "HNPC", "NPCH", "PCNH", "NCPH", "NHPC", "NPCH")):
     fs = [parts[c] for c in order]
     for _ in range(5):
         for f in fs: f(False)
