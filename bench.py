@@ -71,6 +71,10 @@ def parse():
     ap.add_argument("--collective", choices=["c_abi", "torch"], default="c_abi",
                     help="N > 1: hdn_allgather_offsets of the C ABI (default) or torch.distributed.all_gather_into_tensor")
     ap.add_argument("--only-north", action="store_true", help="step = the north-star correlation only (profiling aid)")
+    ap.add_argument("--head-stream", choices=["inline", "after-north", "parallel"], default="after-north",
+                    help="where the homography head runs: in line with the correlations; on its own stream beside the 13x13 and 5x5 "
+                         "launches (default); or on its own stream from the start of the step (fastest step, but the 31x31 kernel "
+                         "then shares the chip while it is being timed for the roofline block)")
     ap.add_argument("--north", choices=["fft", "fftr", "fft2w", "direct", "dense", "mfma"], default=None,
                     help="kernel for the 31x31 (x) 61x61 correlation (default: the library's default, fft = the column-first FFT kernel; fftr = the row-first one); A/B runs")
     ap.add_argument("--config", type=int, choices=[2, 5], default=2,
@@ -173,9 +177,31 @@ def main():
         if world > 1 and collective:
             hdist.all_gather_offsets(st["x"], PAIRS * world, comm=comm)
 
+    head_stream = torch.cuda.Stream(device=dev)
+
     def step(record, collective=True):
         if args.workload == "full":
             return step_full(record, collective)
+        main = torch.cuda.current_stream()
+
+        def head():
+            feats = SF.share_feature(imgs2, folded).reshape(PAIRS, 2, 127, 127)
+            Hm, warped = G.dlt_warp(d["h4p"], d["off"], tmpl)
+            pf = SF.share_feature(warped, folded)
+            G.l1_score2(feats[0, 1], pf[0, 0], feats[0, 0], 1.0 / (127 * 127))
+
+        def fork_head():
+            head_stream.wait_stream(main)
+            with torch.cuda.stream(head_stream):
+                head()
+
+        # The step's two branches are independent, as in the tracker (similarity-branch correlations | homography head).
+        # tools/experiments/exp_streams2.py: one stream 0.324 ms; head beside the 13x13 and 5x5 launches 0.317; head from the start
+        # of the step 0.301 (it fills the SIMDs the persistent 31x31 workers leave as they retire) - but then the roofline
+        # block times the 31x31 kernel while it shares the chip (125-131 us instead of 110), so that is not the default.
+        mode = "inline" if args.only_north else args.head_stream
+        if mode == "parallel":
+            fork_head()
         if record:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -185,14 +211,15 @@ def main():
             north_ev.append((e0, e1))
         if args.only_north:
             return
-        # the step's four groups are independent (two correlation heads, the homography head): this order is 2 % faster than
-        # running the write-heavy 5x5 (x) 29x29 launch in front of the bandwidth-bound 13x13 one (tools/experiments/exp_step_order.py)
+        if mode == "after-north":
+            fork_head()
+        # 13x13 before the write-heavy 5x5 (x) 29x29 launch: 2 % faster than the other way round (tools/experiments/exp_step_order.py)
         X.xcorr_depthwise_multi(d["circ_x"], d["circ_k"], circular=True)
-        feats = SF.share_feature(imgs2, folded).reshape(PAIRS, 2, 127, 127)
-        Hm, warped = G.dlt_warp(d["h4p"], d["off"], tmpl)
-        pf = SF.share_feature(warped, folded)
-        G.l1_score2(feats[0, 1], pf[0, 0], feats[0, 0], 1.0 / (127 * 127))
+        if mode == "inline":
+            head()
         X.xcorr_depthwise_multi(d["prod_x"], d["prod_k"])
+        if mode != "inline":
+            main.wait_stream(head_stream)
         if world > 1 and collective:
             hdist.all_gather_offsets(d["off"], PAIRS * world, comm=comm)
 

@@ -1,6 +1,6 @@
 """Experiment (warm clocks): north alone, then the remaining kernels of the step on 1 / 2 / 3 streams."""
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import hdn_amd
 from hdn_amd import xcorr as X, share_feature as SF, homography as G
 import bench
@@ -38,11 +38,22 @@ def allpar():
     with torch.cuda.stream(s2): prod()
     north()
     main.wait_stream(s1); main.wait_stream(s2)
+def head_par():  # the homography head on its own stream beside the three correlation launches
+    s1.wait_stream(main)
+    with torch.cuda.stream(s1): head()
+    north(); circ(); prod()
+    main.wait_stream(s1)
+def head_par2():  # head beside circ + prod only (the 31x31 kernel fills every SIMD's registers by itself)
+    north()
+    s1.wait_stream(main)
+    with torch.cuda.stream(s1): head()
+    circ(); prod()
+    main.wait_stream(s1)
 def timeit(f, n=100):
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < 0.2: f()
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(n): f()
     torch.cuda.synchronize(); return (time.perf_counter() - t) / n * 1e3
-for name, f in (("serial", serial), ("north, then prod | circ+head", two), ("north, then prod | circ | head", three), ("everything parallel", allpar), ("serial", serial)):
+for name, f in (("serial", serial), ("head | north, circ, prod", head_par), ("north, then head | circ, prod", head_par2), ("serial", serial), ("north, then prod | circ+head", two), ("north, then prod | circ | head", three), ("everything parallel", allpar), ("serial", serial)):
     print(f"{name:34s} {timeit(f):.3f} ms")
