@@ -194,6 +194,8 @@ def main():
             head_stream.wait_stream(main)
             with torch.cuda.stream(head_stream):
                 head()
+                if world > 1 and collective:  # the head's results are gathered while the correlation stream is still busy
+                    hdist.all_gather_offsets(d["off"], PAIRS * world, comm=comm)
 
         # The step's two branches are independent, as in the tracker (similarity-branch correlations | homography head).
         # tools/experiments/exp_streams2.py: one stream 0.324 ms; head beside the 13x13 and 5x5 launches 0.317; head from the start
@@ -220,7 +222,7 @@ def main():
         X.xcorr_depthwise_multi(d["prod_x"], d["prod_k"])
         if mode != "inline":
             main.wait_stream(head_stream)
-        if world > 1 and collective:
+        elif world > 1 and collective:
             hdist.all_gather_offsets(d["off"], PAIRS * world, comm=comm)
 
     def fence():
