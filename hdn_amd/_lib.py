@@ -43,6 +43,7 @@ SIGNATURES = {
     "hdn_frame_warp_perspective_u8": (_i, [_c_float_p] * 3 + [_i] * 3 + [ctypes.c_void_p]),
     "hdn_frame_warp_affine_cubic_u8": (_i, [_c_float_p] * 3 + [_i] * 3 + [ctypes.c_void_p]),
     "hdn_remap_linear_f32": (_i, [_c_float_p] * 4 + [_i] * 5 + [ctypes.c_void_p]),
+    "hdn_trunk_stem_f32": (_i, [_c_float_p] * 4 + [_i] * 4 + [ctypes.c_void_p]),
     "hdn_allgather_offsets": (_i, [_c_float_p] * 2 + [_i, ctypes.c_void_p, ctypes.c_void_p]),
     "hdn_rccl_available": (_i, []),
     "hdn_rccl_unique_id": (_i, [ctypes.c_void_p]),

@@ -68,11 +68,50 @@ def resnet34_homo():
     return HomoResNet((3, 4, 6, 3))
 
 
-def fold_for_inference(net: HomoResNet, channels_last: bool = True) -> nn.Module:
+class FusedStem(nn.Module):
+    """conv1 + folded bn1 + relu + maxpool of the trunk as ONE HIP kernel (hdn_trunk_stem_f32): the 64-channel 64 x 64 conv output
+    never goes through HBM.  Built from a folded conv (weight [64,2,7,7], bias [64]); eval / no-grad only; CUDA tensors only."""
+
+    def __init__(self, conv: nn.Conv2d, channels_last: bool):
+        super().__init__()
+        if tuple(conv.weight.shape) != (64, 2, 7, 7) or conv.stride != (2, 2) or conv.padding != (3, 3) or conv.bias is None:
+            raise ValueError("FusedStem replaces Conv2d(2, 64, 7, 2, 3) with a folded bias")
+        self.register_buffer("wT", conv.weight.detach().permute(1, 2, 3, 0).contiguous())  # [ci][ky][kx][co]
+        self.register_buffer("b", conv.bias.detach().clone())
+        self.channels_last = bool(channels_last)
+
+    def forward(self, x):
+        from . import _lib
+
+        if x.dim() != 4 or x.shape[1] != 2 or x.dtype != self.wT.dtype:
+            raise ValueError("FusedStem takes float32 [B,2,H,W]")
+        B, _, H, W = x.shape
+        if W < 2 or W > 128:  # outside the kernel's range: the same arithmetic through the library
+            import torch.nn.functional as F
+
+            y = F.conv2d(x, self.wT.permute(3, 0, 1, 2), self.b, stride=2, padding=3)
+            return F.max_pool2d(F.relu(y), 3, 2, 1)
+        dev = _lib.require_device(x, self.wT)
+        xs = x.detach().contiguous()  # NCHW
+        Hc, Wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        Hp, Wp = (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1
+        import torch
+
+        out = torch.empty((B, 64, Hp, Wp), dtype=x.dtype, device=dev,
+                          memory_format=torch.channels_last if self.channels_last else torch.contiguous_format)
+        with torch.cuda.device(dev):
+            rc = _lib.load().hdn_trunk_stem_f32(_lib.ptr(xs), _lib.ptr(self.wT), _lib.ptr(self.b), _lib.ptr(out), B, H, W,
+                                                1 if self.channels_last else 0, _lib.stream_ptr(dev))
+        _lib.check(rc, "trunk_stem")
+        return out
+
+
+def fold_for_inference(net: HomoResNet, channels_last: bool = True, fused_stem: bool = False) -> nn.Module:
     """A copy of `net` with every eval-mode BatchNorm folded into the preceding convolution (weights scaled in
     float64, rounded once) and, optionally, NHWC weights for MIOpen's channels-last kernels.  Measured on MI355X at
     B=64: 2.92 ms (as-is) -> 2.47 ms (folded) -> 2.11 ms (folded + NHWC); outputs agree with the un-folded CPU
-    trunk to ~1.5e-6 relative either way (tools/experiments/exp_trunk.py).  The copy does not track later weight changes."""
+    trunk to ~1.5e-6 relative either way (tools/experiments/exp_trunk.py).  The copy does not track later weight changes.
+    fused_stem: replace conv1 / relu / maxpool by FusedStem (GPU only, W <= 128)."""
     import copy
 
     import torch
@@ -99,4 +138,7 @@ def fold_for_inference(net: HomoResNet, channels_last: bool = True) -> nn.Module
     if channels_last:
         import torch as _t
         net = net.to(memory_format=_t.channels_last)
+    if fused_stem:  # conv1 (+ folded bn1) + relu + maxpool in one HIP kernel; the stages behind it stay on MIOpen
+        net.conv1 = FusedStem(net.conv1, channels_last)
+        net.relu, net.maxpool = nn.Identity(), nn.Identity()
     return net

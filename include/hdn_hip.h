@@ -219,6 +219,17 @@ int hdn_remap_linear_f32(const float* src, const float* mapx, const float* mapy,
                          void* stream);
 
 /*
+ * First stage of the homography regressor's trunk, fused:
+ *   out = maxpool3x3/s2/p1( relu( conv7x7/s2/p3(x, w) + b ) ),  x [B,2,H,W] (NCHW) -> out [B,64,Hp,Wp],
+ *   Hc = (H-1)/2 + 1, Hp = (Hc-1)/2 + 1 (127 -> 64 -> 32); 2 <= W <= 128 (else HDN_E_LIMIT).
+ * wT: the conv weights with eval-mode BatchNorm folded in, transposed to [ci=2][ky=7][kx=7][co=64]; bias[64] = the folded
+ * shift.  nhwc != 0: out is written channels-last ([B,Hp,Wp,64] in memory), else NCHW.  fp32; summation order per output =
+ * (input channel, input row, kx).  Replaces conv1 / bn1 / relu / maxpool of ResNet.forward,
+ * homo_estimator/Deep_homography/Oneline_DLTv1/backbone/resnet.py:141-147,183-186 (eval mode only).
+ */
+int hdn_trunk_stem_f32(const float* x, const float* wT, const float* bias, float* out, int B, int H, int W, int nhwc, void* stream);
+
+/*
  * Multi-GPU: template/search pairs are independent, so ranks own disjoint contiguous blocks of pairs
  * and the path's ONLY exchange is one all-gather of the predicted corner offsets, on RCCL over xGMI.
  *   local[Bl,8] (this rank's offsets) -> all[world*Bl,8] on every rank, in rank order; Bl must be equal on all

@@ -908,3 +908,45 @@ def test_graphed_track_proj_matches_eager(dev):
         Hg, sg, ssg = gr(f)
         assert float((He - Hg).abs().max()) < 1e-5
         assert abs(float(se) - float(sg)) < 1e-5 and abs(float(sse) - float(ssg)) < 1e-5
+
+
+# --------------------------------------------------------------------------- trunk, first stage
+@pytest.mark.parametrize("shape", [(2, 127, 127), (1, 9, 13), (3, 64, 128), (2, 5, 7), (1, 126, 125), (1, 2, 2), (1, 4, 1), (1, 3, 130)])
+def test_trunk_fused_stem_vs_torch(dev, shape):
+    """hdn_trunk_stem_f32 (conv 7x7/s2 + folded BN + ReLU + maxpool 3x3/s2 in one kernel) against the same stage of the folded trunk
+    in PyTorch on the CPU; both memory layouts; widths outside the kernel's range take the library path inside FusedStem."""
+    from hdn_amd.trunk import FusedStem, fold_for_inference, resnet34_homo
+    torch.manual_seed(5)
+    base = resnet34_homo().eval()
+    for m in base.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.uniform_(-0.3, 0.3); m.running_var.uniform_(0.5, 2.0); m.weight.data.uniform_(0.5, 1.5); m.bias.data.uniform_(-0.3, 0.3)
+    cpu = fold_for_inference(base, channels_last=False)
+    B, H, W = shape
+    x = torch.randn(B, 2, H, W)
+    with torch.no_grad():
+        ref = cpu.maxpool(cpu.relu(cpu.conv1(x)))
+    for nhwc in (False, True):
+        st = FusedStem(cpu.conv1, nhwc).to(dev)
+        y = st(x.to(dev))
+        assert y.shape == ref.shape
+        if 2 <= W <= 128:
+            assert y.is_contiguous(memory_format=torch.channels_last if nhwc else torch.contiguous_format)
+        assert float((y.cpu() - ref).abs().max()) <= 2e-5 + 2e-6 * float(ref.abs().max())
+    with pytest.raises(ValueError):
+        FusedStem(torch.nn.Conv2d(2, 64, 7, 2, 3, bias=False), False)
+
+
+def test_folded_trunk_with_and_without_fused_stem(dev):
+    from hdn_amd.trunk import fold_for_inference, resnet34_homo
+    torch.manual_seed(6)
+    base = resnet34_homo().eval().to(dev)
+    x = torch.randn(4, 2, 127, 127, device=dev)
+    with torch.no_grad():
+        ref = base(x)
+        for cl in (False, True):
+            a = fold_for_inference(base, channels_last=cl, fused_stem=False)(x.contiguous(memory_format=torch.channels_last) if cl else x)
+            b = fold_for_inference(base, channels_last=cl, fused_stem=True)(x)
+            scale = float(ref.abs().max())
+            assert float((a - ref).abs().max()) <= 2e-4 * scale and float((b - ref).abs().max()) <= 2e-4 * scale
+            assert float((a - b).abs().max()) <= 1e-4 * scale

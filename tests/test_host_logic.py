@@ -379,3 +379,21 @@ def test_committed_bench_line_follows_the_contract(name):
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["value"] > 0
+
+
+def test_fused_stem_host_side():
+    """FusedStem (the trunk's first stage as one HIP kernel): weight layout, the library path for widths outside the kernel's
+    range (works anywhere), and no CPU fallback inside the kernel's range."""
+    from hdn_amd.trunk import FusedStem, fold_for_inference, resnet34_homo
+    torch.manual_seed(2)
+    f = fold_for_inference(resnet34_homo().eval(), channels_last=False)
+    st = FusedStem(f.conv1, False)
+    assert tuple(st.wT.shape) == (2, 7, 7, 64) and torch.equal(st.wT[1, 2, 3], f.conv1.weight[:, 1, 2, 3])
+    x = torch.randn(1, 2, 6, 130)
+    with torch.no_grad():
+        ref = f.maxpool(f.relu(f.conv1(x)))
+        assert torch.allclose(st(x), ref, atol=1e-6)
+    with pytest.raises(Exception):
+        st(torch.randn(1, 2, 9, 9))  # in range: needs the GPU library, never a CPU fallback
+    g = fold_for_inference(resnet34_homo().eval(), channels_last=False, fused_stem=True)
+    assert isinstance(g.conv1, FusedStem) and isinstance(g.maxpool, torch.nn.Identity)

@@ -1,6 +1,6 @@
 """Experiment: how much of the folded NHWC ResNet-34 trunk (B=64, 2x127x127) is its first stage (conv1 7x7 s2 + ReLU + maxpool)?"""
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from hdn_amd.trunk import resnet34_homo, fold_for_inference
 torch.backends.cudnn.benchmark = True
 dev = torch.device("cuda:0")
