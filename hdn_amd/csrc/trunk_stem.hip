@@ -11,6 +11,7 @@
 // used as SGPR pair operands of 8 v_pk_fma_f32 (two output channels per instruction, the input value broadcast by op_sel).
 // Pooling: vertical v_max3 over the three conv rows, horizontal v_max3 with the two neighbour lanes (DPP wave shifts; lanes
 // outside the row hold 0, which never wins after the ReLU and every window has a real element), even lanes store.
+// Zero padding is selected (v_cndmask), never multiplied in: non-finite pixels stay where the reference has them.
 // fp32 throughout; the summation order is (input channel, input row, kx) per output - not MIOpen's, same 1e-5 relative class.
 #include <cstdlib>
 #include <type_traits>
@@ -96,8 +97,7 @@ __global__ __launch_bounds__(HDN_BLOCK, 2) void trunk_stem_kernel(const float* _
   const int HW = H * W;
   // own pair = columns 2c, 2c+1; a pair that would start at the row's last float is read one float earlier (nothing beyond the
   // tensor is touched) and shifted
-  float ok0 = 2 * lane < W ? 1.f : 0.f, ok1 = 2 * lane + 1 < W ? 1.f : 0.f;
-  asm volatile("" : "+v"(ok0), "+v"(ok1));
+  const bool ok0 = 2 * lane < W, ok1 = 2 * lane + 1 < W;
   const uint32_t ix0 = 4u * (uint32_t)min(2 * lane, max(W - 2, 0));
   const bool sh = W >= 2 && 2 * lane == W - 1;
   typedef float2v f2u __attribute__((aligned(4)));
@@ -114,12 +114,12 @@ __global__ __launch_bounds__(HDN_BLOCK, 2) void trunk_stem_kernel(const float* _
     // the 9 input rows iy = 2 (r0 + i) - 3 + ky, each as the four pairs its 7 taps come from:
     //   kx: 0 -> (c-2).y   1, 2 -> (c-1).x, .y   3, 4 -> own .x, .y   5, 6 -> (c+1).x, .y
     float2v raw[NR];
-    float rk[NR];
+    bool rk[NR];
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {  // all 9 loads in flight at once: branch-free, rows beyond the image re-read row 0 and are zeroed
+    for (int i = 0; i < NR; ++i) {  // all 9 loads in flight at once: branch-free, rows beyond the image re-read row 0 and are dropped
       const int iy = 2 * (r0 + i) - 3 + ky;          // wave-uniform
       const bool rok = iy >= 0 && iy < H;
-      rk[i] = rok ? 1.f : 0.f;
+      rk[i] = rok;
       raw[i] = *reinterpret_cast<const f2u*>(reinterpret_cast<const char*>(xb + ci * HW + (rok ? iy : 0) * W) + ix0);
     }
     const cfloat* wr = opaque(wT + cb * CB + (ci * KS + ky) * KS * CO);
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(HDN_BLOCK, 2) void trunk_stem_kernel(const float* _
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
       const float2v v = raw[i];
-      const float2v own = float2v{(sh ? v.y : v.x) * (ok0 * rk[i]), v.y * (ok1 * rk[i])};  // zero padding (finite inputs: 0 * v = 0)
+      const float2v own = float2v{ok0 && rk[i] ? (sh ? v.y : v.x) : 0.f, ok1 && rk[i] ? v.y : 0.f};  // zero padding: selected, not multiplied
       xv[i][1] = float2v{from_prev_lane(own.x), from_prev_lane(own.y)};
       xv[i][0] = float2v{0.f, from_prev_lane(xv[i][1].y)};
       xv[i][2] = own;
