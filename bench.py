@@ -309,6 +309,12 @@ def main():
             "pairs_per_gpu": PAIRS,
             "channels": C,
             "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective except the offsets all-gather",
+            "streams": {"inline": "one stream",
+                        "after-north": "two streams: the homography head (PreShareFeature, DLT+warp, scores) runs beside the 13x13 and "
+                                       "5x5 correlation launches, the 31x31 launch alone (kernel durations of the two streams overlap: "
+                                       "their sum exceeds the step)",
+                        "parallel": "two streams: the homography head runs beside all three correlation launches"}[
+                            "inline" if args.only_north else args.head_stream],
         },
         "roofline": {
             "kernel": "hdn::%s (hdn_xcorr_depthwise_f32, 31x31 (x) 61x61, variant %s)" % (north_kernel, north_variant),
