@@ -1,6 +1,6 @@
 """Experiment: where does the full head's time go, and does the BN-folded NHWC trunk help inside it?"""
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import hdn_amd
 from hdn_amd.homo_model import homo_stages, _regress
 dev = torch.device("cuda:0")

@@ -1,6 +1,6 @@
 """Experiment: is the 31x31 (x) 61x61 kernel clock/power limited?  Time it on random, constant and zero data."""
 import sys, os, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import hdn_amd
 dev = torch.device("cuda:0")
 def timeit(x, k, iters=20):

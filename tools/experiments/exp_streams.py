@@ -1,6 +1,6 @@
 """Experiment: overlap the FMA-bound 31x31 (x) 61x61 correlation with the HBM-bound kernels of the step on two streams."""
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import hdn_amd
 from hdn_amd import xcorr as X, share_feature as SF, homography as G
 import bench

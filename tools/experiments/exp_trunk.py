@@ -1,7 +1,7 @@
 """Experiment: PyTorch-ROCm trunk variants at B=64 (ResNet-34 @127x127, fp32), one fresh process per variant:
     python tools/experiments/exp_trunk.py <benchmark 0|1> <asis|folded|nhwc>"""
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from hdn_amd.trunk import resnet34_homo, fold_for_inference
 if len(sys.argv) < 3:
     import subprocess

@@ -1,6 +1,6 @@
 """Experiment: step time of the bench step as a function of how long the GPU has been busy (clock / power ramp)."""
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import hdn_amd
 from hdn_amd import xcorr as X, share_feature as SF, homography as G
 import bench
