@@ -232,8 +232,12 @@ __global__ __launch_bounds__(HDN_BLOCK) void xcorr_prod29_kernel(XcorrPtrs P, in
         // element e of the group lives at e + (SX - WX) * (e / WX): the planes of a group are consecutive rows and
         // LPLANE = HX * SX, so one division per 16-byte chunk and a carry per element do the whole re-striding
         const int e0 = 4 * i4, row0 = e0 / WX, c0 = e0 - row0 * WX;
+        if (c0 + 3 < WX) {  // the four floats stay in one row: one aligned 16-byte store (e0 and (SX - WX) * row0 are multiples of 4)
+          *reinterpret_cast<float4*>(sx + e0 + (SX - WX) * row0) = r[q];
+        } else {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) sx[e0 + t + (SX - WX) * (row0 + (c0 + t >= WX ? 1 : 0))] = v[t];
+          for (int t = 0; t < 4; ++t) sx[e0 + t + (SX - WX) * (row0 + (c0 + t >= WX ? 1 : 0))] = v[t];
+        }
       }
     }
   } else {
