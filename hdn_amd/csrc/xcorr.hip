@@ -309,9 +309,9 @@ constexpr int LDS_FLOATS = XFLOATS + PPB * OPLANE;   // 8,784 floats = 35 KB: 4 
 
 __global__ __launch_bounds__(HDN_BLOCK) void xcorr_cfg5_kernel(XcorrPtrs P, int planes) {
   using namespace cfg5;
-  __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
+  __shared__ __attribute__((aligned(16))) float smem[XFLOATS];
   float* sx = smem;
-  float* so = smem + XFLOATS;
+  float* so = smem;  // the outputs are staged OVER the inputs once every wave is done reading (19.8 KB: 8 workgroups per CU)
 
   const int tid = threadIdx.x;
   const int lane = tid & (HDN_WAVE - 1);
@@ -329,10 +329,10 @@ __global__ __launch_bounds__(HDN_BLOCK) void xcorr_cfg5_kernel(XcorrPtrs P, int 
   if (tid < WX + 4) sx[PPB * XPLANE + tid] = 0.f;  // the pad row (read by dropped outputs only; kept finite)
   __syncthreads();
 
+  float accs[2][TH];
   if (wave < np) {  // wave-uniform
     const float* __restrict__ kp = k + size_t(plane0 + wave) * KPLANE;  // wave-uniform -> scalar loads
     const float* xs = sx + wave * XPLANE;
-    float* os = so + wave * OPLANE;
     const int j = min(lane & 31, WO - 1);
 #pragma unroll
     for (int rd = 0; rd < 2; ++rd) {
@@ -353,11 +353,20 @@ __global__ __launch_bounds__(HDN_BLOCK) void xcorr_cfg5_kernel(XcorrPtrs P, int 
           for (int t = 0; t < TH; ++t) acc[t] = __builtin_fmaf(col[t + u], kv, acc[t]);
         }
       }
-      if ((lane & 31) < WO) {
 #pragma unroll
-        for (int t = 0; t < TH; ++t)
-          if (TH * b + t < HO) os[(TH * b + t) * WO + j] = acc[t];
-      }
+      for (int t = 0; t < TH; ++t) accs[rd][t] = acc[t];
+    }
+  }
+  __syncthreads();  // nobody reads the inputs any more
+  if (wave < np && (lane & 31) < WO) {
+    float* os = so + wave * OPLANE;
+    const int j = lane & 31;
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+      const int b = 2 * rd + (lane >> 5);
+#pragma unroll
+      for (int t = 0; t < TH; ++t)
+        if (TH * b + t < HO) os[(TH * b + t) * WO + j] = accs[rd][t];
     }
   }
   __syncthreads();
