@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libhdn_hip.so"
 LIB_PATH = os.environ.get("HDN_LIB_PATH", os.path.join(_HERE, LIB_NAME))  # override: A/B builds of the kernels
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _c_float_p = ctypes.c_void_p  # device pointers travel as integers
 _i = ctypes.c_int
@@ -43,6 +43,8 @@ SIGNATURES = {
     "hdn_frame_warp_perspective_u8": (_i, [_c_float_p] * 3 + [_i] * 3 + [ctypes.c_void_p]),
     "hdn_frame_warp_affine_cubic_u8": (_i, [_c_float_p] * 3 + [_i] * 3 + [ctypes.c_void_p]),
     "hdn_remap_linear_f32": (_i, [_c_float_p] * 4 + [_i] * 5 + [ctypes.c_void_p]),
+    "hdn_similarity_translation_f32": (_i, [_c_float_p] * 6 + [_i, _i, ctypes.c_double, ctypes.c_float, ctypes.c_double, ctypes.c_void_p]),
+    "hdn_similarity_logpolar_f32": (_i, [_c_float_p] * 5 + [_i, _i, ctypes.c_float, ctypes.c_double, ctypes.c_float, ctypes.c_void_p]),
     "hdn_trunk_stem_f32": (_i, [_c_float_p] * 4 + [_i] * 4 + [ctypes.c_void_p]),
     "hdn_allgather_offsets": (_i, [_c_float_p] * 2 + [_i, ctypes.c_void_p, ctypes.c_void_p]),
     "hdn_rccl_available": (_i, []),

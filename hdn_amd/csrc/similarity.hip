@@ -1,0 +1,160 @@
+// Decode of the similarity branch's head maps on the device (BASELINE configs[3]).
+//
+//   hdn_similarity_translation_f32   hdnTrackerHomo.track_new, hdn/tracker/hdn_tracker_proj_e2e.py:169-186:
+//                                    _convert_score (hdn/tracker/hdn_tracker.py:84-91), _convert_c (hdn/tracker/base_tracker.py:54-59),
+//                                    Hanning-window blend (cfg.TRACK.WINDOW_INFLUENCE), argmax, the 0.05 gate, centre shift
+//   hdn_similarity_logpolar_f32      :197-214: _convert_score of the log-polar head, argmax, _convert_logpolar_simi
+//                                    (hdn_tracker.py:51-67), the 0.25 gate, scale_delta / rot_delta, H_sim =
+//                                    rot_scale_around_center_shift_tran (hdn/utils/transform.py:250-298), plus what the rest of the
+//                                    frame needs from them: the rotate-back matrix of img_rot_around_center (:223, transform.py:69-100)
+//                                    and the crop parameters of get_subwindow_for_homo (:224-227)
+//
+// The reference does this in numpy after four .cpu().numpy() reads per frame; here the maps never leave the device and the
+// results land in a small float64 state record that the crop / warp kernels of frame.hip read directly, so the whole frame
+// stays capturable in one hipGraph.  One wave per pair; dtypes follow the reference statement by statement (float32 scores and
+// regression values, float64 window blend and geometry); every multiply / add is individually rounded (contraction off).
+#include <math.h>
+
+#include "hdn_common.h"
+
+#pragma clang fp contract(off)
+
+namespace hdn {
+
+// softmax(1)[:, 1] of a 2-class logit pair as ATen's vectorised CPU kernel forms it: exp(x - max) for both, times 1 / sum.
+__device__ __forceinline__ float softmax2_class1(float x0, float x1) {
+  const float m = fmaxf(x0, x1);
+  const float e0 = expf(rn_sub(x0, m)), e1 = expf(rn_sub(x1, m));
+  return rn_mul(e1, rn_div(1.0f, rn_add(e0, e1)));
+}
+
+// np.argmax: the largest value, the lowest index among equals.
+__device__ __forceinline__ void wave_argmax(double& v, int& i) {
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) {
+    const double ov = __shfl_xor(v, s);
+    const int oi = __shfl_xor(i, s);
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+  }
+}
+
+__global__ __launch_bounds__(HDN_WAVE) void similarity_translation_kernel(const float* __restrict__ cls, const float* __restrict__ loc_c,
+                                                                          const double* __restrict__ window, const float* __restrict__ points,
+                                                                          const double* __restrict__ seq, double* __restrict__ state, int S,
+                                                                          double window_influence, float stride_c, double exemplar) {
+  const int b = blockIdx.x, lane = threadIdx.x, n = S * S;
+  cls += size_t(b) * 2 * n;
+  loc_c += size_t(b) * 2 * n;
+  seq += size_t(b) * HDN_SIM_SEQ_DOUBLES;
+  state += size_t(b) * HDN_SIM_STATE_DOUBLES;
+  const float keep = (float)(1.0 - window_influence);  // score (float32 array) * python float stays float32
+  double best = -INFINITY;
+  int best_i = 0x7fffffff;
+  for (int i = lane; i < n; i += HDN_WAVE) {
+    const float sc = softmax2_class1(cls[i], cls[n + i]);
+    const double ps = (double)rn_mul(sc, keep) + window[i] * window_influence;
+    if (ps > best) { best = ps; best_i = i; }  // ascending i per lane: the first maximum stays
+  }
+  wave_argmax(best, best_i);
+  if (lane == 0) {
+    const double scale_z = exemplar / seq[2];
+    double dcx = 0.0, dcy = 0.0, stop = 0.0;
+    if (best < 0.05) {
+      stop = 1.0;
+    } else {
+      const float px = rn_sub(points[2 * best_i], rn_mul(loc_c[best_i], stride_c));
+      const float py = rn_sub(points[2 * best_i + 1], rn_mul(loc_c[n + best_i], stride_c));
+      dcx = (double)px / scale_z;
+      dcy = (double)py / scale_z;
+    }
+    const double cx = dcx + seq[0], cy = dcy + seq[1];
+    state[0] = dcx; state[1] = dcy; state[2] = cx; state[3] = cy; state[4] = stop;
+    state[5] = (double)softmax2_class1(cls[best_i], cls[n + best_i]);  // best_score = score[best_idx] (:205)
+    state[6] = (double)best_i; state[7] = best;
+    // parameters of the second search crop, get_subwindow(img, self.center_pos, INSTANCE_SIZE, s_x, avg) (:191-193)
+    state[8] = cx; state[9] = cy; state[10] = seq[3]; state[11] = seq[5]; state[12] = seq[6]; state[13] = seq[7];
+  }
+}
+
+__device__ __forceinline__ void mat3_mul(const double* a, const double* b, double* o) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[3 * r + c] = (a[3 * r] * b[c] + a[3 * r + 1] * b[3 + c]) + a[3 * r + 2] * b[6 + c];
+}
+
+__global__ __launch_bounds__(HDN_WAVE) void similarity_logpolar_kernel(const float* __restrict__ cls_lp, const float* __restrict__ loc_lp,
+                                                                       const float* __restrict__ points_lp, const double* __restrict__ seq,
+                                                                       double* __restrict__ state, int S, float stride_lp, double mag,
+                                                                       float rot_unit) {
+  const int b = blockIdx.x, lane = threadIdx.x, n = S * S;
+  cls_lp += size_t(b) * 2 * n;
+  loc_lp += size_t(b) * 4 * n;
+  seq += size_t(b) * HDN_SIM_SEQ_DOUBLES;
+  state += size_t(b) * HDN_SIM_STATE_DOUBLES;
+  double best = -INFINITY;  // (float32 scores compared as doubles: exact)
+  int best_i = 0x7fffffff;
+  for (int i = lane; i < n; i += HDN_WAVE) {
+    const double sc = (double)softmax2_class1(cls_lp[i], cls_lp[n + i]);
+    if (sc > best) { best = sc; best_i = i; }
+  }
+  wave_argmax(best, best_i);
+  if (lane == 0) {
+    const double dcx = state[0], dcy = state[1], cx = state[2], cy = state[3];
+    double scale_delta = 1.0, rot_delta = 0.0;  // sim_lp = [1, 1, 0, 0]: 1 * cur_sz / init_s_z == 1 exactly
+    if (!(state[4] != 0.0 || best < 0.25)) {
+      const float d0 = rn_sub(points_lp[2 * best_i], rn_mul(loc_lp[best_i], stride_lp));
+      const float d2 = rn_sub(points_lp[2 * best_i + 1], rn_mul(loc_lp[2 * n + best_i], stride_lp));
+      const float sc = (float)exp((double)d0 * mag);  // np.exp(float32 * np.float64) stored into the float32 array
+      scale_delta = ((double)sc * seq[2]) / seq[2];   // sim_lp[0] * cur_sz / self.init_s_z, cur_sz = init_s_z (:158,206)
+      rot_delta = (double)rn_mul(d2, rot_unit);
+    }
+    // rot_scale_around_center_shift_tran(cx, cy, rot_delta, scale_delta, delta_cx, delta_cy)
+    double tran[9] = {1, 0, dcx, 0, 1, dcy, 0, 0, 1}, tmp[9];
+    if (fabs(scale_delta) > 0 && scale_delta != 1.0) {
+      const double ms[9] = {scale_delta, 0, cx * (1 - scale_delta), 0, scale_delta, cy * (1 - scale_delta), 0, 0, 1};
+      mat3_mul(ms, tran, tmp);
+#pragma unroll
+      for (int q = 0; q < 9; ++q) tran[q] = tmp[q];
+    }
+    if (fabs(rot_delta) > 0) {
+      const double cc = cos(rot_delta), ss = sin(rot_delta);
+      const double mr[9] = {cc, -ss, (cx - cx * cc) + cy * ss, ss, cc, (cy - cy * cc) - cx * ss, 0, 0, 1};
+      mat3_mul(mr, tran, tmp);
+#pragma unroll
+      for (int q = 0; q < 9; ++q) tran[q] = tmp[q];
+    }
+    state[16] = scale_delta; state[17] = rot_delta; state[18] = (double)best_i; state[19] = best;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) state[20 + q] = tran[q];
+    // img_rot_around_center(img, cx, cy, w, h, -rot_delta): the 2x3 matrix handed to cv2.warpAffine (transform.py:81-97)
+    const double cc = cos(-rot_delta), ss = sin(-rot_delta);
+    state[32] = cc; state[33] = -ss; state[34] = (cx - cx * cc) + cy * ss;
+    state[35] = ss; state[36] = cc;  state[37] = (cy - cy * cc) - cx * ss;
+    // get_subwindow_for_homo(rot_img_homo, self.center_pos, EXEMPLAR_SIZE, self.init_s_z_sm * scale_delta, avg) (:224-227)
+    state[40] = cx; state[41] = cy; state[42] = seq[4] * scale_delta; state[43] = seq[5]; state[44] = seq[6]; state[45] = seq[7];
+  }
+}
+
+}  // namespace hdn
+
+extern "C" int hdn_similarity_translation_f32(const float* cls, const float* loc_c, const double* window, const float* points,
+                                              const double* seq, double* state, int B, int S, double window_influence, float stride_c,
+                                              double exemplar_size, void* stream) {
+  if (!cls || !loc_c || !window || !points || !seq || !state) return HDN_E_NULL;
+  if (B <= 0 || S <= 0 || !(exemplar_size > 0)) return HDN_E_SHAPE;
+  if (S > 1024) return HDN_E_LIMIT;
+  hipLaunchKernelGGL(hdn::similarity_translation_kernel, dim3(B), dim3(HDN_WAVE), 0, (hipStream_t)stream, cls, loc_c, window, points, seq, state,
+                     S, window_influence, stride_c, exemplar_size);
+  return hdn::launch_status();
+}
+
+extern "C" int hdn_similarity_logpolar_f32(const float* cls_lp, const float* loc_lp, const float* points_lp, const double* seq, double* state,
+                                           int B, int S, float stride_lp, double mag, float rot_unit, void* stream) {
+  if (!cls_lp || !loc_lp || !points_lp || !seq || !state) return HDN_E_NULL;
+  if (B <= 0 || S <= 0) return HDN_E_SHAPE;
+  if (S > 1024) return HDN_E_LIMIT;
+  hipLaunchKernelGGL(hdn::similarity_logpolar_kernel, dim3(B), dim3(HDN_WAVE), 0, (hipStream_t)stream, cls_lp, loc_lp, points_lp, seq, state, S,
+                     stride_lp, mag, rot_unit);
+  return hdn::launch_status();
+}

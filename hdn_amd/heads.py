@@ -98,8 +98,9 @@ def _param_versions(branches):
 
 
 def invalidate_template_cache(head):
-    """Drop the cached template-branch features of a MultiBAN / MultiCircBAN (hooked by install() into
-    ModelBuilder.template(); call it yourself after mutating weights through .data)."""
+    """Drop the cached template-branch features of a MultiBAN / MultiCircBAN.  install() wraps ModelBuilder.template() so that
+    every new template calls this for both heads; call it yourself after mutating weights through .data (which bypasses the
+    version counters the cache is keyed on) without re-running template()."""
     object.__setattr__(head, "_hdn_template_cache", None)
 
 

@@ -15,11 +15,17 @@ attribute the reference resolves at call time:
     ModelBuilder.track_proj                              replaced by the fused version
     hdn.models.logpolar.STN_Polar (+ its from-import in model_builder…:24)   device-resident log-polar sampler
     MultiBAN.forward / MultiCircBAN.forward              one correlation launch per head + cached template branch
+    ModelBuilder.track_new_lp                            same ops, the zero `polar` argument cached on the device (:145: a pageable
+                                                         host->device copy per frame, which a hipGraph capture cannot hold)
+    ModelBuilder.template                                unchanged, then drops the heads' cached template-branch features
+    hdn.tracker.tracker_builder.TRACKS['hdnTrackerHomoProje2e']   (install(tracker=True)) the device-resident tracker loop
 """
 from __future__ import annotations
 
 import importlib
 import types
+
+import torch
 
 from . import heads, homo_model, homography, logpolar, share_feature, xcorr
 
@@ -50,6 +56,32 @@ REBINDINGS = (
 def _track_proj_method(self, data, tmp_mask):
     """ModelBuilder.track_proj with the fused stages; self.hm_net supplies ShareFeature/backbone/avgpool/fc."""
     return homo_model.track_proj(self.hm_net, data, tmp_mask)
+
+
+def _track_new_lp_method(self, x, delta=[0, 0]):
+    """ModelBuilder.track_new_lp (model_builder_e2e_unconstrained_v2.py:144-158), statement for statement, except that the
+    all-zero `polar` lives on the device instead of being built on the host and uploaded every frame."""
+    polar = getattr(self, "_hdn_polar0", None)
+    if polar is None or polar.device != x.device or polar.shape[0] != x.shape[0]:
+        polar = torch.zeros((x.shape[0], 2), dtype=torch.float32, device=x.device)
+        object.__setattr__(self, "_hdn_polar0", polar)
+    x_lp, grid = self.logpolar_instance(x, polar, delta)
+    xf_lp = self.feature_extractor(x_lp)
+    if hasattr(self, "neck_lp"):          # cfg.ADJUST.ADJUST (the constructor creates the necks under the same condition, :45-49)
+        xf_lp = self.neck_lp(xf_lp)
+    cls_lp, loc_lp = self.head_lp(self.zf_lp, xf_lp)
+    return {"x_lp": x_lp, "cls_lp": cls_lp, "loc_lp": loc_lp, "grid": grid}
+
+
+def _make_template_method(orig):
+    def template(self, z):
+        out = orig(self, z)
+        for name in ("head", "head_lp"):
+            if hasattr(self, name):
+                heads.invalidate_template_cache(getattr(self, name))
+        return out
+    template._hdn_wraps = orig
+    return template
 
 
 _MISSING = object()
@@ -87,8 +119,11 @@ def uninstall() -> int:
     return n
 
 
-def install(strict: bool = False, modules: dict = None) -> list:
-    """Apply the rebindings.  `modules` (name -> module) lets tests supply stand-in modules; by default the
+def install(strict: bool = False, modules: dict = None, tracker: bool = False) -> list:
+    """Apply the rebindings.  tracker=True also registers hdn_amd.tracker.DeviceTrackerHomo under
+    TRACKS['hdnTrackerHomoProje2e'] (hdn/tracker/tracker_builder.py:12-19), so build_tracker(model) of tools/test.py:72 /
+    tools/demo.py returns the device-resident loop (frames uploaded once, crops / warps / decodes as kernels, one host read per
+    frame) instead of the host-side one.  `modules` (name -> module) lets tests supply stand-in modules; by default the
     real reference modules are imported.  Returns the list of (module, attribute) pairs that were rebound;
     with strict=True a site that cannot be imported raises instead of being skipped.  uninstall() reverses it."""
     done = []
@@ -131,4 +166,21 @@ def install(strict: bool = False, modules: dict = None) -> list:
     if mb is not None and hasattr(mb, "ModelBuilder"):
         _rebind(mb.ModelBuilder, "track_proj", _track_proj_method)
         done.append(("hdn.models.model_builder_e2e_unconstrained_v2", "ModelBuilder.track_proj"))
+        if "track_new_lp" in mb.ModelBuilder.__dict__:
+            _rebind(mb.ModelBuilder, "track_new_lp", _track_new_lp_method)
+            done.append(("hdn.models.model_builder_e2e_unconstrained_v2", "ModelBuilder.track_new_lp"))
+        orig_t = mb.ModelBuilder.__dict__.get("template")
+        if orig_t is not None and not hasattr(orig_t, "_hdn_wraps"):
+            _rebind(mb.ModelBuilder, "template", _make_template_method(orig_t))
+            done.append(("hdn.models.model_builder_e2e_unconstrained_v2", "ModelBuilder.template"))
+
+    if tracker:
+        tb = get("hdn.tracker.tracker_builder")
+        if tb is None or not isinstance(getattr(tb, "TRACKS", None), dict):
+            if strict:
+                raise AttributeError("hdn.tracker.tracker_builder.TRACKS not found: reference layout changed?")
+        else:
+            from .tracker import DeviceTrackerHomo
+            _rebind(tb.TRACKS, "hdnTrackerHomoProje2e", DeviceTrackerHomo, item=True)
+            done.append(("hdn.tracker.tracker_builder", "TRACKS['hdnTrackerHomoProje2e']"))
     return done

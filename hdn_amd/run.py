@@ -16,6 +16,8 @@ Options (before the script path):
                            provides optional dependencies; the parity tests use it to stub cv2 in the build container
     --no-build             do not (re)compile the library even if its sources are newer
     --no-strict            skip rebinding sites that cannot be imported instead of failing
+    --host-tracker         keep the reference's host-side tracker loop (numpy / OpenCV crops, six syncs per frame); by default
+                           TRACKS['hdnTrackerHomoProje2e'] is the device-resident loop (hdn_amd.tracker.DeviceTrackerHomo)
 """
 from __future__ import annotations
 
@@ -34,7 +36,7 @@ def _usage(msg=None):
 
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
-    root, preload, build, strict = None, [], True, True
+    root, preload, build, strict, dev_tracker = None, [], True, True, True
     while argv and argv[0].startswith("--"):
         opt = argv.pop(0)
         if opt == "--reference-root":
@@ -45,6 +47,8 @@ def main(argv=None):
             build = False
         elif opt == "--no-strict":
             strict = False
+        elif opt == "--host-tracker":
+            dev_tracker = False
         elif opt in ("-h", "--help"):
             _usage()
         else:
@@ -77,7 +81,7 @@ def main(argv=None):
     from hdn_amd import _lib, install
 
     _lib.load()  # fail now, loudly, rather than at the first frame
-    done = install.install(strict=strict)
+    done = install.install(strict=strict, tracker=dev_tracker)
     print(f"[hdn_amd.run] {len(done)} hot-path sites rebound to libhdn_hip.so; running {script}", file=sys.stderr, flush=True)
 
     sys.argv = [script] + argv[1:]

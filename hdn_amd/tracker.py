@@ -1,56 +1,48 @@
-"""The per-frame tracker loop around the homography head, device-resident (BASELINE config 4).
+"""The per-frame tracker loop, device-resident (BASELINE config 4).
 
     HomoTracker.init(img, bbox, poly, gt_points, first_point)        <- hdnTrackerHomo.init,      hdn/tracker/hdn_tracker_proj_e2e.py:60-120
     HomoTracker.track_new(fr_idx, img, gt_box, gt_poly, gt_points)   <- hdnTrackerHomo.track_new, hdn_tracker_proj_e2e.py:141-285
+    DeviceTrackerHomo(model)                                         <- the class hdn/tracker/tracker_builder.py:12-19 registers as
+                                                                        TRACKS['hdnTrackerHomoProje2e'] (hdn_amd.install.install(tracker=True))
 
 Same call signatures and the same result dictionary ('bbox_aligned', 'best_score', 'polygon', 'points', 'bbox') as the
-reference's tracker, for the part of a frame this repository owns: undo the accumulated motion (full-frame warp by
-inv(H_total), :154), cut the 127-px homography crop (get_subwindow_for_homo + get_search_info, :223-239), run the refinement
-loop around ModelBuilder.track_proj (:242-250), un-scale / un-shift the residual (:251-258), gate it (`homo_score > 2.5`,
-:261-264), accumulate H_total and project the initial corners (:266-272).
+reference's tracker.  Per frame: undo the accumulated motion (full-frame warp by inv(H_total), :150-155); the similarity
+estimate on the stabilised frame (:157-214: search crop, ModelBuilder.track_new, decode, moved crop, track_new_lp, decode, H_sim —
+hdn_amd.similarity); rotate back and cut the 127-px homography crop (:223-239); the refinement loop around
+ModelBuilder.track_proj (:242-250); un-scale / un-shift the residual (:251-258), gate it (`homo_score > 2.5`, :261-264),
+accumulate H_total and project the initial corners (:266-272).
 
-The similarity branch (translation and log-polar scale / rotation: ResNet-50 backbone, necks, MultiBAN / MultiCircBAN heads,
-:164-214) belongs to PyTorch-ROCm and the reference's own modules (north_star); it enters here through the optional
-`similarity` callable, `similarity(frame_u8_device, center_pos) -> (delta_cx, delta_cy, scale_delta, rot_delta, best_score)`.
-Without one the similarity estimate is the identity: that is the harness configuration of tests/ and tests/tools/sequence_bench.py
-(one planar target per sequence; sequences are independent, so N GPUs run N sequences: replicas only, no collective).
+The networks of the similarity branch (ResNet-50 backbone, necks, the 3x3 / 1x1 convolutions of the heads) are PyTorch-ROCm's, as
+north_star assigns them; they are reached through `similarity` (hdn_amd.similarity.DeviceSimilarity around an object with the
+reference's ModelBuilder interface).  Without one the similarity estimate is the identity.
 
-What the reference does on the host per frame — cv2 warps of the full frame, numpy crops, three crop uploads and six
-.cpu().numpy() syncs — is here: ONE upload of the uint8 frame, kernels (hdn_amd.frame, hdn_amd.refine) and 3x3 float64
-bookkeeping on the device; the only host read is the 4 projected corners the caller asks for (`sync=True`).
+What the reference does on the host per frame — cv2 warps of the full frame, numpy crops, three crop uploads, numpy decodes of the
+head maps and six .cpu().numpy() syncs — is here ONE upload of the uint8 frame, kernels (hdn_amd.frame, .similarity, .refine) and
+3x3 float64 bookkeeping on the device; the only host read is the 4 projected corners + best_score the caller asks for
+(`sync=True`).  Nothing in the body depends on host values, so it replays as one hipGraph (`graph=True`) with or without the
+similarity branch.  Sequences are independent: N GPUs run N sequences (replicas only, no collective).
 """
 from __future__ import annotations
 
-import math
+import os
 
 import numpy as np
 import torch
 
 from . import frame as FR
 from .refine import homo_refine
-
-EXEMPLAR_SIZE = 127      # cfg.TRACK.EXEMPLAR_SIZE (hdn/core/config.py)
-CONTEXT_AMOUNT = 0.5     # cfg.TRACK.CONTEXT_AMOUNT
-
-
-def rot_scale_around_center_shift_tran(cx, cy, rot, scale, sx, sy):
-    """hdn/utils/transform.py:250-298 (host, float64)."""
-    tran = np.array([[1, 0, sx], [0, 1, sy], [0, 0, 1]], np.float64)
-    if abs(scale) > 0 and scale != 1:
-        tran = np.array([[scale, 0, cx * (1 - scale)], [0, scale, cy * (1 - scale)], [0, 0, 1]], np.float64) @ tran
-    if abs(rot) > 0:
-        cc, ss = math.cos(rot), math.sin(rot)
-        tran = np.array([[cc, -ss, cx - cx * cc + cy * ss], [ss, cc, cy - cy * cc - cx * ss], [0, 0, 1]], np.float64) @ tran
-    return tran
+from .similarity import DeviceSimilarity, TrackerConfig
 
 
 class HomoTracker:
-    def __init__(self, hm_net, iterations: int = 1, similarity=None, score_gate: float = 2.5, graph: bool = False):
+    def __init__(self, hm_net, iterations: int = 1, similarity=None, score_gate: float = 2.5, graph: bool = False, cfg: TrackerConfig = None):
         """hm_net: hdn_amd.HomoModelBuilder (or the reference's, after install()) in eval mode on the GPU.
         iterations: trip count of the refinement loop (1 in the shipped tracker, :242; 2 in BASELINE config 5).
-        graph: replay the whole per-frame body as ONE hipGraph (about 200 launches at B = 1 are launch-latency bound);
-        only without a `similarity` callable, whose host-side decisions cannot be captured."""
+        similarity: None (identity) or a DeviceSimilarity: `.init(frame, init_pos, init_s_z, init_s_z_sm, avg)` once per
+        sequence, `(stabilised_frame) -> views into its device state record` per frame (no host values).
+        graph: replay the whole per-frame body as ONE hipGraph (several hundred launches at B = 1 are launch-latency bound)."""
         self.net = hm_net
+        self.cfg = cfg or (similarity.cfg if similarity is not None and hasattr(similarity, "cfg") else TrackerConfig())
         self.use_graph = bool(graph)
         self._graph = None
         self._capturing = False
@@ -62,12 +54,13 @@ class HomoTracker:
     # -------------------------------------------------------------------------------------------------- init
     def init(self, img, bbox, poly, gt_points, first_point=None):
         """img: BGR uint8 [H,W,3]; bbox (x, y, w, h); poly (cx, cy, w, h, theta); gt_points: the 4 corners."""
+        c = self.cfg
         self.dev = next(self.net.parameters()).device
         self.init_pos = np.array([poly[0], poly[1]], np.float64)
         self.center_pos = self.init_pos.copy()
         self.size = np.array([poly[2], poly[3]], np.float64)
-        w_z = self.size[0] + CONTEXT_AMOUNT * np.sum(self.size)
-        h_z = self.size[1] + CONTEXT_AMOUNT * np.sum(self.size)
+        w_z = self.size[0] + c.context_amount * np.sum(self.size)
+        h_z = self.size[1] + c.context_amount * np.sum(self.size)
         self.init_s_z = float(np.floor(np.sqrt(w_z * h_z)))
         self.init_s_z_sm = float(np.floor(np.sqrt(self.size[0] * self.size[1])))
         frame = FR.upload(img)
@@ -77,17 +70,21 @@ class HomoTracker:
         H, W, _ = frame.shape
         self.z_crop_points_sm = FR.crop_points(self.center_pos, self.init_s_z_sm, H, W)
         # get_template_info(get_subwindow_for_homo(...)[:, 0:3]) : the normalised gray template, constant for the sequence
-        self.init_homo_tmp = FR.get_search_info(frame, self.center_pos, self.init_s_z_sm, self.channel_average)
+        self.init_homo_tmp = FR.get_search_info(frame, self.center_pos, self.init_s_z_sm, self.channel_average, model_sz=c.exemplar_size)
+        if self.similarity is not None:
+            self.similarity.init(frame, self.init_pos, self.init_s_z, self.init_s_z_sm, self.channel_average)   # model.template(z_crop), :99-107
         self.init_points = torch.tensor(np.asarray(gt_points, np.float64).reshape(-1, 2), dtype=torch.float64, device=self.dev)
         self._init_points_h = torch.cat([self.init_points, torch.ones_like(self.init_points[:, :1])], dim=1)
         self.H_total = torch.eye(3, dtype=torch.float64, device=self.dev)
         self._eye = torch.eye(3, dtype=torch.float64, device=self.dev)
+        self._zero = torch.zeros((), dtype=torch.float64, device=self.dev)
         self._const_params = FR._dev_f64([self.init_pos[0], self.init_pos[1], self.init_s_z_sm] + [float(a) for a in self.channel_average], self.dev)
         self._graph = None
         # un-scale / un-shift of the residual (:251-258) are constants of the sequence: H_homo = A @ H_hm_comp @ B
         cw = self.z_crop_points_sm[2] - self.z_crop_points_sm[0] + 1
         ch = self.z_crop_points_sm[3] - self.z_crop_points_sm[1] + 1
-        S = np.diag([EXEMPLAR_SIZE / cw, EXEMPLAR_SIZE / ch, 1.0]).astype(np.float32)          # float32, as :251-257 build them
+        E = c.exemplar_size
+        S = np.diag([E / cw, E / ch, 1.0]).astype(np.float32)          # float32, as :251-257 build them
         Sh = np.array([[1, 0, -self.z_crop_points_sm[0]], [0, 1, -self.z_crop_points_sm[1]], [0, 0, 1]], np.float32)
         A = np.linalg.inv(Sh).astype(np.float64) @ np.linalg.inv(S).astype(np.float64)           # (float32 inverses, numpy's dtype rule)
         self._A = torch.tensor(A, dtype=torch.float64, device=self.dev)
@@ -99,17 +96,24 @@ class HomoTracker:
         return (m[0, 0] * (m[1, 1] * m[2, 2] - m[1, 2] * m[2, 1]) - m[0, 1] * (m[1, 0] * m[2, 2] - m[1, 2] * m[2, 0])
                 + m[0, 2] * (m[1, 0] * m[2, 1] - m[1, 1] * m[2, 0]))
 
-    def _body(self, frame, params, H_sim, rot_delta=0.0, cx=None, cy=None):
+    def _body(self, frame):
         """Everything of a frame that runs on the device, from the uploaded frame to the 4 projected corners; no host
-        reads, no allocations that depend on data: capturable in a hipGraph when its inputs are static buffers."""
+        reads, no allocations that depend on data: capturable in a hipGraph when the frame is a static buffer.
+        -> (H_total', out float32 [9] = 4 corners (x, y) + best_score, homo_score)."""
         # :150-155  undo the accumulated motion (a singular H_total is reset to the identity, as the reference does).
         # hdn_frame_warp_perspective_u8 inverts its matrix itself (cv2 semantics), so it is handed inv(H_total) = adj / det.
         det = self._det3(self.H_total)
         Ht = torch.where(det == 0, self._eye, self.H_total)
         frame = FR.warp_perspective(frame, torch.linalg.inv(Ht).reshape(-1) if not self._capturing else self._inv3(Ht).reshape(-1))
-        # :223-239  rotate back, cut the homography crop, normalise
-        rot_img = FR.rot_around_center(frame, cx, cy, -rot_delta) if rot_delta != 0 else frame  # (rot 0: bicubic identity)
-        search = FR.get_search_info(rot_img, None, None, None, params=params)
+        if self.similarity is not None:
+            # :157-214 on the STABILISED frame; :223 rotate back by -rot_delta about the new centre (bicubic; rot 0 = identity)
+            sim = self.similarity(frame)
+            H_sim, params, best_score = sim["H_sim"], sim["params_homo"], sim["best_score"]
+            rot_img = FR.warp_affine_cubic(frame, sim["rot_matrix"])
+        else:
+            H_sim, params, best_score, rot_img = self._eye, self._const_params, self._zero, frame
+        # :224-239  cut the homography crop, normalise
+        search = FR.get_search_info(rot_img, None, None, None, model_sz=self.cfg.exemplar_size, params=params)
         # :242-250  refinement loop around track_proj
         H_comp, homo_score, _ = homo_refine(self.net, self.init_homo_tmp, search, iterations=self.iterations)
         # :251-266  un-scale, un-shift, gate, accumulate
@@ -120,7 +124,8 @@ class HomoTracker:
         # :272  cv2.perspectiveTransform(init_points, H_total)
         p = self._init_points_h @ H.T
         pts = (p[:, :2] / p[:, 2:3]).to(torch.float32)
-        return H, pts, homo_score
+        out = torch.cat([pts.reshape(-1), best_score.to(torch.float32).reshape(1)])
+        return H, out, homo_score
 
     def _inv3(self, m):
         """Closed-form 3x3 inverse from elementwise ops (graph capture cannot hold the solver call of torch.linalg.inv)."""
@@ -131,8 +136,8 @@ class HomoTracker:
         return adj / self._det3(m)
 
     def _capture(self, frame_shape):
-        """hipGraph of the whole per-frame body (similarity = identity only: its parameters are constants of the sequence).
-        The frame lands in a static device buffer; H_total is carried in a static tensor updated by the graph itself."""
+        """hipGraph of the whole per-frame body.  The frame lands in a static device buffer; H_total is carried in a static
+        tensor updated by the graph itself; the similarity state record is a static tensor of the DeviceSimilarity."""
         self._static_frame = torch.empty(frame_shape, dtype=torch.uint8, device=self.dev)
         self._capturing = True
         side = torch.cuda.Stream()
@@ -140,19 +145,18 @@ class HomoTracker:
         H0 = self.H_total.clone()
         with torch.cuda.stream(side):
             for _ in range(3):  # warm-up on the side stream (MIOpen find, lazy initialisations) without touching the state
-                self._body(self._static_frame, self._const_params, self._eye)
+                self._body(self._static_frame)
         torch.cuda.current_stream().wait_stream(side)
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
-            H, pts, score = self._body(self._static_frame, self._const_params, self._eye)
+            H, out, score = self._body(self._static_frame)
             self.H_total.copy_(H)            # the recurrence lives inside the graph
-            self._g_pts, self._g_score = pts, score
+            self._g_out, self._g_score = out, score
         self.H_total.copy_(H0)
         self._capturing = False
 
     def track_new(self, fr_idx, img, gt_box=None, gt_poly=None, gt_points=None, sync: bool = True):
-        best_score = 0.0
-        if self.use_graph and self.similarity is None:
+        if self.use_graph:
             t = img if isinstance(img, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(img))
             if self._graph is None:
                 self._capture(tuple(t.shape))
@@ -160,26 +164,39 @@ class HomoTracker:
                 raise ValueError(f"graph mode was captured for uint8 frames of shape {tuple(self._static_frame.shape)}, got {t.dtype} {tuple(t.shape)}")
             self._static_frame.copy_(t, non_blocking=True)
             self._graph.replay()
-            pts, homo_score = self._g_pts, self._g_score
+            out, homo_score = self._g_out, self._g_score
+            if not sync:  # the graph's static outputs are overwritten by the next replay: hand out copies
+                out, homo_score = out.clone(), homo_score.clone()
         else:
-            frame = FR.upload(img)
-            cx0, cy0 = self.init_pos
-            if self.similarity is not None:
-                dcx, dcy, scale_delta, rot_delta, best_score = self.similarity(frame, self.init_pos)
-                cx, cy = cx0 + dcx, cy0 + dcy
-                self.center_pos = np.array([cx, cy], np.float64)
-                H_sim = torch.tensor(rot_scale_around_center_shift_tran(cx, cy, rot_delta, scale_delta, dcx, dcy),
-                                     dtype=torch.float64).to(self.dev, non_blocking=True)
-                params = FR._dev_f64([cx, cy, self.init_s_z_sm * scale_delta] + [float(a) for a in self.channel_average], self.dev)
-                H, pts, homo_score = self._body(frame, params, H_sim, rot_delta, cx, cy)
-            else:
-                H, pts, homo_score = self._body(frame, self._const_params, self._eye)
+            H, out, homo_score = self._body(FR.upload(img))
             self.H_total = H
+        pts = out[:8].view(4, 2)
         self.last_points, self.last_score = pts, homo_score
         if not sync:
-            return {"points": pts, "polygon": pts, "best_score": best_score}
-        pn = pts.cpu().numpy()
+            return {"points": pts, "polygon": pts, "best_score": out[8]}
+        host = out.cpu().numpy()
         self.host_syncs += 1
+        pn, best_score = host[:8].reshape(4, 2), host[8]
         mx, mn = pn.max(0), pn.min(0)
         bbox = [mn[0], mn[1], mx[0] - mn[0], mx[1] - mn[1]]
         return {"bbox_aligned": bbox, "best_score": best_score, "polygon": pn, "points": pn, "bbox": bbox}
+
+
+class DeviceTrackerHomo(HomoTracker):
+    """Drop-in for hdnTrackerHomo (hdn_tracker_proj_e2e.py:22-285) behind build_tracker(model)
+    (hdn/tracker/tracker_builder.py:18-19): same constructor argument, same init / track_new signatures and result keys.
+    `model` is the reference's ModelBuilder (hm_net = the homography estimator, template / track_new / track_new_lp = the
+    similarity branch).  HDN_TRACKER_GRAPH=1 replays each frame as one hipGraph."""
+
+    def __init__(self, model, graph: bool = None, iterations: int = 1):
+        cfg = TrackerConfig()
+        try:
+            from hdn.core.config import cfg as ref_cfg     # the reference's node, after tools/test.py merged the YAML
+            cfg = TrackerConfig.from_reference(ref_cfg)
+        except ImportError:
+            pass
+        if graph is None:
+            graph = os.environ.get("HDN_TRACKER_GRAPH", "0") not in ("", "0")
+        model.eval()
+        self.model = model
+        super().__init__(model.hm_net, iterations=iterations, similarity=DeviceSimilarity(model, cfg), graph=graph, cfg=cfg)

@@ -32,7 +32,7 @@ extern "C" {
 /* RCCL failures are returned as -(2000 + ncclResult_t). */
 
 /* ABI version of this header; hdn_abi_version() of the loaded library must match. */
-#define HDN_ABI_VERSION 2
+#define HDN_ABI_VERSION 3
 int hdn_abi_version(void);
 
 /* Name of the kernel variant the last hdn_xcorr_* call on this thread dispatched to
@@ -217,6 +217,38 @@ int hdn_frame_warp_perspective_u8(const unsigned char* src, const double* M, uns
 int hdn_frame_warp_affine_cubic_u8(const unsigned char* src, const double* M, unsigned char* dst, int H, int W, int C, void* stream);
 int hdn_remap_linear_f32(const float* src, const float* mapx, const float* mapy, float* dst, int C, int Hs, int Ws, int Hd, int Wd,
                          void* stream);
+
+/*
+ * Decode of the similarity branch's head maps (BASELINE configs[3]: the tracker loop), one wave per
+ * pair, nothing leaves the device.  Replaces the numpy half of hdnTrackerHomo.track_new between the two network calls and the
+ * homography crop, hdn/tracker/hdn_tracker_proj_e2e.py:169-186 and :197-214, i.e. hdnTracker._convert_score
+ * (hdn/tracker/hdn_tracker.py:84-91), SiameseTracker._convert_c (hdn/tracker/base_tracker.py:54-59), the Hanning-window blend /
+ * argmax / 0.05 gate, hdnTracker._convert_logpolar_simi (hdn_tracker.py:51-67), the 0.25 gate and
+ * rot_scale_around_center_shift_tran (hdn/utils/transform.py:250-298) — with their four .cpu().numpy() reads per frame.
+ *
+ * seq[B][HDN_SIM_SEQ_DOUBLES] (float64, constants of a sequence, written by the host at init):
+ *   [0] init_pos.x  [1] init_pos.y  [2] init_s_z  [3] s_x = floor(init_s_z * round(INSTANCE / EXEMPLAR))  [4] init_s_z_sm
+ *   [5..7] channel_average (B, G, R)
+ * state[B][HDN_SIM_STATE_DOUBLES] (float64, written by the two calls, read by hdn_subwindow_f32 / hdn_frame_warp_affine_cubic_u8
+ * and the caller's 3x3 bookkeeping):
+ *   translation call: [0] delta_cx [1] delta_cy [2] cx [3] cy [4] stop_update_flag [5] best_score = score[best_idx]
+ *                     [6] best_idx [7] pscore[best_idx]  [8..13] hdn_subwindow_f32 params of the moved search crop (cx, cy, s_x, avg)
+ *   log-polar call:   [16] scale_delta [17] rot_delta [18] best_idx_lp [19] score_lp[best_idx_lp]  [20..28] H_sim (row major)
+ *                     [32..37] 2x3 matrix of img_rot_around_center(img, cx, cy, w, h, -rot_delta) (transform.py:69-100)
+ *                     [40..45] hdn_subwindow_f32 params of the homography crop (cx, cy, init_s_z_sm * scale_delta, avg)
+ * cls[B,2,S,S], loc_c[B,2,S,S], cls_lp[B,2,S,S], loc_lp[B,4,S,S]: the heads' outputs (ModelBuilder.track_new / track_new_lp,
+ * hdn/models/model_builder_e2e_unconstrained_v2.py:131-158).  window[S*S] float64 and points[S*S,2] float32: the tables the
+ * reference's constructor builds (hdn_tracker_proj_e2e.py:26-32).  mag = log(EXEMPLAR / 2) / EXEMPLAR and
+ * rot_unit = (float)(2 pi / EXEMPLAR) are passed in as the host computed them.  The log-polar call reads the state record the
+ * translation call wrote.  np.argmax semantics (first maximum); NaN logits are not ordered the way numpy orders them.
+ */
+#define HDN_SIM_SEQ_DOUBLES 8
+#define HDN_SIM_STATE_DOUBLES 48
+int hdn_similarity_translation_f32(const float* cls, const float* loc_c, const double* window, const float* points, const double* seq,
+                                   double* state, int B, int S, double window_influence, float stride_c, double exemplar_size,
+                                   void* stream);
+int hdn_similarity_logpolar_f32(const float* cls_lp, const float* loc_lp, const float* points_lp, const double* seq, double* state, int B,
+                                int S, float stride_lp, double mag, float rot_unit, void* stream);
 
 /*
  * First stage of the homography regressor's trunk, fused:

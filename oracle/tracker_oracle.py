@@ -1,6 +1,7 @@
 """TEST INFRASTRUCTURE ONLY: CPU restatement (numpy + PyTorch-CPU) of the tracker loop hdn_amd.tracker.HomoTracker runs on
 the device, i.e. of hdnTrackerHomo.init / track_new (hdn/tracker/hdn_tracker_proj_e2e.py:60-120,141-285) for the stages in
-scope, with the similarity estimate fixed to the identity.  Built from oracle/frame_oracle.py (crops pinned, OpenCV pieces
+scope; the similarity estimate is the identity unless a `similarity` callable is given (SimilarityOracle below restates
+hdn_tracker_proj_e2e.py:164-214 and is pinned to tests/golden/similarity.npz).  Built from oracle/frame_oracle.py (crops pinned, OpenCV pieces
 restated and unpinned) and oracle/hdn_oracle.py (head pinned to the reference's goldens)."""
 from __future__ import annotations
 
@@ -11,17 +12,150 @@ from . import frame_oracle as F
 from . import hdn_oracle as O
 
 
+EXEMPLAR_SIZE, INSTANCE_SIZE, STRIDE, STRIDE_LP, BASE_SIZE, OUTPUT_SIZE_LP = 127, 255, 8, 8, 8, 13   # hdn/core/config.py
+WINDOW_INFLUENCE = 0.1632532824922313   # experiments/tracker_homo_config/proj_e2e_GOT_unconstrained_v2.yaml (config.py:530 default 0.45)
+CONTEXT_AMOUNT = 0.5
+
+
+def generate_points(stride, size):
+    """hdnTracker.generate_points / generate_points_lp (hdn/tracker/hdn_tracker.py:32-49): cell centres, float32 [size*size, 2]."""
+    ori = -(size // 2) * stride
+    x, y = np.meshgrid([ori + stride * dx for dx in np.arange(0, size)], [ori + stride * dy for dy in np.arange(0, size)])
+    points = np.zeros((size * size, 2), dtype=np.float32)
+    points[:, 0], points[:, 1] = x.astype(np.float32).flatten(), y.astype(np.float32).flatten()
+    return points
+
+
+def hanning_window(score_size):
+    """hdn_tracker_proj_e2e.py:26-29: np.outer(np.hanning(n), np.hanning(n)).flatten(), float64."""
+    h = np.hanning(score_size)
+    return np.outer(h, h).flatten()
+
+
+def convert_score(score):
+    """hdnTracker._convert_score (hdn_tracker.py:84-91), cls_out_channels = 2: softmax over the two classes, class 1."""
+    score = score.permute(1, 2, 3, 0).contiguous().view(2, -1).permute(1, 0)
+    return score.softmax(1).detach()[:, 1].cpu().numpy()
+
+
+def convert_c(delta, point):
+    """SiameseTracker._convert_c (base_tracker.py:54-59)."""
+    delta = delta.permute(1, 2, 3, 0).contiguous().view(2, -1).detach().cpu().numpy().copy()
+    delta[0, :] = point[:, 0] - delta[0, :] * 8
+    delta[1, :] = point[:, 1] - delta[1, :] * 8
+    return delta
+
+
+def convert_logpolar_simi(delta, point):
+    """hdnTracker._convert_logpolar_simi (hdn_tracker.py:51-67): rows (scale, scale, rotation, unused)."""
+    delta = delta.permute(1, 2, 3, 0).contiguous().view(4, -1).detach().cpu().numpy().copy()
+    delta[2, :] = point[:, 1] - delta[2, :] * STRIDE_LP
+    delta[3, :] = point[:, 1] + delta[3, :] * STRIDE_LP
+    delta[0, :] = point[:, 0] - delta[0, :] * STRIDE_LP
+    delta[1, :] = point[:, 0] + delta[1, :] * STRIDE_LP
+    scale = delta[0, :]
+    rotation = delta[2, :]
+    rotation = rotation * (2 * np.pi / EXEMPLAR_SIZE)
+    mag = np.log(EXEMPLAR_SIZE / 2) / EXEMPLAR_SIZE
+    delta[0, :] = np.exp(scale * mag)        # (float32 array * np.float64 scalar: float64 under NumPy 2, stored back as float32)
+    delta[1, :] = delta[0, :]
+    delta[2, :] = rotation
+    return delta
+
+
+def rot_scale_around_center_shift_tran(cx, cy, rot, scale, sx, sy):
+    """hdn/utils/transform.py:250-298, float64."""
+    import math
+    tran = np.array([[1, 0, sx], [0, 1, sy], [0, 0, 1]]).astype(np.float64)
+    if abs(scale) > 0 and scale != 1:
+        tran = np.array([[scale, 0, cx * (1 - scale)], [0, scale, cy * (1 - scale)], [0, 0, 1]]).astype(np.float64) @ tran
+    if abs(rot) > 0:
+        cc, ss = math.cos(rot), math.sin(rot)
+        tran = np.array([[cc, -ss, cx - cx * cc + cy * ss], [ss, cc, cy - cy * cc - cx * ss], [0, 0, 1]]).astype(np.float64) @ tran
+    return tran
+
+
+def decode_translation(cls, loc_c, window, points, init_s_z, window_influence=WINDOW_INFLUENCE):
+    """hdn_tracker_proj_e2e.py:169-186: score, window blend, argmax, the 0.05 gate -> (center [2] in frame pixels, stop flag, ...)."""
+    scale_z = EXEMPLAR_SIZE / np.float64(init_s_z)   # init_s_z is np.floor's np.float64 in the tracker (:97): float32 / it -> float64
+    score = convert_score(cls)
+    pred_c = convert_c(loc_c, points)
+    pscore = score * (1 - window_influence) + window * window_influence
+    best_idx = int(np.argmax(pscore))
+    stop = 0
+    if pscore[best_idx] < 0.05:
+        center, stop = np.array([0.0, 0.0]), 1
+    else:
+        center = pred_c[:, best_idx] / scale_z
+    return {"score": score, "pred_c": pred_c, "pscore": pscore, "best_idx": best_idx, "stop": stop,
+            "center": np.asarray(center, np.float64), "best_score": score[best_idx]}
+
+
+def decode_logpolar(cls_lp, loc_lp, points_lp, stop, cur_sz, init_s_z):
+    """hdn_tracker_proj_e2e.py:197-212: argmax of the log-polar score, _convert_logpolar_simi, the 0.25 gate -> (scale_delta, rot_delta)."""
+    score_lp = convert_score(cls_lp)
+    pred = convert_logpolar_simi(loc_lp, points_lp)
+    best = int(np.argmax(score_lp))
+    sim_lp = pred[:, best]
+    if stop or score_lp[best] < 0.25:
+        sim_lp = [1, 1, 0, 0]
+    scale_delta = sim_lp[0] * np.float64(cur_sz) / np.float64(init_s_z)
+    rot_delta = sim_lp[2]
+    return {"score_lp": score_lp, "pred_center_lp": pred, "best_idx_lp": best, "sim_lp": np.asarray(sim_lp, np.float64),
+            "scale_delta": float(scale_delta), "rot_delta": float(rot_delta)}
+
+
+class SimilarityOracle:
+    """The similarity half of track_new on the CPU (hdn_tracker_proj_e2e.py:157-214) around a model exposing the reference's
+    ModelBuilder.track_new / track_new_lp (model_builder_e2e_unconstrained_v2.py:131-158); crops from oracle/frame_oracle.py.
+    Call: (stabilised frame uint8 [H,W,3], init_pos, init_s_z, channel_average) -> dict(dcx, dcy, cx, cy, scale_delta,
+    rot_delta, best_score, H_sim)."""
+
+    def __init__(self, model, window_influence=WINDOW_INFLUENCE):
+        self.model, self.window_influence = model, window_influence
+        score_size = (INSTANCE_SIZE - EXEMPLAR_SIZE) // STRIDE + 1 + BASE_SIZE
+        self.window = hanning_window(score_size)
+        self.points = generate_points(STRIDE, score_size)
+        self.points_lp = generate_points(STRIDE_LP, OUTPUT_SIZE_LP)
+
+    def __call__(self, img, init_pos, init_s_z, channel_average):
+        s_x = np.floor(init_s_z * np.round(INSTANCE_SIZE / EXEMPLAR_SIZE))
+        x_crop = F.get_subwindow(img, init_pos, INSTANCE_SIZE, s_x, channel_average)
+        with torch.no_grad():
+            out = self.model.track_new(torch.from_numpy(x_crop))
+        tr = decode_translation(out["cls"], out["loc_c"], self.window, self.points, init_s_z, self.window_influence)
+        cx, cy = tr["center"][0] + init_pos[0], tr["center"][1] + init_pos[1]
+        x_moved = F.get_subwindow(img, np.array([cx, cy]), INSTANCE_SIZE, s_x, channel_average)
+        with torch.no_grad():
+            out = self.model.track_new_lp(torch.from_numpy(x_moved), [0, 0])
+        lp = decode_logpolar(out["cls_lp"], out["loc_lp"], self.points_lp, tr["stop"], init_s_z, init_s_z)
+        H_sim = rot_scale_around_center_shift_tran(cx, cy, lp["rot_delta"], lp["scale_delta"], tr["center"][0], tr["center"][1])
+        return {"dcx": tr["center"][0], "dcy": tr["center"][1], "cx": cx, "cy": cy, "scale_delta": lp["scale_delta"],
+                "rot_delta": lp["rot_delta"], "best_score": float(tr["best_score"]), "H_sim": H_sim}
+
+
 class HomoTrackerOracle:
-    def __init__(self, sf_sd: dict, regress, iterations: int = 1, score_gate: float = 2.5):
+    def __init__(self, sf_sd: dict, regress, iterations: int = 1, score_gate: float = 2.5, similarity: SimilarityOracle = None):
         self.sf_sd, self.regress, self.iterations, self.score_gate = sf_sd, regress, iterations, score_gate
+        self.similarity = similarity
 
     def init(self, img, bbox, poly, gt_points, first_point=None):
         self.init_pos = np.array([poly[0], poly[1]], np.float64)
         self.size = np.array([poly[2], poly[3]], np.float64)
+        w_z = self.size[0] + CONTEXT_AMOUNT * np.sum(self.size)
+        h_z = self.size[1] + CONTEXT_AMOUNT * np.sum(self.size)
+        self.init_s_z = np.floor(np.sqrt(w_z * h_z))
         self.init_s_z_sm = float(np.floor(np.sqrt(self.size[0] * self.size[1])))
         self.channel_average = np.mean(img, axis=(0, 1))
         crop, self.z_crop_points_sm = F.get_subwindow_for_homo(img, self.init_pos, 127, self.init_s_z_sm, self.channel_average)
         self.init_homo_tmp = F.search_info(crop[0])                      # float64 [1,127,127]
+        if self.similarity is not None:   # :99-107  z_crop with the log-polar channels appended (islog=1), model.template(z_crop)
+            z = F.get_subwindow(img, self.init_pos, 127, self.init_s_z, self.channel_average)
+            z_u8 = z[0].transpose(1, 2, 0).astype(np.uint8)
+            z_log = F.get_polar_img(z_u8).transpose(2, 0, 1)[None].astype(np.float32)
+            self.z_crop = np.concatenate([z, z_log], axis=1)
+            with torch.no_grad():
+                self.similarity.model.template(torch.from_numpy(self.z_crop))
         self.init_points = np.asarray(gt_points, np.float32).reshape(-1, 2)
         self.H_total = np.eye(3, dtype=np.float32)
 
@@ -30,9 +164,13 @@ class HomoTrackerOracle:
             self.H_total = np.eye(3, dtype=np.float32)
         img = F.warp_perspective_u8(img, np.linalg.inv(self.H_total))
         cx, cy = self.init_pos
-        H_sim = np.eye(3)
-        # rot_delta = 0: img_rot_around_center is the bicubic identity
-        crop, _ = F.get_subwindow_for_homo(img, self.init_pos, 127, self.init_s_z_sm * 1.0, self.channel_average)
+        H_sim, scale_delta, best_score, sim = np.eye(3), 1.0, 0.0, None
+        rot_img = img   # rot_delta = 0: img_rot_around_center is the bicubic identity
+        if self.similarity is not None:
+            sim = self.similarity(img, self.init_pos, self.init_s_z, self.channel_average)
+            cx, cy, H_sim, scale_delta, best_score = sim["cx"], sim["cy"], sim["H_sim"], sim["scale_delta"], sim["best_score"]
+            rot_img = F.warp_affine_cubic_u8(img, F.rot_matrix_2x3(cx, cy, -sim["rot_delta"]))   # :223
+        crop, _ = F.get_subwindow_for_homo(rot_img, np.array([cx, cy]), 127, self.init_s_z_sm * scale_delta, self.channel_average)
         search = F.search_info(crop[0])
         tmpl = torch.from_numpy(self.init_homo_tmp).float().unsqueeze(0)
         srch = torch.from_numpy(search).float().unsqueeze(0)
@@ -50,4 +188,4 @@ class HomoTrackerOracle:
         self.H_total = H
         p = np.concatenate([self.init_points.astype(np.float64), np.ones((len(self.init_points), 1))], 1) @ H.T
         pts = (p[:, :2] / p[:, 2:3]).astype(np.float32)
-        return {"points": pts, "polygon": pts, "score": float(score)}
+        return {"points": pts, "polygon": pts, "score": float(score), "best_score": best_score, "similarity": sim}

@@ -481,10 +481,127 @@ def gen_frame(ref_bt, ref_gi):
     save("frame", **out)
 
 
+def gen_similarity(ref_te, cfg):
+    """The similarity half of hdnTrackerHomo.track_new (hdn/tracker/hdn_tracker_proj_e2e.py:164-214) from the two heads'
+    output maps to H_sim.  Every numeric routine is the reference's own, called on a real hdnTrackerHomo instance (its
+    constructor builds the Hanning window :26-29 and the anchor points): hdnTracker._convert_score
+    (hdn_tracker.py:84-91), SiameseTracker._convert_c (base_tracker.py:54-59), hdnTracker._convert_logpolar_simi
+    (hdn_tracker.py:51-67), rot_scale_around_center_shift_tran (hdn/utils/transform.py:250-298).  The statements between
+    those calls (:172-185 window blend / argmax / 0.05 gate, :203-214 argmax / 0.25 gate / scale_delta / rot_delta) are
+    re-executed here in the reference's order on the reference's dtypes; they cannot be reached through track_new itself,
+    which needs cv2 for the crops in between.  cfg.TRACK.WINDOW_INFLUENCE is the production YAML's except where a case
+    overrides it (with the shipped value the 0.05 gate cannot fire: the window alone contributes WINDOW_INFLUENCE at the
+    centre)."""
+    import hdn.utils.transform as ref_tf
+
+    class _NoModel(torch.nn.Module):
+        pass
+
+    trk = ref_te.hdnTrackerHomo(_NoModel())
+    g = rng(1000)
+    wi_prod = float(cfg.TRACK.WINDOW_INFLUENCE)
+
+    def maps(peak=None, peak_lp=None, cls_bias=0.0, lp_bias=0.0, loc_sigma=0.4, lp_sigma=0.3):
+        cls = g.standard_normal((1, 2, 25, 25)).astype(np.float32)
+        cls[0, 1] += np.float32(cls_bias)
+        loc = (loc_sigma * g.standard_normal((1, 2, 25, 25))).astype(np.float32)
+        cls_lp = g.standard_normal((1, 2, 13, 13)).astype(np.float32)
+        cls_lp[0, 1] += np.float32(lp_bias)
+        loc_lp = (lp_sigma * g.standard_normal((1, 4, 13, 13))).astype(np.float32)
+        if peak is not None:
+            cls[0, 1, peak[0], peak[1]] += np.float32(6.0)
+        if peak_lp is not None:
+            cls_lp[0, 1, peak_lp[0], peak_lp[1]] += np.float32(6.0)
+        return cls, loc, cls_lp, loc_lp
+
+    cases = []
+    # 0: clear peaks near the centre; 1: peaks towards the border, larger regression values
+    cases.append(dict(m=maps((13, 11), (6, 7)), size=(150.0, 100.0), pos=(320.0, 180.0), wi=wi_prod))
+    cases.append(dict(m=maps((4, 20), (2, 10), loc_sigma=1.5, lp_sigma=1.0), size=(201.0, 77.0), pos=(611.5, 402.25), wi=wi_prod))
+    # 2: translation gate fires (window influence 0, class-1 logits far below class 0) -> centre (0, 0), sim_lp = [1,1,0,0]
+    cases.append(dict(m=maps(None, (5, 5), cls_bias=-8.0), size=(150.0, 100.0), pos=(300.0, 200.0), wi=0.0))
+    # 3: log-polar gate fires (every score_lp < 0.25)
+    cases.append(dict(m=maps((12, 12), None, lp_bias=-9.0), size=(90.0, 120.0), pos=(100.0, 80.0), wi=wi_prod))
+    # 4: exact ties: equal logits at (i, j) and (j, i) (the window is symmetric bit for bit), and two equal log-polar cells
+    c4 = maps(None, None)
+    for (i, j) in ((9, 15), (15, 9)):
+        c4[0][0, 0, i, j], c4[0][0, 1, i, j] = np.float32(-2.0), np.float32(5.0)
+    for (i, j) in ((8, 3), (3, 8)):
+        c4[2][0, 0, i, j], c4[2][0, 1, i, j] = np.float32(-1.0), np.float32(7.0)
+    cases.append(dict(m=c4, size=(150.0, 100.0), pos=(320.0, 180.0), wi=wi_prod))
+    # 5: config.py's default window influence (0.45) and a peak the window out-votes
+    cases.append(dict(m=maps((1, 1), (11, 2), cls_bias=-1.0), size=(64.0, 64.0), pos=(50.0, 40.0), wi=0.45))
+    # 6: no regression at all (zeros) on the centre cell: scale 1 / rotation 0 exactly -> identity branches of H_sim
+    c6 = maps((12, 12), (6, 6))
+    c6[1][:] = 0
+    c6[3][:] = 0
+    cases.append(dict(m=c6, size=(150.0, 100.0), pos=(320.0, 180.0), wi=wi_prod))
+
+    out = {"window": trk.window, "points": trk.points, "points_lp": trk.points_lp, "n_cases": np.array(len(cases)),
+           "window_influence_production": np.array(wi_prod)}
+    for n, cs in enumerate(cases):
+        cls, loc_c, cls_lp, loc_lp = cs["m"]
+        size = np.array(cs["size"])
+        cfg.TRACK.WINDOW_INFLUENCE = cs["wi"]
+        # hdnTrackerHomo.init :85-94
+        w_z = size[0] + cfg.TRACK.CONTEXT_AMOUNT * np.sum(size)
+        h_z = size[1] + cfg.TRACK.CONTEXT_AMOUNT * np.sum(size)
+        init_s_z = np.floor(np.sqrt(w_z * h_z))
+        center_pos = np.array(cs["pos"])
+        # track_new :157-186
+        s_z = init_s_z
+        cur_sz = init_s_z
+        scale_z = cfg.TRACK.EXEMPLAR_SIZE / s_z
+        outputs = {"cls": t(cls), "loc_c": t(loc_c.copy())}
+        score = trk._convert_score(outputs["cls"])
+        pred_c = trk._convert_c(outputs["loc_c"], trk.points)
+        pscore = score
+        pscore = pscore * (1 - cfg.TRACK.WINDOW_INFLUENCE) + trk.window * cfg.TRACK.WINDOW_INFLUENCE
+        best_idx = np.argmax(pscore)
+        stop_update_flag = 0
+        if pscore[best_idx] < 0.05:
+            center = [0, 0]
+            stop_update_flag = 1
+        else:
+            center = pred_c[:, best_idx] / scale_z
+        cx = center[0] + center_pos[0]
+        cy = center[1] + center_pos[1]
+        delta_cx = center[0]
+        delta_cy = center[1]
+        # :196-214
+        outputs = {"cls_lp": t(cls_lp), "loc_lp": t(loc_lp.copy())}
+        score_lp = trk._convert_score(outputs["cls_lp"])
+        peak_idx = np.argmax(score_lp.copy())
+        pred_center_lp = trk._convert_logpolar_simi(outputs["loc_lp"], trk.points_lp, peak_idx, 1)
+        pscore_lp = score_lp
+        best_idx_lp = np.argmax(pscore_lp)
+        sim_lp = pred_center_lp[:, best_idx_lp]
+        if stop_update_flag or pscore_lp[best_idx_lp] < 0.25:
+            sim_lp = [1, 1, 0, 0]
+        best_score = score[best_idx]
+        scale_delta = sim_lp[0] * cur_sz / init_s_z
+        rot_delta = sim_lp[2]
+        H_sim = ref_tf.rot_scale_around_center_shift_tran(cx, cy, rot_delta, scale_delta, delta_cx, delta_cy)
+        k = f"c{n}__"
+        out.update({k + "cls": cls, k + "loc_c": loc_c, k + "cls_lp": cls_lp, k + "loc_lp": loc_lp, k + "size": size,
+                    k + "center_pos": center_pos, k + "window_influence": np.array(cs["wi"]), k + "init_s_z": np.array(init_s_z),
+                    k + "score": score, k + "pred_c": pred_c, k + "pscore": pscore, k + "best_idx": np.array(best_idx),
+                    k + "stop": np.array(stop_update_flag), k + "center": np.array(center, np.float64),
+                    k + "cxcy": np.array([cx, cy], np.float64), k + "score_lp": score_lp, k + "pred_center_lp": pred_center_lp,
+                    k + "best_idx_lp": np.array(best_idx_lp), k + "sim_lp": np.array(sim_lp, np.float64),
+                    k + "best_score": np.array(best_score), k + "scale_delta": np.array(scale_delta, np.float64),
+                    k + "rot_delta": np.array(rot_delta, np.float64), k + "H_sim": H_sim})
+    cfg.TRACK.WINDOW_INFLUENCE = wi_prod
+    save("similarity", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
+    ap.add_argument("--only", default="", help="comma-separated fixture names to regenerate (default: all)")
     args = ap.parse_args()
+    only = set(x for x in args.only.split(",") if x)
+    want = lambda *names: not only or bool(only & set(names))
     if not os.path.isdir(args.reference):
         sys.exit(f"reference tree not found at {args.reference}")
     install_stubs()
@@ -501,20 +618,31 @@ def main():
     import homo_estimator.Deep_homography.Oneline_DLTv1.tools.get_img_info as ref_gi
 
     print("generating golden vectors from", args.reference)
-    gen_xcorr(ref_xcorr)
-    gen_share_feature(ref_pre)
-    gen_dlt(ref_utils)
-    gen_transform(ref_utils)
-    hm_seeded, hm_data = gen_homo_model(ref_hmb, ref_gi)
-    import hdn.models.model_builder_e2e_unconstrained_v2 as ref_mb
-    gen_track_proj(ref_mb, hm_seeded, hm_data)
-    import hdn.models.logpolar as ref_lp
-    gen_logpolar(ref_lp)
-    import hdn.models.head.ban as ref_ban
-    import hdn.models.head.ban_lp as ref_ban_lp
-    gen_heads(ref_ban, ref_ban_lp)
-    import hdn.tracker.base_tracker as ref_bt
-    gen_frame(ref_bt, ref_gi)
+    if want("xcorr_depthwise", "xcorr_depthwise_circular", "xcorr_depthwise_sampled", "xcorr_fast"):
+        gen_xcorr(ref_xcorr)
+    if want("share_feature"):
+        gen_share_feature(ref_pre)
+    if want("dlt_solve"):
+        gen_dlt(ref_utils)
+    if want("transform", "transformer"):
+        gen_transform(ref_utils)
+    if want("homo_forward", "track_proj"):
+        hm_seeded, hm_data = gen_homo_model(ref_hmb, ref_gi)
+        import hdn.models.model_builder_e2e_unconstrained_v2 as ref_mb
+        gen_track_proj(ref_mb, hm_seeded, hm_data)
+    if want("logpolar"):
+        import hdn.models.logpolar as ref_lp
+        gen_logpolar(ref_lp)
+    if want("heads", "heads256"):
+        import hdn.models.head.ban as ref_ban
+        import hdn.models.head.ban_lp as ref_ban_lp
+        gen_heads(ref_ban, ref_ban_lp)
+    if want("frame"):
+        import hdn.tracker.base_tracker as ref_bt
+        gen_frame(ref_bt, ref_gi)
+    if want("similarity"):
+        import hdn.tracker.hdn_tracker_proj_e2e as ref_te
+        gen_similarity(ref_te, cfg)
     print("torch", torch.__version__, "numpy", np.__version__)
 
 

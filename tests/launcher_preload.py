@@ -1,6 +1,7 @@
 """--preload hook of tests/test_host_logic.py::test_unchanged_launcher_runs_the_reference_test_script: makes the reference's
-tools/test.py importable in the build container (no cv2 / yacs / GPU there) and stops it right after ModelBuilder() has
-been constructed, reporting what it was built from.  Not part of the product."""
+tools/test.py importable in the build container (no cv2 / yacs / GPU there), lets it construct ModelBuilder() and call
+build_tracker(model) (tools/test.py:65-72), and stops it at the next statement (the dataset, which does not exist here),
+reporting what the model and the tracker were built from.  Not part of the product."""
 import os
 import sys
 
@@ -33,6 +34,21 @@ def prepare():
               isinstance(model.logpolar_instance, hdn_amd.STN_Polar),
               type(model).track_proj is hi._track_proj_method,
               ban.xcorr_depthwise is hdn_amd.xcorr_depthwise, flush=True)
-        raise SystemExit(0)
+        return model     # no snapshot in this container: carry on with the seeded weights
 
     ml.load_pretrain = stop_here
+    import torch
+    if not torch.cuda.is_available.__module__.startswith("torch"):   # make_golden's stub is active: no GPU in this container
+        torch.cuda.current_device = lambda: 0                        # tools/test.py:74
+    import toolkit.datasets as ds
+
+    class _Factory:
+        @staticmethod
+        def create_dataset(**kw):
+            import hdn_amd.tracker as T
+            trk = sys._getframe(1).f_locals.get("tracker")     # main()'s local of tools/test.py:72
+            print("LAUNCHER_REACHED_DATASET", type(trk) is T.DeviceTrackerHomo, type(trk.similarity).__name__,
+                  trk.net is sys._getframe(1).f_locals["model"].hm_net, flush=True)
+            raise SystemExit(0)
+
+    ds.DatasetFactory = _Factory

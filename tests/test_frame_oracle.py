@@ -69,9 +69,10 @@ def test_opencv_restatements_properties():
 
 
 def test_similarity_homography_builder_matches_reference():
-    """hdn_amd.tracker.rot_scale_around_center_shift_tran (host arithmetic of the tracker loop) against the reference's
-    hdn/utils/transform.py:250-298."""
-    from hdn_amd.tracker import rot_scale_around_center_shift_tran
+    """oracle.tracker_oracle.rot_scale_around_center_shift_tran against the reference's hdn/utils/transform.py:250-298 (the
+    product builds H_sim on the device, hdn_similarity_logpolar_f32: tests/test_gpu_tracker.py holds it to this and to
+    tests/golden/similarity.npz)."""
+    from oracle.tracker_oracle import rot_scale_around_center_shift_tran
     g = load_golden("frame")
     for row, H in zip(g["sim_params"], g["sim_H"]):
         np.testing.assert_allclose(rot_scale_around_center_shift_tran(*row), H, rtol=0, atol=1e-12)

@@ -73,3 +73,154 @@ def test_graphed_tracker_loop_matches_eager(dev):
         assert success_4pts_error(pa, pb) <= (1e-3 if i <= 3 else 2e-2), (i, pa, pb)
     assert b._graph is not None
     np.testing.assert_allclose(a.H_total.cpu().numpy(), b.H_total.cpu().numpy(), rtol=1e-4, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------ similarity half (configs[3])
+def _decode_case(dev, g, n, dec_cache):
+    from hdn_amd.similarity import SimilarityDecoder, TrackerConfig, sequence_constants, state_fields
+    k = f"c{n}__"
+    wi = float(g[k + "window_influence"])
+    if wi not in dec_cache:
+        dec_cache[wi] = SimilarityDecoder(dev, TrackerConfig(window_influence=wi))
+    dec = dec_cache[wi]
+    size = g[k + "size"]
+    seq = sequence_constants(g[k + "center_pos"], float(g[k + "init_s_z"]), float(np.floor(np.sqrt(size[0] * size[1]))), [10.0, 20.0, 30.0], dec.cfg)
+    seq_d = torch.from_numpy(seq).to(dev).view(1, -1)
+    state = dec.new_state(1)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    dec.translation(T(g[k + "cls"]), T(g[k + "loc_c"]), seq_d, state)
+    dec.logpolar(T(g[k + "cls_lp"]), T(g[k + "loc_lp"]), seq_d, state)
+    return {kk: v.cpu().numpy() for kk, v in state_fields(state.view(-1)).items()}, seq
+
+
+def test_similarity_decode_golden(dev):
+    """hdn_similarity_translation_f32 / hdn_similarity_logpolar_f32 against the reference's own decode
+    (tests/golden/similarity.npz: hdn_tracker_proj_e2e.py:169-214 on seeded head maps, both gates, exact argmax ties).
+    Indices, gates and the centre are exact; scores / scale / rotation within 1e-6 (expf / exp of the device library vs the
+    host's: at most an ulp of float32); H_sim within 1e-9 relative to its largest entry."""
+    from conftest import load_golden
+    g = load_golden("similarity")
+    cache = {}
+    for n in range(int(g["n_cases"])):
+        k = f"c{n}__"
+        st, seq = _decode_case(dev, g, n, cache)
+        assert int(st["best_idx"]) == int(g[k + "best_idx"]), n
+        assert int(st["stop"]) == int(g[k + "stop"]), n
+        assert int(st["best_idx_lp"]) == int(g[k + "best_idx_lp"]), n
+        np.testing.assert_allclose(st["delta"], g[k + "center"], rtol=1e-12, atol=1e-12, err_msg=f"case {n}")
+        np.testing.assert_allclose(st["center"], g[k + "cxcy"], rtol=1e-12, atol=1e-12, err_msg=f"case {n}")
+        assert abs(float(st["best_score"]) - float(g[k + "best_score"])) <= 1e-6, n
+        assert abs(float(st["pscore"]) - float(g[k + "pscore"][int(g[k + "best_idx"])])) <= 1e-6, n
+        assert abs(float(st["score_lp"]) - float(g[k + "score_lp"][int(g[k + "best_idx_lp"])])) <= 1e-6, n
+        sd, rd = float(g[k + "scale_delta"]), float(g[k + "rot_delta"])
+        assert abs(float(st["scale_delta"]) - sd) <= 1e-6 * max(1.0, abs(sd)), (n, float(st["scale_delta"]), sd)
+        assert float(st["rot_delta"]) == rd, (n, float(st["rot_delta"]), rd)      # float32 arithmetic only: exact
+        H = g[k + "H_sim"]
+        # H_sim inherits the <= 1-ulp(float32) difference of scale_delta; given the device's own scale it is exact to 1e-12
+        from oracle import tracker_oracle as TO
+        H_own = TO.rot_scale_around_center_shift_tran(st["center"][0], st["center"][1], float(st["rot_delta"]), float(st["scale_delta"]),
+                                                      st["delta"][0], st["delta"][1])
+        np.testing.assert_allclose(st["H_sim"], H_own, rtol=0, atol=1e-12 * max(1.0, np.abs(H).max()), err_msg=f"case {n}")
+        np.testing.assert_allclose(st["H_sim"], H, rtol=0, atol=2e-6 * max(1.0, np.abs(H).max()), err_msg=f"case {n}")
+        # what the next kernels read: rotate-back matrix and crop parameters
+        cx, cy = st["center"]
+        cc, ss = np.cos(-float(st["rot_delta"])), np.sin(-float(st["rot_delta"]))
+        np.testing.assert_allclose(st["rot_matrix"], [cc, -ss, cx - cx * cc + cy * ss, ss, cc, cy - cy * cc - cx * ss], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(st["params_moved"], [cx, cy, seq[3], 10.0, 20.0, 30.0], rtol=0, atol=0)
+        np.testing.assert_allclose(st["params_homo"], [cx, cy, seq[4] * float(st["scale_delta"]), 10.0, 20.0, 30.0], rtol=1e-15, atol=0)
+
+
+def test_similarity_decode_batch_and_errors(dev):
+    """B > 1 records are independent; argument errors come back as HDN_E_* before anything is launched."""
+    from conftest import load_golden
+    from hdn_amd.similarity import SimilarityDecoder, sequence_constants, state_fields
+    g = load_golden("similarity")
+    dec = SimilarityDecoder(dev)
+    ns = [0, 1, 3, 4, 6]     # the cases generated under the production window influence
+    T = lambda name: torch.from_numpy(np.concatenate([g[f"c{n}__{name}"] for n in ns])).to(dev)
+    seqs = np.stack([sequence_constants(g[f"c{n}__center_pos"], float(g[f"c{n}__init_s_z"]), 100.0, [1.0, 2.0, 3.0], dec.cfg) for n in ns])
+    seq_d, state = torch.from_numpy(seqs).to(dev), dec.new_state(len(ns))
+    dec.translation(T("cls"), T("loc_c"), seq_d, state)
+    dec.logpolar(T("cls_lp"), T("loc_lp"), seq_d, state)
+    for j, n in enumerate(ns):
+        f = state_fields(state[j])
+        assert int(f["best_idx"]) == int(g[f"c{n}__best_idx"]) and int(f["best_idx_lp"]) == int(g[f"c{n}__best_idx_lp"])
+        np.testing.assert_allclose(f["H_sim"].cpu().numpy(), g[f"c{n}__H_sim"], rtol=0, atol=2e-6 * max(1.0, np.abs(g[f"c{n}__H_sim"]).max()))
+    with pytest.raises(ValueError):
+        dec.translation(T("cls")[:, :, :24], T("loc_c"), seq_d, state)
+    with pytest.raises(ValueError):
+        dec.logpolar(T("cls_lp"), T("loc_lp"), seq_d, state[:2])
+    with pytest.raises(Exception):
+        dec.translation(T("cls").cpu(), T("loc_c").cpu(), seq_d, state)
+
+
+def _similarity_pair(dev):
+    import standin_model as SM
+    from test_gpu_parity import _seeded_net
+    from hdn_amd.similarity import DeviceSimilarity
+    from hdn_amd.tracker import HomoTracker
+    from oracle.tracker_oracle import HomoTrackerOracle, SimilarityOracle
+    net = _seeded_net()
+    net_cpu = copy.deepcopy(net)
+    twin = SM.StandInSiamese(net).eval()
+    cpu = SM.StandInSiameseCPU(twin)
+    sd = {k: v.clone() for k, v in net_cpu.ShareFeature.state_dict().items()}
+    ref = HomoTrackerOracle(sd, lambda f: net_cpu.fc(net_cpu.avgpool(net_cpu.backbone(f)).flatten(1)), similarity=SimilarityOracle(cpu))
+    twin = twin.to(dev)
+    make = lambda **kw: HomoTracker(twin.hm_net, similarity=DeviceSimilarity(twin), **kw)
+    return ref, make, twin
+
+
+def test_sequence_stream_with_similarity_device_vs_cpu(dev):
+    """configs[3] end to end: the whole track_new of hdn_tracker_proj_e2e.py:141-285 on the device — stabilising warp,
+    translation crop + head + decode, moved crop + log-polar head + decode, H_sim, rotate-back, homography crop, track_proj,
+    accumulation — against the CPU restatement of the same loop, frame by frame, with a NON-identity similarity estimate
+    (a seeded stand-in for the reference's ModelBuilder, tests/standin_model.py).  One host read per frame."""
+    from synth_sequence import make_sequence, success_4pts_error
+    frames, corners, init = make_sequence(n_frames=12, frame_hw=(360, 640), target_wh=(150, 100), seed=7)
+    ref, make, twin = _similarity_pair(dev)
+    trk = make()
+    ref.init(frames[0], init["bbox"], init["poly"], init["gt_points"], init["first_point"])
+    trk.init(frames[0], init["bbox"], init["poly"], init["gt_points"], init["first_point"])
+    assert trk.init_s_z == float(ref.init_s_z)
+    # template crop incl. its log-polar channels (restated cv2.logPolar), and the template features
+    for a, b in zip(twin.zf + twin.zf_lp, ref.similarity.model.zf + ref.similarity.model.zf_lp):
+        np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), atol=1e-4)
+    syncs0 = trk.host_syncs
+    errs, moved = [], 0
+    for t in range(1, len(frames)):
+        a = trk.track_new(t, frames[t])
+        b = ref.track_new(t, frames[t])
+        s = b["similarity"]
+        st = trk.similarity.state.view(-1).cpu().numpy()        # (test-only read; not counted in host_syncs)
+        # the decoded similarity itself: same argmax cells, same gates -> centre / scale / rotation agree to rounding
+        assert abs(st[0] - s["dcx"]) <= 2e-2 and abs(st[1] - s["dcy"]) <= 2e-2, (t, st[:2], s["dcx"], s["dcy"])
+        assert abs(st[16] - s["scale_delta"]) <= 1e-3 and abs(st[17] - s["rot_delta"]) <= 1e-3, (t, st[16:18], s)
+        moved += int(abs(s["dcx"]) + abs(s["dcy"]) > 0.05 and abs(s["scale_delta"] - 1) > 1e-3 and abs(s["rot_delta"]) > 1e-3)
+        assert set(a) == {"bbox_aligned", "best_score", "polygon", "points", "bbox"} and a["points"].shape == (4, 2)
+        assert abs(float(a["best_score"]) - s["best_score"]) <= 1e-4
+        errs.append(success_4pts_error(a["points"], b["points"]))
+    assert moved == len(frames) - 1, "the stand-in's similarity estimate must be non-trivial in every component"
+    assert errs[0] <= 1e-3, errs                 # observed 2e-5 ... 1.4e-4 px over the 11 frames
+    assert max(errs) <= 0.05, errs
+    assert trk.host_syncs - syncs0 == len(frames) - 1          # ONE read (4 corners + best_score) per frame
+    print("similarity sequence corner errors (px):", " ".join(f"{e:.2e}" for e in errs))
+
+
+def test_graphed_tracker_with_similarity_matches_eager(dev):
+    """The frame body incl. the similarity branch replays as ONE hipGraph: same corners as the eager loop."""
+    from synth_sequence import make_sequence, success_4pts_error
+    frames, corners, init = make_sequence(n_frames=7, frame_hw=(360, 640), target_wh=(150, 100), seed=9)
+    _, make, _ = _similarity_pair(dev)
+    a, b = make(), make(graph=True)
+    for t in (a, b):
+        t.init(frames[0], init["bbox"], init["poly"], init["gt_points"], init["first_point"])
+    held = []
+    for i in range(1, len(frames)):
+        pa = a.track_new(i, frames[i])["points"]
+        ob = b.track_new(i, frames[i], sync=False)
+        held.append(ob["points"])
+        assert success_4pts_error(pa, ob["points"].cpu().numpy()) <= (1e-3 if i <= 3 else 5e-2), (i, pa, ob["points"])
+    assert b._graph is not None
+    # sync=False results are copies, not aliases of the graph's static output (each frame's corners stay what they were)
+    assert not torch.equal(held[0], held[-1]) and held[0].data_ptr() != held[-1].data_ptr()

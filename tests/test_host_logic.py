@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_library_loads_and_reports_abi():
     lib = _lib.load()
-    assert lib.hdn_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.hdn_abi_version() == _lib.ABI_VERSION == 3
     assert lib.hdn_last_xcorr_variant() == b"none"
 
 
@@ -52,6 +52,10 @@ def test_c_abi_argument_errors_need_no_gpu():
     assert lib.hdn_allgather_offsets(one, one, 4, None, None) == -1 and lib.hdn_allgather_offsets(one, one, 0, one, None) == -2
     assert lib.hdn_rccl_comm_create(ctypes.byref(ctypes.c_void_p()), 2, 2, ctypes.c_char_p(b"\0" * 128)) == -2
     assert lib.hdn_rccl_unique_id(None) == -1 and lib.hdn_rccl_available() in (0, 1)
+    assert lib.hdn_similarity_translation_f32(one, one, one, one, one, None, 1, 25, 0.16, 8.0, 127.0, None) == -1
+    assert lib.hdn_similarity_translation_f32(one, one, one, one, one, one, 1, 0, 0.16, 8.0, 127.0, None) == -2
+    assert lib.hdn_similarity_logpolar_f32(one, one, None, one, one, 1, 13, 8.0, 0.03, 0.05, None) == -1
+    assert lib.hdn_similarity_logpolar_f32(one, one, one, one, one, 0, 13, 8.0, 0.03, 0.05, None) == -2
     with pytest.raises(_lib.HdnHipError, match="ncclResult_t 3"):
         _lib.check(-2003, "x")
     with pytest.raises(ValueError):
@@ -190,6 +194,9 @@ def test_install_rebinds_the_reference_sites():
             return sentinel
 
     mods[names[6]].ModelBuilder = ModelBuilder
+    tb = types.ModuleType("hdn.tracker.tracker_builder")
+    tb.TRACKS = {"hdnTracker": sentinel, "hdnTrackerHomoProje2e": sentinel}
+    mods["hdn.tracker.tracker_builder"] = tb
 
     class MultiBAN:
         def forward(self, z_fs, x_fs):
@@ -202,6 +209,12 @@ def test_install_rebinds_the_reference_sites():
     mods["hdn.models.head.ban_lp"].MultiCircBAN = MultiCircBAN
     done = hinstall.install(modules=mods)
     assert len(done) == len(hinstall.REBINDINGS) + 4
+    assert tb.TRACKS["hdnTrackerHomoProje2e"] is sentinel          # the tracker is only registered on request
+    hinstall.uninstall()
+    done = hinstall.install(modules=mods, tracker=True)
+    assert len(done) == len(hinstall.REBINDINGS) + 5
+    from hdn_amd.tracker import DeviceTrackerHomo
+    assert tb.TRACKS["hdnTrackerHomoProje2e"] is DeviceTrackerHomo and tb.TRACKS["hdnTracker"] is sentinel
     assert "forward" in MultiBAN.__dict__ and "forward" in MultiCircBAN.__dict__
     assert mods["hdn.models.head.ban"].xcorr_depthwise is hdn_amd.xcorr_depthwise
     assert mods["hdn.models.head.ban_lp"].xcorr_depthwise_circular is hdn_amd.xcorr_depthwise_circular
@@ -224,6 +237,7 @@ def test_install_rebinds_the_reference_sites():
     assert MultiBAN().forward([], []) is sentinel and "forward" not in MultiCircBAN.__dict__
     assert "_hdn_orig_forward" not in MultiBAN.__dict__
     assert ModelBuilder().track_proj(None, None) is sentinel
+    assert tb.TRACKS["hdnTrackerHomoProje2e"] is sentinel
     assert hinstall.uninstall() == 0
 
 
@@ -307,15 +321,32 @@ mg.install_stubs(); sys.path.insert(0, "/root/reference")
 from hdn.core.config import cfg
 cfg.merge_from_file("/root/reference/experiments/tracker_homo_config/proj_e2e_GOT_unconstrained_v2.yaml")
 import hdn_amd, hdn_amd.install as hi
-done = hi.install(strict=True)
-assert len(done) == len(hi.REBINDINGS) + 4, done
+done = hi.install(strict=True, tracker=True)
+assert len(done) == len(hi.REBINDINGS) + 7, done
 import hdn.models.head.ban as ban, hdn.models.head.ban_lp as ban_lp
 assert ban.xcorr_depthwise is hdn_amd.xcorr_depthwise and ban_lp.xcorr_depthwise_circular is hdn_amd.xcorr_depthwise_circular
 from hdn.models.model_builder_e2e_unconstrained_v2 import ModelBuilder
 m = ModelBuilder()
 assert isinstance(m.hm_net.ShareFeature, hdn_amd.PreShareFeature)
 assert isinstance(m.logpolar_instance, hdn_amd.STN_Polar)
-assert ModelBuilder.track_proj is hi._track_proj_method
+assert ModelBuilder.track_proj is hi._track_proj_method and ModelBuilder.track_new_lp is hi._track_new_lp_method
+# build_tracker(model) (hdn/tracker/tracker_builder.py:18-19) now returns the device-resident loop around the reference's model
+from hdn.tracker.tracker_builder import build_tracker, TRACKS
+from hdn_amd.tracker import DeviceTrackerHomo
+from hdn_amd.similarity import DeviceSimilarity
+trk = build_tracker(m)
+assert type(trk) is DeviceTrackerHomo and trk.net is m.hm_net and isinstance(trk.similarity, DeviceSimilarity) and trk.similarity.model is m
+assert trk.cfg.window_influence == cfg.TRACK.WINDOW_INFLUENCE and trk.cfg.score_size == 25 and not m.training
+assert all(hasattr(trk, a) for a in ("init", "track_new"))
+# template() still runs the reference's statements, then drops the heads' cached template features
+class _Probe(dict): pass
+m.head._hdn_template_cache = "stale"; m.head_lp._hdn_template_cache = "stale"
+with torch.no_grad():
+    m.template(torch.zeros(1, 6, 127, 127))
+assert m.head._hdn_template_cache is None and m.head_lp._hdn_template_cache is None and len(m.zf) == 3 and len(m.zf_lp) == 3
+n = hi.uninstall()
+assert TRACKS["hdnTrackerHomoProje2e"].__name__ == "hdnTrackerHomo" and "_hdn_wraps" not in vars(ModelBuilder.template)
+hi.install(strict=True, tracker=True)
 # the reference's own HomoModelBuilder and ours agree on parameter names, so snapshots load either way
 ours = hdn_amd.HomoModelBuilder()
 assert list(m.hm_net.state_dict().keys()) == list(ours.state_dict().keys())
@@ -329,7 +360,8 @@ print("INSTALL_OK")
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference tree only exists in the build container")
 def test_unchanged_launcher_runs_the_reference_test_script():
     """python -m hdn_amd.run /root/reference/tools/test.py ...: the reference's own benchmark script, byte for byte, with the
-    hot path rebound before it starts; driven up to ModelBuilder() (the snapshot and cv2 do not exist in this container)."""
+    hot path rebound before it starts; driven through ModelBuilder() and build_tracker(model) up to the dataset (the snapshot,
+    POT-210 and cv2 do not exist in this container): build_tracker returns the device-resident tracker."""
     import subprocess
     import sys
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "tests")]))
@@ -338,6 +370,7 @@ def test_unchanged_launcher_runs_the_reference_test_script():
                         "--config", "/root/reference/experiments/tracker_homo_config/proj_e2e_GOT_unconstrained_v2.yaml"],
                        capture_output=True, text=True, timeout=600, env=env, cwd="/tmp")
     assert "LAUNCHER_REACHED_LOAD_PRETRAIN True True True True" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "LAUNCHER_REACHED_DATASET True DeviceSimilarity True" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
     assert "hot-path sites rebound" in r.stderr
     # the script on disk is the reference's own
     assert r.returncode == 0

@@ -289,3 +289,39 @@ def test_refine_step_composes_normalised_inverse():
     w, _ = O.refine_step(Hs, img, np.eye(3))
     np.testing.assert_allclose(w[:, 4:124], img[:, :120], rtol=0, atol=1e-6)
     np.testing.assert_array_equal(w[:, :4], np.repeat(img[:, :1], 4, axis=1))
+
+
+def test_similarity_decode_oracle_vs_reference():
+    """oracle.tracker_oracle's restatement of hdn_tracker_proj_e2e.py:164-214 against tests/golden/similarity.npz (the
+    reference's own _convert_score / _convert_c / _convert_logpolar_simi / window / rot_scale_around_center_shift_tran on
+    seeded head maps: both gates, exact argmax ties, the identity branches of H_sim).  Same numpy / ATen calls in the same
+    order: bit-exact."""
+    from oracle import tracker_oracle as TO
+    g = load_golden("similarity")
+    np.testing.assert_array_equal(TO.hanning_window(25), g["window"])
+    np.testing.assert_array_equal(TO.generate_points(8, 25), g["points"])
+    np.testing.assert_array_equal(TO.generate_points(8, 13), g["points_lp"])
+    assert float(g["window_influence_production"]) == TO.WINDOW_INFLUENCE
+    n_cases = int(g["n_cases"])
+    assert n_cases == 7
+    fired = {"stop": 0, "lp_gate": 0}
+    for n in range(n_cases):
+        k = f"c{n}__"
+        s_z = float(g[k + "init_s_z"])
+        tr = TO.decode_translation(T(g[k + "cls"]), T(g[k + "loc_c"]), g["window"], g["points"], s_z, float(g[k + "window_influence"]))
+        for name in ("score", "pred_c", "pscore", "center"):
+            np.testing.assert_array_equal(tr[name], g[k + name], err_msg=f"case {n} {name}")
+        assert tr["best_idx"] == int(g[k + "best_idx"]) and tr["stop"] == int(g[k + "stop"])
+        assert tr["best_score"] == g[k + "best_score"]
+        lp = TO.decode_logpolar(T(g[k + "cls_lp"]), T(g[k + "loc_lp"]), g["points_lp"], tr["stop"], s_z, s_z)
+        for name in ("score_lp", "pred_center_lp", "sim_lp"):
+            np.testing.assert_array_equal(lp[name], g[k + name], err_msg=f"case {n} {name}")
+        assert lp["best_idx_lp"] == int(g[k + "best_idx_lp"])
+        assert lp["scale_delta"] == float(g[k + "scale_delta"]) and lp["rot_delta"] == float(g[k + "rot_delta"])
+        cx, cy = tr["center"][0] + g[k + "center_pos"][0], tr["center"][1] + g[k + "center_pos"][1]
+        np.testing.assert_array_equal(np.array([cx, cy]), g[k + "cxcy"])
+        H = TO.rot_scale_around_center_shift_tran(cx, cy, lp["rot_delta"], lp["scale_delta"], tr["center"][0], tr["center"][1])
+        np.testing.assert_array_equal(H, g[k + "H_sim"], err_msg=f"case {n} H_sim")
+        fired["stop"] += tr["stop"]
+        fired["lp_gate"] += int(not tr["stop"] and lp["score_lp"][lp["best_idx_lp"]] < 0.25 and list(lp["sim_lp"]) == [1, 1, 0, 0])
+    assert fired["stop"] == 1 and fired["lp_gate"] == 1   # both gate branches are in the fixture
