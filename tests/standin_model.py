@@ -40,14 +40,14 @@ def _seed_head(head, seed, loc_scale):
 
 
 class StandInSiamese(nn.Module):
-    def __init__(self, hm_net, seed: int = 11):
+    def __init__(self, hm_net, seed: int = 11, loc_scale: float = 0.4, loc_scale_lp: float = 0.05):
         super().__init__()
         from hdn_amd import heads as HD
         from hdn_amd.logpolar import STN_Polar
         torch.manual_seed(seed)
         self.backbone = _levels(seed + 1)
-        self.head = _seed_head(HD.MultiBAN([C] * 3, 2, weighted=True), seed + 2, 0.4)
-        self.head_lp = _seed_head(HD.MultiCircBAN([C] * 3, 2, weighted=True), seed + 3, 0.05)
+        self.head = _seed_head(HD.MultiBAN([C] * 3, 2, weighted=True), seed + 2, loc_scale)
+        self.head_lp = _seed_head(HD.MultiCircBAN([C] * 3, 2, weighted=True), seed + 3, loc_scale_lp)
         self.logpolar_instance = STN_Polar(255)
         self.hm_net = hm_net
         yy, xx = torch.meshgrid(torch.arange(25.0), torch.arange(25.0), indexing="ij")

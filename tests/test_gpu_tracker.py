@@ -154,15 +154,16 @@ def test_similarity_decode_batch_and_errors(dev):
         dec.translation(T("cls").cpu(), T("loc_c").cpu(), seq_d, state)
 
 
-def _similarity_pair(dev):
+def _similarity_pair(dev, fc_bias_scale=1.0, **standin_kw):
     import standin_model as SM
     from test_gpu_parity import _seeded_net
     from hdn_amd.similarity import DeviceSimilarity
     from hdn_amd.tracker import HomoTracker
     from oracle.tracker_oracle import HomoTrackerOracle, SimilarityOracle
     net = _seeded_net()
+    net.fc.bias.data.mul_(fc_bias_scale)
     net_cpu = copy.deepcopy(net)
-    twin = SM.StandInSiamese(net).eval()
+    twin = SM.StandInSiamese(net, **standin_kw).eval()
     cpu = SM.StandInSiameseCPU(twin)
     sd = {k: v.clone() for k, v in net_cpu.ShareFeature.state_dict().items()}
     ref = HomoTrackerOracle(sd, lambda f: net_cpu.fc(net_cpu.avgpool(net_cpu.backbone(f)).flatten(1)), similarity=SimilarityOracle(cpu))
@@ -224,3 +225,25 @@ def test_graphed_tracker_with_similarity_matches_eager(dev):
     assert b._graph is not None
     # sync=False results are copies, not aliases of the graph's static output (each frame's corners stay what they were)
     assert not torch.equal(held[0], held[-1]) and held[0].data_ptr() != held[-1].data_ptr()
+
+
+def test_long_sequence_720p_graph_loop_vs_cpu(dev):
+    """configs[3] at the size BASELINE names: 61 frames of 1280 x 720 through the device loop with the similarity branch,
+    each frame ONE hipGraph replay, against the CPU restatement on every frame.  (Seeded heads with small regression outputs,
+    so that 60 compounded frames stay a usable sequence: ~2 px, ~0.7 %, ~3 mrad of similarity motion and ~0.3 px of residual
+    homography per frame.)"""
+    from synth_sequence import make_sequence, success_4pts_error
+    frames, corners, init = make_sequence(n_frames=61, frame_hw=(720, 1280), target_wh=(300, 200), seed=20260928)
+    ref, make, _ = _similarity_pair(dev, fc_bias_scale=0.1, loc_scale_lp=0.01)
+    trk = make(graph=True)
+    ref.init(frames[0], init["bbox"], init["poly"], init["gt_points"], init["first_point"])
+    trk.init(frames[0], init["bbox"], init["poly"], init["gt_points"], init["first_point"])
+    syncs0, errs = trk.host_syncs, []
+    for t in range(1, len(frames)):
+        a = trk.track_new(t, frames[t])
+        b = ref.track_new(t, frames[t])
+        errs.append(success_4pts_error(a["points"], b["points"]))
+    print("720p graph loop, corner error vs CPU loop (px): first %.2e  median %.2e  max %.2e" % (errs[0], float(np.median(errs)), max(errs)))
+    assert trk._graph is not None and trk.host_syncs - syncs0 == len(frames) - 1
+    assert errs[0] <= 1e-3 and max(errs[:10]) <= 1e-2, errs[:10]
+    assert max(errs) <= 0.25, errs

@@ -7,7 +7,10 @@ Reported: wall time per frame with the host reading the corners EVERY frame (wha
 host syncs per frame, the same loop without the per-frame read (pipelined), corner error (success_4pts_error) of the device
 loop against the CPU restatement of the same loop on the first --parity frames, and — for the B=1 head alone — eager vs
 hipGraph replay, each synchronised per frame.
-    python tests/tools/sequence_bench.py [--frames 200] [--parity 12]
+--similarity runs the loop WITH the similarity branch (crop, heads, device decode, moved crop, log-polar heads, decode, H_sim,
+rotate-back) around tests/standin_model.py's seeded stand-in for the reference's ModelBuilder: the ResNet-50 backbone of the
+deployment is PyTorch-ROCm's and is not shipped here, so these times cover everything of a frame EXCEPT two backbone passes.
+    python tests/tools/sequence_bench.py [--frames 200] [--parity 12] [--similarity]
 """
 import argparse, copy, json, os, sys, time
 import numpy as np
@@ -17,7 +20,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import hdn_amd
 from hdn_amd.graph import GraphedTrackProj
 from hdn_amd.tracker import HomoTracker
-from oracle.tracker_oracle import HomoTrackerOracle
+from oracle.tracker_oracle import HomoTrackerOracle, SimilarityOracle
 from synth_sequence import make_sequence, success_4pts_error
 
 
@@ -34,23 +37,32 @@ def seeded_net():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=200); ap.add_argument("--parity", type=int, default=12)
-    ap.add_argument("--iterations", type=int, default=1)
+    ap.add_argument("--iterations", type=int, default=1); ap.add_argument("--similarity", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     frames, corners, init = make_sequence(n_frames=args.frames, frame_hw=(720, 1280), target_wh=(300, 200))
     net = seeded_net(); net_cpu = copy.deepcopy(net)
     sd = {k: v.clone() for k, v in net_cpu.ShareFeature.state_dict().items()}
+    sim_cpu = twin = None
+    if args.similarity:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import standin_model as SM
+        from hdn_amd.similarity import DeviceSimilarity
+        net.fc.bias.data.mul_(0.1); net_cpu = copy.deepcopy(net)
+        twin = SM.StandInSiamese(net, loc_scale_lp=0.01).eval()
+        sim_cpu = SimilarityOracle(SM.StandInSiameseCPU(twin))
+        twin = twin.to(dev)
     netd = net.to(dev)
     torch.backends.cudnn.benchmark = True
     netd.optimize_for_inference(channels_last=True)
 
     def new_tracker(graph=False):
-        t = HomoTracker(netd, iterations=args.iterations, graph=graph)
+        t = HomoTracker(netd, iterations=args.iterations, graph=graph, similarity=DeviceSimilarity(twin) if twin is not None else None)
         t.init(frames[0], init["bbox"], init["poly"], init["gt_points"], init["first_point"])
         return t
 
     # parity of the whole per-frame chain, device vs CPU restatement
-    ref = HomoTrackerOracle(sd, lambda f: net_cpu.fc(net_cpu.avgpool(net_cpu.backbone(f)).flatten(1)), args.iterations)
+    ref = HomoTrackerOracle(sd, lambda f: net_cpu.fc(net_cpu.avgpool(net_cpu.backbone(f)).flatten(1)), args.iterations, similarity=sim_cpu)
     ref.init(frames[0], init["bbox"], init["poly"], init["gt_points"], init["first_point"])
     trk = new_tracker()
     errs = [success_4pts_error(trk.track_new(t, frames[t])["points"], ref.track_new(t, frames[t])["points"])
@@ -89,7 +101,7 @@ def main():
     graphed = head(gr)
     print(json.dumps({
         "sequence": f"{args.frames} frames 1280x720, 300x200 target, seed 20260928 (tools/synth_sequence.py)",
-        "refinement_iterations": args.iterations,
+        "refinement_iterations": args.iterations, "similarity_branch": "stand-in heads (tests/standin_model.py), device decode" if args.similarity else "identity",
         "ms_per_frame_loop_host_reads_corners_each_frame": ms_sync, "p99_ms": p99, "fps": 1e3 / ms_sync,
         "host_syncs_per_frame": syncs, "reference_host_syncs_per_frame": 6,
         "ms_per_frame_loop_no_host_read": ms_async,
