@@ -103,6 +103,25 @@ def make_inputs(dev, rank):
     return d
 
 
+def build_full_head(dev, imgs, h4p):
+    """The BASELINE configs[2] network exactly as the `full_head` block and --workload full time it: seeded HomoModelBuilder,
+    MIOpen find mode, BN-folded NHWC trunk with the fused first stage and fused block epilogues.  -> (net on dev, data, CPU
+    state_dict of the un-folded net).  tests/test_gpu_parity.py::test_benchmarked_full_head_configuration_parity holds THIS
+    configuration to the CPU oracle."""
+    import hdn_amd
+
+    torch.manual_seed(SEED + 7)
+    net = hdn_amd.HomoModelBuilder().eval()
+    net.fc.weight.data.mul_(0.01)
+    cpu_sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    torch.backends.cudnn.benchmark = True  # MIOpen find mode for the trunk's fixed shapes (searched during warm-up)
+    net = net.to(dev).optimize_for_inference(channels_last=True)
+    n = imgs.shape[0]
+    data = {"org_imgs": imgs, "input_tensors": imgs, "h4p": h4p,
+            "patch_indices": torch.arange(127 * 127, dtype=torch.float32, device=dev).repeat(n, 1)}
+    return net, data, cpu_sd
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", 0))
@@ -158,15 +177,7 @@ def main():
     full_net = full_data = None
 
     def build_full():
-        torch.manual_seed(SEED + 7)
-        net = hdn_amd.HomoModelBuilder().eval()
-        net.fc.weight.data.mul_(0.01)
-        cpu_sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
-        torch.backends.cudnn.benchmark = True  # MIOpen find mode for the trunk's fixed shapes (searched during warm-up)
-        net = net.to(dev).optimize_for_inference(channels_last=True)
-        data = {"org_imgs": d["imgs"], "input_tensors": d["imgs"], "h4p": d["h4p"],
-                "patch_indices": torch.arange(127 * 127, dtype=torch.float32, device=dev).repeat(PAIRS, 1)}
-        return net, data, cpu_sd
+        return build_full_head(dev, d["imgs"], d["h4p"])
 
     from hdn_amd.homo_model import homo_stages
     if args.workload == "full":
@@ -361,7 +372,7 @@ def main():
             el = float(tt.item())
         result["full_head"] = {
             "workload": "BASELINE configs[2] per GPU: full HomoModelBuilder head (PreShareFeature x2 -> PyTorch-ROCm ResNet-34 "
-                        "trunk, BN-folded NHWC under MIOpen find mode -> fused DLT+warp -> PreShareFeature) on 64 pairs"
+                        "trunk, BN-folded NHWC under MIOpen find mode, first stage and block epilogues as HIP kernels -> fused DLT+warp -> PreShareFeature) on 64 pairs"
                         + (", offsets all-gathered" if world > 1 else ""),
             "value": PAIRS * world * args.full_head_steps / el, "unit": "frames/s", "steps": args.full_head_steps,
             "ms_per_step": el / args.full_head_steps * 1e3, "n_gpus": world,

@@ -1,0 +1,87 @@
+// Residual-block epilogues of the homography regressor's trunk, fused:
+//
+//   y = relu(y + bias[c])                 after conv1 of a BasicBlock   (bn1 folded into the conv: bias = folded shift)
+//   y = relu(y + bias[c] + residual)      after conv2                   (out += residual; relu)
+//
+// Replaces, per block of homo_estimator/Deep_homography/Oneline_DLTv1/backbone/resnet.py:78-94 (eval mode, BatchNorm
+// folded), the separate bias-add, residual-add and ReLU launches PyTorch issues around the MIOpen convolutions: 83 elementwise
+// launches per forward become 32, each ONE pass over the activation (16 bytes per lane, in place).  HBM-bound by construction:
+// y read + written once, the residual read once, the per-channel bias from the scalar / L1 path.
+// Arithmetic: (y + bias) + residual, individually rounded, then max(., 0) - the order PyTorch's own kernels use
+// (conv bias first, `out += residual` second).
+#include "hdn_common.h"
+
+#pragma clang fp contract(off)
+
+namespace hdn {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// NHWC: the channel is the fastest index; C % 4 == 0, so a 16-byte word holds 4 consecutive channels of one pixel.
+// NCHW with HW % 4 == 0: a 16-byte word lies inside one (b, c) plane.
+template <bool NHWC, bool RES>
+__global__ __launch_bounds__(HDN_BLOCK) void bias_act_kernel(f4* __restrict__ y, const f4* __restrict__ res, const float* __restrict__ bias,
+                                                             unsigned n4, unsigned C, unsigned HW4) {
+  const unsigned stride = gridDim.x * HDN_BLOCK;
+  const unsigned C4 = C >> 2, mask = C4 - 1;
+  const bool pow2 = (C4 & mask) == 0;  // 64 / 128 / 256 / 512 channels: the channel word is a mask away
+  for (unsigned i = blockIdx.x * HDN_BLOCK + threadIdx.x; i < n4; i += stride) {
+    f4 v = y[i];
+    f4 b;
+    if (NHWC) {
+      b = reinterpret_cast<const f4*>(bias)[pow2 ? (i & mask) : (i % C4)];
+    } else {
+      const float s = bias[(i / HW4) % C];
+      b = f4{s, s, s, s};
+    }
+    v = v + b;
+    if (RES) v = v + res[i];
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    y[i] = v;
+  }
+}
+
+// any layout / size: one float per lane
+template <bool RES>
+__global__ __launch_bounds__(HDN_BLOCK) void bias_act_scalar_kernel(float* __restrict__ y, const float* __restrict__ res,
+                                                                    const float* __restrict__ bias, long long n, int C, int HW, int nhwc) {
+  const long long stride = (long long)gridDim.x * HDN_BLOCK;
+  for (long long i = (long long)blockIdx.x * HDN_BLOCK + threadIdx.x; i < n; i += stride) {
+    const int c = nhwc ? (int)(i % C) : (int)((i / HW) % C);
+    float v = y[i] + bias[c];
+    if (RES) v = v + res[i];
+    y[i] = fmaxf(v, 0.f);
+  }
+}
+
+template <bool NHWC>
+static void launch_vec(float* y, const float* res, const float* bias, unsigned n4, unsigned C, unsigned HW4, int blocks, hipStream_t s) {
+  f4* y4 = reinterpret_cast<f4*>(y);
+  const f4* r4 = reinterpret_cast<const f4*>(res);
+  if (res) hipLaunchKernelGGL((bias_act_kernel<NHWC, true>), dim3(blocks), dim3(HDN_BLOCK), 0, s, y4, r4, bias, n4, C, HW4);
+  else hipLaunchKernelGGL((bias_act_kernel<NHWC, false>), dim3(blocks), dim3(HDN_BLOCK), 0, s, y4, r4, bias, n4, C, HW4);
+}
+
+}  // namespace hdn
+
+extern "C" int hdn_bias_relu_f32(float* y, const float* bias, const float* residual, int B, int C, int HW, int nhwc, void* stream) {
+  if (!y || !bias) return HDN_E_NULL;
+  if (B <= 0 || C <= 0 || HW <= 0) return HDN_E_SHAPE;
+  if (residual == y) return HDN_E_ALIAS;
+  const long long n = (long long)B * C * HW;
+  if (n > 0x7fffffffLL) return HDN_E_LIMIT;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool vec = hdn::aligned16(y) && (!residual || hdn::aligned16(residual)) && (nhwc ? (C % 4 == 0 && hdn::aligned16(bias)) : (HW % 4 == 0));
+  if (vec) {
+    const long long n4 = n >> 2, want = (n4 + HDN_BLOCK - 1) / HDN_BLOCK;
+    const int blocks = (int)(want < 2048 ? want : 2048);  // 8 workgroups per CU x 256 CUs at most, then a grid-stride loop
+    if (nhwc) hdn::launch_vec<true>(y, residual, bias, (unsigned)n4, (unsigned)C, (unsigned)(HW >> 2), blocks, s);
+    else hdn::launch_vec<false>(y, residual, bias, (unsigned)n4, (unsigned)C, (unsigned)(HW >> 2), blocks, s);
+  } else {
+    const long long want = (n + HDN_BLOCK - 1) / HDN_BLOCK;
+    const int blocks = (int)(want < 4096 ? want : 4096);
+    if (residual) hipLaunchKernelGGL((hdn::bias_act_scalar_kernel<true>), dim3(blocks), dim3(HDN_BLOCK), 0, s, y, residual, bias, n, C, HW, nhwc);
+    else hipLaunchKernelGGL((hdn::bias_act_scalar_kernel<false>), dim3(blocks), dim3(HDN_BLOCK), 0, s, y, residual, bias, n, C, HW, nhwc);
+  }
+  return hdn::launch_status();
+}

@@ -123,285 +123,7 @@ __global__ __launch_bounds__(HDN_BLOCK) void share_feature_kernel(const float* _
 }
 
 // ---------------------------------------------------------------------------------------
-// W <= 128 (the 127x127 crops of the tracker), LDS form: one workgroup = 4 output rows x the full width.
-//   * no horizontal halo recompute: columns outside the image are the convs' own zero padding;
-//   * all three layers issue v_pk_fma_f32 on natural pairs: the intermediates live in LDS as
-//     (channel 2p, channel 2p+1) float2 per pixel, the weights as (w[2p], w[2p+1]) SGPR pairs, and each
-//     accumulator pair holds the partial sums over even / odd input channels (added once at the end);
-//   * pixel = lane index: rows x 128 columns = full rounds of 256 threads.
-// (Round 1's tile kernel - every 4-row tile recomputing its 8 / 6 halo-inclusive rows of layers 1 / 2 - is gone; the rolling-row
-// kernel below does the same arithmetic per pixel with 396 instead of 576 FMAs and stays selectable as HDN_SF_LDS=1.)
-// ---------------------------------------------------------------------------------------
-// A wave-uniform pointer into the (read-only) parameter block, re-typed to the constant address space so its loads
-// are scalar (s_load), and passed through an empty asm so the compiler cannot hoist every weight of the layer out of
-// the tap loop (which overflows the ~100 SGPRs and spills through v_readlane/v_writelane).
-typedef const float2v __attribute__((address_space(4))) cfloat2v;
-__device__ __forceinline__ const cfloat2v* opaque_const(const float2v* p) {
-  uint64_t a = reinterpret_cast<uint64_t>(p);
-  asm volatile("" : "+s"(a));
-  return (const cfloat2v*)a;
-}
-
-// ---------------------------------------------------------------------------------------
-// W <= 128, rolling rows ("ring"): a tile kernel recomputes, for every 4-row tile, 8 rows of layer 1 and 6 rows of
-// layer 2 (2x and 1.5x the work: measured, its time follows its FMA count).  Here a workgroup walks DOWN a strip of
-// consecutive tiles of one image and keeps the intermediate rows it already has: the 4-channel layer-1 rows live in an 8-row
-// ring, the 8-channel layer-2 rows in a 6-row ring (slot = row mod ring size, wave-uniform, so a row's LDS address is one
-// scalar-offset add and everything else stays an immediate), and every tile after the first of a strip computes only its 4
-// NEW rows per layer: 396 FMAs per pixel instead of 576.  A strip is images' tiles [k*T/n, (k+1)*T/n): n strips per image,
-// n = (workgroups the chip holds) / images, so short batches still fill the chip (one-tile strips = the old kernel's work).
-// 48.5 KB of LDS (3 workgroups per CU); same arithmetic per output pixel as round 1's tile kernel (bit-identical).
-// ---------------------------------------------------------------------------------------
-namespace sfr {
-constexpr int R = 4, CS = 130;
-constexpr int IN_H = R + 6, A_RING = 8, B_RING = 6;
-constexpr int IN_N = IN_H * CS, A_N = A_RING * CS, B_N = B_RING * CS;
-constexpr int W_N = 424;
-constexpr int LDS_FLOATS = IN_N + 2 * (2 * A_N) + 2 * (4 * B_N) + W_N;
-constexpr int LDS_BYTES = LDS_FLOATS * 4;
-}  // namespace sfr
-
-// rows first .. first + 2*NQ - 1 of the input (rows 2q + rr of the window) for the NEXT tile, in registers
-template <int NQ>
-__device__ __forceinline__ void sfr_fetch(float (&pin)[5], const float* __restrict__ src, int first_row, int H, int W, int c, int rr) {
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const int gr = first_row + 2 * q + rr;
-    const bool ok = gr >= 0 && gr < H && c < W;
-    pin[q] = src[ok ? gr * W + c : 0];
-    pin[q] = ok ? pin[q] : 0.f;
-  }
-}
-
-// One tile (output rows r0 .. r0+3).  INC: the layer-1 rows r0-2 .. r0+1 and the layer-2 rows r0-1, r0 are in the rings
-// already (left there by the tile above); only rows r0+2 .. r0+5 / r0+1 .. r0+4 are computed.  The input window in s_in
-// starts at row r0-3 (full) or r0+1 (INC).
-// layer-2 / layer-3 weights of the rolling-row kernel through the scalar cache into SGPRs (48 per tap row) instead of LDS
-// broadcasts: a tap's LDS reads drop from 8 + NPX to NPX (measured 42.3 -> 39.9 us at 128 images); -DSFR_LDS_WEIGHTS reverts
-#ifndef SFR_LDS_WEIGHTS
-#define SFR_SGPR_WEIGHTS 1
-#endif
-#ifndef SFR_UNROLL_T
-#define SFR_UNROLL_T 1
-#endif
-#ifndef SFR_UNROLL_H
-#define SFR_UNROLL_H 1
-#endif
-template <bool INC>
-__device__ __forceinline__ void sfr_tile(const float* s_in, float2v* s_a, float2v* s_b, const float* s_w, float* __restrict__ outp,
-                                         int r0, int H, int W, int c, int rr, const float* __restrict__ prm) {
-  using namespace sfr;
-  const float2v* w2p = reinterpret_cast<const float2v*>(s_w + SF_W2);  // [2][9][8]
-  const float2v* w3p = reinterpret_cast<const float2v*>(s_w + SF_W3);  // [4][9]
-  auto aslot = [&](int grow) { return (grow + 2) & (A_RING - 1); };                                // rows >= -2
-  auto bslot = [&](int grow) { return (grow + 1) % B_RING; };                                   // rows >= -1
-
-  // ---- layer 1: 1 -> 4 at rows r0-2 .. r0+5 (INC: r0+2 .. r0+5) ----------------------------------------------------------
-  {
-    float w1[9][4], al[4], be[4];
-#pragma unroll
-    for (int k9 = 0; k9 < 9; ++k9)
-#pragma unroll
-      for (int co = 0; co < 4; ++co) w1[k9][co] = s_w[SF_W1 + k9 * 4 + co];
-#pragma unroll
-    for (int co = 0; co < 4; ++co) {
-      al[co] = s_w[SF_ALPHA + co];
-      be[co] = s_w[SF_BETA + co];
-    }
-    constexpr int NQ = INC ? 2 : 4;
-#pragma unroll 2
-    for (int q = 0; q < NQ; ++q) {
-      const int r = 2 * q + rr;                       // row of the s_in window whose 3x3 neighbourhood starts here
-      const int gr = (INC ? r0 + 2 : r0 - 2) + r;     // layer-1 row being produced
-      float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const float v = s_in[(r + ky) * CS + c + kx];
-#pragma unroll
-          for (int co = 0; co < 4; ++co) acc[co] = __builtin_fmaf(v, w1[ky * 3 + kx][co], acc[co]);
-        }
-      const bool inside = gr >= 0 && gr < H && c < W;
-      float y[4];
-#pragma unroll
-      for (int co = 0; co < 4; ++co) {
-        const float t = fmaxf(__builtin_fmaf(acc[co], al[co], be[co]), 0.f);
-        y[co] = inside ? t : 0.f;
-      }
-      const int sl = aslot(gr);
-      s_a[(0 * A_RING + sl) * CS + c + 1] = float2v{y[0], y[1]};
-      s_a[(1 * A_RING + sl) * CS + c + 1] = float2v{y[2], y[3]};
-    }
-  }
-  __syncthreads();
-
-  // ---- layer 2: 4 -> 8 at rows r0-1 .. r0+4 (INC: r0+1 .. r0+4) ----------------------------------------------------------
-  {
-    constexpr int NPX = INC ? 2 : 3;
-    const int b_first = INC ? r0 + 1 : r0 - 1;
-    // LDS row bases (element offsets inside a plane) of the 3 x NPX layer-1 rows this thread reads: ring slots are runtime
-    int arow[NPX][3];
-#pragma unroll
-    for (int q = 0; q < NPX; ++q)
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky) arow[q][ky] = aslot(b_first + 2 * q + rr - 1 + ky) * CS + c;
-    float2v acc[NPX][8];
-#pragma unroll
-    for (int q = 0; q < NPX; ++q)
-#pragma unroll
-      for (int co = 0; co < 8; ++co) acc[q][co] = float2v{0.f, 0.f};
-#pragma unroll SFR_UNROLL_T
-    for (int t = 0; t < 6; ++t) {  // t = cp * 3 + ky
-      const int cp = t / 3, ky = t - cp * 3;
-#ifdef SFR_SGPR_WEIGHTS
-      const cfloat2v* w = opaque_const(reinterpret_cast<const float2v*>(prm + SF_W2) + t * 24);  // scalar loads: 48 SGPRs per tap row
-#else
-      const float2v* w = w2p + t * 24;  // [kx][co]
-#endif
-      int rowq[NPX];
-#pragma unroll
-      for (int q = 0; q < NPX; ++q) rowq[q] = cp * A_N + (ky == 0 ? arow[q][0] : (ky == 1 ? arow[q][1] : arow[q][2]));
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        float2v v[NPX];
-#pragma unroll
-        for (int q = 0; q < NPX; ++q) v[q] = s_a[rowq[q] + kx];
-#pragma unroll
-        for (int co = 0; co < 8; ++co) {
-          const float2v wv = w[kx * 8 + co];
-#pragma unroll
-          for (int q = 0; q < NPX; ++q) acc[q][co] = __builtin_elementwise_fma(v[q], wv, acc[q][co]);
-        }
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < NPX; ++q) {
-      const int gr = b_first + 2 * q + rr;
-      const bool inside = gr >= 0 && gr < H && c < W;
-      float y[8];
-#pragma unroll
-      for (int co = 0; co < 8; ++co) {
-        const float t = fmaxf(__builtin_fmaf(acc[q][co].x + acc[q][co].y, s_w[SF_ALPHA + 4 + co], s_w[SF_BETA + 4 + co]), 0.f);
-        y[co] = inside ? t : 0.f;
-      }
-      const int sl = bslot(gr);
-#pragma unroll
-      for (int p = 0; p < 4; ++p) s_b[(p * B_RING + sl) * CS + c + 1] = float2v{y[2 * p], y[2 * p + 1]};
-    }
-  }
-  __syncthreads();
-
-  // ---- layer 3: 8 -> 1 at rows r0 .. r0+3, straight to HBM ------------------------------------------------------------------
-  {
-    constexpr int NPX = R / 2;
-    int brow[NPX][3];
-#pragma unroll
-    for (int q = 0; q < NPX; ++q)
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky) brow[q][ky] = bslot(r0 + 2 * q + rr - 1 + ky) * CS + c;
-    float2v acc[NPX];
-#pragma unroll
-    for (int q = 0; q < NPX; ++q) acc[q] = float2v{0.f, 0.f};
-#pragma unroll SFR_UNROLL_H
-    for (int h = 0; h < 2; ++h) {  // two channel pairs (36 weights) per iteration
-#ifdef SFR_SGPR_WEIGHTS
-      const cfloat2v* w = opaque_const(reinterpret_cast<const float2v*>(prm + SF_W3) + h * 18);
-#else
-      const float2v* w = w3p + h * 18;
-#endif
-#pragma unroll
-      for (int cq = 0; cq < 2; ++cq)
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx) {
-            const float2v wv = w[cq * 9 + ky * 3 + kx];
-#pragma unroll
-            for (int q = 0; q < NPX; ++q) acc[q] = __builtin_elementwise_fma(s_b[(2 * h + cq) * B_N + brow[q][ky] + kx], wv, acc[q]);
-          }
-    }
-#pragma unroll
-    for (int q = 0; q < NPX; ++q) {
-      const int gr = r0 + 2 * q + rr;
-      const float t = fmaxf(__builtin_fmaf(acc[q].x + acc[q].y, s_w[SF_ALPHA + 12], s_w[SF_BETA + 12]), 0.f);
-      if (gr < H && c < W) outp[size_t(gr) * W + c] = t;
-    }
-  }
-}
-
-__global__ __launch_bounds__(HDN_BLOCK) void share_feature_ring_kernel(const float* __restrict__ img, const float* __restrict__ prm,
-                                                                       float* __restrict__ out, int H, int W, int tiles_per_img,
-                                                                       int strips_per_img, int total_strips) {
-  using namespace sfr;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* s_in = smem;
-  float2v* s_a = reinterpret_cast<float2v*>(smem + IN_N);            // [2][A_RING][CS]
-  float2v* s_b = reinterpret_cast<float2v*>(smem + IN_N + 4 * A_N);  // [4][B_RING][CS]
-  float* s_w = smem + IN_N + 4 * A_N + 8 * B_N;
-
-  const int tid = threadIdx.x;
-  const int c = tid & 127, rr = tid >> 7;
-  for (int idx = tid; idx < HDN_SF_PARAMS; idx += HDN_BLOCK) s_w[idx] = prm[idx];
-  // zero, once, the halo columns (-1 and 128) of the input window and of both rings
-  if (tid < 2 * IN_H) s_in[(tid >> 1) * CS + (tid & 1) * (CS - 1)] = 0.f;
-  if (tid < 2 * (2 * A_RING + 4 * B_RING)) {
-    const int side = tid & 1, row = tid >> 1;
-    if (row < 2 * A_RING) s_a[row * CS + side * (CS - 1)] = float2v{0.f, 0.f};
-    else s_b[(row - 2 * A_RING) * CS + side * (CS - 1)] = float2v{0.f, 0.f};
-  }
-
-#pragma unroll 1
-  for (int strip = blockIdx.x; strip < total_strips; strip += gridDim.x) {
-    const int bimg = strip / strips_per_img, k = strip - bimg * strips_per_img;
-    const int t_first = (k * tiles_per_img) / strips_per_img, t_end = ((k + 1) * tiles_per_img) / strips_per_img;
-    const float* __restrict__ src = img + size_t(bimg) * H * W;
-    float* __restrict__ dst = out + size_t(bimg) * H * W;
-    float pin[5];
-    sfr_fetch<5>(pin, src, t_first * R - 3, H, W, c, rr);   // first tile of the strip: full 10-row window
-#pragma unroll 1
-    for (int t = t_first; t < t_end; ++t) {
-      const int r0 = t * R;
-      const bool inc = t > t_first;
-      __syncthreads();  // the previous tile's readers of s_in / of the ring slots about to be overwritten are done
-      if (!inc) {
-#pragma unroll
-        for (int q = 0; q < 5; ++q) s_in[(2 * q + rr) * CS + c + 1] = pin[q];
-      } else {
-#pragma unroll
-        for (int q = 0; q < 3; ++q) s_in[(2 * q + rr) * CS + c + 1] = pin[q];
-      }
-      if (t + 1 < t_end) sfr_fetch<3>(pin, src, (t + 1) * R + 1, H, W, c, rr);  // the next tile's 6 new-window rows, in flight meanwhile
-      __syncthreads();
-      if (inc) sfr_tile<true>(s_in, s_a, s_b, s_w, dst, r0, H, W, c, rr, prm);
-      else sfr_tile<false>(s_in, s_a, s_b, s_w, dst, r0, H, W, c, rr, prm);
-    }
-  }
-}
-
-static int launch_sf_ring(const float* img, const float* folded, float* out, int B, int H, int W, hipStream_t stream) {
-  static PerDeviceOnce attr;
-  const int dev_ = PerDeviceOnce::device();
-  if (!attr.done(dev_)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&share_feature_ring_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sfr::LDS_BYTES);
-    if (e != hipSuccess) return -(1000 + (int)e);
-    attr.set(dev_);
-  }
-  const int tiles_per_img = cdiv(H, sfr::R);
-  const int cap = 256 * (163840 / sfr::LDS_BYTES);  // workgroups the chip holds at once (3 per CU)
-  int strips = cap / B;                             // strips per image: enough to fill the chip, never shorter than a tile
-  strips = strips < 1 ? 1 : (strips > tiles_per_img ? tiles_per_img : strips);
-  const long long total = (long long)strips * B;
-  if (total > 0x7fffffffLL) return HDN_E_LIMIT;
-  const int grid = (int)(total < cap ? total : cap);
-  hipLaunchKernelGGL(share_feature_ring_kernel, dim3(grid), dim3(HDN_BLOCK), sfr::LDS_BYTES, stream, img, folded, out, H, W,
-                     tiles_per_img, strips, (int)total);
-  return launch_status();
-}
-
-// ---------------------------------------------------------------------------------------
-// W <= 128, rows in registers ("sfv", default since round 2): one WAVE owns a strip of output rows over the full width and
+// W <= 128, rows in registers ("sfv"; the LDS tile / rolling-row kernels of rounds 1-2 were superseded by it and removed in round 3): one WAVE owns a strip of output rows over the full width and
 // never touches the LDS or a barrier.  Lane l holds columns 2l and 2l+1 as one packed pair, so every layer is
 // v_pk_fma_f32 over the two pixels with the weight as a broadcast SGPR operand.  Rows roll through three-deep register
 // rings (the row loop is unrolled by 3, so ring slots are register names):
@@ -412,7 +134,7 @@ static int launch_sf_ring(const float* img, const float* folded, float* out, int
 //   output row i-3   -> epilogue, stored.
 // Per output row and wave: 36 + 288 + 72 packed FMAs, ~60 epilogue / shift / mask instructions, 25 scalar weight loads.
 // A strip of n rows costs n + 2 layer-2 rows (the halo is recomputed), n is chosen so that the launch is 2-3 waves per SIMD.
-// Summation order differs from the LDS kernels (no even / odd input-channel partial sums): same 1e-4 bound, not bit-identical.
+// Summation order differs from the generic LDS kernel above (no even / odd input-channel partial sums): same 1e-4 bound, not bit-identical.
 // ---------------------------------------------------------------------------------------
 namespace sfv {
 typedef const float __attribute__((address_space(4))) cfloat;
@@ -735,8 +457,6 @@ extern "C" int hdn_share_feature_f32(const float* img, const float* folded, floa
   if (B > 65535 || (long long)H * W > 0x7fffffffLL / 4) return HDN_E_LIMIT;
   if (out == img) return HDN_E_ALIAS;
   if (W <= 128) {
-    static const bool lds = [] { const char* e = getenv("HDN_SF_LDS"); return e && e[0] == '1'; }();  // A/B switch: the LDS (rolling rows) kernel
-    if (lds) return hdn::launch_sf_ring(img, folded, out, B, H, W, static_cast<hipStream_t>(stream));
     return hdn::launch_sf_rows(img, folded, out, B, H, W, static_cast<hipStream_t>(stream));
   }
   dim3 grid(hdn::cdiv(W, hdn::SF_COLS), hdn::cdiv(H, hdn::SF_ROWS), B);

@@ -6,16 +6,15 @@
 // operator, so there is nothing for MFMA to contract; the production shapes are
 // HBM-bound (5 FLOP/B) and the 31x31 (x) 61x61 stress shape is fp32-FMA-bound (82 FLOP/B).
 //
-// Kernel family "f1" (compile-time shapes):
-//   * one workgroup = 4 waves = PPB = 4*PPW consecutive planes: their x planes are ONE
-//     contiguous HBM range, fetched with 16-byte coalesced loads into LDS (linear image
-//     when SX == WX, else re-strided so 16-byte LDS reads stay aligned and conflict-free);
-//   * one wave owns one plane at a time; its HKxWK taps are wave-uniform and are read
-//     through the scalar cache into SGPRs (no LDS/VGPR cost, FMA takes the SGPR operand);
-//   * a lane owns a 1 x TW strip of outputs: per tap row it reads TW+WK-1 floats from LDS
-//     and issues TW*WK FMAs, accumulating in a fixed (u,v) order (deterministic);
-//   * results are staged in LDS and leave as one contiguous 16-byte coalesced store.
-// Circular variant: the padded plane (rows wrap, columns clamp) is built in LDS only.
+// Shape-specialised kernels (compile-time shapes): xcorr_prod29_kernel (5x5 (x) 29x29), xcorr_cfg5_kernel (5x5 (x) 35x35),
+// xcorr_north_kernel / xcorr_north_mfma_kernel (31x31 (x) 61x61 direct forms; the FFT forms are in xcorr_fft.hip),
+// xcorr_circ13f_kernel (circular 13x13).  Common structure:
+//   * a workgroup's planes are ONE contiguous HBM range for x, k and out, moved with 16-byte coalesced accesses;
+//   * taps are wave-uniform and are read through the scalar cache into SGPRs (FMA takes the SGPR operand);
+//   * accumulation order is fixed (deterministic); results leave as one contiguous 16-byte coalesced store.
+// Circular variant: the padded plane (rows wrap, columns clamp) is never built in HBM.
+// (Rounds 1-2 also carried a strip-per-row template "f1" for the two 5x5 shapes and the direct-sum circular kernel
+// "circ13r"; both were superseded, had no test of their own, and were removed in round 3.)
 //
 // Kernel "generic" (runtime shapes): one workgroup per plane, LDS-staged when the plane
 // fits, straight from L2 otherwise.  Correct for any Hk<=Hx, Wk<=Wx; not tuned.
@@ -38,153 +37,12 @@ struct XcorrPtrs {
   float* out[XC_MAX_PROBLEMS];
 };
 
-template <int HX_, int WX_, int HK_, int WK_, int TW_, int SX_, int PPW_, bool CIRC_, bool REUSE_>
-struct F1Cfg {
-  static constexpr int HX = HX_, WX = WX_, HK = HK_, WK = WK_, TW = TW_, SX = SX_, PPW = PPW_;
-  static constexpr bool CIRC = CIRC_, REUSE = REUSE_;
-  static constexpr int HP = CIRC ? HX + 2 * (HX / 2) : HX;  // plane as correlated (padded if circular)
-  static constexpr int WP = CIRC ? WX + 2 * (WX / 2) : WX;
-  static constexpr int HO = HP - HK + 1, WO = WP - WK + 1;
-  static constexpr int NSEG = cdiv(WO, TW);
-  static constexpr int UNITS = HO * NSEG;      // strips per plane
-  static constexpr int XW = TW + WK - 1;       // LDS floats a strip reads per tap row
-  static constexpr int PPB = 4 * PPW;          // planes per workgroup
-  static constexpr int XPLANE = HP * SX;       // LDS floats per staged plane
-  static constexpr int OPLANE = HO * WO;
-  static constexpr int SLACK = 64;             // the last strip of the last row may over-read (never stored)
-  static constexpr int XFLOATS = round_up(PPB * XPLANE + SLACK, 4);
-  static constexpr int LDS_FLOATS = XFLOATS + (REUSE ? 0 : round_up(PPB * OPLANE, 4));
-  static constexpr size_t LDS_BYTES = size_t(LDS_FLOATS) * sizeof(float);
-  static_assert(SX >= WP, "row stride shorter than the plane");
-  static_assert(!REUSE || (OPLANE <= XPLANE && PPW == 1), "outputs reuse the x region: one plane per wave, and they must fit");
-  static_assert((NSEG - 1) * TW + XW <= SX + SLACK, "strip over-read exceeds the slack");
-};
-
-template <class Cfg>
-__global__ __launch_bounds__(HDN_BLOCK) void xcorr_f1_kernel(XcorrPtrs P, int planes) {
-  constexpr int HX = Cfg::HX, WX = Cfg::WX, HK = Cfg::HK, WK = Cfg::WK, TW = Cfg::TW, SX = Cfg::SX;
-  constexpr int HP = Cfg::HP, WP = Cfg::WP, WO = Cfg::WO, NSEG = Cfg::NSEG, UNITS = Cfg::UNITS;
-  constexpr int XW = Cfg::XW, PPW = Cfg::PPW, PPB = Cfg::PPB, XPLANE = Cfg::XPLANE, OPLANE = Cfg::OPLANE;
-
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sx = smem;
-  float* so = Cfg::REUSE ? smem : smem + Cfg::XFLOATS;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & (HDN_WAVE - 1);
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int prob = blockIdx.y;
-  const float* __restrict__ x = P.x[prob];
-  const float* __restrict__ k = P.k[prob];
-  float* __restrict__ out = P.out[prob];
-
-  const int plane0 = blockIdx.x * PPB;
-  const int np = min(PPB, planes - plane0);
-
-  // ---- stage the x planes of this workgroup in LDS ------------------------------------
-  const float* xg = x + size_t(plane0) * (HX * WX);
-  if constexpr (!Cfg::CIRC && SX == WX) {
-    if (np == PPB && aligned16(xg)) copy_g2l_full<PPB * HX * WX>(xg, sx, tid);  // all loads in flight at once
-    else copy_g2l(xg, sx, np * HX * WX, tid);
-  } else if constexpr (!Cfg::CIRC) {
-    for (int idx = tid; idx < np * HX * WX; idx += HDN_BLOCK) {
-      const int p = idx / (HX * WX), rem = idx - p * (HX * WX);
-      const int r = rem / WX, c = rem - r * WX;
-      sx[p * XPLANE + r * SX + c] = xg[idx];
-    }
-  } else {
-    // rows wrap by HX/2 (angle axis), columns clamp by WX/2 (log-radius axis): xcorr.py:52-53.
-    // Re-reads hit L1/L2; HBM sees each x element once.
-    for (int idx = tid; idx < np * HP * WP; idx += HDN_BLOCK) {
-      const int p = idx / (HP * WP), rem = idx - p * (HP * WP);
-      const int r = rem / WP, c = rem - r * WP;
-      int sr = r - HX / 2;
-      sr = sr < 0 ? sr + HX : (sr >= HX ? sr - HX : sr);
-      const int sc = min(max(c - WX / 2, 0), WX - 1);
-      sx[p * XPLANE + r * SX + c] = xg[p * (HX * WX) + sr * WX + sc];
-    }
-  }
-  __syncthreads();
-
-  // ---- correlate: one wave per plane, one lane per 1 x TW output strip -----------------
-#pragma unroll 1
-  for (int pw = 0; pw < PPW; ++pw) {
-    const int slot = wave * PPW + pw;  // wave-uniform
-    if (slot < np) {
-      const float* __restrict__ kp = k + size_t(plane0 + slot) * (HK * WK);  // wave-uniform -> scalar loads
-      const float* xs = sx + slot * XPLANE;
-      float* os = so + slot * OPLANE;  // REUSE: compact image over the (by then dead) x planes
-      constexpr int ROUNDS = cdiv(UNITS, HDN_WAVE);
-      float res[ROUNDS][TW];  // a lane's strips of this plane stay in registers until every strip is done
-#pragma unroll
-      for (int rd = 0; rd < ROUNDS; ++rd) {
-        const int unit = rd * HDN_WAVE + lane;
-        const int uu = unit < UNITS ? unit : UNITS - 1;
-        const int i = uu / NSEG, s = uu - i * NSEG;
-        const float* xr = xs + i * SX + s * TW;
-        float acc[TW];
-#pragma unroll
-        for (int j = 0; j < TW; ++j) acc[j] = 0.f;
-
-        if constexpr (HK * WK <= 64) {
-#pragma unroll
-          for (int u = 0; u < HK; ++u) {
-            float xv[XW];
-#pragma unroll
-            for (int c = 0; c < XW; ++c) xv[c] = xr[u * SX + c];
-#pragma unroll
-            for (int v = 0; v < WK; ++v) {
-              const float kv = kp[u * WK + v];
-#pragma unroll
-              for (int j = 0; j < TW; ++j) acc[j] = __builtin_fmaf(xv[j + v], kv, acc[j]);
-            }
-          }
-        } else {
-#pragma unroll 1
-          for (int u = 0; u < HK; ++u) {
-            float xv[XW];
-#pragma unroll
-            for (int c = 0; c < XW; ++c) xv[c] = xr[u * SX + c];
-#pragma unroll
-            for (int v = 0; v < WK; ++v) {
-              const float kv = kp[u * WK + v];
-#pragma unroll
-              for (int j = 0; j < TW; ++j) acc[j] = __builtin_fmaf(xv[j + v], kv, acc[j]);
-            }
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < TW; ++j) res[rd][j] = acc[j];
-      }
-      if constexpr (Cfg::REUSE) __syncthreads();  // every wave's x reads precede the overwrite (np < 4: see below)
-#pragma unroll
-      for (int rd = 0; rd < ROUNDS; ++rd) {
-        const int unit = rd * HDN_WAVE + lane;
-        if (unit < UNITS) {
-          const int i = unit / NSEG, s = unit - i * NSEG;
-#pragma unroll
-          for (int j = 0; j < TW; ++j)
-            if (s * TW + j < WO) os[i * WO + s * TW + j] = res[rd][j];
-        }
-      }
-    } else if constexpr (Cfg::REUSE) {
-      __syncthreads();  // idle wave of a tail workgroup: keep the barrier count equal
-    }
-  }
-  __syncthreads();
-
-  // ---- contiguous store of the workgroup's output planes -------------------------------
-  float* og = out + size_t(plane0) * OPLANE;
-  if (np == PPB && aligned16(og)) copy_l2g_full<PPB * OPLANE>(so, og, tid);
-  else copy_l2g(so, og, np * OPLANE, tid);
-}
-
 // ---------------------------------------------------------------------------------------
 // 5x5 (x) 29x29 -> 25x25: the production correlation (3 levels x {cls,loc} per frame, ban.py:76).  HBM-bound.
 //
-// Same workgroup structure as the f1 family (4 planes = one contiguous HBM range in, one out, one wave per plane,
-// taps in SGPRs), with the LDS access pattern made conflict-free: PMC on the f1 version showed 43 % of its LDS
-// cycles were bank conflicts (horizontal 1x5 strips at row stride 29 put lanes 2-way on a bank).  Here a lane owns a
+// 4 planes per workgroup = one contiguous HBM range in, one out, one wave per plane, taps in SGPRs, with the LDS access
+// pattern made conflict-free: PMC on the first version (horizontal 1x5 strips at row stride 29, lanes 2-way on a bank)
+// showed 43 % of its LDS cycles were bank conflicts.  Here a lane owns a
 // VERTICAL 5x1 strip (5-row block b, column j; j fastest across lanes) and the plane rows are re-strided to 37
 // floats: 25 consecutive columns of one block, then 5*37 = 185 = 25 (mod 32) for the next block => the 32 lanes of
 // a bank group always hit 32 distinct banks.  Per tap column a lane reads 9 floats and issues 25 FMAs.
@@ -851,146 +709,6 @@ __global__ __launch_bounds__(HDN_BLOCK, 2) void xcorr_north_mfma_kernel(XcorrPtr
 }
 
 // ---------------------------------------------------------------------------------------
-// circular 13x13 (x) 13x13 -> 13x13 (log-polar head, ban_lp.py:38).  ~ridge: 28 FLOP/B.
-//
-// The 25x25 padded plane is never built: x and k stay in LDS as raw 13x13 linear images (both are contiguous
-// 16-plane chunks in HBM -> two all-in-flight 16-byte copies), and the wrap / clamp is folded into the operands:
-//   padded row  (i+u)  -> source row (i+u+7) mod 13      (rows = angle, wraps): one add per tap row
-//   padded cols 0..5 / 19..24 replicate x[0] / x[12]:   broadcast pairs (op_sel), no loads at all
-// A lane owns one output row of one plane.  Same even/odd scheme as the 31x31 direct kernel: operand pairs
-// R[n] = (xp[2n], xp[2n+1]); even taps accumulate (out[2j], out[2j+1]), odd taps (out[2j-1], out[2j]).
-// Per tap row: 7 + 7 two-dword LDS reads (x row, k row) and 76 packed FMAs + 5 adds.
-// This is the DIRECT sum (HDN_CIRC13_DIRECT=1); the default since round 2 is the DFT form further down.
-// ---------------------------------------------------------------------------------------
-// Work split: a workgroup owns 256 consecutive OUTPUT ROWS of the [planes*13, 13] result
-// (one per lane: every lane busy, where 4 planes of 13 rows per wave would leave 12 of 64 idle) and stages the 20-21 planes
-// those rows belong to.  Its outputs are one contiguous 16-byte-aligned range; planes cut by a workgroup border are
-// staged by both neighbours (+5 % reads, mostly L2 hits).
-namespace circ13r {
-constexpr int N = 13, PL = N * N, ROWS = HDN_BLOCK;
-constexpr int MAXP = (ROWS + N - 2) / N + 1;          // 21 planes can be touched by 256 consecutive rows
-constexpr int WIN = ((MAXP * PL + 3) / 4 + 1) * 4;    // 16-byte aligned window incl. up to 3 floats of head slack: 3556
-constexpr int WIN4 = WIN / 4, WITER = (WIN4 + HDN_BLOCK - 1) / HDN_BLOCK;
-}  // namespace circ13r
-
-__global__ __launch_bounds__(HDN_BLOCK, 3) void xcorr_circ13r_kernel(XcorrPtrs P, int planes) {
-  using namespace circ13r;
-  __shared__ __attribute__((aligned(16))) float smem[2 * WIN];
-  float* sx = smem;
-  float* sk = smem + WIN;
-
-  const int tid = threadIdx.x;
-  const int prob = blockIdx.y;
-  const long long total_rows = (long long)planes * N, total = (long long)planes * PL;
-  const long long row0 = (long long)blockIdx.x * ROWS;
-  const int nrows = (int)min((long long)ROWS, total_rows - row0);
-  const int p0 = (int)(row0 / N), p1 = (int)min((row0 + ROWS - 1) / N, (long long)planes - 1);
-  const int np = p1 - p0 + 1;
-  const float* xg = P.x[prob];
-  const float* kg = P.k[prob];
-  const long long base = (long long)p0 * PL;
-  const int head = (int)(base & 3);
-  const long long first = base - head;
-
-  if (aligned16(xg) && aligned16(kg) && first + WIN <= total) {  // all 16-byte loads of both windows in flight at once
-    const float4* x4 = reinterpret_cast<const float4*>(xg + first);
-    const float4* k4 = reinterpret_cast<const float4*>(kg + first);
-    float4 rx[WITER], rk[WITER];
-#pragma unroll
-    for (int q = 0; q < WITER; ++q) {
-      const int i = min(tid + q * HDN_BLOCK, WIN4 - 1);
-      rx[q] = x4[i];
-      rk[q] = k4[i];
-    }
-#pragma unroll
-    for (int q = 0; q < WITER; ++q) {
-      const int i = tid + q * HDN_BLOCK;
-      if (i < WIN4) {
-        reinterpret_cast<float4*>(sx)[i] = rx[q];
-        reinterpret_cast<float4*>(sk)[i] = rk[q];
-      }
-    }
-  } else {
-    for (int i = tid; i < np * PL; i += HDN_BLOCK) {
-      sx[head + i] = xg[base + i];
-      sk[head + i] = kg[base + i];
-    }
-  }
-  __syncthreads();
-
-  const bool live = tid < nrows;
-  const long long g = row0 + min(tid, nrows - 1);
-  const int plane = (int)(g / N);
-  const int i = (int)(g - (long long)plane * N);  // output row
-  const float* xs = sx + head + (plane - p0) * PL;
-  const float* ks = sk + head + (plane - p0) * PL;
-  float2v accE[7], accO[7];
-#pragma unroll
-  for (int j = 0; j < 7; ++j) accE[j] = accO[j] = float2v{0.f, 0.f};
-  int r = i + 7;  // source row of padded row i + u, u = 0
-  r = r >= N ? r - N : r;
-#pragma unroll 1
-  for (int u = 0; u < N; ++u) {
-    const float* xr = xs + r * N;
-    const float* kr = ks + u * N;
-    float2v X[7], K[7];  // (x[2m], x[2m+1]) and (k[2m], k[2m+1]); x[13] is never used, k[13] is taken as 0
-#pragma unroll
-    for (int m = 0; m < 7; ++m) {
-      X[m] = float2v{xr[2 * m], xr[2 * m + 1]};
-      K[m] = m < 6 ? float2v{kr[2 * m], kr[2 * m + 1]} : float2v{kr[12], 0.f};
-    }
-    const float2v lo = X[0].xx, hi = X[6].xx;  // replicated columns: (x0,x0) and (x12,x12)
-    // Operand pair n of the padded row is (x0,x0) for n < 3 and (x12,x12) for n > 8: every tap that meets such a pair
-    // multiplies the SAME value, so those taps are summed first (packed prefix / suffix sums: .x = even taps, .y = odd taps)
-    // and cost one FMA per accumulator instead of one per tap: 63 + 13 FMAs + 5 adds per tap row instead of 91 FMAs.
-    const float2v P1 = K[0], P2 = P1 + K[1], P3 = P2 + K[2];              // (k0, k1), (k0+k2, k1+k3), (k0+k2+k4, k1+k3+k5)
-    const float2v Q1 = K[6], Q2 = K[5] + Q1, Q3 = K[4] + Q2, Q4 = K[3] + Q3;  // (k12, 0), (k10+k12, k11), ..., (k6+..+k12, k7+k9+k11)
-    accE[0] = __builtin_elementwise_fma(lo, P3.xx, accE[0]);
-    accE[1] = __builtin_elementwise_fma(lo, P2.xx, accE[1]);
-    accE[2] = __builtin_elementwise_fma(lo, P1.xx, accE[2]);
-    accE[3] = __builtin_elementwise_fma(hi, Q1.xx, accE[3]);
-    accE[4] = __builtin_elementwise_fma(hi, Q2.xx, accE[4]);
-    accE[5] = __builtin_elementwise_fma(hi, Q3.xx, accE[5]);
-    accE[6] = __builtin_elementwise_fma(hi, Q4.xx, accE[6]);
-    accO[0] = __builtin_elementwise_fma(lo, P3.yy, accO[0]);
-    accO[1] = __builtin_elementwise_fma(lo, P2.yy, accO[1]);
-    accO[2] = __builtin_elementwise_fma(lo, P1.yy, accO[2]);
-    accO[4] = __builtin_elementwise_fma(hi, Q2.yy, accO[4]);
-    accO[5] = __builtin_elementwise_fma(hi, Q3.yy, accO[5]);
-    accO[6] = __builtin_elementwise_fma(hi, Q4.yy, accO[6]);
-#pragma unroll
-    for (int w = 0; w < 7; ++w) {
-      {
-        const float2v kk = K[w].xx;  // tap 2w
-#pragma unroll
-        for (int j = 0; j < 7; ++j)
-          if (j + w >= 3 && j + w <= 8) accE[j] = __builtin_elementwise_fma(X[j + w - 3], kk, accE[j]);
-      }
-      if (w < 6) {
-        const float2v kk = K[w].yy;  // tap 2w+1
-#pragma unroll
-        for (int j = 0; j < 7; ++j)
-          if (j + w >= 3 && j + w <= 8) accO[j] = __builtin_elementwise_fma(X[j + w - 3], kk, accO[j]);
-      }
-    }
-    r = (r + 1 == N) ? 0 : r + 1;
-  }
-  __syncthreads();  // every lane is done with sx: the output rows are staged over it
-  if (live) {
-    float* os = sx + tid * N;
-#pragma unroll
-    for (int j = 0; j < 7; ++j) {
-      os[2 * j] = accE[j].x + accO[j].y;
-      if (j < 6) os[2 * j + 1] = accE[j].y + accO[j + 1].x;
-    }
-  }
-  __syncthreads();
-  float* og = P.out[prob] + row0 * N;
-  if (nrows == ROWS && aligned16(og)) copy_l2g_full<ROWS * N>(sx, og, tid);
-  else copy_l2g(sx, og, nrows * N, tid);
-}
-
-// ---------------------------------------------------------------------------------------
 // 13x13 circular, DFT form (default since round 2).  The row axis of the padded plane wraps, so a 13-point DFT along it turns
 // the 13 x 13 tap sum of every output into 7 independent complex 1-D correlations along the (clamped) column axis:
 //   X_f[s] = sum_r x[r][s] w^(f r),  K_f[j] = sum_u k[u][j] w^(f u),  w = exp(-2 pi i / 13), f = 0..6 (real input)
@@ -1282,24 +1000,6 @@ __global__ __launch_bounds__(HDN_BLOCK) void xcorr_generic_kernel(XcorrPtrs P, i
 // ---------------------------------------------------------------------------------------
 static thread_local const char* g_last_variant = "none";
 
-template <class Cfg>
-static int launch_f1(const XcorrPtrs& P, int n, int planes, hipStream_t stream, const char* name) {
-  static PerDeviceOnce attr;  // dynamic LDS above 64 KiB needs the opt-in once per kernel and device
-  const int dev_ = PerDeviceOnce::device();
-  if (!attr.done(dev_)) {
-    if (Cfg::LDS_BYTES > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xcorr_f1_kernel<Cfg>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
-      if (e != hipSuccess) return -(1000 + (int)e);
-    }
-    attr.set(dev_);
-  }
-  dim3 grid(cdiv(planes, Cfg::PPB), n);
-  hipLaunchKernelGGL(xcorr_f1_kernel<Cfg>, grid, dim3(HDN_BLOCK), Cfg::LDS_BYTES, stream, P, planes);
-  g_last_variant = name;
-  return launch_status();
-}
-
 // Variant of the 31x31 (x) 61x61 kernel: set by hdn_xcorr_north_variant(), initially from the environment
 // (HDN_NORTH = fft | direct | dense | mfma; legacy: HDN_NORTH_MFMA=1, HDN_NORTH_TAPS=dense, HDN_NORTH_FFT=0).
 static std::atomic<int> g_north_variant{-1};
@@ -1385,25 +1085,14 @@ static int launch_prod29(const XcorrPtrs& P, int n, int planes, hipStream_t stre
 }
 
 static int launch_circ13(const XcorrPtrs& P, int n, int planes, hipStream_t stream) {
-  static const bool direct = [] { const char* e = getenv("HDN_CIRC13_DIRECT"); return e && e[0] == '1'; }();  // A/B switch: the direct-sum kernel
-  if (!direct) {
-    // a wave owns a group of 9 planes; the groups of all problems of the launch are one flat grid
-    const int gpp = cdiv(planes, circ13f::PPW);
-    const long long total = (long long)gpp * n;
-    if (total > 0x7fffffffLL) return HDN_E_LIMIT;
-    hipLaunchKernelGGL(xcorr_circ13f_kernel, dim3(cdiv((int)total, circ13f::WAVES)), dim3(HDN_BLOCK), 0, stream, P, planes, gpp, (int)total);
-    g_last_variant = "circ13";
-    return launch_status();
-  }
-  const long long blocks = ((long long)planes * circ13r::N + circ13r::ROWS - 1) / circ13r::ROWS;
-  hipLaunchKernelGGL(xcorr_circ13r_kernel, dim3((unsigned)blocks, n), dim3(HDN_BLOCK), 0, stream, P, planes);
+  // a wave owns a group of 9 planes; the groups of all problems of the launch are one flat grid
+  const int gpp = cdiv(planes, circ13f::PPW);
+  const long long total = (long long)gpp * n;
+  if (total > 0x7fffffffLL) return HDN_E_LIMIT;
+  hipLaunchKernelGGL(xcorr_circ13f_kernel, dim3(cdiv((int)total, circ13f::WAVES)), dim3(HDN_BLOCK), 0, stream, P, planes, gpp, (int)total);
   g_last_variant = "circ13";
   return launch_status();
 }
-
-//                 HX  WX  HK  WK  TW  SX  PPW  CIRC   REUSE
-using F1_29_5 = F1Cfg<29, 29, 5, 5, 5, 29, 1, false, false>;      // production: 3 levels x {cls,loc}, ban.py:76
-using F1_35_5 = F1Cfg<35, 35, 5, 5, 8, 35, 1, false, false>;      // INSTANCE_SIZE 303 (BASELINE config 5)
 
 static int xcorr_dispatch(const XcorrPtrs& P, int n, int circular, int B, int C, int Hx, int Wx, int Hk, int Wk,
                           hipStream_t stream) {
@@ -1415,12 +1104,9 @@ static int xcorr_dispatch(const XcorrPtrs& P, int n, int circular, int B, int C,
                                                                          // per-block; this bounds the total too
   if (!circular) {
     if (Hx == 29 && Wx == 29 && Hk == 5 && Wk == 5) {
-      static const bool f1 = [] { const char* e = getenv("HDN_PROD_F1"); return e && e[0] == '1'; }();  // A/B switch
-      return f1 ? launch_f1<F1_29_5>(P, n, planes, stream, "f1_29x29_5x5") : launch_prod29(P, n, planes, stream);
+      return launch_prod29(P, n, planes, stream);
     }
     if (Hx == 35 && Wx == 35 && Hk == 5 && Wk == 5) {
-      static const bool f1 = [] { const char* e = getenv("HDN_CFG5_F1"); return e && e[0] == '1'; }();  // A/B switch
-      if (f1) return launch_f1<F1_35_5>(P, n, planes, stream, "f1_35x35_5x5");
       hipLaunchKernelGGL(xcorr_cfg5_kernel, dim3(cdiv(planes, cfg5::PPB), n), dim3(HDN_BLOCK), 0, stream, P, planes);
       g_last_variant = "cfg5_35x35_5x5";
       return launch_status();

@@ -1749,21 +1749,16 @@ int launch_north_fft3(const float* x, const float* k, float* out, int planes, in
   if (!tab) return -(1000 + (int)hipErrorInvalidSymbol);
   const int npairs = planes / 2;
   const int workers = npairs < max_blocks ? npairs : max_blocks;
-  static const int wpg = [] { const char* e = getenv("HDN_FFT_WPG"); return (e && atoi(e) == 1) ? 1 : 8; }();
-  if (wpg == 1) {
-    hipLaunchKernelGGL(xcorr_north_fft3_kernel<1>, dim3(workers), dim3(64), nf3::LDS_BYTES, stream, x, k, out, npairs, planes, tab);
-  } else {
-    static PerDeviceOnce attr;
-    const int dev_ = PerDeviceOnce::device();
-    if (!attr.done(dev_)) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xcorr_north_fft3_kernel<8>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 8 * nf3::NF3_WAVE_LDS);
-      if (e != hipSuccess) return -(1000 + (int)e);
-      attr.set(dev_);
-    }
-    hipLaunchKernelGGL(xcorr_north_fft3_kernel<8>, dim3((workers + 7) / 8), dim3(512), 8 * nf3::NF3_WAVE_LDS, stream, x, k, out,
-                       npairs, planes, tab);
+  static PerDeviceOnce attr;
+  const int dev_ = PerDeviceOnce::device();
+  if (!attr.done(dev_)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xcorr_north_fft3_kernel<8>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 8 * nf3::NF3_WAVE_LDS);
+    if (e != hipSuccess) return -(1000 + (int)e);
+    attr.set(dev_);
   }
+  hipLaunchKernelGGL(xcorr_north_fft3_kernel<8>, dim3((workers + 7) / 8), dim3(512), 8 * nf3::NF3_WAVE_LDS, stream, x, k, out,
+                     npairs, planes, tab);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? HDN_OK : -(1000 + (int)e);
 }
@@ -1792,23 +1787,17 @@ int launch_north_fft2(const float* x, const float* k, float* out, int planes, in
   const int nmain = nfast < max_blocks ? nfast : max_blocks;
   const int tail_worker = nfast < npairs ? nmain : -1;
   const int workers = nmain + (tail_worker >= 0 ? 1 : 0);
-  static const int wpg = [] { const char* e = getenv("HDN_FFT_WPG"); return (e && atoi(e) == 1) ? 1 : 4; }();
-  if (wpg == 1) {
-    hipLaunchKernelGGL(xcorr_north_fft2_kernel<1>, dim3(workers), dim3(64), NF2_WAVE_LDS, stream, x, k, out, nfast, nmain,
-                       planes, all ? nfull : 0x7fffffff, tail_worker, tab);
-  } else {
-    static PerDeviceOnce attr;  // 4 x 31 KB of dynamic LDS needs the opt-in once per device
-    const int dev_ = PerDeviceOnce::device();
-    if (!attr.done(dev_)) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xcorr_north_fft2_kernel<4>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 4 * NF2_WAVE_LDS);
-      if (e != hipSuccess) return -(1000 + (int)e);
-      attr.set(dev_);
-    }
-    const int grid = (workers + 3) / 4;
-    hipLaunchKernelGGL(xcorr_north_fft2_kernel<4>, dim3(grid), dim3(256), 4 * NF2_WAVE_LDS, stream, x, k, out, nfast, nmain,
-                       planes, all ? nfull : 0x7fffffff, tail_worker, tab);
+  static PerDeviceOnce attr;  // 4 x 31 KB of dynamic LDS needs the opt-in once per device
+  const int dev_ = PerDeviceOnce::device();
+  if (!attr.done(dev_)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xcorr_north_fft2_kernel<4>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 4 * NF2_WAVE_LDS);
+    if (e != hipSuccess) return -(1000 + (int)e);
+    attr.set(dev_);
   }
+  const int grid = (workers + 3) / 4;
+  hipLaunchKernelGGL(xcorr_north_fft2_kernel<4>, dim3(grid), dim3(256), 4 * NF2_WAVE_LDS, stream, x, k, out, nfast, nmain,
+                     planes, all ? nfull : 0x7fffffff, tail_worker, tab);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? HDN_OK : -(1000 + (int)e);
 }

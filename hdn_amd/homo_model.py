@@ -27,7 +27,7 @@ def _regress(net, feats):
     return net.fc(x)
 
 
-def optimize_trunk(net, enable: bool = True, channels_last: bool = False, fused_stem: bool = None):
+def optimize_trunk(net, enable: bool = True, channels_last: bool = False, fused_stem: bool = None, fused_epilogue: bool = None):
     """Attach the BN-folded trunk to any module with a `.backbone` (also the reference's HomoModelBuilder).
 
     Measured at B=64 on MI355X (tools/experiments/exp_trunk.py, fresh process each): as-is 2.92 ms, folded 2.47 ms; with
@@ -35,9 +35,12 @@ def optimize_trunk(net, enable: bool = True, channels_last: bool = False, fused_
     folded + channels_last 2.06 ms.  Without find mode channels_last does not pay (2.96 ms), hence the default."""
     from .trunk import fold_for_inference
 
-    if fused_stem is None:  # the fused first stage needs the HIP library and weights on a GPU
-        fused_stem = next(net.backbone.parameters()).is_cuda
-    object.__setattr__(net, "_hdn_fast_trunk", fold_for_inference(net.backbone, channels_last, fused_stem) if enable else None)
+    on_gpu = next(net.backbone.parameters()).is_cuda
+    if fused_stem is None:  # the fused first stage / block epilogues need the HIP library and weights on a GPU
+        fused_stem = on_gpu
+    if fused_epilogue is None:
+        fused_epilogue = on_gpu
+    object.__setattr__(net, "_hdn_fast_trunk", fold_for_inference(net.backbone, channels_last, fused_stem, fused_epilogue) if enable else None)
     # the fused stem reads NCHW and writes the layout the rest of the trunk runs in: no input conversion then
     object.__setattr__(net, "_hdn_fast_nhwc", bool(enable and channels_last and not fused_stem))
 
@@ -111,10 +114,10 @@ class HomoModelBuilder(nn.Module):
     def track_proj(self, data, tmp_mask=None, cached_patch_1=None):
         return track_proj(self, data, tmp_mask, cached_patch_1)
 
-    def optimize_for_inference(self, enable: bool = True, channels_last: bool = False, fused_stem: bool = None):
+    def optimize_for_inference(self, enable: bool = True, channels_last: bool = False, fused_stem: bool = None, fused_epilogue: bool = None):
         """Build (or drop) the BN-folded copy of the trunk used by eval-mode forwards (§8f rank 4).
         Call it after the weights are loaded and the module is on its device; call again if they change."""
-        optimize_trunk(self, enable, channels_last, fused_stem)
+        optimize_trunk(self, enable, channels_last, fused_stem, fused_epilogue)
         return self
 
     def forward(self, data):

@@ -106,12 +106,73 @@ class FusedStem(nn.Module):
         return out
 
 
-def fold_for_inference(net: HomoResNet, channels_last: bool = True, fused_stem: bool = False) -> nn.Module:
+def bias_relu_(y, bias, residual=None):
+    """In place: y = relu(y + bias[c] (+ residual)) through hdn_bias_relu_f32; y / residual [B,C,H,W] float32, both NCHW-contiguous
+    or both channels-last."""
+    import torch
+
+    from . import _lib
+
+    dev = _lib.require_device(y, bias) if residual is None else _lib.require_device(y, bias, residual)
+    if y.dim() != 4 or bias.numel() != y.shape[1] or (residual is not None and residual.shape != y.shape):
+        raise ValueError(f"bias_relu_: y [B,C,H,W], bias [C], residual like y; got {tuple(y.shape)}, {tuple(bias.shape)}")
+    B, C, H, W = y.shape
+    if y.is_contiguous():   # (a [B,C,1,1] tensor is both: NCHW arithmetic is right for it)
+        nhwc = 0
+    elif y.is_contiguous(memory_format=torch.channels_last):
+        nhwc = 1
+    else:
+        raise ValueError("bias_relu_: y must be NCHW-contiguous or channels-last")
+    if residual is not None and not (residual.is_contiguous(memory_format=torch.channels_last) if nhwc else residual.is_contiguous()):
+        residual = residual.contiguous(memory_format=torch.channels_last if nhwc else torch.contiguous_format)
+    with torch.cuda.device(dev):
+        rc = _lib.load().hdn_bias_relu_f32(_lib.ptr(y), _lib.ptr(bias), _lib.ptr(residual) if residual is not None else None, B, C, H * W,
+                                           nhwc, _lib.stream_ptr(dev))
+    _lib.check(rc, "bias_relu")
+    return y
+
+
+class FusedBasicBlock(nn.Module):
+    """BasicBlock.forward (backbone/resnet.py:78-94) of the BN-folded trunk with its elementwise tail fused: the convolutions
+    run bias-free on MIOpen, `relu(y + b1)` and `relu(y + b2 + residual)` are one HIP pass each (hdn_bias_relu_f32) instead of
+    bias-add + ReLU and bias-add + add + ReLU launches.  A folded downsample branch contributes its bias to b2 and its raw
+    convolution as the residual.  GPU / eval only."""
+
+    def __init__(self, blk: "BasicBlock"):
+        super().__init__()
+        import torch
+
+        for c in (blk.conv1, blk.conv2) + ((blk.downsample,) if blk.downsample is not None else ()):
+            if not isinstance(c, nn.Conv2d) or c.bias is None:
+                raise ValueError("FusedBasicBlock takes a block whose BatchNorms were folded into biased convolutions")
+        self.stride = blk.conv1.stride
+        self.w1 = nn.Parameter(blk.conv1.weight.detach().clone(), requires_grad=False)
+        self.w2 = nn.Parameter(blk.conv2.weight.detach().clone(), requires_grad=False)
+        self.register_buffer("b1", blk.conv1.bias.detach().clone())
+        b2 = blk.conv2.bias.detach().clone()
+        if blk.downsample is not None:
+            self.wd = nn.Parameter(blk.downsample.weight.detach().clone(), requires_grad=False)
+            self.ds_stride = blk.downsample.stride
+            b2 = b2 + blk.downsample.bias.detach()     # (b2 + bd) once, instead of per element: differs from the unfused sum by rounding
+        else:
+            self.wd = None
+        self.register_buffer("b2", b2)
+
+    def forward(self, x):
+        import torch.nn.functional as F
+
+        y = bias_relu_(F.conv2d(x, self.w1, None, self.stride, 1), self.b1)
+        idt = x if self.wd is None else F.conv2d(x, self.wd, None, self.ds_stride)
+        return bias_relu_(F.conv2d(y, self.w2, None, 1, 1), self.b2, idt)
+
+
+def fold_for_inference(net: HomoResNet, channels_last: bool = True, fused_stem: bool = False, fused_epilogue: bool = False) -> nn.Module:
     """A copy of `net` with every eval-mode BatchNorm folded into the preceding convolution (weights scaled in
     float64, rounded once) and, optionally, NHWC weights for MIOpen's channels-last kernels.  Measured on MI355X at
     B=64: 2.92 ms (as-is) -> 2.47 ms (folded) -> 2.11 ms (folded + NHWC); outputs agree with the un-folded CPU
     trunk to ~1.5e-6 relative either way (tools/experiments/exp_trunk.py).  The copy does not track later weight changes.
-    fused_stem: replace conv1 / relu / maxpool by FusedStem (GPU only, W <= 128)."""
+    fused_stem: replace conv1 / relu / maxpool by FusedStem (GPU only, W <= 128).
+    fused_epilogue: replace every BasicBlock by FusedBasicBlock (GPU only): 83 elementwise launches per forward -> 32."""
     import copy
 
     import torch
@@ -138,6 +199,12 @@ def fold_for_inference(net: HomoResNet, channels_last: bool = True, fused_stem: 
     if channels_last:
         import torch as _t
         net = net.to(memory_format=_t.channels_last)
+    if fused_epilogue:
+        for name in ("layer1", "layer2", "layer3", "layer4"):
+            setattr(net, name, nn.Sequential(*[FusedBasicBlock(blk) for blk in getattr(net, name)]))
+        if channels_last:
+            import torch as _t
+            net = net.to(memory_format=_t.channels_last)
     if fused_stem:  # conv1 (+ folded bn1) + relu + maxpool in one HIP kernel; the stages behind it stay on MIOpen
         net.conv1 = FusedStem(net.conv1, channels_last)
         net.relu, net.maxpool = nn.Identity(), nn.Identity()

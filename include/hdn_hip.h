@@ -262,6 +262,18 @@ int hdn_similarity_logpolar_f32(const float* cls_lp, const float* loc_lp, const 
 int hdn_trunk_stem_f32(const float* x, const float* wT, const float* bias, float* out, int B, int H, int W, int nhwc, void* stream);
 
 /*
+ * Residual-block epilogues of the same trunk, in place:
+ *   y = relu(y + bias[c])                (residual == NULL)     after conv1 of a BasicBlock, bn1 folded into the conv
+ *   y = relu((y + bias[c]) + residual)                          after conv2: `out += residual; out = relu(out)`
+ * y / residual: [B,C,H,W] fp32 with HW = H*W, either NCHW-contiguous (nhwc == 0) or channels-last in memory (nhwc != 0);
+ * bias[C] = the folded BatchNorm shift (plus the downsample branch's, when that branch is a folded conv).  One pass, 16 bytes
+ * per lane when the layout allows (NHWC: C % 4 == 0; NCHW: HW % 4 == 0; 16-byte aligned pointers), one float per lane otherwise.
+ * Replaces the bias-add / residual-add / ReLU launches around the convolutions of BasicBlock.forward,
+ * homo_estimator/Deep_homography/Oneline_DLTv1/backbone/resnet.py:78-94 (eval mode only).
+ */
+int hdn_bias_relu_f32(float* y, const float* bias, const float* residual, int B, int C, int HW, int nhwc, void* stream);
+
+/*
  * Multi-GPU: template/search pairs are independent, so ranks own disjoint contiguous blocks of pairs
  * and the path's ONLY exchange is one all-gather of the predicted corner offsets, on RCCL over xGMI.
  *   local[Bl,8] (this rank's offsets) -> all[world*Bl,8] on every rank, in rank order; Bl must be equal on all

@@ -274,6 +274,26 @@ def test_xcorr_fast_and_slow_golden(dev):
         hdn_amd.xcorr_fast(torch.zeros(1, 3, 5, 5, device=dev), torch.zeros(1, 4, 3, 3, device=dev))
 
 
+@pytest.mark.parametrize("O_", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("ksz", [(5, 5), (3, 4)])
+def test_xcorr_fast_every_output_width(dev, O_, ksz):
+    """Every compiled instantiation of xcorr_fast_kernel<O, K> (O = 1..8 output maps; 5x5 taps unrolled, other sizes generic)
+    against the oracle's F.conv2d form (hdn/core/xcorr.py:22-34), ragged channel count, signed data."""
+    r = np.random.default_rng(100 * O_ + ksz[1])
+    B, C = 3, 37
+    x = r.standard_normal((B, C, 13, 11), dtype=np.float32)
+    k = r.standard_normal((B, O_ * C, ksz[0], ksz[1]), dtype=np.float32)
+    y = hdn_amd.xcorr_fast(T(x).to(dev), T(k).to(dev))
+    assert torch.equal(y, hdn_amd.xcorr_fast(T(x).to(dev), T(k).to(dev)))   # fixed reduction order
+    ref = O.xcorr_fast(T(x), T(k)).numpy()
+    mag = O.xcorr_fast(T(np.abs(x)), T(np.abs(k))).numpy()
+    assert y.shape == ref.shape
+    assert np.all(np.abs(y.cpu().numpy() - ref) <= 1e-4 + 2e-6 * mag)
+    if O_ == 8:
+        with pytest.raises(ValueError):   # HDN_E_LIMIT: XF_MAX_O
+            hdn_amd.xcorr_fast(T(x).to(dev), torch.zeros((B, 9 * C, 5, 5), device=dev))
+
+
 def test_xcorr_multi_launch_equals_single(dev):
     r = np.random.default_rng(21)
     xs = [T(relu_normal(r, (2, 32, 29, 29))).to(dev) for _ in range(6)]
@@ -950,3 +970,93 @@ def test_folded_trunk_with_and_without_fused_stem(dev):
             scale = float(ref.abs().max())
             assert float((a - ref).abs().max()) <= 2e-4 * scale and float((b - ref).abs().max()) <= 2e-4 * scale
             assert float((a - b).abs().max()) <= 1e-4 * scale
+
+
+# --------------------------------------------------------------------------- trunk epilogues + the benchmarked configuration
+@pytest.mark.parametrize("shape,nhwc", [((3, 64, 8, 8), True), ((2, 12, 5, 7), True), ((2, 6, 5, 7), True), ((3, 10, 4, 6), False),
+                                         ((2, 5, 3, 3), False), ((64, 64, 32, 32), True), ((64, 512, 4, 4), True), ((2, 128, 16, 16), False)])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_bias_relu_epilogue_bitexact(dev, shape, nhwc, with_res):
+    """hdn_bias_relu_f32 (every kernel instantiation: 16-byte NHWC with power-of-two and other channel counts, 16-byte NCHW,
+    the one-float-per-lane form for layouts that do not vectorise; with and without residual) against PyTorch's own
+    relu((y + b) + r): same operations in the same order, so bit-exact."""
+    from hdn_amd.trunk import bias_relu_
+    g = torch.Generator().manual_seed(sum(shape) + 7 * nhwc + with_res)
+    y = torch.randn(shape, generator=g)
+    b = torch.randn(shape[1], generator=g)
+    r = torch.randn(shape, generator=g) if with_res else None
+    ref = y + b.view(1, -1, 1, 1)
+    if with_res:
+        ref = ref + r
+    ref = torch.relu(ref)
+    fmt = torch.channels_last if nhwc else torch.contiguous_format
+    yd = y.to(dev).contiguous(memory_format=fmt)
+    rd = r.to(dev).contiguous(memory_format=fmt) if with_res else None
+    out = bias_relu_(yd, b.to(dev), rd)
+    assert out.data_ptr() == yd.data_ptr()
+    assert torch.equal(out.cpu(), ref)
+    with pytest.raises(ValueError):
+        bias_relu_(yd, b.to(dev)[:-1])
+    if with_res:
+        with pytest.raises(ValueError):     # HDN_E_ALIAS
+            bias_relu_(yd, b.to(dev), yd)
+
+
+def test_fused_epilogue_trunk_vs_unfused(dev):
+    """The BN-folded trunk with FusedBasicBlock (bias-free MIOpen convolutions + hdn_bias_relu_f32) against the same folded
+    trunk on PyTorch's own bias / add / relu kernels, NCHW and NHWC: the only arithmetic difference is (b2 + b_downsample)
+    being added once."""
+    from hdn_amd.trunk import fold_for_inference, resnet34_homo, FusedBasicBlock
+    torch.manual_seed(3)
+    net = resnet34_homo().eval().to(dev)
+    gen = torch.Generator().manual_seed(4)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.empty(m.num_features).uniform_(-0.2, 0.2, generator=gen))
+            m.running_var.copy_(torch.empty(m.num_features).uniform_(0.8, 1.2, generator=gen))
+    x = torch.randn(8, 2, 127, 127, generator=gen).to(dev)
+    with torch.no_grad():
+        for cl in (False, True):
+            plain = fold_for_inference(net, channels_last=cl, fused_stem=False, fused_epilogue=False)
+            fused = fold_for_inference(net, channels_last=cl, fused_stem=False, fused_epilogue=True)
+            assert sum(isinstance(m, FusedBasicBlock) for m in fused.modules()) == 16
+            xin = x.contiguous(memory_format=torch.channels_last) if cl else x
+            a, b = plain(xin), fused(xin)
+            scale = float(a.abs().max())
+            assert float((a - b).abs().max()) <= 2e-5 * scale, (cl, float((a - b).abs().max()), scale)
+
+
+def test_benchmarked_full_head_configuration_parity(dev):
+    """The configuration bench.py's `full_head` block times — built by bench.build_full_head itself: B = 64, MIOpen find mode
+    (cudnn.benchmark), BN-folded NHWC trunk, fused first stage, fused block epilogues — against the CPU oracle on a
+    16-pair sample of the same batch: predicted corner offsets x within the north-star bound 1e-4, on two runs (find mode may pick
+    split-K convolution kernels that accumulate atomically: the run-to-run difference is reported and bounded too)."""
+    import bench
+    from hdn_amd.homo_model import homo_stages
+    g = torch.Generator().manual_seed(bench.SEED)
+    imgs = torch.randn(bench.PAIRS, 2, 127, 127, generator=g)
+    h4p = torch.tensor([[0, 0, 0, 127, 127, 127, 127, 0]], dtype=torch.float32).repeat(bench.PAIRS, 1)
+    saved = torch.backends.cudnn.benchmark
+    try:
+        net, data, cpu_sd = bench.build_full_head(dev, imgs.to(dev), h4p.to(dev))
+        from hdn_amd.trunk import FusedBasicBlock, FusedStem
+        fast = net._hdn_fast_trunk
+        assert isinstance(fast.conv1, FusedStem) and sum(isinstance(m, FusedBasicBlock) for m in fast.modules()) == 16
+        for _ in range(3):                     # the find-mode search happens on the first calls
+            homo_stages(net, data)
+        x1 = homo_stages(net, data)["x"].cpu()
+        x2 = homo_stages(net, data)["x"].cpu()
+    finally:
+        torch.backends.cudnn.benchmark = saved
+    idx = torch.arange(0, bench.PAIRS, 4)      # 16 of the 64 pairs
+    ref_net = hdn_amd.HomoModelBuilder().eval()
+    ref_net.load_state_dict(cpu_sd)
+    sd = {k: v.clone() for k, v in ref_net.ShareFeature.state_dict().items()}
+    sub = {"org_imgs": imgs[idx], "input_tensors": imgs[idx], "h4p": h4p[idx]}
+    with torch.no_grad():
+        _, _, _, aux = O.track_proj(sub, sd, lambda f: ref_net.fc(ref_net.avgpool(ref_net.backbone(f)).flatten(1)))
+    e1, e2 = float((x1[idx] - aux["x"]).abs().max()), float((x2[idx] - aux["x"]).abs().max())
+    rr = float((x1 - x2).abs().max())
+    print(f"benchmarked full head: max|x - oracle| = {e1:.2e} / {e2:.2e} over 16 pairs, run-to-run max|dx| = {rr:.2e} over 64 pairs")
+    assert e1 <= 1e-4 and e2 <= 1e-4, (e1, e2)
+    assert rr <= 2e-5, rr

@@ -52,6 +52,8 @@ def test_c_abi_argument_errors_need_no_gpu():
     assert lib.hdn_allgather_offsets(one, one, 4, None, None) == -1 and lib.hdn_allgather_offsets(one, one, 0, one, None) == -2
     assert lib.hdn_rccl_comm_create(ctypes.byref(ctypes.c_void_p()), 2, 2, ctypes.c_char_p(b"\0" * 128)) == -2
     assert lib.hdn_rccl_unique_id(None) == -1 and lib.hdn_rccl_available() in (0, 1)
+    assert lib.hdn_bias_relu_f32(one, None, None, 1, 4, 4, 1, None) == -1 and lib.hdn_bias_relu_f32(one, one, None, 1, 0, 4, 1, None) == -2
+    assert lib.hdn_bias_relu_f32(one, one, one, 1, 4, 4, 1, None) == -4 and lib.hdn_bias_relu_f32(one, one, None, 65536, 512, 4096, 1, None) == -3
     assert lib.hdn_similarity_translation_f32(one, one, one, one, one, None, 1, 25, 0.16, 8.0, 127.0, None) == -1
     assert lib.hdn_similarity_translation_f32(one, one, one, one, one, one, 1, 0, 0.16, 8.0, 127.0, None) == -2
     assert lib.hdn_similarity_logpolar_f32(one, one, None, one, one, 1, 13, 8.0, 0.03, 0.05, None) == -1
