@@ -77,7 +77,8 @@ def _worker(rank, world, port, n_pairs, q):
         q.put((rank, repr(ex)))
 
 
-@pytest.mark.parametrize("world,n_pairs", [(2, 64), (2, 7), (3, 10)])
+# (8, 512) is BASELINE configs[2] itself: 512 pairs over the 8 GPUs of a node, 64 per rank; (8, 509) its ragged version
+@pytest.mark.parametrize("world,n_pairs", [(2, 64), (2, 7), (3, 10), (8, 512), (8, 509)])
 def test_sharded_offsets_all_gather(world, n_pairs):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -147,3 +147,30 @@ def test_sharded_offsets_two_ranks_on_one_gpu(dev, pairs):
     res = _results(outs)
     ok = {"torch": True, "checksum_equal": True}
     assert res == {0: ok, 1: ok}, "\n----\n".join(o[-2000:] for o in outs)
+
+
+@pytest.mark.parametrize("workload", ["full", "kernels"])
+def test_bench_two_ranks_one_device_json_contract(dev, workload):
+    """bench.py's N > 1 path (`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...`) on the one-GPU box:
+    HDN_BENCH_ONE_DEVICE=1 puts both ranks on GPU 0 over gloo (RCCL refuses two ranks on a device).  Rank 0 prints ONE JSON
+    line with the driver's fields; value = pairs of BOTH ranks / max-over-ranks time."""
+    import json
+    port = _free_port()
+    env = dict(os.environ, HDN_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--prewarm-ms", "5",
+           "--no-cpu-baseline", "--no-breakdown", "--no-full-head", "--roofline-steps", "2"]
+    if workload == "full":
+        cmd += ["--workload", "full"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config"):
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["unit"] == "frames/s" and d["dtype"] == "f32"
+    assert abs(d["value"] - 2 * 64 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]      # whole-job aggregate over both ranks
+    assert "workload" in d["config"] and "model" not in d["config"]
+    if workload == "kernels":
+        assert "roofline" in d and d["roofline"]["bound"] == "hbm" and "all-gather" in d["config"]["workload"]
