@@ -153,9 +153,14 @@ __global__ __launch_bounds__(HDN_BLOCK) void xcorr_prod29_kernel(XcorrPtrs P, in
 // given exactly ONE block of 31 columns (lane 31 of the group repeats column 30: same address, a broadcast): whatever
 // the row stride, the 32 lanes of a group then read 31 consecutive floats, i.e. conflict-free on the LINEAR image, and
 // the re-striding scatter of the 29x29 kernel is not needed.  A lane owns a VERTICAL 8x1 strip: per tap column it reads
-// 12 floats and issues 40 FMAs; 4 row blocks x 31 columns = 124 strips = two rounds of a wave (97 % of the lanes), the
-// 32nd row of the last block is computed and dropped (its taps read one row beyond the plane: the next plane's first
-// row or the pad behind the last plane).
+// 12 floats (6 ds_read2_b32 = 6 vertical operand pairs) and issues 22 v_pk_fma_f32 (cfg5::strip below); 4 row blocks x 31
+// columns = 124 strips = two rounds of a wave (97 % of the lanes), the 32nd row of the last block is computed and dropped (its
+// taps read one row beyond the plane: the next plane's first row or the pad behind the last plane).
+// Round 3 (profiles/round3_cfg5_experiments.txt): the kernel runs at the rate the memory system gives its traffic SHAPE
+// (19.6 KB in, 15.4 KB out per workgroup, tools/experiments/ubench_stream.hip: 157.9 us with no arithmetic at all at 8 workgroups
+// per CU; this kernel 157-159 us).  Fewer resident workgroups would stream faster (144.5 us at 4 per CU) but then no longer hide
+// each other's barriers and LDS phases (176 us); a persistent form with the next group fetched by LDS-DMA into a second image
+// (4 per CU, a group in flight per workgroup all the time) was built, bit-identical, and measured at 160 us: removed again.
 // ---------------------------------------------------------------------------------------
 namespace cfg5 {
 constexpr int HX = 35, WX = 35, HK = 5, WK = 5, HO = 31, WO = 31;
@@ -163,6 +168,67 @@ constexpr int XPLANE = HX * WX, OPLANE = HO * WO, KPLANE = HK * WK;
 constexpr int PPB = 4, TH = 8;                       // planes per workgroup, strip height
 constexpr int XFLOATS = round_up(PPB * XPLANE + WX + 4, 4);   // + the row the last block's dropped output reads
 constexpr int LDS_FLOATS = XFLOATS + PPB * OPLANE;   // 8,784 floats = 35 KB: 4 workgroups per CU
+
+// One 8 x 1 output strip (rows r0 .. r0 + 7 of column j) of one plane, packed over VERTICAL neighbours.
+//   P[m] = (x[r0 + 2m][c], x[r0 + 2m + 1][c])   one ds_read2_b32 each, 6 per tap column c = j + v (12 input rows)
+//   even tap rows u = 2w:      accE[q] = (out[2q],     out[2q + 1]) += P[q + w] * k[u][v]      q = 0..3
+//   odd  tap rows u = 2w + 1:  accO[q] = (out[2q - 1], out[2q])     += P[q + w] * k[u][v]      q = 0..4
+// (the operand pair of an odd tap row is aligned again once the OUTPUT pair is shifted by one row: the scheme of the 31x31
+// direct kernel, turned by 90 degrees), out[2q] = accE[q].x + accO[q].y, out[2q + 1] = accE[q].y + accO[q + 1].x.
+// 110 v_pk_fma_f32 + 8 adds and 30 LDS reads per strip; the compiler's own packing of the scalar form needed 100 v_pk_fma_f32
+// plus ~107 v_mov_b32 to build its operand pairs.  `a` = LDS byte address of x[r0][j].
+typedef const float __attribute__((address_space(4))) cfloat;
+template <int V, int M>
+__device__ __forceinline__ void strip_pairs(float2v (&Pm)[6], uint32_t a0, uint32_t a1) {
+  if constexpr (M < 6) {
+    if constexpr (M < 3) Pm[M] = lds_read_pair<(2 * M) * WX + V, (2 * M + 1) * WX + V>(a0);
+    else Pm[M] = lds_read_pair<(2 * M - 6) * WX + V, (2 * M - 5) * WX + V>(a1);
+    strip_pairs<V, M + 1>(Pm, a0, a1);
+  }
+}
+template <int V>
+__device__ __forceinline__ void strip_column(float2v (&accE)[4], float2v (&accO)[5], uint32_t a0, uint32_t a1, const cfloat* kp) {
+  float2v Pm[6];
+  strip_pairs<V, 0>(Pm, a0, a1);
+  lds_wait_all();
+#pragma unroll
+  for (int m = 0; m < 6; ++m) pin(Pm[m]);
+#pragma unroll
+  for (int u = 0; u < HK; ++u) {
+    const float kv = kp[u * WK + V];
+    const float2v kk = {kv, kv};
+    if (u % 2 == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) accE[q] = __builtin_elementwise_fma(Pm[q + u / 2], kk, accE[q]);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 5; ++q) accO[q] = __builtin_elementwise_fma(Pm[q + u / 2], kk, accO[q]);
+    }
+  }
+}
+__device__ __forceinline__ void strip(float (&acc)[TH], const float* x00, const cfloat* kp) {
+  float2v accE[4], accO[5];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) accE[q] = float2v{0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 5; ++q) accO[q] = float2v{0.f, 0.f};
+  const uint32_t a0 = lds_addr(x00), a1 = a0 + 6 * WX * 4;
+  strip_column<0>(accE, accO, a0, a1, kp);
+  strip_column<1>(accE, accO, a0, a1, kp);
+  strip_column<2>(accE, accO, a0, a1, kp);
+  strip_column<3>(accE, accO, a0, a1, kp);
+  strip_column<4>(accE, accO, a0, a1, kp);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    acc[2 * q] = accE[q].x + accO[q].y;
+    acc[2 * q + 1] = accE[q].y + accO[q + 1].x;
+  }
+}
+__device__ __forceinline__ const cfloat* scalar_ptr(const float* p) {  // wave-uniform pointer -> constant address space: scalar loads
+  uint64_t a = reinterpret_cast<uint64_t>(p);
+  asm volatile("" : "+s"(a));
+  return (const cfloat*)a;
+}
 }  // namespace cfg5
 
 __global__ __launch_bounds__(HDN_BLOCK) void xcorr_cfg5_kernel(XcorrPtrs P, int planes) {
@@ -189,30 +255,13 @@ __global__ __launch_bounds__(HDN_BLOCK) void xcorr_cfg5_kernel(XcorrPtrs P, int 
 
   float accs[2][TH];
   if (wave < np) {  // wave-uniform
-    const float* __restrict__ kp = k + size_t(plane0 + wave) * KPLANE;  // wave-uniform -> scalar loads
+    const cfloat* kp = scalar_ptr(k + size_t(plane0 + wave) * KPLANE);  // wave-uniform -> scalar loads
     const float* xs = sx + wave * XPLANE;
     const int j = min(lane & 31, WO - 1);
 #pragma unroll
     for (int rd = 0; rd < 2; ++rd) {
       const int b = 2 * rd + (lane >> 5);  // one row block per 32-lane bank group
-      const float* xc = xs + (TH * b) * WX + j;
-      float acc[TH];
-#pragma unroll
-      for (int t = 0; t < TH; ++t) acc[t] = 0.f;
-#pragma unroll
-      for (int v = 0; v < WK; ++v) {
-        float col[TH + HK - 1];
-#pragma unroll
-        for (int r = 0; r < TH + HK - 1; ++r) col[r] = xc[r * WX + v];
-#pragma unroll
-        for (int u = 0; u < HK; ++u) {
-          const float kv = kp[u * WK + v];
-#pragma unroll
-          for (int t = 0; t < TH; ++t) acc[t] = __builtin_fmaf(col[t + u], kv, acc[t]);
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < TH; ++t) accs[rd][t] = acc[t];
+      strip(accs[rd], xs + (TH * b) * WX + j, kp);
     }
   }
   __syncthreads();  // nobody reads the inputs any more
