@@ -357,6 +357,23 @@ extern "C" int hdn_debug_read_kimg(float* host_dst) { return (int)hipMemcpyFromS
 #define NFFT_DBG_DUMP_KIMG()
 #endif
 
+// Experiment switch of the two-waves-per-SIMD kernel (round 3, profiles/round3_north_experiments.txt): issue priority by phase.
+// NF3_PRIO_MODE 1: high while a wave issues LDS / global traffic and waits for it, low in the arithmetic stretches (the
+// partner wave's memory instructions then never queue behind this wave's FFT); 2: the opposite.  0 (default): no s_setprio.
+#ifndef NF3_PRIO_MODE
+#define NF3_PRIO_MODE 0
+#endif
+#if NF3_PRIO_MODE == 1
+#define NF3_PRIO_MEM() __builtin_amdgcn_s_setprio(3)
+#define NF3_PRIO_ALU() __builtin_amdgcn_s_setprio(0)
+#elif NF3_PRIO_MODE == 2
+#define NF3_PRIO_MEM() __builtin_amdgcn_s_setprio(0)
+#define NF3_PRIO_ALU() __builtin_amdgcn_s_setprio(3)
+#else
+#define NF3_PRIO_MEM()
+#define NF3_PRIO_ALU()
+#endif
+
 static const nfft::cf* north_fft_table() {
   static const nfft::cf* tab[64] = {};  // per device
   const int d = PerDeviceOnce::device();
@@ -1471,6 +1488,7 @@ NF_DEV void column_pass(cf (&X)[32], uint32_t a_p, uint32_t a_q, cf hm, cf sg) {
     }
     return n;
   };
+  NF3_PRIO_MEM();
   issue(std::integral_constant<int, 0>{});
   sfor<0, NCH>([&](auto Ci) NF2_LAMBDA {
     constexpr int c = decltype(Ci)::value;
@@ -1499,6 +1517,7 @@ NF_DEV void column_pass(cf (&X)[32], uint32_t a_p, uint32_t a_q, cf hm, cf sg) {
       }
     });
   });
+  NF3_PRIO_ALU();
   fft<5, -1, (NR < 32 ? NR : 32), 32>(X);
 }
 
@@ -1538,6 +1557,7 @@ __global__ __launch_bounds__(64 * WPG, WPG == 1 ? 2 : 1) void xcorr_north_fft3_k
   NFFT_DBG_BEGIN(worker)
   for (int p = worker; p < npairs; p += nworkers) {
     // ---- the two search planes: coalesced 16-byte chunks of each plane's aligned window (clamped at the tensor end)
+    NF3_PRIO_MEM();
     f4v RA[PQ], RB[PQ];
     const long long baseA = (long long)(2 * p) * XPL, baseB = baseA + XPL;
     const long long firstA = baseA & ~3LL, firstB = baseB & ~3LL;
@@ -1572,6 +1592,7 @@ __global__ __launch_bounds__(64 * WPG, WPG == 1 ? 2 : 1) void xcorr_north_fft3_k
         sfor<0, 31>([&](auto Mi) NF2_LAMBDA { constexpr int m = decltype(Mi)::value; rb[m] = lr2x32<2 * m, 2 * m + 1>(aB); });
       }
       wait_lgkm<0>();
+      NF3_PRIO_ALU();
       cf v[64];
       sfor<0, 31>([&](auto Mi) NF2_LAMBDA {
         constexpr int j = 2 * decltype(Mi)::value;
@@ -1582,6 +1603,7 @@ __global__ __launch_bounds__(64 * WPG, WPG == 1 ? 2 : 1) void xcorr_north_fft3_k
         if constexpr (j + 1 < HX) v[bitrev(j + 1, 6)] = hi;
       });
       fft<6, -1, HX, 64>(v);
+      NF3_PRIO_MEM();
       cf sbp[32];  // plane B's half waits in registers while plane A's goes through the column pass
       sfor<0, 16>([&](auto F) NF2_LAMBDA {
         constexpr int f = 2 * decltype(F)::value;
@@ -1595,6 +1617,7 @@ __global__ __launch_bounds__(64 * WPG, WPG == 1 ? 2 : 1) void xcorr_north_fft3_k
         if (lane < HX) lw2x64<f, f + 1>(a_rowx, sa0, sa1);
       });
       column_pass<HX, 0>(X[0], a_colx, 0, hm, sg);
+      NF3_PRIO_MEM();
       if (lane < HX) {
         sfor<0, 16>([&](auto F) NF2_LAMBDA { constexpr int f = 2 * decltype(F)::value; lw2x64<f, f + 1>(a_rowx, sbp[f], sbp[f + 1]); });
       }
@@ -1612,6 +1635,7 @@ __global__ __launch_bounds__(64 * WPG, WPG == 1 ? 2 : 1) void xcorr_north_fft3_k
         constexpr int mul = half ? 3 : 1;
         cf v[32];
         f4v a0, a1, a2, a3, b0, b1, b2, b3;
+        NF3_PRIO_MEM();
         gload128<0>(a0, vA, kpair); gload128<16>(a1, vA, kpair); gload128<32>(a2, vA, kpair); gload128<48>(a3, vA, kpair);
         gload128<0>(b0, vB, kpair); gload128<16>(b1, vB, kpair); gload128<32>(b2, vB, kpair); gload128<48>(b3, vB, kpair);
         f4v a4, a5, a6, b4, b5, b6;
@@ -1619,6 +1643,7 @@ __global__ __launch_bounds__(64 * WPG, WPG == 1 ? 2 : 1) void xcorr_north_fft3_k
         gload128<64>(a4, vA, kpair); gload128<80>(a5, vA, kpair); gload128<96>(a6, vA, kpair); gload96<112>(a7, vA, kpair);
         gload128<64>(b4, vB, kpair); gload128<80>(b5, vB, kpair); gload128<96>(b6, vB, kpair); gload96<112>(b7, vB, kpair);
         wait_vm<8>();
+        NF3_PRIO_ALU();
         auto tw4 = [&](auto J, const f4v& fa, const f4v& fb) NF2_LAMBDA {
           constexpr int j = decltype(J)::value;
           cf l0, h0, l1, h1;
@@ -1641,6 +1666,7 @@ __global__ __launch_bounds__(64 * WPG, WPG == 1 ? 2 : 1) void xcorr_north_fft3_k
           v[bitrev(28, 5)] = l0; v[bitrev(29, 5)] = h0; v[bitrev(30, 5)] = l1;
         }
         fft<5, -1, HK, 32>(v);
+        NF3_PRIO_MEM();
         if (lane < HK) {
           sfor<0, 16>([&](auto Gi) NF2_LAMBDA {
             constexpr int g = 2 * decltype(Gi)::value;
@@ -1686,7 +1712,9 @@ __global__ __launch_bounds__(64 * WPG, WPG == 1 ? 2 : 1) void xcorr_north_fft3_k
       {
         cf V[32];
         sfor<0, 32>([&](auto G) NF2_LAMBDA { constexpr int g = decltype(G)::value; V[bitrev(g, 5)] = X[pl][g]; });
+        NF3_PRIO_ALU();
         fft<5, +1, 32, HO>(V);
+        NF3_PRIO_MEM();
         sfor<0, HO>([&](auto R) NF2_LAMBDA { constexpr int r = decltype(R)::value; lw64<r * RSK * 8>(a_lane, V[r]); });
       }
       // row lane r: Y(r, c) = E'[r][c] + w64^{-r} O'[r][c], columns in chunks of 8
@@ -1712,7 +1740,9 @@ __global__ __launch_bounds__(64 * WPG, WPG == 1 ? 2 : 1) void xcorr_north_fft3_k
         v[bitrev(f, 6)] = c0;
         v[bitrev(63 - f, 6)] = c1;
       });
+      NF3_PRIO_ALU();
       fft<6, +1, 64, HO>(v);
+      NF3_PRIO_MEM();
       if (lane < HO) {
         sfor<0, 16>([&](auto Ji) NF2_LAMBDA {
           constexpr int j = 2 * decltype(Ji)::value;
