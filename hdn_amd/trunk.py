@@ -132,6 +132,53 @@ def bias_relu_(y, bias, residual=None):
     return y
 
 
+def pack_conv3x3(weight):
+    """[C, C, 3, 3] fp32 conv weights -> the layout hdn_conv3x3_bias_relu_f32 streams: every value split exactly into three bf16
+    pieces (w = p0 + p1 + p2, round-to-nearest-even each), arranged [C / BN][C / 16][9 taps][3 pieces][2 k halves][BN][8] as int16
+    bit patterns.  S is implied by C in the trunk (64 -> 32, 128 -> 16, 256 -> 8, 512 -> 4)."""
+    import torch
+
+    from . import _lib
+
+    C = weight.shape[0]
+    if tuple(weight.shape) != (C, C, 3, 3):
+        raise ValueError(f"pack_conv3x3 takes [C, C, 3, 3] weights, got {tuple(weight.shape)}")
+    S = {64: 32, 128: 16, 256: 8, 512: 4}.get(C)
+    BN = _lib.load().hdn_conv3x3_block_n(S, C) if S else -3
+    if BN <= 0:
+        raise ValueError(f"no matrix-core kernel for {C} channels")
+    w = weight.detach().to(torch.float32).cpu()
+    p0 = w.to(torch.bfloat16)
+    r1 = w - p0.float()
+    p1 = r1.to(torch.bfloat16)
+    p2 = (r1 - p1.float()).to(torch.bfloat16)
+    pieces = torch.stack([p0, p1, p2])                                   # [3, Cout, Cin, ky, kx]
+    t = pieces.permute(0, 1, 3, 4, 2).reshape(3, C // BN, BN, 9, C // 16, 2, 8)   # [piece, nb, n, tap, kc, g, 8]
+    t = t.permute(1, 4, 3, 0, 5, 2, 6).contiguous()                     # [nb, kc, tap, piece, g, n, 8]
+    return t.view(torch.int16)
+
+
+def conv3x3_bias_relu(x, wpacked, bias, residual=None):
+    """relu(conv3x3(x) + bias (+ residual)) through hdn_conv3x3_bias_relu_f32; x / residual channels-last [B,C,S,S] float32."""
+    import torch
+
+    from . import _lib
+
+    dev = _lib.require_device(x, bias) if residual is None else _lib.require_device(x, bias, residual)
+    B, C, S, S2 = x.shape
+    cl = torch.channels_last
+    if S != S2 or not x.is_contiguous(memory_format=cl) or (residual is not None and (residual.shape != x.shape or not residual.is_contiguous(memory_format=cl))):
+        raise ValueError("conv3x3_bias_relu: square channels-last inputs of equal shape")
+    if wpacked.dtype != torch.int16 or wpacked.device != dev or wpacked.numel() != 27 * C * C or bias.numel() != C:
+        raise ValueError("conv3x3_bias_relu: weights must come from pack_conv3x3 for this channel count, on the input's device")
+    out = torch.empty_like(x, memory_format=cl)
+    with torch.cuda.device(dev):
+        rc = _lib.load().hdn_conv3x3_bias_relu_f32(_lib.ptr(x), _lib.ptr(wpacked), _lib.ptr(bias), _lib.ptr(residual) if residual is not None else None,
+                                                   _lib.ptr(out), B, S, C, _lib.stream_ptr(dev))
+    _lib.check(rc, "conv3x3_bias_relu")
+    return out
+
+
 class FusedBasicBlock(nn.Module):
     """BasicBlock.forward (backbone/resnet.py:78-94) of the BN-folded trunk with its elementwise tail fused: the convolutions
     run bias-free on MIOpen, `relu(y + b1)` and `relu(y + b2 + residual)` are one HIP pass each (hdn_bias_relu_f32) instead of

@@ -276,6 +276,22 @@ int hdn_trunk_stem_f32(const float* x, const float* wT, const float* bias, float
 int hdn_bias_relu_f32(float* y, const float* bias, const float* residual, int B, int C, int HW, int nhwc, void* stream);
 
 /*
+ * A whole residual-block convolution of that trunk on the matrix cores:
+ *   out = relu(conv3x3/s1/p1(x, W) + bias[c] (+ residual)),  x / residual / out [B,S,S,C] fp32 CHANNELS-LAST in memory, C -> C channels.
+ * Supported (S, C): (32, 64), (16, 128), (8, 256), (4, 512) - the four stride-1 shapes of the ResNet-34 trunk at 127-px crops;
+ * anything else returns HDN_E_LIMIT (the caller keeps MIOpen for it).  fp32 accuracy from the bf16 pipe: activations and weights are
+ * split exactly into three bf16 pieces each and six piece products are accumulated in fp32 (conv3x3.hip); the result differs from an
+ * fp32 convolution by summation order and < 2^-23 relative per product.
+ * wpacked: the BatchNorm-folded weights split and laid out by the host as
+ *   [C / BN][C / 16][9 taps][3 pieces][2 k halves][BN][8] bf16,  BN = hdn_conv3x3_block_n(S, C)  (hdn_amd.trunk.pack_conv3x3 builds it),
+ * 16-byte aligned.  Replaces conv1 / conv2 + bn + relu (+ `out += residual`) of BasicBlock.forward,
+ * homo_estimator/Deep_homography/Oneline_DLTv1/backbone/resnet.py:78-94 (eval mode only).
+ */
+int hdn_conv3x3_block_n(int S, int C);
+int hdn_conv3x3_bias_relu_f32(const float* x, const void* wpacked, const float* bias, const float* residual, float* out, int B, int S, int C,
+                              void* stream);
+
+/*
  * Multi-GPU: template/search pairs are independent, so ranks own disjoint contiguous blocks of pairs
  * and the path's ONLY exchange is one all-gather of the predicted corner offsets, on RCCL over xGMI.
  *   local[Bl,8] (this rank's offsets) -> all[world*Bl,8] on every rank, in rank order; Bl must be equal on all
