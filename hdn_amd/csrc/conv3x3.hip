@@ -9,15 +9,19 @@
 // three bf16 pieces x = x0 + x1 + x2 (8 + 8 + 8 significand bits) and six piece products are accumulated in fp32
 // (x0 w0, x0 w1, x1 w0, x1 w1, x0 w2, x2 w0; the three dropped ones are below 2^-24 of the product): 6 x 32 clk per K = 16
 // against 8 x 64 clk on v_mfma_f32_32x32x2_f32, with a result that differs from an fp32 convolution by summation order and
-// < 2^-23 relative per product.  The weights are split once on the host (conv3x3_pack_weights), the activations while they are
-// staged into LDS.
+// ~2^-23 relative per product.  The weights are split once on the host (hdn_amd.trunk.pack_conv3x3), the activations while they
+// are staged into LDS.
 //
 // Workgroup = 4 waves, tile = BM output pixels (consecutive in (b, y, x) order: whole image rows) x BN output channels.
-//   LDS A image: the tile's input pixels with a one-pixel halo (zeros outside the image), one K chunk of 16 input channels at a
-//                time, as [piece][k half][pixel] x 16 B: an MFMA A fragment (lane = (pixel row i, k half g), 8 bf16 = 16 B) is
+//   LDS A image: the tile's input pixels with a one-pixel halo (zeros outside the image), one K chunk of 16 * KS input channels at
+//                a time, as [piece][k step][k half][pixel] x 16 B: an MFMA A fragment (lane = (pixel row i, k half g), 8 bf16) is
 //                one conflict-free ds_read_b128, and a tap is a constant address offset.
-//   LDS W image: [piece][k half][cout] x 16 B per tap, double buffered, streamed from the host-packed layout.
-//   wave tile  : MT x NT MFMA tiles of 32 x 32; accumulators stay in registers over the whole K loop (C / 16 chunks x 9 taps);
+//   LDS W image: [tap of the stage][k step][piece][k half][cout] x 16 B, one STAGE = one kernel row (3 taps) of one chunk, double
+//                buffered, streamed from the host-packed layout (which is exactly this order).
+//   pipeline   : the next chunk's activations and the next stage's weights are in flight in registers (global loads) while the
+//                current stage runs on the matrix cores; inside a stage the next step's fragments are read from LDS before the
+//                current step's MFMAs are issued.
+//   wave tile  : MT x NT MFMA tiles of 32 x 32; accumulators stay in registers over the whole K loop;
 //   epilogue   : + bias[cout] (+ residual) -> ReLU -> NHWC store, 128 contiguous bytes per pixel row and half wave.
 #include "hdn_common.h"
 
@@ -33,47 +37,46 @@ __device__ __forceinline__ f32x16 mfma(const u32x4& a, const u32x4& b, const f32
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// round-to-nearest-even fp32 -> bf16 bits (finite inputs)
-__device__ __forceinline__ unsigned bf16_rne(float f) {
-  const unsigned u = __float_as_uint(f);
-  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
-// two fp32 values -> their three bf16 pieces, packed (lo = first value)
+// two fp32 values -> their three bf16 pieces (round-to-nearest-even by v_cvt_pk_bf16_f32), packed (lo = first value):
+// x = p0 + p1 + p2 up to 2^-24 |x|; each residual is exact in fp32
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split3x2(float x, float y, unsigned& p0, unsigned& p1, unsigned& p2) {
-  const unsigned a0 = bf16_rne(x), b0 = bf16_rne(y);
-  const float xr = x - __uint_as_float(a0 << 16), yr = y - __uint_as_float(b0 << 16);
-  const unsigned a1 = bf16_rne(xr), b1 = bf16_rne(yr);
-  const float xs = xr - __uint_as_float(a1 << 16), ys = yr - __uint_as_float(b1 << 16);
-  const unsigned a2 = bf16_rne(xs), b2 = bf16_rne(ys);
-  p0 = a0 | (b0 << 16);
-  p1 = a1 | (b1 << 16);
-  p2 = a2 | (b2 << 16);
+  const f2 v = {x, y};
+  p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+  const f2 r1 = v - f2{__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xffff0000u)};
+  p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
+  const f2 r2 = r1 - f2{__uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u)};
+  p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
 }
 
-template <int S_, int C_, int WM_, int WN_, int MT_, int NT_>
+template <int S_, int C_, int WM_, int WN_, int MT_, int NT_, int KS_>
 struct Cfg {
-  static constexpr int S = S_, C = C_, WM = WM_, WN = WN_, MT = MT_, NT = NT_;
+  static constexpr int S = S_, C = C_, WM = WM_, WN = WN_, MT = MT_, NT = NT_, KS = KS_;
   static constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
   static_assert(WM * WN == 4, "4 waves per workgroup");
-  static_assert(C % BN == 0 && C % 16 == 0, "channel blocking");
+  static_assert(C % BN == 0 && C % (16 * KS) == 0, "channel blocking");
   static_assert((BM % S == 0) && ((S * S) % BM == 0 || BM % (S * S) == 0), "a tile is whole rows of one image, or whole images");
   static constexpr int IMGS = BM > S * S ? BM / (S * S) : 1;      // images per tile
   static constexpr int R = BM / (S * IMGS);                      // output rows per image in the tile
   static constexpr int PW = S + 2, PH = R + 2;                   // halo'ed image patch
   static constexpr int LP = IMGS * PH * PW;                      // LDS pixels
-  static constexpr int KG_BYTES = LP * 16, PIECE_BYTES = 2 * KG_BYTES, A_BYTES = 3 * PIECE_BYTES;
-  static constexpr int WKG_BYTES = BN * 16, WPIECE_BYTES = 2 * WKG_BYTES, WTAP_BYTES = 3 * WPIECE_BYTES;
-  static constexpr int LDS_BYTES = A_BYTES + 2 * WTAP_BYTES;
-  static constexpr int KC = C / 16, NB = C / BN;
-  static constexpr int W4 = WTAP_BYTES / 16;                     // 16-byte words of one tap's weights
+  static constexpr int KG_BYTES = LP * 16, KSTEP_BYTES = 2 * KG_BYTES, PIECE_BYTES = KS * KSTEP_BYTES, A_BYTES = 3 * PIECE_BYTES;
+  static constexpr int WKG_BYTES = BN * 16, WPIECE_BYTES = 2 * WKG_BYTES, WSTEP_BYTES = 3 * WPIECE_BYTES;   // one (tap, k step)
+  static constexpr int WSTAGE_BYTES = 3 * KS * WSTEP_BYTES;      // one kernel row of one chunk
+  static constexpr int EPI_STRIDE = BN + 4;                      // floats per pixel row of the output staging (pad: bank spread of the two half waves)
+  static constexpr int EPI_BYTES = BM * EPI_STRIDE * 4;
+  static constexpr int LDS_BYTES = (A_BYTES + 2 * WSTAGE_BYTES) > EPI_BYTES ? (A_BYTES + 2 * WSTAGE_BYTES) : EPI_BYTES;
+  static constexpr int NCHUNK = C / (16 * KS), NB = C / BN, NSTAGE = 3 * NCHUNK;
+  static constexpr int W4 = WSTAGE_BYTES / 16;                   // 16-byte words of one stage's weights
   static constexpr int WITER = cdiv(W4, HDN_BLOCK);
-  static constexpr int AITEMS = LP * 2, AITER = cdiv(AITEMS, HDN_BLOCK);
+  static constexpr int AITEMS = LP * 2 * KS, AITER = cdiv(AITEMS, HDN_BLOCK);   // (pixel, k step, k half) items of 8 channels
 };
 
 template <class Cf, bool RES>
 __global__ __launch_bounds__(HDN_BLOCK) void conv3x3_kernel(const float* __restrict__ x, const u32x4* __restrict__ wp, const float* __restrict__ bias,
                                                             const float* __restrict__ res, float* __restrict__ out, int B) {
-  constexpr int S = Cf::S, C = Cf::C, MT = Cf::MT, NT = Cf::NT, BM = Cf::BM, BN = Cf::BN;
+  constexpr int S = Cf::S, C = Cf::C, MT = Cf::MT, NT = Cf::NT, BM = Cf::BM, BN = Cf::BN, KS = Cf::KS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const sA = smem;
   unsigned char* const sW = smem + Cf::A_BYTES;
@@ -86,14 +89,16 @@ __global__ __launch_bounds__(HDN_BLOCK) void conv3x3_kernel(const float* __restr
   const int b0 = (int)(m0 / (S * S)), y0 = (int)((m0 % (S * S)) / S);
   const long long M = (long long)B * S * S;
 
-  // ---- per-lane LDS pixel of each of this wave's M tiles (tap (1, 1)); a tap adds a constant
-  int lp[MT];
+  // ---- per-lane LDS byte offsets: A fragments of this wave's M tiles (centre tap), B fragments of its N tiles
+  uint32_t aoff[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int i = (wm * MT + mt) * 32 + li;                  // pixel inside the tile
     const int img = i / (Cf::R * S), yy = (i / S) % Cf::R, xx = i % S;
-    lp[mt] = img * (Cf::PH * Cf::PW) + (yy + 1) * Cf::PW + (xx + 1);
+    aoff[mt] = lds_addr(sA) + g * Cf::KG_BYTES + (img * (Cf::PH * Cf::PW) + (yy + 1) * Cf::PW + (xx + 1)) * 16;
   }
+  const uint32_t boff = lds_addr(sW) + g * Cf::WKG_BYTES + (wn * NT * 32 + li) * 16;
+
   f32x16 acc[MT][NT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -102,108 +107,180 @@ __global__ __launch_bounds__(HDN_BLOCK) void conv3x3_kernel(const float* __restr
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-  const u32x4* wblock = wp + (size_t)nb * Cf::KC * 9 * Cf::W4;   // this channel block's packed weights: [kc][tap][piece][k half][n][8 bf16]
-  auto load_w = [&](u32x4 (&wr)[Cf::WITER], int kc, int tap) {
-    const u32x4* src = wblock + (size_t)(kc * 9 + tap) * Cf::W4;
+  // this channel block's packed weights: [chunk][kernel row][tap in row][k step][piece][k half][n][8 bf16] = [stage][W4 words]
+  const u32x4* wblock = wp + (size_t)nb * Cf::NSTAGE * Cf::W4;
+  u32x4 wr[Cf::WITER];
+  auto load_w = [&](int stage) {
+#ifdef CV_EXP_NOWLOAD
+    if (stage > 0) return;
+#endif
+    const u32x4* src = wblock + (size_t)stage * Cf::W4;
 #pragma unroll
     for (int q = 0; q < Cf::WITER; ++q) wr[q] = src[min(tid + q * HDN_BLOCK, Cf::W4 - 1)];
   };
-  auto store_w = [&](const u32x4 (&wr)[Cf::WITER], int buf) {
-    u32x4* dst = reinterpret_cast<u32x4*>(sW + buf * Cf::WTAP_BYTES);
+  auto store_w = [&](int buf) {
+    u32x4* dst = reinterpret_cast<u32x4*>(sW + buf * Cf::WSTAGE_BYTES);
 #pragma unroll
     for (int q = 0; q < Cf::WITER; ++q)
       if (tid + q * HDN_BLOCK < Cf::W4) dst[tid + q * HDN_BLOCK] = wr[q];
   };
-
-  for (int kc = 0; kc < Cf::KC; ++kc) {
-    u32x4 wr[Cf::WITER];
-    load_w(wr, kc, 0);
-    // ---- stage the input chunk: (LDS pixel, k half) items, 8 channels = 32 bytes each, split into the three pieces
-    f4 v[Cf::AITER][2];
+  // input chunk: (pixel, k step, k half) items of 8 channels = 32 bytes
+  f4 av[Cf::AITER][2];
+  auto load_a = [&](int chunk) {
+#ifdef CV_EXP_NOALOAD
+    if (chunk > 0) return;
+#endif
 #pragma unroll
     for (int q = 0; q < Cf::AITER; ++q) {
       const int item = tid + q * HDN_BLOCK;
-      const int px = min(item >> 1, Cf::LP - 1), kg = item & 1;
+      const int px = min(item / (2 * KS), Cf::LP - 1), sub = item % (2 * KS);
       const int img = px / (Cf::PH * Cf::PW), ry = (px / Cf::PW) % Cf::PH, rx = px % Cf::PW;
       const int b = b0 + img, y = y0 + ry - 1, xx = rx - 1;
       const bool ok = item < Cf::AITEMS && b < B && y >= 0 && y < S && xx >= 0 && xx < S;
-      const f4* src = reinterpret_cast<const f4*>(x + (((size_t)b * S + y) * S + xx) * C + kc * 16 + kg * 8);
-      v[q][0] = ok ? src[0] : f4{0.f, 0.f, 0.f, 0.f};
-      v[q][1] = ok ? src[1] : f4{0.f, 0.f, 0.f, 0.f};
+      const f4* src = reinterpret_cast<const f4*>(x + (((size_t)b * S + y) * S + xx) * C + chunk * (16 * KS) + sub * 8);
+      av[q][0] = ok ? src[0] : f4{0.f, 0.f, 0.f, 0.f};
+      av[q][1] = ok ? src[1] : f4{0.f, 0.f, 0.f, 0.f};
     }
-    __syncthreads();  // the previous chunk's fragments have all been read
+  };
+  auto store_a = [&]() {
+#ifdef CV_EXP_NOSTAGE
+    return;
+#endif
 #pragma unroll
     for (int q = 0; q < Cf::AITER; ++q) {
       const int item = tid + q * HDN_BLOCK;
       if (item < Cf::AITEMS) {
-        const int px = item >> 1, kg = item & 1;
+        const int px = item / (2 * KS), sub = item % (2 * KS);   // sub = k step * 2 + k half
         unsigned q0[4], q1[4], q2[4];
-        split3x2(v[q][0].x, v[q][0].y, q0[0], q1[0], q2[0]);
-        split3x2(v[q][0].z, v[q][0].w, q0[1], q1[1], q2[1]);
-        split3x2(v[q][1].x, v[q][1].y, q0[2], q1[2], q2[2]);
-        split3x2(v[q][1].z, v[q][1].w, q0[3], q1[3], q2[3]);
-        const u32x4 p0 = {q0[0], q0[1], q0[2], q0[3]}, p1 = {q1[0], q1[1], q1[2], q1[3]}, p2 = {q2[0], q2[1], q2[2], q2[3]};
-        unsigned char* dst = sA + kg * Cf::KG_BYTES + px * 16;
-        *reinterpret_cast<u32x4*>(dst) = p0;
-        *reinterpret_cast<u32x4*>(dst + Cf::PIECE_BYTES) = p1;
-        *reinterpret_cast<u32x4*>(dst + 2 * Cf::PIECE_BYTES) = p2;
+        split3x2(av[q][0].x, av[q][0].y, q0[0], q1[0], q2[0]);
+        split3x2(av[q][0].z, av[q][0].w, q0[1], q1[1], q2[1]);
+        split3x2(av[q][1].x, av[q][1].y, q0[2], q1[2], q2[2]);
+        split3x2(av[q][1].z, av[q][1].w, q0[3], q1[3], q2[3]);
+        unsigned char* dst = sA + sub * Cf::KG_BYTES + px * 16;
+        *reinterpret_cast<u32x4*>(dst) = u32x4{q0[0], q0[1], q0[2], q0[3]};
+        *reinterpret_cast<u32x4*>(dst + Cf::PIECE_BYTES) = u32x4{q1[0], q1[1], q1[2], q1[3]};
+        *reinterpret_cast<u32x4*>(dst + 2 * Cf::PIECE_BYTES) = u32x4{q2[0], q2[1], q2[2], q2[3]};
       }
     }
-    store_w(wr, 0);
-    __syncthreads();
+  };
 
+  struct Frags {
+    u32x4 a[MT][3], b[NT][3];
+  };
+  // fragments of step (tap t of the stage's kernel row ky, k step ks) from W buffer `buf`
+  auto read_frags = [&](Frags& f, int ky, int t, int ks, int buf) {
+#ifdef CV_EXP_NOREAD
+    if (ky + t + ks + buf >= 0) return;
+#endif
+    const int toff = ((ky - 1) * Cf::PW + (t - 1)) * 16 + ks * Cf::KSTEP_BYTES;
+    const uint32_t wb = boff + buf * Cf::WSTAGE_BYTES + (t * KS + ks) * Cf::WSTEP_BYTES;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+        asm volatile("ds_read_b128 %0, %1" : "=v"(f.a[mt][s]) : "v"(aoff[mt] + toff + s * Cf::PIECE_BYTES));
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+        asm volatile("ds_read_b128 %0, %1" : "=v"(f.b[nt][s]) : "v"(wb + s * Cf::WPIECE_BYTES + nt * 32 * 16));
+  };
+  auto mma = [&](const Frags& f) {
+#ifdef CV_EXP_NOMFMA
+    return;
+#endif
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        f32x16 c = acc[mt][nt];
+        c = mfma(f.a[mt][2], f.b[nt][0], c);  // smallest terms first
+        c = mfma(f.a[mt][0], f.b[nt][2], c);
+        c = mfma(f.a[mt][1], f.b[nt][1], c);
+        c = mfma(f.a[mt][1], f.b[nt][0], c);
+        c = mfma(f.a[mt][0], f.b[nt][1], c);
+        c = mfma(f.a[mt][0], f.b[nt][0], c);
+        acc[mt][nt] = c;
+      }
+  };
+
+  load_a(0);
+  load_w(0);
+  store_a();
+  store_w(0);
+  __syncthreads();
+  constexpr int NSTEP = 3 * KS;   // steps of a stage
 #pragma unroll 1
-    for (int tap = 0; tap < 9; ++tap) {
-      if (tap + 1 < 9) load_w(wr, kc, tap + 1);
-      const int toff = ((tap / 3) - 1) * Cf::PW + (tap % 3) - 1;
-      const unsigned char* wb = sW + (tap & 1) * Cf::WTAP_BYTES + g * Cf::WKG_BYTES + (wn * NT * 32 + li) * 16;
-      u32x4 a[MT][3], bb[NT][3];
+  for (int chunk = 0; chunk < Cf::NCHUNK; ++chunk) {
+    if (chunk + 1 < Cf::NCHUNK) load_a(chunk + 1);             // in flight during the whole chunk
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+    for (int ky = 0; ky < 3; ++ky) {
+      const int stage = chunk * 3 + ky, buf = stage & 1;
+      if (stage + 1 < Cf::NSTAGE) load_w(stage + 1);           // in flight during this stage
+      Frags f[2];
+      read_frags(f[0], ky, 0, 0, buf);
 #pragma unroll
-        for (int s = 0; s < 3; ++s)
-          a[mt][s] = *reinterpret_cast<const u32x4*>(sA + s * Cf::PIECE_BYTES + g * Cf::KG_BYTES + (lp[mt] + toff) * 16);
+      for (int st = 0; st < NSTEP; ++st) {
+        if (st + 1 < NSTEP) read_frags(f[(st + 1) & 1], ky, (st + 1) / KS, (st + 1) % KS, buf);
+        // the fragments of step st have landed when at most the next step's reads are outstanding
+        if (st + 1 < NSTEP) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((MT + NT) * 3) : "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int s = 0; s < 3; ++s) bb[nt][s] = *reinterpret_cast<const u32x4*>(wb + s * Cf::WPIECE_BYTES + nt * 32 * 16);
+          for (int s = 0; s < 3; ++s) asm volatile("" : "+v"(f[st & 1].a[mt][s]));
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          f32x16 c = acc[mt][nt];
-          c = mfma(a[mt][2], bb[nt][0], c);  // smallest terms first
-          c = mfma(a[mt][0], bb[nt][2], c);
-          c = mfma(a[mt][1], bb[nt][1], c);
-          c = mfma(a[mt][1], bb[nt][0], c);
-          c = mfma(a[mt][0], bb[nt][1], c);
-          c = mfma(a[mt][0], bb[nt][0], c);
-          acc[mt][nt] = c;
+          for (int s = 0; s < 3; ++s) asm volatile("" : "+v"(f[st & 1].b[nt][s]));
+        mma(f[st & 1]);
+      }
+      if (stage + 1 < Cf::NSTAGE) {
+        if (ky == 2) {                                          // chunk boundary: the A image is rewritten as well
+          __syncthreads();                                      // everyone is done reading this chunk's A image
+          store_a();
         }
-      if (tap + 1 < 9) {
-        store_w(wr, (tap + 1) & 1);
+        store_w(buf ^ 1);                                       // (read last during stage - 1: a barrier ago)
         __syncthreads();
       }
     }
   }
 
-  // ---- epilogue: C/D layout of v_mfma_f32_32x32x16_bf16: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  // ---- epilogue.  C/D layout of v_mfma_f32_32x32x16_bf16: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+  // The tile goes through LDS once ([pixel][BN] fp32) so that the residual is read and the result written as 16 bytes per lane,
+  // a pixel's BN channels (contiguous in NHWC) by BN / 4 consecutive lanes.
+  __syncthreads();  // every wave is done with the A / W images
+  float* const sO = reinterpret_cast<float*>(smem);
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int co = nb * BN + (wn * NT + nt) * 32 + li;
-    const float bv = bias[co];
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * g;
-        const long long m = m0 + (wm * MT + mt) * 32 + row;
-        if (m < M) {
-          float vv = acc[mt][nt][r] + bv;
-          if (RES) vv = vv + res[m * C + co];
-          out[m * C + co] = fmaxf(vv, 0.f);
-        }
+        const int row = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+        sO[row * Cf::EPI_STRIDE + (wn * NT + nt) * 32 + li] = acc[mt][nt][r];
       }
+  __syncthreads();
+  constexpr int N4 = BN / 4, TOT4 = BM * N4, EITER = cdiv(TOT4, HDN_BLOCK);
+  f4 rv[EITER];
+  if (RES) {
+#pragma unroll
+    for (int q = 0; q < EITER; ++q) {
+      const int idx = tid + q * HDN_BLOCK, px = idx / N4, c4 = idx % N4;
+      const long long m = min(m0 + px, M - 1);
+      rv[q] = *reinterpret_cast<const f4*>(res + m * C + nb * BN + c4 * 4);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < EITER; ++q) {
+    const int idx = tid + q * HDN_BLOCK, px = idx / N4, c4 = idx % N4;
+    const long long m = m0 + px;
+    if (idx < TOT4 && m < M) {
+      f4 v = *reinterpret_cast<const f4*>(sO + px * Cf::EPI_STRIDE + c4 * 4);
+      v = v + *reinterpret_cast<const f4*>(bias + nb * BN + c4 * 4);
+      if (RES) v = v + rv[q];
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      *reinterpret_cast<f4*>(out + m * C + nb * BN + c4 * 4) = v;
     }
   }
 }
@@ -229,18 +306,22 @@ static int launch(const float* x, const void* wp, const float* bias, const float
 }  // namespace cv
 }  // namespace hdn
 
-//            S    C   WM WN MT NT
-using CV_L1 = hdn::cv::Cfg<32, 64, 4, 1, 2, 2>;    // 256 pixels (8 rows) x 64 channels
-using CV_L2 = hdn::cv::Cfg<16, 128, 4, 1, 1, 2>;   // 128 pixels (8 rows) x 64 channels
-using CV_L3 = hdn::cv::Cfg<8, 256, 2, 2, 1, 1>;    // 64 pixels (one image) x 64 channels
-using CV_L4 = hdn::cv::Cfg<4, 512, 1, 4, 1, 1>;    // 32 pixels (two images) x 128 channels
+//            S    C   WM WN MT NT KS
+using CV_L1 = hdn::cv::Cfg<32, 64, 4, 1, 1, 2, 1>;    // 128 pixels (4 rows) x 64 channels: 512 workgroups at B = 64, two per CU
+using CV_L2 = hdn::cv::Cfg<16, 128, 4, 1, 1, 2, 1>;   // 128 pixels (8 rows) x 64 channels
+using CV_L3 = hdn::cv::Cfg<8, 256, 2, 2, 1, 1, 1>;    // 64 pixels (one image) x 64 channels
+using CV_L4 = hdn::cv::Cfg<4, 512, 1, 4, 1, 1, 1>;    // 32 pixels (two images) x 128 channels
 
-extern "C" int hdn_conv3x3_block_n(int S, int C) {
-  if (S == 32 && C == 64) return CV_L1::BN;
-  if (S == 16 && C == 128) return CV_L2::BN;
-  if (S == 8 && C == 256) return CV_L3::BN;
-  if (S == 4 && C == 512) return CV_L4::BN;
-  return HDN_E_LIMIT;
+extern "C" int hdn_conv3x3_pack_info(int S, int C, int* block_n, int* k_steps) {
+  int bn = 0, ks = 0;
+  if (S == 32 && C == 64) { bn = CV_L1::BN; ks = CV_L1::KS; }
+  else if (S == 16 && C == 128) { bn = CV_L2::BN; ks = CV_L2::KS; }
+  else if (S == 8 && C == 256) { bn = CV_L3::BN; ks = CV_L3::KS; }
+  else if (S == 4 && C == 512) { bn = CV_L4::BN; ks = CV_L4::KS; }
+  else return HDN_E_LIMIT;
+  if (block_n) *block_n = bn;
+  if (k_steps) *k_steps = ks;
+  return HDN_OK;
 }
 
 extern "C" int hdn_conv3x3_bias_relu_f32(const float* x, const void* wpacked, const float* bias, const float* residual, float* out, int B, int S,
@@ -249,7 +330,7 @@ extern "C" int hdn_conv3x3_bias_relu_f32(const float* x, const void* wpacked, co
   if (B <= 0 || S <= 0 || C <= 0) return HDN_E_SHAPE;
   if (out == x) return HDN_E_ALIAS;  // (out == residual is fine: each element is read before it is written, by the same lane)
   if ((long long)B * S * S * C > 0x7fffffffLL) return HDN_E_LIMIT;
-  if (!hdn::aligned16(x) || !hdn::aligned16(wpacked)) return HDN_E_LIMIT;
+  if (!hdn::aligned16(x) || !hdn::aligned16(wpacked) || !hdn::aligned16(out) || !hdn::aligned16(bias) || (residual && !hdn::aligned16(residual))) return HDN_E_LIMIT;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (S == 32 && C == 64) return hdn::cv::launch<CV_L1>(x, wpacked, bias, residual, out, B, s);
   if (S == 16 && C == 128) return hdn::cv::launch<CV_L2>(x, wpacked, bias, residual, out, B, s);

@@ -134,8 +134,11 @@ def bias_relu_(y, bias, residual=None):
 
 def pack_conv3x3(weight):
     """[C, C, 3, 3] fp32 conv weights -> the layout hdn_conv3x3_bias_relu_f32 streams: every value split exactly into three bf16
-    pieces (w = p0 + p1 + p2, round-to-nearest-even each), arranged [C / BN][C / 16][9 taps][3 pieces][2 k halves][BN][8] as int16
-    bit patterns.  S is implied by C in the trunk (64 -> 32, 128 -> 16, 256 -> 8, 512 -> 4)."""
+    pieces (w = p0 + p1 + p2, round-to-nearest-even each), arranged
+    [C / BN][C / (16 KS)][3 kernel rows][3 taps][KS][3 pieces][2 k halves][BN][8] as int16 bit patterns, (BN, KS) from the library.
+    S is implied by C in the trunk (64 -> 32, 128 -> 16, 256 -> 8, 512 -> 4)."""
+    import ctypes
+
     import torch
 
     from . import _lib
@@ -143,18 +146,19 @@ def pack_conv3x3(weight):
     C = weight.shape[0]
     if tuple(weight.shape) != (C, C, 3, 3):
         raise ValueError(f"pack_conv3x3 takes [C, C, 3, 3] weights, got {tuple(weight.shape)}")
-    S = {64: 32, 128: 16, 256: 8, 512: 4}.get(C)
-    BN = _lib.load().hdn_conv3x3_block_n(S, C) if S else -3
-    if BN <= 0:
+    S = {64: 32, 128: 16, 256: 8, 512: 4}.get(C, 0)
+    bn, ks = ctypes.c_int(0), ctypes.c_int(0)
+    if _lib.load().hdn_conv3x3_pack_info(S, C, ctypes.byref(bn), ctypes.byref(ks)) != 0:
         raise ValueError(f"no matrix-core kernel for {C} channels")
+    BN, KS = bn.value, ks.value
     w = weight.detach().to(torch.float32).cpu()
     p0 = w.to(torch.bfloat16)
     r1 = w - p0.float()
     p1 = r1.to(torch.bfloat16)
     p2 = (r1 - p1.float()).to(torch.bfloat16)
     pieces = torch.stack([p0, p1, p2])                                   # [3, Cout, Cin, ky, kx]
-    t = pieces.permute(0, 1, 3, 4, 2).reshape(3, C // BN, BN, 9, C // 16, 2, 8)   # [piece, nb, n, tap, kc, g, 8]
-    t = t.permute(1, 4, 3, 0, 5, 2, 6).contiguous()                     # [nb, kc, tap, piece, g, n, 8]
+    t = pieces.permute(0, 1, 3, 4, 2).reshape(3, C // BN, BN, 3, 3, C // (16 * KS), KS, 2, 8)   # [piece, nb, n, ky, kx, chunk, ks, g, 8]
+    t = t.permute(1, 5, 3, 4, 6, 0, 7, 2, 8).contiguous()               # [nb, chunk, ky, kx, ks, piece, g, n, 8]
     return t.view(torch.int16)
 
 

@@ -283,11 +283,11 @@ int hdn_bias_relu_f32(float* y, const float* bias, const float* residual, int B,
  * split exactly into three bf16 pieces each and six piece products are accumulated in fp32 (conv3x3.hip); the result differs from an
  * fp32 convolution by summation order and < 2^-23 relative per product.
  * wpacked: the BatchNorm-folded weights split and laid out by the host as
- *   [C / BN][C / 16][9 taps][3 pieces][2 k halves][BN][8] bf16,  BN = hdn_conv3x3_block_n(S, C)  (hdn_amd.trunk.pack_conv3x3 builds it),
- * 16-byte aligned.  Replaces conv1 / conv2 + bn + relu (+ `out += residual`) of BasicBlock.forward,
+ *   [C / BN][C / (16 KS)][3 kernel rows][3 taps][KS k steps][3 pieces][2 k halves][BN][8] bf16, input channel = chunk * 16 KS +
+ *   step * 16 + half * 8 + j, with (BN, KS) = hdn_conv3x3_pack_info(S, C)  (hdn_amd.trunk.pack_conv3x3 builds it), 16-byte aligned.  Replaces conv1 / conv2 + bn + relu (+ `out += residual`) of BasicBlock.forward,
  * homo_estimator/Deep_homography/Oneline_DLTv1/backbone/resnet.py:78-94 (eval mode only).
  */
-int hdn_conv3x3_block_n(int S, int C);
+int hdn_conv3x3_pack_info(int S, int C, int* block_n, int* k_steps);
 int hdn_conv3x3_bias_relu_f32(const float* x, const void* wpacked, const float* bias, const float* residual, float* out, int B, int S, int C,
                               void* stream);
 
