@@ -146,7 +146,7 @@ def pack_conv3x3(weight):
     C = weight.shape[0]
     if tuple(weight.shape) != (C, C, 3, 3):
         raise ValueError(f"pack_conv3x3 takes [C, C, 3, 3] weights, got {tuple(weight.shape)}")
-    S = {64: 32, 128: 16, 256: 8, 512: 4}.get(C, 0)
+    S = _MC_SIDE.get(C, 0)
     bn, ks = ctypes.c_int(0), ctypes.c_int(0)
     if _lib.load().hdn_conv3x3_pack_info(S, C, ctypes.byref(bn), ctypes.byref(ks)) != 0:
         raise ValueError(f"no matrix-core kernel for {C} channels")
@@ -183,13 +183,20 @@ def conv3x3_bias_relu(x, wpacked, bias, residual=None):
     return out
 
 
-class FusedBasicBlock(nn.Module):
-    """BasicBlock.forward (backbone/resnet.py:78-94) of the BN-folded trunk with its elementwise tail fused: the convolutions
-    run bias-free on MIOpen, `relu(y + b1)` and `relu(y + b2 + residual)` are one HIP pass each (hdn_bias_relu_f32) instead of
-    bias-add + ReLU and bias-add + add + ReLU launches.  A folded downsample branch contributes its bias to b2 and its raw
-    convolution as the residual.  GPU / eval only."""
+# channel counts whose stride-1 3x3 convolutions run on hdn_conv3x3_bias_relu_f32 instead of MIOpen (measured per shape at
+# B = 64, profiles/round3_conv3x3.txt: the kernel is kept only where it wins)
+MATRIX_CORE_CHANNELS = (64, 128, 256)
+_MC_SIDE = {64: 32, 128: 16, 256: 8, 512: 4}
 
-    def __init__(self, blk: "BasicBlock"):
+
+class FusedBasicBlock(nn.Module):
+    """BasicBlock.forward (backbone/resnet.py:78-94) of the BN-folded trunk with its elementwise tail fused.  Stride-1 3x3
+    convolutions of MATRIX_CORE_CHANNELS run, bias / residual / ReLU included, as ONE launch of the split-bf16 matrix-core kernel
+    (hdn_conv3x3_bias_relu_f32, channels-last only); every other convolution runs bias-free on MIOpen with `relu(y + b1)` /
+    `relu(y + b2 + residual)` as one HIP pass each (hdn_bias_relu_f32).  A folded downsample branch contributes its bias to b2 and
+    its raw convolution as the residual.  GPU / eval only."""
+
+    def __init__(self, blk: "BasicBlock", matrix_core: bool = False):
         super().__init__()
         import torch
 
@@ -208,22 +215,41 @@ class FusedBasicBlock(nn.Module):
         else:
             self.wd = None
         self.register_buffer("b2", b2)
+        # packed split-bf16 weights for the matrix-core kernel (stride 1, C -> C only)
+        dev = self.w1.device
+        cin, cout = self.w1.shape[1], self.w1.shape[0]
+        use1 = matrix_core and self.stride == (1, 1) and cin == cout and cout in MATRIX_CORE_CHANNELS
+        use2 = matrix_core and cout in MATRIX_CORE_CHANNELS
+        self.register_buffer("p1", pack_conv3x3(self.w1).to(dev) if use1 else None)
+        self.register_buffer("p2", pack_conv3x3(self.w2).to(dev) if use2 else None)
 
     def forward(self, x):
+        import torch
         import torch.nn.functional as F
 
-        y = bias_relu_(F.conv2d(x, self.w1, None, self.stride, 1), self.b1)
+        def shape_ok(t):   # the kernel's shapes: square, side tied to the channel count (127-px crops), channels-last
+            return t.is_contiguous(memory_format=torch.channels_last) and t.shape[2] == t.shape[3] == _MC_SIDE.get(t.shape[1], -1)
+
+        if self.p1 is not None and shape_ok(x):
+            y = conv3x3_bias_relu(x, self.p1, self.b1)
+        else:
+            y = bias_relu_(F.conv2d(x, self.w1, None, self.stride, 1), self.b1)
         idt = x if self.wd is None else F.conv2d(x, self.wd, None, self.ds_stride)
+        if self.p2 is not None and shape_ok(y) and idt.is_contiguous(memory_format=torch.channels_last):
+            return conv3x3_bias_relu(y, self.p2, self.b2, idt)
         return bias_relu_(F.conv2d(y, self.w2, None, 1, 1), self.b2, idt)
 
 
-def fold_for_inference(net: HomoResNet, channels_last: bool = True, fused_stem: bool = False, fused_epilogue: bool = False) -> nn.Module:
+def fold_for_inference(net: HomoResNet, channels_last: bool = True, fused_stem: bool = False, fused_epilogue: bool = False,
+                       matrix_core: bool = None) -> nn.Module:
     """A copy of `net` with every eval-mode BatchNorm folded into the preceding convolution (weights scaled in
     float64, rounded once) and, optionally, NHWC weights for MIOpen's channels-last kernels.  Measured on MI355X at
     B=64: 2.92 ms (as-is) -> 2.47 ms (folded) -> 2.11 ms (folded + NHWC); outputs agree with the un-folded CPU
     trunk to ~1.5e-6 relative either way (tools/experiments/exp_trunk.py).  The copy does not track later weight changes.
     fused_stem: replace conv1 / relu / maxpool by FusedStem (GPU only, W <= 128).
-    fused_epilogue: replace every BasicBlock by FusedBasicBlock (GPU only): 83 elementwise launches per forward -> 32."""
+    fused_epilogue: replace every BasicBlock by FusedBasicBlock (GPU only): 83 elementwise launches per forward -> 32.
+    matrix_core (default: fused_epilogue and channels_last): the stride-1 3x3 convolutions of MATRIX_CORE_CHANNELS as one launch of
+    the split-bf16 matrix-core kernel each, epilogue included."""
     import copy
 
     import torch
@@ -252,7 +278,8 @@ def fold_for_inference(net: HomoResNet, channels_last: bool = True, fused_stem: 
         net = net.to(memory_format=_t.channels_last)
     if fused_epilogue:
         for name in ("layer1", "layer2", "layer3", "layer4"):
-            setattr(net, name, nn.Sequential(*[FusedBasicBlock(blk) for blk in getattr(net, name)]))
+            setattr(net, name, nn.Sequential(*[FusedBasicBlock(blk, bool(channels_last) if matrix_core is None else bool(matrix_core))
+                                               for blk in getattr(net, name)]))
         if channels_last:
             import torch as _t
             net = net.to(memory_format=_t.channels_last)

@@ -1002,6 +1002,42 @@ def test_bias_relu_epilogue_bitexact(dev, shape, nhwc, with_res):
             bias_relu_(yd, b.to(dev), yd)
 
 
+@pytest.mark.parametrize("C,S", [(64, 32), (128, 16), (256, 8), (512, 4)])
+@pytest.mark.parametrize("B", [1, 3, 64])
+def test_conv3x3_matrix_core_vs_float64(dev, C, S, B):
+    """hdn_conv3x3_bias_relu_f32 (split-bf16 implicit GEMM on the matrix cores, fused bias / residual / ReLU) against a float64
+    convolution: its error must stay within 4x the error of PyTorch's own fp32 convolution + 1e-5 of the output scale (observed
+    3-8e-6 on outputs of O(5); fp32: 1e-6), odd and single batch sizes included (ragged last tiles)."""
+    import torch.nn.functional as F
+    from hdn_amd.trunk import pack_conv3x3, conv3x3_bias_relu
+    g = torch.Generator().manual_seed(C + B)
+    w = torch.randn(C, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5
+    b = torch.randn(C, generator=g) * 0.1
+    nb = min(B, 5)                                      # the float64 truth on the first and last images only
+    x = torch.randn(B, C, S, S, generator=g).clamp_min_(0)
+    r = torch.randn(B, C, S, S, generator=g)
+    cl = torch.channels_last
+    wp, bd = pack_conv3x3(w).to(dev), b.to(dev)
+    xd, rd = x.to(dev).contiguous(memory_format=cl), r.to(dev).contiguous(memory_format=cl)
+    y = conv3x3_bias_relu(xd, wp, bd, rd)
+    y0 = conv3x3_bias_relu(xd, wp, bd)
+    assert torch.equal(y, conv3x3_bias_relu(xd, wp, bd, rd))          # deterministic
+    assert y.is_contiguous(memory_format=cl) and y.shape == x.shape
+    for sl in (slice(0, nb), slice(B - nb, B)):
+        conv = F.conv2d(x[sl].double(), w.double(), b.double(), padding=1)
+        t, t0 = torch.relu(conv + r[sl].double()), torch.relu(conv)
+        ref = torch.relu(F.conv2d(x[sl], w, b, padding=1) + r[sl])
+        e_ref = float((ref.double() - t).abs().max())
+        scale = float(t.abs().max())
+        for got, truth in ((y, t), (y0, t0)):
+            e = float((got[sl].cpu().double() - truth).abs().max())
+            assert e <= 4 * e_ref + 1e-5 * scale, (e, e_ref, scale)
+    with pytest.raises(ValueError):
+        conv3x3_bias_relu(xd.contiguous(), wp, bd)                    # NCHW input
+    with pytest.raises(ValueError):
+        conv3x3_bias_relu(xd, wp[:-1], bd)
+
+
 def test_fused_epilogue_trunk_vs_unfused(dev):
     """The BN-folded trunk with FusedBasicBlock (bias-free MIOpen convolutions + hdn_bias_relu_f32) against the same folded
     trunk on PyTorch's own bias / add / relu kernels, NCHW and NHWC: the only arithmetic difference is (b2 + b_downsample)
@@ -1018,12 +1054,16 @@ def test_fused_epilogue_trunk_vs_unfused(dev):
     with torch.no_grad():
         for cl in (False, True):
             plain = fold_for_inference(net, channels_last=cl, fused_stem=False, fused_epilogue=False)
-            fused = fold_for_inference(net, channels_last=cl, fused_stem=False, fused_epilogue=True)
-            assert sum(isinstance(m, FusedBasicBlock) for m in fused.modules()) == 16
             xin = x.contiguous(memory_format=torch.channels_last) if cl else x
-            a, b = plain(xin), fused(xin)
+            a = plain(xin)
             scale = float(a.abs().max())
-            assert float((a - b).abs().max()) <= 2e-5 * scale, (cl, float((a - b).abs().max()), scale)
+            for mc in ((False, True) if cl else (False,)):
+                fused = fold_for_inference(net, channels_last=cl, fused_stem=False, fused_epilogue=True, matrix_core=mc)
+                assert sum(isinstance(m, FusedBasicBlock) for m in fused.modules()) == 16
+                assert sum(m.p1 is not None for m in fused.modules() if isinstance(m, FusedBasicBlock)) == (11 if mc else 0)
+                b = fused(xin)
+                # MIOpen path: only (b2 + b_downsample) differs; matrix-core path: split-bf16 products, ~1e-6 relative per layer
+                assert float((a - b).abs().max()) <= (1e-4 if mc else 2e-5) * scale, (cl, mc, float((a - b).abs().max()), scale)
 
 
 def test_benchmarked_full_head_configuration_parity(dev):
