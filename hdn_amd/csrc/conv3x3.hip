@@ -23,6 +23,8 @@
 //                current step's MFMAs are issued.
 //   wave tile  : MT x NT MFMA tiles of 32 x 32; accumulators stay in registers over the whole K loop;
 //   epilogue   : + bias[cout] (+ residual) -> ReLU -> NHWC store, 128 contiguous bytes per pixel row and half wave.
+#include <type_traits>
+
 #include "hdn_common.h"
 
 namespace hdn {
@@ -67,15 +69,19 @@ struct Cfg {
   static constexpr int EPI_STRIDE = BN + 4;                      // floats per pixel row of the output staging (pad: bank spread of the two half waves)
   static constexpr int EPI_BYTES = BM * EPI_STRIDE * 4;
   static constexpr int LDS_BYTES = (A_BYTES + 2 * WSTAGE_BYTES) > EPI_BYTES ? (A_BYTES + 2 * WSTAGE_BYTES) : EPI_BYTES;
+  static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit the LDS");
   static constexpr int NCHUNK = C / (16 * KS), NB = C / BN, NSTAGE = 3 * NCHUNK;
   static constexpr int W4 = WSTAGE_BYTES / 16;                   // 16-byte words of one stage's weights
   static constexpr int WITER = cdiv(W4, HDN_BLOCK);
   static constexpr int AITEMS = LP * 2 * KS, AITER = cdiv(AITEMS, HDN_BLOCK);   // (pixel, k step, k half) items of 8 channels
 };
 
-template <class Cf, bool RES>
+// MODE 0: out = relu(conv + bias); 1: out = relu(conv + bias + res); 2: the K slice blockIdx.z of `cps` chunks, raw sums to
+// out[blockIdx.z][M][C] (the workspace; conv3x3_reduce_kernel finishes)
+template <class Cf, int MODE>
 __global__ __launch_bounds__(HDN_BLOCK) void conv3x3_kernel(const float* __restrict__ x, const u32x4* __restrict__ wp, const float* __restrict__ bias,
-                                                            const float* __restrict__ res, float* __restrict__ out, int B) {
+                                                            const float* __restrict__ res, float* __restrict__ out, int B, int cps) {
+  constexpr bool RES = MODE == 1, PARTIAL = MODE == 2;
   constexpr int S = Cf::S, C = Cf::C, MT = Cf::MT, NT = Cf::NT, BM = Cf::BM, BN = Cf::BN, KS = Cf::KS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const sA = smem;
@@ -108,21 +114,24 @@ __global__ __launch_bounds__(HDN_BLOCK) void conv3x3_kernel(const float* __restr
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
   // this channel block's packed weights: [chunk][kernel row][tap in row][k step][piece][k half][n][8 bf16] = [stage][W4 words]
-  const u32x4* wblock = wp + (size_t)nb * Cf::NSTAGE * Cf::W4;
-  u32x4 wr[Cf::WITER];
-  auto load_w = [&](int stage) {
+  const int chunk0 = PARTIAL ? (int)blockIdx.z * cps : 0, nchunk = PARTIAL ? cps : Cf::NCHUNK, nstage = 3 * nchunk;   // this launch's K range
+  const u32x4* wblock = wp + ((size_t)nb * Cf::NSTAGE + (size_t)chunk0 * 3) * Cf::W4;
+  u32x4 wr[2][Cf::WITER];   // two stages in flight: stage s travels in wr[s & 1] from the start of stage s - 2 to the end of stage s - 1
+  auto load_w = [&](int stage, auto P) {
+    constexpr int p = decltype(P)::value;
 #ifdef CV_EXP_NOWLOAD
-    if (stage > 0) return;
+    if (stage > 1) return;
 #endif
     const u32x4* src = wblock + (size_t)stage * Cf::W4;
 #pragma unroll
-    for (int q = 0; q < Cf::WITER; ++q) wr[q] = src[min(tid + q * HDN_BLOCK, Cf::W4 - 1)];
+    for (int q = 0; q < Cf::WITER; ++q) wr[p][q] = src[min(tid + q * HDN_BLOCK, Cf::W4 - 1)];
   };
-  auto store_w = [&](int buf) {
-    u32x4* dst = reinterpret_cast<u32x4*>(sW + buf * Cf::WSTAGE_BYTES);
+  auto store_w = [&](auto P) {
+    constexpr int p = decltype(P)::value;
+    u32x4* dst = reinterpret_cast<u32x4*>(sW + p * Cf::WSTAGE_BYTES);
 #pragma unroll
     for (int q = 0; q < Cf::WITER; ++q)
-      if (tid + q * HDN_BLOCK < Cf::W4) dst[tid + q * HDN_BLOCK] = wr[q];
+      if (tid + q * HDN_BLOCK < Cf::W4) dst[tid + q * HDN_BLOCK] = wr[p][q];
   };
   // input chunk: (pixel, k step, k half) items of 8 channels = 32 bytes
   f4 av[Cf::AITER][2];
@@ -137,7 +146,7 @@ __global__ __launch_bounds__(HDN_BLOCK) void conv3x3_kernel(const float* __restr
       const int img = px / (Cf::PH * Cf::PW), ry = (px / Cf::PW) % Cf::PH, rx = px % Cf::PW;
       const int b = b0 + img, y = y0 + ry - 1, xx = rx - 1;
       const bool ok = item < Cf::AITEMS && b < B && y >= 0 && y < S && xx >= 0 && xx < S;
-      const f4* src = reinterpret_cast<const f4*>(x + (((size_t)b * S + y) * S + xx) * C + chunk * (16 * KS) + sub * 8);
+      const f4* src = reinterpret_cast<const f4*>(x + (((size_t)b * S + y) * S + xx) * C + (chunk0 + chunk) * (16 * KS) + sub * 8);
       av[q][0] = ok ? src[0] : f4{0.f, 0.f, 0.f, 0.f};
       av[q][1] = ok ? src[1] : f4{0.f, 0.f, 0.f, 0.f};
     }
@@ -204,46 +213,63 @@ __global__ __launch_bounds__(HDN_BLOCK) void conv3x3_kernel(const float* __restr
       }
   };
 
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
   load_a(0);
-  load_w(0);
+  load_w(0, P0{});
+  load_w(1, P1{});
   store_a();
-  store_w(0);
+  store_w(P0{});
   __syncthreads();
   constexpr int NSTEP = 3 * KS;   // steps of a stage
-#pragma unroll 1
-  for (int chunk = 0; chunk < Cf::NCHUNK; ++chunk) {
-    if (chunk + 1 < Cf::NCHUNK) load_a(chunk + 1);             // in flight during the whole chunk
+  auto run_stage = [&](int chunk, auto KY, auto P) {
+    constexpr int ky = decltype(KY)::value, p = decltype(P)::value;
+    const int stage = chunk * 3 + ky;
+    if (ky == 0 && chunk + 1 < nchunk) load_a(chunk + 1);       // in flight during the whole chunk
+    if (stage + 2 < nstage) load_w(stage + 2, decltype(P){});   // in flight during this stage and the next
+    Frags f[2];
+    read_frags(f[0], ky, 0, 0, p);
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int stage = chunk * 3 + ky, buf = stage & 1;
-      if (stage + 1 < Cf::NSTAGE) load_w(stage + 1);           // in flight during this stage
-      Frags f[2];
-      read_frags(f[0], ky, 0, 0, buf);
+    for (int st = 0; st < NSTEP; ++st) {
+      if (st + 1 < NSTEP) read_frags(f[(st + 1) & 1], ky, (st + 1) / KS, (st + 1) % KS, p);
+      // the fragments of step st have landed when at most the next step's reads are outstanding
+      if (st + 1 < NSTEP) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((MT + NT) * 3) : "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-      for (int st = 0; st < NSTEP; ++st) {
-        if (st + 1 < NSTEP) read_frags(f[(st + 1) & 1], ky, (st + 1) / KS, (st + 1) % KS, buf);
-        // the fragments of step st have landed when at most the next step's reads are outstanding
-        if (st + 1 < NSTEP) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((MT + NT) * 3) : "memory");
-        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int s = 0; s < 3; ++s) asm volatile("" : "+v"(f[st & 1].a[mt][s]));
 #pragma unroll
-          for (int s = 0; s < 3; ++s) asm volatile("" : "+v"(f[st & 1].a[mt][s]));
+      for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-          for (int s = 0; s < 3; ++s) asm volatile("" : "+v"(f[st & 1].b[nt][s]));
-        mma(f[st & 1]);
-      }
-      if (stage + 1 < Cf::NSTAGE) {
-        if (ky == 2) {                                          // chunk boundary: the A image is rewritten as well
-          __syncthreads();                                      // everyone is done reading this chunk's A image
-          store_a();
-        }
-        store_w(buf ^ 1);                                       // (read last during stage - 1: a barrier ago)
-        __syncthreads();
-      }
+        for (int s = 0; s < 3; ++s) asm volatile("" : "+v"(f[st & 1].b[nt][s]));
+      mma(f[st & 1]);
     }
+    if (stage + 1 < nstage) {
+      if (ky == 2) {                                            // chunk boundary: the A image is rewritten as well
+        __syncthreads();                                        // everyone is done reading this chunk's A image
+        store_a();
+      }
+      store_w(std::integral_constant<int, 1 - p>{});           // stage + 1 -> the buffer read last during stage - 1: a barrier ago
+      __syncthreads();
+    }
+  };
+  // the stage loop is unrolled over two chunks (six stages) so that the register set / LDS buffer of a stage is static;
+  // an odd chunk count ends with one more chunk, which starts on buffer 0 again
+  int c2 = 0;
+#pragma unroll 1
+  for (; c2 + 1 < nchunk; c2 += 2) {
+    run_stage(c2, std::integral_constant<int, 0>{}, P0{});
+    run_stage(c2, std::integral_constant<int, 1>{}, P1{});
+    run_stage(c2, std::integral_constant<int, 2>{}, P0{});
+    run_stage(c2 + 1, std::integral_constant<int, 0>{}, P1{});
+    run_stage(c2 + 1, std::integral_constant<int, 1>{}, P0{});
+    run_stage(c2 + 1, std::integral_constant<int, 2>{}, P1{});
+  }
+  if (c2 < nchunk) {
+    run_stage(c2, std::integral_constant<int, 0>{}, P0{});
+    run_stage(c2, std::integral_constant<int, 1>{}, P1{});
+    run_stage(c2, std::integral_constant<int, 2>{}, P0{});
   }
 
   // ---- epilogue.  C/D layout of v_mfma_f32_32x32x16_bf16: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
@@ -277,64 +303,127 @@ __global__ __launch_bounds__(HDN_BLOCK) void conv3x3_kernel(const float* __restr
     const long long m = m0 + px;
     if (idx < TOT4 && m < M) {
       f4 v = *reinterpret_cast<const f4*>(sO + px * Cf::EPI_STRIDE + c4 * 4);
-      v = v + *reinterpret_cast<const f4*>(bias + nb * BN + c4 * 4);
-      if (RES) v = v + rv[q];
-      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-      *reinterpret_cast<f4*>(out + m * C + nb * BN + c4 * 4) = v;
+      if (PARTIAL) {
+        *reinterpret_cast<f4*>(out + ((long long)blockIdx.z * M + m) * C + nb * BN + c4 * 4) = v;
+      } else {
+        v = v + *reinterpret_cast<const f4*>(bias + nb * BN + c4 * 4);
+        if (RES) v = v + rv[q];
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        *reinterpret_cast<f4*>(out + m * C + nb * BN + c4 * 4) = v;
+      }
     }
   }
 }
 
-template <class Cf>
-static int launch(const float* x, const void* wp, const float* bias, const float* res, float* out, int B, hipStream_t stream) {
-  static PerDeviceOnce attr[2];
-  const int dev_ = PerDeviceOnce::device();
-  const int which = res ? 1 : 0;
-  if (!attr[which].done(dev_)) {
-    const void* fn = res ? reinterpret_cast<const void*>(&conv3x3_kernel<Cf, true>) : reinterpret_cast<const void*>(&conv3x3_kernel<Cf, false>);
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS_BYTES);
-    if (e != hipSuccess) return -(1000 + (int)e);
-    attr[which].set(dev_);
+// out = relu(bias + sum over the K slices, in slice order (deterministic) (+ residual)): 16 bytes per lane
+template <bool RES>
+__global__ __launch_bounds__(HDN_BLOCK) void conv3x3_reduce_kernel(const f4* __restrict__ ws, const f4* __restrict__ bias, const f4* __restrict__ res,
+                                                                   f4* __restrict__ out, unsigned n4, unsigned c4n, int slices) {
+  for (unsigned i = blockIdx.x * HDN_BLOCK + threadIdx.x; i < n4; i += gridDim.x * HDN_BLOCK) {
+    f4 v = ws[i];
+    for (int z = 1; z < slices; ++z) v = v + ws[(size_t)z * n4 + i];
+    v = v + bias[i % c4n];
+    if (RES) v = v + res[i];
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    out[i] = v;
   }
+}
+
+// K slices for a launch: 1 when the output tiles alone fill the chip, else the smallest power of two (dividing the chunk count)
+// that brings the workgroup count to ~one per CU
+template <class Cf>
+static int k_slices(int B) {
   const long long M = (long long)B * Cf::S * Cf::S;
-  const dim3 grid((unsigned)((M + Cf::BM - 1) / Cf::BM), Cf::NB);
-  if (res) hipLaunchKernelGGL((conv3x3_kernel<Cf, true>), grid, dim3(HDN_BLOCK), Cf::LDS_BYTES, stream, x, (const u32x4*)wp, bias, res, out, B);
-  else hipLaunchKernelGGL((conv3x3_kernel<Cf, false>), grid, dim3(HDN_BLOCK), Cf::LDS_BYTES, stream, x, (const u32x4*)wp, bias, res, out, B);
+  const long long tiles = ((M + Cf::BM - 1) / Cf::BM) * Cf::NB;
+  int z = 1;
+  while (tiles * z < 200 && z * 2 <= Cf::NCHUNK && Cf::NCHUNK % (z * 2) == 0) z *= 2;
+  return z;
+}
+
+template <class Cf>
+static int launch(const float* x, const void* wp, const float* bias, const float* res, float* out, float* ws, size_t ws_bytes, int B,
+                  hipStream_t stream) {
+  const long long M = (long long)B * Cf::S * Cf::S;
+  const int z = k_slices<Cf>(B);
+  if (z > 1) {  // argument errors before anything touches the device
+    if (!ws) return HDN_E_NULL;
+    if (ws_bytes < (size_t)z * M * Cf::C * sizeof(float) || !aligned16(ws)) return HDN_E_LIMIT;
+  }
+  static PerDeviceOnce attr;
+  const int dev_ = PerDeviceOnce::device();
+  if (!attr.done(dev_)) {
+    for (const void* fn : {reinterpret_cast<const void*>(&conv3x3_kernel<Cf, 0>), reinterpret_cast<const void*>(&conv3x3_kernel<Cf, 1>),
+                           reinterpret_cast<const void*>(&conv3x3_kernel<Cf, 2>)}) {
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS_BYTES);
+      if (e != hipSuccess) return -(1000 + (int)e);
+    }
+    attr.set(dev_);
+  }
+  const dim3 grid((unsigned)((M + Cf::BM - 1) / Cf::BM), Cf::NB, z);
+  const u32x4* w4 = (const u32x4*)wp;
+  if (z == 1) {
+    if (res) hipLaunchKernelGGL((conv3x3_kernel<Cf, 1>), grid, dim3(HDN_BLOCK), Cf::LDS_BYTES, stream, x, w4, bias, res, out, B, Cf::NCHUNK);
+    else hipLaunchKernelGGL((conv3x3_kernel<Cf, 0>), grid, dim3(HDN_BLOCK), Cf::LDS_BYTES, stream, x, w4, bias, res, out, B, Cf::NCHUNK);
+    return launch_status();
+  }
+  hipLaunchKernelGGL((conv3x3_kernel<Cf, 2>), grid, dim3(HDN_BLOCK), Cf::LDS_BYTES, stream, x, w4, bias, res, ws, B, Cf::NCHUNK / z);
+  const unsigned n4 = (unsigned)(M * Cf::C / 4);
+  const int blocks = (int)((n4 + HDN_BLOCK - 1) / HDN_BLOCK < 1024 ? (n4 + HDN_BLOCK - 1) / HDN_BLOCK : 1024);
+  if (res) hipLaunchKernelGGL((conv3x3_reduce_kernel<true>), dim3(blocks), dim3(HDN_BLOCK), 0, stream, (const f4*)ws, (const f4*)bias, (const f4*)res, (f4*)out, n4, Cf::C / 4, z);
+  else hipLaunchKernelGGL((conv3x3_reduce_kernel<false>), dim3(blocks), dim3(HDN_BLOCK), 0, stream, (const f4*)ws, (const f4*)bias, (const f4*)res, (f4*)out, n4, Cf::C / 4, z);
   return launch_status();
 }
 
 }  // namespace cv
 }  // namespace hdn
 
-//            S    C   WM WN MT NT KS
-using CV_L1 = hdn::cv::Cfg<32, 64, 4, 1, 1, 2, 1>;    // 128 pixels (4 rows) x 64 channels: 512 workgroups at B = 64, two per CU
-using CV_L2 = hdn::cv::Cfg<16, 128, 4, 1, 1, 2, 1>;   // 128 pixels (8 rows) x 64 channels
-using CV_L3 = hdn::cv::Cfg<8, 256, 2, 2, 1, 1, 1>;    // 64 pixels (one image) x 64 channels
-using CV_L4 = hdn::cv::Cfg<4, 512, 1, 4, 1, 1, 1>;    // 32 pixels (two images) x 128 channels
+// Tile configurations.  When the output tiles alone do not fill the chip (the 4 x 4 stage at any batch size, every stage at the
+// tracker's B = 1) the K dimension is split over workgroups as well (k_slices) and a second launch reduces the slices.
+//              S    C   WM WN MT NT KS
+using CV_L1  = hdn::cv::Cfg<32, 64, 4, 1, 1, 2, 1>;    // 128 pixels (4 rows) x 64 channels: 512 workgroups at B = 64, two per CU
+using CV_L2  = hdn::cv::Cfg<16, 128, 4, 1, 1, 2, 1>;   // 128 pixels (8 rows) x 64 channels
+using CV_L3  = hdn::cv::Cfg<8, 256, 2, 2, 1, 1, 2>;    // 64 pixels (one image) x 64 channels
+using CV_L4  = hdn::cv::Cfg<4, 512, 4, 1, 2, 2, 1>;    // 256 pixels (16 images) x 64 channels, K split 8 ways at B = 64
 
-extern "C" int hdn_conv3x3_pack_info(int S, int C, int* block_n, int* k_steps) {
-  int bn = 0, ks = 0;
-  if (S == 32 && C == 64) { bn = CV_L1::BN; ks = CV_L1::KS; }
-  else if (S == 16 && C == 128) { bn = CV_L2::BN; ks = CV_L2::KS; }
-  else if (S == 8 && C == 256) { bn = CV_L3::BN; ks = CV_L3::KS; }
-  else if (S == 4 && C == 512) { bn = CV_L4::BN; ks = CV_L4::KS; }
-  else return HDN_E_LIMIT;
-  if (block_n) *block_n = bn;
-  if (k_steps) *k_steps = ks;
-  return HDN_OK;
+template <class F>
+static int cv_dispatch(int S, int C, F&& f) {
+  if (S == 32 && C == 64) return f(CV_L1{});
+  if (S == 16 && C == 128) return f(CV_L2{});
+  if (S == 8 && C == 256) return f(CV_L3{});
+  if (S == 4 && C == 512) return f(CV_L4{});
+  return HDN_E_LIMIT;
 }
 
-extern "C" int hdn_conv3x3_bias_relu_f32(const float* x, const void* wpacked, const float* bias, const float* residual, float* out, int B, int S,
-                                         int C, void* stream) {
+extern "C" int hdn_conv3x3_pack_info(int S, int C, int* block_n, int* k_steps) {
+  return cv_dispatch(S, C, [&](auto cfg) {
+    if (block_n) *block_n = decltype(cfg)::BN;
+    if (k_steps) *k_steps = decltype(cfg)::KS;
+    return HDN_OK;
+  });
+}
+
+// bytes of workspace hdn_conv3x3_bias_relu_f32 needs for this problem (0: none), or HDN_E_LIMIT
+extern "C" long long hdn_conv3x3_workspace_bytes(int B, int S, int C) {
+  if (B <= 0) return HDN_E_SHAPE;
+  long long out = 0;
+  const int rc = cv_dispatch(S, C, [&](auto cfg) {
+    using Cf = decltype(cfg);
+    const int z = hdn::cv::k_slices<Cf>(B);
+    out = z > 1 ? (long long)z * B * S * S * C * 4 : 0;
+    return HDN_OK;
+  });
+  return rc == HDN_OK ? out : rc;
+}
+
+extern "C" int hdn_conv3x3_bias_relu_f32(const float* x, const void* wpacked, const float* bias, const float* residual, float* out, float* workspace,
+                                         long long workspace_bytes, int B, int S, int C, void* stream) {
   if (!x || !wpacked || !bias || !out) return HDN_E_NULL;
   if (B <= 0 || S <= 0 || C <= 0) return HDN_E_SHAPE;
   if (out == x) return HDN_E_ALIAS;  // (out == residual is fine: each element is read before it is written, by the same lane)
   if ((long long)B * S * S * C > 0x7fffffffLL) return HDN_E_LIMIT;
   if (!hdn::aligned16(x) || !hdn::aligned16(wpacked) || !hdn::aligned16(out) || !hdn::aligned16(bias) || (residual && !hdn::aligned16(residual))) return HDN_E_LIMIT;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (S == 32 && C == 64) return hdn::cv::launch<CV_L1>(x, wpacked, bias, residual, out, B, s);
-  if (S == 16 && C == 128) return hdn::cv::launch<CV_L2>(x, wpacked, bias, residual, out, B, s);
-  if (S == 8 && C == 256) return hdn::cv::launch<CV_L3>(x, wpacked, bias, residual, out, B, s);
-  if (S == 4 && C == 512) return hdn::cv::launch<CV_L4>(x, wpacked, bias, residual, out, B, s);
-  return HDN_E_LIMIT;
+  return cv_dispatch(S, C, [&](auto cfg) {
+    return hdn::cv::launch<decltype(cfg)>(x, wpacked, bias, residual, out, workspace, workspace_bytes > 0 ? (size_t)workspace_bytes : 0, B, s);
+  });
 }

@@ -176,16 +176,21 @@ def conv3x3_bias_relu(x, wpacked, bias, residual=None):
     if wpacked.dtype != torch.int16 or wpacked.device != dev or wpacked.numel() != 27 * C * C or bias.numel() != C:
         raise ValueError("conv3x3_bias_relu: weights must come from pack_conv3x3 for this channel count, on the input's device")
     out = torch.empty_like(x, memory_format=cl)
+    lib = _lib.load()
+    nws = lib.hdn_conv3x3_workspace_bytes(B, S, C)
+    if nws < 0:
+        _lib.check(int(nws), "conv3x3_bias_relu")
+    ws = torch.empty(nws // 4, dtype=torch.float32, device=dev) if nws else None   # (from torch's caching allocator: no sync, graph-safe)
     with torch.cuda.device(dev):
-        rc = _lib.load().hdn_conv3x3_bias_relu_f32(_lib.ptr(x), _lib.ptr(wpacked), _lib.ptr(bias), _lib.ptr(residual) if residual is not None else None,
-                                                   _lib.ptr(out), B, S, C, _lib.stream_ptr(dev))
+        rc = lib.hdn_conv3x3_bias_relu_f32(_lib.ptr(x), _lib.ptr(wpacked), _lib.ptr(bias), _lib.ptr(residual) if residual is not None else None,
+                                           _lib.ptr(out), _lib.ptr(ws) if ws is not None else None, nws, B, S, C, _lib.stream_ptr(dev))
     _lib.check(rc, "conv3x3_bias_relu")
     return out
 
 
 # channel counts whose stride-1 3x3 convolutions run on hdn_conv3x3_bias_relu_f32 instead of MIOpen (measured per shape at
 # B = 64, profiles/round3_conv3x3.txt: the kernel is kept only where it wins)
-MATRIX_CORE_CHANNELS = (64, 128, 256)
+MATRIX_CORE_CHANNELS = (64, 128, 256, 512)
 _MC_SIDE = {64: 32, 128: 16, 256: 8, 512: 4}
 
 

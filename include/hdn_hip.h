@@ -288,8 +288,13 @@ int hdn_bias_relu_f32(float* y, const float* bias, const float* residual, int B,
  * homo_estimator/Deep_homography/Oneline_DLTv1/backbone/resnet.py:78-94 (eval mode only).
  */
 int hdn_conv3x3_pack_info(int S, int C, int* block_n, int* k_steps);
-int hdn_conv3x3_bias_relu_f32(const float* x, const void* wpacked, const float* bias, const float* residual, float* out, int B, int S, int C,
-                              void* stream);
+/* Workspace: when the output tiles alone do not fill the chip (S = 4 at any batch size, every shape at small B) the K dimension is
+ * split over workgroups, the slices' partial sums go to `workspace` ([slices][B,S,S,C] fp32) and a second launch adds them in slice
+ * order (deterministic) with the bias / residual / ReLU.  hdn_conv3x3_workspace_bytes: bytes needed for (B, S, C), 0 = none
+ * (workspace may then be NULL), negative = HDN_E_*. */
+long long hdn_conv3x3_workspace_bytes(int B, int S, int C);
+int hdn_conv3x3_bias_relu_f32(const float* x, const void* wpacked, const float* bias, const float* residual, float* out, float* workspace,
+                              long long workspace_bytes, int B, int S, int C, void* stream);
 
 /*
  * Multi-GPU: template/search pairs are independent, so ranks own disjoint contiguous blocks of pairs

@@ -1060,7 +1060,7 @@ def test_fused_epilogue_trunk_vs_unfused(dev):
             for mc in ((False, True) if cl else (False,)):
                 fused = fold_for_inference(net, channels_last=cl, fused_stem=False, fused_epilogue=True, matrix_core=mc)
                 assert sum(isinstance(m, FusedBasicBlock) for m in fused.modules()) == 16
-                assert sum(m.p1 is not None for m in fused.modules() if isinstance(m, FusedBasicBlock)) == (11 if mc else 0)
+                assert sum(m.p1 is not None for m in fused.modules() if isinstance(m, FusedBasicBlock)) == (13 if mc else 0)
                 b = fused(xin)
                 # MIOpen path: only (b2 + b_downsample) differs; matrix-core path: split-bf16 products, ~1e-6 relative per layer
                 assert float((a - b).abs().max()) <= (1e-4 if mc else 2e-5) * scale, (cl, mc, float((a - b).abs().max()), scale)
