@@ -321,7 +321,12 @@ __global__ __launch_bounds__(HDN_BLOCK) void conv3x3_reduce_kernel(const f4* __r
                                                                    f4* __restrict__ out, unsigned n4, unsigned c4n, int slices) {
   for (unsigned i = blockIdx.x * HDN_BLOCK + threadIdx.x; i < n4; i += gridDim.x * HDN_BLOCK) {
     f4 v = ws[i];
-    for (int z = 1; z < slices; ++z) v = v + ws[(size_t)z * n4 + i];
+    int z = 1;
+    for (; z + 3 < slices; z += 4) {   // four slices in flight; the additions stay in slice order
+      const f4 a0 = ws[(size_t)z * n4 + i], a1 = ws[(size_t)(z + 1) * n4 + i], a2 = ws[(size_t)(z + 2) * n4 + i], a3 = ws[(size_t)(z + 3) * n4 + i];
+      v = (((v + a0) + a1) + a2) + a3;
+    }
+    for (; z < slices; ++z) v = v + ws[(size_t)z * n4 + i];
     v = v + bias[i % c4n];
     if (RES) v = v + res[i];
     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
