@@ -47,8 +47,9 @@ SIGNATURES = {
     "hdn_similarity_logpolar_f32": (_i, [_c_float_p] * 5 + [_i, _i, ctypes.c_float, ctypes.c_double, ctypes.c_float, ctypes.c_void_p]),
     "hdn_trunk_stem_f32": (_i, [_c_float_p] * 4 + [_i] * 4 + [ctypes.c_void_p]),
     "hdn_bias_relu_f32": (_i, [_c_float_p] * 3 + [_i] * 4 + [ctypes.c_void_p]),
-    "hdn_conv3x3_pack_info": (_i, [_i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
-    "hdn_conv3x3_workspace_bytes": (ctypes.c_longlong, [_i, _i, _i]),
+    "hdn_conv3x3_pack_info": (_i, [_i, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+    "hdn_conv3x3_workspace_bytes": (ctypes.c_longlong, [_i, _i, _i, _i]),
+    "hdn_conv3x3s2_ds_f32": (_i, [_c_float_p] * 6 + [ctypes.c_longlong] + [_i] * 3 + [ctypes.c_void_p]),
     "hdn_conv3x3_bias_relu_f32": (_i, [_c_float_p] * 6 + [ctypes.c_longlong] + [_i] * 3 + [ctypes.c_void_p]),
     "hdn_allgather_offsets": (_i, [_c_float_p] * 2 + [_i, ctypes.c_void_p, ctypes.c_void_p]),
     "hdn_rccl_available": (_i, []),

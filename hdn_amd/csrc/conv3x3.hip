@@ -23,6 +23,7 @@
 //                current step's MFMAs are issued.
 //   wave tile  : MT x NT MFMA tiles of 32 x 32; accumulators stay in registers over the whole K loop;
 //   epilogue   : + bias[cout] (+ residual) -> ReLU -> NHWC store, 128 contiguous bytes per pixel row and half wave.
+#include <cstdlib>
 #include <type_traits>
 
 #include "hdn_common.h"
@@ -52,37 +53,45 @@ __device__ __forceinline__ void split3x2(float x, float y, unsigned& p0, unsigne
   p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
 }
 
-template <int S_, int C_, int WM_, int WN_, int MT_, int NT_, int KS_>
+// S = OUTPUT side, CI -> CO channels, STRIDE 1 or 2 (input side S * STRIDE); DS: the block's 1x1 / stride-2 downsample branch is
+// computed alongside from the same staged activations (it is the centre tap with its own weights) into a second output.
+template <int S_, int CI_, int CO_, int STRIDE_, bool DS_, int WM_, int WN_, int MT_, int NT_, int KS_>
 struct Cfg {
-  static constexpr int S = S_, C = C_, WM = WM_, WN = WN_, MT = MT_, NT = NT_, KS = KS_;
+  static constexpr int S = S_, CI = CI_, CO = CO_, STRIDE = STRIDE_, WM = WM_, WN = WN_, MT = MT_, NT = NT_, KS = KS_;
+  static constexpr bool DS = DS_;
+  static constexpr int SI = S * STRIDE;
   static constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
   static_assert(WM * WN == 4, "4 waves per workgroup");
-  static_assert(C % BN == 0 && C % (16 * KS) == 0, "channel blocking");
+  static_assert(STRIDE == 1 || STRIDE == 2, "stride");
+  static_assert(CO % BN == 0 && CI % (16 * KS) == 0, "channel blocking");
   static_assert((BM % S == 0) && ((S * S) % BM == 0 || BM % (S * S) == 0), "a tile is whole rows of one image, or whole images");
   static constexpr int IMGS = BM > S * S ? BM / (S * S) : 1;      // images per tile
   static constexpr int R = BM / (S * IMGS);                      // output rows per image in the tile
-  static constexpr int PW = S + 2, PH = R + 2;                   // halo'ed image patch
+  static constexpr int PW = SI + 2, PH = STRIDE == 1 ? R + 2 : 2 * R + 1;   // halo'ed input patch
   static constexpr int LP = IMGS * PH * PW;                      // LDS pixels
   static constexpr int KG_BYTES = LP * 16, KSTEP_BYTES = 2 * KG_BYTES, PIECE_BYTES = KS * KSTEP_BYTES, A_BYTES = 3 * PIECE_BYTES;
   static constexpr int WKG_BYTES = BN * 16, WPIECE_BYTES = 2 * WKG_BYTES, WSTEP_BYTES = 3 * WPIECE_BYTES;   // one (tap, k step)
-  static constexpr int WSTAGE_BYTES = 3 * KS * WSTEP_BYTES;      // one kernel row of one chunk
+  static constexpr int NTAP = DS ? 4 : 3;                        // taps of a stage: a kernel row (+ the downsample tap, used in the middle row)
+  static constexpr int WSTAGE_BYTES = NTAP * KS * WSTEP_BYTES;   // one kernel row of one chunk
   static constexpr int EPI_STRIDE = BN + 4;                      // floats per pixel row of the output staging (pad: bank spread of the two half waves)
   static constexpr int EPI_BYTES = BM * EPI_STRIDE * 4;
   static constexpr int LDS_BYTES = (A_BYTES + 2 * WSTAGE_BYTES) > EPI_BYTES ? (A_BYTES + 2 * WSTAGE_BYTES) : EPI_BYTES;
   static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit the LDS");
-  static constexpr int NCHUNK = C / (16 * KS), NB = C / BN, NSTAGE = 3 * NCHUNK;
+  static constexpr int NCHUNK = CI / (16 * KS), NB = CO / BN, NSTAGE = 3 * NCHUNK;
   static constexpr int W4 = WSTAGE_BYTES / 16;                   // 16-byte words of one stage's weights
   static constexpr int WITER = cdiv(W4, HDN_BLOCK);
   static constexpr int AITEMS = LP * 2 * KS, AITER = cdiv(AITEMS, HDN_BLOCK);   // (pixel, k step, k half) items of 8 channels
 };
 
 // MODE 0: out = relu(conv + bias); 1: out = relu(conv + bias + res); 2: the K slice blockIdx.z of `cps` chunks, raw sums to
-// out[blockIdx.z][M][C] (the workspace; conv3x3_reduce_kernel finishes)
+// out[blockIdx.z][M][CO] (the workspace; conv3x3_reduce_kernel finishes).  Cf::DS: out2 = the downsample branch (raw sums, no
+// bias / ReLU; mode 2: out2[blockIdx.z][M][CO]).
 template <class Cf, int MODE>
 __global__ __launch_bounds__(HDN_BLOCK) void conv3x3_kernel(const float* __restrict__ x, const u32x4* __restrict__ wp, const float* __restrict__ bias,
-                                                            const float* __restrict__ res, float* __restrict__ out, int B, int cps) {
-  constexpr bool RES = MODE == 1, PARTIAL = MODE == 2;
-  constexpr int S = Cf::S, C = Cf::C, MT = Cf::MT, NT = Cf::NT, BM = Cf::BM, BN = Cf::BN, KS = Cf::KS;
+                                                            const float* __restrict__ res, float* __restrict__ out, float* __restrict__ out2, int B,
+                                                            int cps) {
+  constexpr bool RES = MODE == 1, PARTIAL = MODE == 2, DS = Cf::DS;
+  constexpr int S = Cf::S, SI = Cf::SI, CI = Cf::CI, C = Cf::CO, MT = Cf::MT, NT = Cf::NT, BM = Cf::BM, BN = Cf::BN, KS = Cf::KS, ST = Cf::STRIDE;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const sA = smem;
   unsigned char* const sW = smem + Cf::A_BYTES;
@@ -101,7 +110,7 @@ __global__ __launch_bounds__(HDN_BLOCK) void conv3x3_kernel(const float* __restr
   for (int mt = 0; mt < MT; ++mt) {
     const int i = (wm * MT + mt) * 32 + li;                  // pixel inside the tile
     const int img = i / (Cf::R * S), yy = (i / S) % Cf::R, xx = i % S;
-    aoff[mt] = lds_addr(sA) + g * Cf::KG_BYTES + (img * (Cf::PH * Cf::PW) + (yy + 1) * Cf::PW + (xx + 1)) * 16;
+    aoff[mt] = lds_addr(sA) + g * Cf::KG_BYTES + (img * (Cf::PH * Cf::PW) + (ST * yy + 1) * Cf::PW + (ST * xx + 1)) * 16;
   }
   const uint32_t boff = lds_addr(sW) + g * Cf::WKG_BYTES + (wn * NT * 32 + li) * 16;
 
@@ -112,6 +121,15 @@ __global__ __launch_bounds__(HDN_BLOCK) void conv3x3_kernel(const float* __restr
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+  f32x16 accd[DS ? MT : 1][DS ? NT : 1];   // the downsample branch
+  if (DS) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accd[mt][nt][r] = 0.f;
+  }
 
   // this channel block's packed weights: [chunk][kernel row][tap in row][k step][piece][k half][n][8 bf16] = [stage][W4 words]
   const int chunk0 = PARTIAL ? (int)blockIdx.z * cps : 0, nchunk = PARTIAL ? cps : Cf::NCHUNK, nstage = 3 * nchunk;   // this launch's K range
@@ -144,9 +162,9 @@ __global__ __launch_bounds__(HDN_BLOCK) void conv3x3_kernel(const float* __restr
       const int item = tid + q * HDN_BLOCK;
       const int px = min(item / (2 * KS), Cf::LP - 1), sub = item % (2 * KS);
       const int img = px / (Cf::PH * Cf::PW), ry = (px / Cf::PW) % Cf::PH, rx = px % Cf::PW;
-      const int b = b0 + img, y = y0 + ry - 1, xx = rx - 1;
-      const bool ok = item < Cf::AITEMS && b < B && y >= 0 && y < S && xx >= 0 && xx < S;
-      const f4* src = reinterpret_cast<const f4*>(x + (((size_t)b * S + y) * S + xx) * C + (chunk0 + chunk) * (16 * KS) + sub * 8);
+      const int b = b0 + img, y = ST * y0 + ry - 1, xx = rx - 1;
+      const bool ok = item < Cf::AITEMS && b < B && y >= 0 && y < SI && xx >= 0 && xx < SI;
+      const f4* src = reinterpret_cast<const f4*>(x + (((size_t)b * SI + y) * SI + xx) * CI + (chunk0 + chunk) * (16 * KS) + sub * 8);
       av[q][0] = ok ? src[0] : f4{0.f, 0.f, 0.f, 0.f};
       av[q][1] = ok ? src[1] : f4{0.f, 0.f, 0.f, 0.f};
     }
@@ -181,7 +199,7 @@ __global__ __launch_bounds__(HDN_BLOCK) void conv3x3_kernel(const float* __restr
 #ifdef CV_EXP_NOREAD
     if (ky + t + ks + buf >= 0) return;
 #endif
-    const int toff = ((ky - 1) * Cf::PW + (t - 1)) * 16 + ks * Cf::KSTEP_BYTES;
+    const int toff = (t == 3 ? 0 : ((ky - 1) * Cf::PW + (t - 1)) * 16) + ks * Cf::KSTEP_BYTES;   // (tap 3: the downsample branch reads the centre)
     const uint32_t wb = boff + buf * Cf::WSTAGE_BYTES + (t * KS + ks) * Cf::WSTEP_BYTES;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -194,22 +212,24 @@ __global__ __launch_bounds__(HDN_BLOCK) void conv3x3_kernel(const float* __restr
       for (int s = 0; s < 3; ++s)
         asm volatile("ds_read_b128 %0, %1" : "=v"(f.b[nt][s]) : "v"(wb + s * Cf::WPIECE_BYTES + nt * 32 * 16));
   };
-  auto mma = [&](const Frags& f) {
+  auto mma = [&](const Frags& f, auto TODS) {
 #ifdef CV_EXP_NOMFMA
     return;
 #endif
+    constexpr bool tods = decltype(TODS)::value;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        f32x16 c = acc[mt][nt];
+        f32x16 c = tods ? accd[DS ? mt : 0][DS ? nt : 0] : acc[mt][nt];
         c = mfma(f.a[mt][2], f.b[nt][0], c);  // smallest terms first
         c = mfma(f.a[mt][0], f.b[nt][2], c);
         c = mfma(f.a[mt][1], f.b[nt][1], c);
         c = mfma(f.a[mt][1], f.b[nt][0], c);
         c = mfma(f.a[mt][0], f.b[nt][1], c);
         c = mfma(f.a[mt][0], f.b[nt][0], c);
-        acc[mt][nt] = c;
+        if (tods) accd[DS ? mt : 0][DS ? nt : 0] = c;
+        else acc[mt][nt] = c;
       }
   };
 
@@ -221,9 +241,9 @@ __global__ __launch_bounds__(HDN_BLOCK) void conv3x3_kernel(const float* __restr
   store_a();
   store_w(P0{});
   __syncthreads();
-  constexpr int NSTEP = 3 * KS;   // steps of a stage
   auto run_stage = [&](int chunk, auto KY, auto P) {
     constexpr int ky = decltype(KY)::value, p = decltype(P)::value;
+    constexpr int NSTEP = ((DS && ky == 1) ? 4 : 3) * KS;   // steps of this stage: (tap, k step); the middle row also feeds the downsample branch
     const int stage = chunk * 3 + ky;
     if (ky == 0 && chunk + 1 < nchunk) load_a(chunk + 1);       // in flight during the whole chunk
     if (stage + 2 < nstage) load_w(stage + 2, decltype(P){});   // in flight during this stage and the next
@@ -243,7 +263,8 @@ __global__ __launch_bounds__(HDN_BLOCK) void conv3x3_kernel(const float* __restr
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int s = 0; s < 3; ++s) asm volatile("" : "+v"(f[st & 1].b[nt][s]));
-      mma(f[st & 1]);
+      if (DS && st / KS == 3) mma(f[st & 1], std::true_type{});   // (st is a constant after unrolling)
+      else mma(f[st & 1], std::false_type{});
     }
     if (stage + 1 < nstage) {
       if (ky == 2) {                                            // chunk boundary: the A image is rewritten as well
@@ -313,10 +334,32 @@ __global__ __launch_bounds__(HDN_BLOCK) void conv3x3_kernel(const float* __restr
       }
     }
   }
+  if (DS) {   // the downsample branch: raw sums (its bias travels with the block's second convolution)
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+          sO[row * Cf::EPI_STRIDE + (wn * NT + nt) * 32 + li] = accd[DS ? mt : 0][DS ? nt : 0][r];
+        }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < EITER; ++q) {
+      const int idx = tid + q * HDN_BLOCK, px = idx / N4, c4 = idx % N4;
+      const long long m = m0 + px;
+      if (idx < TOT4 && m < M)
+        *reinterpret_cast<f4*>(out2 + ((PARTIAL ? (long long)blockIdx.z * M : 0) + m) * C + nb * BN + c4 * 4) =
+            *reinterpret_cast<const f4*>(sO + px * Cf::EPI_STRIDE + c4 * 4);
+    }
+  }
 }
 
-// out = relu(bias + sum over the K slices, in slice order (deterministic) (+ residual)): 16 bytes per lane
-template <bool RES>
+// out = relu(bias + sum over the K slices, in slice order (deterministic) (+ residual)): 16 bytes per lane.  ACT = false: the plain
+// sum (the downsample branch).
+template <bool RES, bool ACT>
 __global__ __launch_bounds__(HDN_BLOCK) void conv3x3_reduce_kernel(const f4* __restrict__ ws, const f4* __restrict__ bias, const f4* __restrict__ res,
                                                                    f4* __restrict__ out, unsigned n4, unsigned c4n, int slices) {
   for (unsigned i = blockIdx.x * HDN_BLOCK + threadIdx.x; i < n4; i += gridDim.x * HDN_BLOCK) {
@@ -327,9 +370,11 @@ __global__ __launch_bounds__(HDN_BLOCK) void conv3x3_reduce_kernel(const f4* __r
       v = (((v + a0) + a1) + a2) + a3;
     }
     for (; z < slices; ++z) v = v + ws[(size_t)z * n4 + i];
-    v = v + bias[i % c4n];
-    if (RES) v = v + res[i];
-    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    if (ACT) {
+      v = v + bias[i % c4n];
+      if (RES) v = v + res[i];
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
     out[i] = v;
   }
 }
@@ -340,19 +385,26 @@ template <class Cf>
 static int k_slices(int B) {
   const long long M = (long long)B * Cf::S * Cf::S;
   const long long tiles = ((M + Cf::BM - 1) / Cf::BM) * Cf::NB;
+  static const int target = [] { const char* e = getenv("HDN_CV_SLICE_TARGET"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 200; }();  // A/B switch
   int z = 1;
-  while (tiles * z < 200 && z * 2 <= Cf::NCHUNK && Cf::NCHUNK % (z * 2) == 0) z *= 2;
+  while (tiles * z < target && z * 2 <= Cf::NCHUNK && Cf::NCHUNK % (z * 2) == 0) z *= 2;
   return z;
 }
 
 template <class Cf>
-static int launch(const float* x, const void* wp, const float* bias, const float* res, float* out, float* ws, size_t ws_bytes, int B,
+static size_t workspace_bytes(int B) {
+  const int z = k_slices<Cf>(B);
+  return z > 1 ? (size_t)(Cf::DS ? 2 : 1) * z * B * Cf::S * Cf::S * Cf::CO * sizeof(float) : 0;
+}
+
+template <class Cf>
+static int launch(const float* x, const void* wp, const float* bias, const float* res, float* out, float* out2, float* ws, size_t ws_bytes, int B,
                   hipStream_t stream) {
   const long long M = (long long)B * Cf::S * Cf::S;
   const int z = k_slices<Cf>(B);
   if (z > 1) {  // argument errors before anything touches the device
     if (!ws) return HDN_E_NULL;
-    if (ws_bytes < (size_t)z * M * Cf::C * sizeof(float) || !aligned16(ws)) return HDN_E_LIMIT;
+    if (ws_bytes < workspace_bytes<Cf>(B) || !aligned16(ws)) return HDN_E_LIMIT;
   }
   static PerDeviceOnce attr;
   const int dev_ = PerDeviceOnce::device();
@@ -367,15 +419,18 @@ static int launch(const float* x, const void* wp, const float* bias, const float
   const dim3 grid((unsigned)((M + Cf::BM - 1) / Cf::BM), Cf::NB, z);
   const u32x4* w4 = (const u32x4*)wp;
   if (z == 1) {
-    if (res) hipLaunchKernelGGL((conv3x3_kernel<Cf, 1>), grid, dim3(HDN_BLOCK), Cf::LDS_BYTES, stream, x, w4, bias, res, out, B, Cf::NCHUNK);
-    else hipLaunchKernelGGL((conv3x3_kernel<Cf, 0>), grid, dim3(HDN_BLOCK), Cf::LDS_BYTES, stream, x, w4, bias, res, out, B, Cf::NCHUNK);
+    if (res) hipLaunchKernelGGL((conv3x3_kernel<Cf, 1>), grid, dim3(HDN_BLOCK), Cf::LDS_BYTES, stream, x, w4, bias, res, out, out2, B, Cf::NCHUNK);
+    else hipLaunchKernelGGL((conv3x3_kernel<Cf, 0>), grid, dim3(HDN_BLOCK), Cf::LDS_BYTES, stream, x, w4, bias, res, out, out2, B, Cf::NCHUNK);
     return launch_status();
   }
-  hipLaunchKernelGGL((conv3x3_kernel<Cf, 2>), grid, dim3(HDN_BLOCK), Cf::LDS_BYTES, stream, x, w4, bias, res, ws, B, Cf::NCHUNK / z);
-  const unsigned n4 = (unsigned)(M * Cf::C / 4);
+  float* ws2 = ws + (size_t)z * M * Cf::CO;
+  hipLaunchKernelGGL((conv3x3_kernel<Cf, 2>), grid, dim3(HDN_BLOCK), Cf::LDS_BYTES, stream, x, w4, bias, res, ws, ws2, B, Cf::NCHUNK / z);
+  const unsigned n4 = (unsigned)(M * Cf::CO / 4);
   const int blocks = (int)((n4 + HDN_BLOCK - 1) / HDN_BLOCK < 1024 ? (n4 + HDN_BLOCK - 1) / HDN_BLOCK : 1024);
-  if (res) hipLaunchKernelGGL((conv3x3_reduce_kernel<true>), dim3(blocks), dim3(HDN_BLOCK), 0, stream, (const f4*)ws, (const f4*)bias, (const f4*)res, (f4*)out, n4, Cf::C / 4, z);
-  else hipLaunchKernelGGL((conv3x3_reduce_kernel<false>), dim3(blocks), dim3(HDN_BLOCK), 0, stream, (const f4*)ws, (const f4*)bias, (const f4*)res, (f4*)out, n4, Cf::C / 4, z);
+  const f4* b4 = (const f4*)bias;
+  if (res) hipLaunchKernelGGL((conv3x3_reduce_kernel<true, true>), dim3(blocks), dim3(HDN_BLOCK), 0, stream, (const f4*)ws, b4, (const f4*)res, (f4*)out, n4, Cf::CO / 4, z);
+  else hipLaunchKernelGGL((conv3x3_reduce_kernel<false, true>), dim3(blocks), dim3(HDN_BLOCK), 0, stream, (const f4*)ws, b4, (const f4*)res, (f4*)out, n4, Cf::CO / 4, z);
+  if (Cf::DS) hipLaunchKernelGGL((conv3x3_reduce_kernel<false, false>), dim3(blocks), dim3(HDN_BLOCK), 0, stream, (const f4*)ws2, b4, (const f4*)nullptr, (f4*)out2, n4, Cf::CO / 4, z);
   return launch_status();
 }
 
@@ -384,51 +439,81 @@ static int launch(const float* x, const void* wp, const float* bias, const float
 
 // Tile configurations.  When the output tiles alone do not fill the chip (the 4 x 4 stage at any batch size, every stage at the
 // tracker's B = 1) the K dimension is split over workgroups as well (k_slices) and a second launch reduces the slices.
-//              S    C   WM WN MT NT KS
-using CV_L1  = hdn::cv::Cfg<32, 64, 4, 1, 1, 2, 1>;    // 128 pixels (4 rows) x 64 channels: 512 workgroups at B = 64, two per CU
-using CV_L2  = hdn::cv::Cfg<16, 128, 4, 1, 1, 2, 1>;   // 128 pixels (8 rows) x 64 channels
-using CV_L3  = hdn::cv::Cfg<8, 256, 2, 2, 1, 1, 2>;    // 64 pixels (one image) x 64 channels
-using CV_L4  = hdn::cv::Cfg<4, 512, 4, 1, 2, 2, 1>;    // 256 pixels (16 images) x 64 channels, K split 8 ways at B = 64
+//                         S   CI   CO  ST  DS    WM WN MT NT KS
+using CV_L1  = hdn::cv::Cfg<32, 64, 64, 1, false, 4, 1, 1, 2, 1>;    // 128 pixels (4 rows) x 64 channels: 512 workgroups at B = 64, two per CU
+using CV_L2  = hdn::cv::Cfg<16, 128, 128, 1, false, 4, 1, 1, 2, 1>;  // 128 pixels (8 rows) x 64 channels
+using CV_L3  = hdn::cv::Cfg<8, 256, 256, 1, false, 2, 2, 1, 1, 2>;   // 64 pixels (one image) x 64 channels
+using CV_L4  = hdn::cv::Cfg<4, 512, 512, 1, false, 4, 1, 2, 2, 1>;   // 256 pixels (16 images) x 64 channels, K split 8 ways at B = 64
+// first convolution of a stage (stride 2, channels doubled) together with the block's 1x1 / stride-2 downsample branch
+using CV_D2  = hdn::cv::Cfg<16, 64, 128, 2, true, 4, 1, 1, 2, 1>;    // 128 output pixels (8 rows of 16) x 64 channels
+using CV_D3  = hdn::cv::Cfg<8, 128, 256, 2, true, 2, 2, 1, 1, 1>;    // 64 output pixels (one image) x 64 channels
+using CV_D4  = hdn::cv::Cfg<4, 256, 512, 2, true, 2, 2, 1, 1, 1>;    // 64 output pixels (4 images) x 64 channels
 
+// (S = output side, CI input channels, stride) -> configuration
 template <class F>
-static int cv_dispatch(int S, int C, F&& f) {
-  if (S == 32 && C == 64) return f(CV_L1{});
-  if (S == 16 && C == 128) return f(CV_L2{});
-  if (S == 8 && C == 256) return f(CV_L3{});
-  if (S == 4 && C == 512) return f(CV_L4{});
+static int cv_dispatch(int S, int CI, int stride, F&& f) {
+  if (stride == 1) {
+    if (S == 32 && CI == 64) return f(CV_L1{});
+    if (S == 16 && CI == 128) return f(CV_L2{});
+    if (S == 8 && CI == 256) return f(CV_L3{});
+    if (S == 4 && CI == 512) return f(CV_L4{});
+  } else if (stride == 2) {
+    if (S == 16 && CI == 64) return f(CV_D2{});
+    if (S == 8 && CI == 128) return f(CV_D3{});
+    if (S == 4 && CI == 256) return f(CV_D4{});
+  }
   return HDN_E_LIMIT;
 }
 
-extern "C" int hdn_conv3x3_pack_info(int S, int C, int* block_n, int* k_steps) {
-  return cv_dispatch(S, C, [&](auto cfg) {
+extern "C" int hdn_conv3x3_pack_info(int S, int CI, int stride, int* block_n, int* k_steps) {
+  return cv_dispatch(S, CI, stride, [&](auto cfg) {
     if (block_n) *block_n = decltype(cfg)::BN;
     if (k_steps) *k_steps = decltype(cfg)::KS;
     return HDN_OK;
   });
 }
 
-// bytes of workspace hdn_conv3x3_bias_relu_f32 needs for this problem (0: none), or HDN_E_LIMIT
-extern "C" long long hdn_conv3x3_workspace_bytes(int B, int S, int C) {
+// bytes of workspace the convolution entry points need for this problem (0: none), or HDN_E_*
+extern "C" long long hdn_conv3x3_workspace_bytes(int B, int S, int CI, int stride) {
   if (B <= 0) return HDN_E_SHAPE;
   long long out = 0;
-  const int rc = cv_dispatch(S, C, [&](auto cfg) {
-    using Cf = decltype(cfg);
-    const int z = hdn::cv::k_slices<Cf>(B);
-    out = z > 1 ? (long long)z * B * S * S * C * 4 : 0;
+  const int rc = cv_dispatch(S, CI, stride, [&](auto cfg) {
+    out = (long long)hdn::cv::workspace_bytes<decltype(cfg)>(B);
     return HDN_OK;
   });
   return rc == HDN_OK ? out : rc;
 }
 
+static int cv_check(const void* x, const void* w, const void* bias, const void* out, long long n_out) {
+  if (!x || !w || !bias || !out) return HDN_E_NULL;
+  if (out == x) return HDN_E_ALIAS;
+  if (n_out > 0x7fffffffLL) return HDN_E_LIMIT;
+  if (!hdn::aligned16(x) || !hdn::aligned16(w) || !hdn::aligned16(out) || !hdn::aligned16(bias)) return HDN_E_LIMIT;
+  return HDN_OK;
+}
+
 extern "C" int hdn_conv3x3_bias_relu_f32(const float* x, const void* wpacked, const float* bias, const float* residual, float* out, float* workspace,
                                          long long workspace_bytes, int B, int S, int C, void* stream) {
-  if (!x || !wpacked || !bias || !out) return HDN_E_NULL;
   if (B <= 0 || S <= 0 || C <= 0) return HDN_E_SHAPE;
-  if (out == x) return HDN_E_ALIAS;  // (out == residual is fine: each element is read before it is written, by the same lane)
-  if ((long long)B * S * S * C > 0x7fffffffLL) return HDN_E_LIMIT;
-  if (!hdn::aligned16(x) || !hdn::aligned16(wpacked) || !hdn::aligned16(out) || !hdn::aligned16(bias) || (residual && !hdn::aligned16(residual))) return HDN_E_LIMIT;
+  const int rc = cv_check(x, wpacked, bias, out, (long long)B * S * S * C);  // (out == residual is fine: each element is read before it is written, by the same lane)
+  if (rc) return rc;
+  if (residual && !hdn::aligned16(residual)) return HDN_E_LIMIT;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  return cv_dispatch(S, C, [&](auto cfg) {
-    return hdn::cv::launch<decltype(cfg)>(x, wpacked, bias, residual, out, workspace, workspace_bytes > 0 ? (size_t)workspace_bytes : 0, B, s);
+  return cv_dispatch(S, C, 1, [&](auto cfg) {
+    return hdn::cv::launch<decltype(cfg)>(x, wpacked, bias, residual, out, nullptr, workspace, workspace_bytes > 0 ? (size_t)workspace_bytes : 0, B, s);
+  });
+}
+
+extern "C" int hdn_conv3x3s2_ds_f32(const float* x, const void* wpacked, const float* bias, float* out, float* out_ds, float* workspace,
+                                    long long workspace_bytes, int B, int S, int CI, void* stream) {
+  if (B <= 0 || S <= 0 || CI <= 0) return HDN_E_SHAPE;
+  const int rc = cv_check(x, wpacked, bias, out, (long long)B * S * S * CI * 4);   // (the input has 2S x 2S x CI elements = the output's count x 2)
+  if (rc) return rc;
+  if (!out_ds) return HDN_E_NULL;
+  if (out_ds == out || out_ds == x) return HDN_E_ALIAS;
+  if (!hdn::aligned16(out_ds)) return HDN_E_LIMIT;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return cv_dispatch(S, CI, 2, [&](auto cfg) {
+    return hdn::cv::launch<decltype(cfg)>(x, wpacked, bias, nullptr, out, out_ds, workspace, workspace_bytes > 0 ? (size_t)workspace_bytes : 0, B, s);
   });
 }

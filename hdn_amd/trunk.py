@@ -132,34 +132,57 @@ def bias_relu_(y, bias, residual=None):
     return y
 
 
-def pack_conv3x3(weight):
-    """[C, C, 3, 3] fp32 conv weights -> the layout hdn_conv3x3_bias_relu_f32 streams: every value split exactly into three bf16
-    pieces (w = p0 + p1 + p2, round-to-nearest-even each), arranged
-    [C / BN][C / (16 KS)][3 kernel rows][3 taps][KS][3 pieces][2 k halves][BN][8] as int16 bit patterns, (BN, KS) from the library.
-    S is implied by C in the trunk (64 -> 32, 128 -> 16, 256 -> 8, 512 -> 4)."""
+def _split_bf16(w):
+    """fp32 -> three bf16 pieces, w = p0 + p1 + p2 (round-to-nearest-even each; the residuals are exact in fp32)."""
+    import torch
+
+    p0 = w.to(torch.bfloat16)
+    r1 = w - p0.float()
+    p1 = r1.to(torch.bfloat16)
+    p2 = (r1 - p1.float()).to(torch.bfloat16)
+    return torch.stack([p0, p1, p2])
+
+
+def _pack(w4, S, CI, stride):
+    """w4 [CO, CI, 3, T] fp32 (T taps per kernel row) -> [CO / BN][CI / (16 KS)][3][T][KS][3 pieces][2][BN][8] int16 bit patterns."""
     import ctypes
 
     import torch
 
     from . import _lib
 
+    bn, ks = ctypes.c_int(0), ctypes.c_int(0)
+    if _lib.load().hdn_conv3x3_pack_info(S, CI, stride, ctypes.byref(bn), ctypes.byref(ks)) != 0:
+        raise ValueError(f"no matrix-core kernel for {CI} input channels at output side {S}, stride {stride}")
+    BN, KS = bn.value, ks.value
+    CO, T = w4.shape[0], w4.shape[3]
+    pieces = _split_bf16(w4.detach().to(torch.float32).cpu())           # [3, CO, CI, ky, t]
+    t = pieces.permute(0, 1, 3, 4, 2).reshape(3, CO // BN, BN, 3, T, CI // (16 * KS), KS, 2, 8)   # [piece, nb, n, ky, t, chunk, ks, g, 8]
+    t = t.permute(1, 5, 3, 4, 6, 0, 7, 2, 8).contiguous()               # [nb, chunk, ky, t, ks, piece, g, n, 8]
+    return t.view(torch.int16)
+
+
+def pack_conv3x3(weight):
+    """[C, C, 3, 3] fp32 weights of a stride-1 convolution -> the layout hdn_conv3x3_bias_relu_f32 streams (include/hdn_hip.h).
+    The side S is implied by C in the trunk (64 -> 32, 128 -> 16, 256 -> 8, 512 -> 4)."""
     C = weight.shape[0]
     if tuple(weight.shape) != (C, C, 3, 3):
         raise ValueError(f"pack_conv3x3 takes [C, C, 3, 3] weights, got {tuple(weight.shape)}")
-    S = _MC_SIDE.get(C, 0)
-    bn, ks = ctypes.c_int(0), ctypes.c_int(0)
-    if _lib.load().hdn_conv3x3_pack_info(S, C, ctypes.byref(bn), ctypes.byref(ks)) != 0:
-        raise ValueError(f"no matrix-core kernel for {C} channels")
-    BN, KS = bn.value, ks.value
-    w = weight.detach().to(torch.float32).cpu()
-    p0 = w.to(torch.bfloat16)
-    r1 = w - p0.float()
-    p1 = r1.to(torch.bfloat16)
-    p2 = (r1 - p1.float()).to(torch.bfloat16)
-    pieces = torch.stack([p0, p1, p2])                                   # [3, Cout, Cin, ky, kx]
-    t = pieces.permute(0, 1, 3, 4, 2).reshape(3, C // BN, BN, 3, 3, C // (16 * KS), KS, 2, 8)   # [piece, nb, n, ky, kx, chunk, ks, g, 8]
-    t = t.permute(1, 5, 3, 4, 6, 0, 7, 2, 8).contiguous()               # [nb, chunk, ky, kx, ks, piece, g, n, 8]
-    return t.view(torch.int16)
+    return _pack(weight, _MC_SIDE.get(C, 0), C, 1)
+
+
+def pack_conv3x3s2_ds(weight, ds_weight):
+    """[2C, C, 3, 3] weights of the stride-2 convolution + [2C, C, 1, 1] weights of the block's downsample branch -> the 4-tap layout of
+    hdn_conv3x3s2_ds_f32: the 1x1 weights ride as a 4th tap of the middle kernel row."""
+    import torch
+
+    CO, CI = weight.shape[0], weight.shape[1]
+    if tuple(weight.shape) != (2 * CI, CI, 3, 3) or tuple(ds_weight.shape) != (2 * CI, CI, 1, 1):
+        raise ValueError(f"pack_conv3x3s2_ds takes [2C, C, 3, 3] and [2C, C, 1, 1] weights, got {tuple(weight.shape)}, {tuple(ds_weight.shape)}")
+    w4 = torch.zeros(CO, CI, 3, 4, dtype=torch.float32)
+    w4[:, :, :, :3] = weight.detach().float().cpu()
+    w4[:, :, 1, 3] = ds_weight.detach().float().cpu()[:, :, 0, 0]
+    return _pack(w4, _MC_SIDE.get(CO, 0), CI, 2)
 
 
 def conv3x3_bias_relu(x, wpacked, bias, residual=None):
@@ -177,7 +200,7 @@ def conv3x3_bias_relu(x, wpacked, bias, residual=None):
         raise ValueError("conv3x3_bias_relu: weights must come from pack_conv3x3 for this channel count, on the input's device")
     out = torch.empty_like(x, memory_format=cl)
     lib = _lib.load()
-    nws = lib.hdn_conv3x3_workspace_bytes(B, S, C)
+    nws = lib.hdn_conv3x3_workspace_bytes(B, S, C, 1)
     if nws < 0:
         _lib.check(int(nws), "conv3x3_bias_relu")
     ws = torch.empty(nws // 4, dtype=torch.float32, device=dev) if nws else None   # (from torch's caching allocator: no sync, graph-safe)
@@ -192,6 +215,34 @@ def conv3x3_bias_relu(x, wpacked, bias, residual=None):
 # B = 64, profiles/round3_conv3x3.txt: the kernel is kept only where it wins)
 MATRIX_CORE_CHANNELS = (64, 128, 256, 512)
 _MC_SIDE = {64: 32, 128: 16, 256: 8, 512: 4}
+
+
+def conv3x3s2_ds(x, wpacked, bias):
+    """(relu(conv3x3/s2(x) + bias), conv1x1/s2(x)) through hdn_conv3x3s2_ds_f32; x channels-last [B,C,2S,2S] -> two [B,2C,S,S]."""
+    import torch
+
+    from . import _lib
+
+    dev = _lib.require_device(x, bias)
+    B, CI, H, W = x.shape
+    cl = torch.channels_last
+    if H != W or H % 2 or not x.is_contiguous(memory_format=cl):
+        raise ValueError("conv3x3s2_ds: square, even-sided channels-last input")
+    S, CO = H // 2, 2 * CI
+    if wpacked.dtype != torch.int16 or wpacked.device != dev or wpacked.numel() != 3 * 3 * 4 * CI * CO or bias.numel() != CO:
+        raise ValueError("conv3x3s2_ds: weights must come from pack_conv3x3s2_ds for this channel count, on the input's device")
+    out = torch.empty((B, CO, S, S), dtype=torch.float32, device=dev, memory_format=cl)
+    out_ds = torch.empty_like(out, memory_format=cl)
+    lib = _lib.load()
+    nws = lib.hdn_conv3x3_workspace_bytes(B, S, CI, 2)
+    if nws < 0:
+        _lib.check(int(nws), "conv3x3s2_ds")
+    ws = torch.empty(nws // 4, dtype=torch.float32, device=dev) if nws else None
+    with torch.cuda.device(dev):
+        rc = lib.hdn_conv3x3s2_ds_f32(_lib.ptr(x), _lib.ptr(wpacked), _lib.ptr(bias), _lib.ptr(out), _lib.ptr(out_ds),
+                                      _lib.ptr(ws) if ws is not None else None, nws, B, S, CI, _lib.stream_ptr(dev))
+    _lib.check(rc, "conv3x3s2_ds")
+    return out, out_ds
 
 
 class FusedBasicBlock(nn.Module):
@@ -225,8 +276,11 @@ class FusedBasicBlock(nn.Module):
         cin, cout = self.w1.shape[1], self.w1.shape[0]
         use1 = matrix_core and self.stride == (1, 1) and cin == cout and cout in MATRIX_CORE_CHANNELS
         use2 = matrix_core and cout in MATRIX_CORE_CHANNELS
+        use_s2 = (matrix_core and self.stride == (2, 2) and self.wd is not None and cout == 2 * cin and cout in MATRIX_CORE_CHANNELS
+                  and self.ds_stride == (2, 2))
         self.register_buffer("p1", pack_conv3x3(self.w1).to(dev) if use1 else None)
         self.register_buffer("p2", pack_conv3x3(self.w2).to(dev) if use2 else None)
+        self.register_buffer("p1s2", pack_conv3x3s2_ds(self.w1, self.wd).to(dev) if use_s2 else None)
 
     def forward(self, x):
         import torch
@@ -235,11 +289,15 @@ class FusedBasicBlock(nn.Module):
         def shape_ok(t):   # the kernel's shapes: square, side tied to the channel count (127-px crops), channels-last
             return t.is_contiguous(memory_format=torch.channels_last) and t.shape[2] == t.shape[3] == _MC_SIDE.get(t.shape[1], -1)
 
-        if self.p1 is not None and shape_ok(x):
-            y = conv3x3_bias_relu(x, self.p1, self.b1)
+        if (self.p1s2 is not None and x.is_contiguous(memory_format=torch.channels_last)
+                and x.shape[2] == x.shape[3] == 2 * _MC_SIDE.get(2 * x.shape[1], -1)):
+            y, idt = conv3x3s2_ds(x, self.p1s2, self.b1)       # stride-2 convolution + the downsample branch from one staged input
         else:
-            y = bias_relu_(F.conv2d(x, self.w1, None, self.stride, 1), self.b1)
-        idt = x if self.wd is None else F.conv2d(x, self.wd, None, self.ds_stride)
+            if self.p1 is not None and shape_ok(x):
+                y = conv3x3_bias_relu(x, self.p1, self.b1)
+            else:
+                y = bias_relu_(F.conv2d(x, self.w1, None, self.stride, 1), self.b1)
+            idt = x if self.wd is None else F.conv2d(x, self.wd, None, self.ds_stride)
         if self.p2 is not None and shape_ok(y) and idt.is_contiguous(memory_format=torch.channels_last):
             return conv3x3_bias_relu(y, self.p2, self.b2, idt)
         return bias_relu_(F.conv2d(y, self.w2, None, 1, 1), self.b2, idt)

@@ -276,25 +276,33 @@ int hdn_trunk_stem_f32(const float* x, const float* wT, const float* bias, float
 int hdn_bias_relu_f32(float* y, const float* bias, const float* residual, int B, int C, int HW, int nhwc, void* stream);
 
 /*
- * A whole residual-block convolution of that trunk on the matrix cores:
- *   out = relu(conv3x3/s1/p1(x, W) + bias[c] (+ residual)),  x / residual / out [B,S,S,C] fp32 CHANNELS-LAST in memory, C -> C channels.
- * Supported (S, C): (32, 64), (16, 128), (8, 256), (4, 512) - the four stride-1 shapes of the ResNet-34 trunk at 127-px crops;
- * anything else returns HDN_E_LIMIT (the caller keeps MIOpen for it).  fp32 accuracy from the bf16 pipe: activations and weights are
- * split exactly into three bf16 pieces each and six piece products are accumulated in fp32 (conv3x3.hip); the result differs from an
- * fp32 convolution by summation order and < 2^-23 relative per product.
- * wpacked: the BatchNorm-folded weights split and laid out by the host as
- *   [C / BN][C / (16 KS)][3 kernel rows][3 taps][KS k steps][3 pieces][2 k halves][BN][8] bf16, input channel = chunk * 16 KS +
- *   step * 16 + half * 8 + j, with (BN, KS) = hdn_conv3x3_pack_info(S, C)  (hdn_amd.trunk.pack_conv3x3 builds it), 16-byte aligned.  Replaces conv1 / conv2 + bn + relu (+ `out += residual`) of BasicBlock.forward,
- * homo_estimator/Deep_homography/Oneline_DLTv1/backbone/resnet.py:78-94 (eval mode only).
+ * Whole residual-block convolutions of that trunk on the matrix cores, channels-last fp32 in and out:
+ *   hdn_conv3x3_bias_relu_f32:  out = relu(conv3x3/s1/p1(x, W) + bias[c] (+ residual)),  x / residual / out [B,S,S,C], C -> C channels,
+ *       (S, C) = (32, 64), (16, 128), (8, 256), (4, 512): conv1 / conv2 + bn + relu (+ `out += residual`) of BasicBlock.forward;
+ *   hdn_conv3x3s2_ds_f32:       out = relu(conv3x3/s2/p1(x, W1) + bias[c]) and out_ds = conv1x1/s2(x, Wd) from the SAME staged input,
+ *       x [B,2S,2S,CI] -> out / out_ds [B,S,S,2 CI], (S, CI) = (16, 64), (8, 128), (4, 256): conv1 + bn1 + relu and the `downsample`
+ *       branch of the first block of layer2..4 (out_ds carries no bias: the caller adds the folded downsample shift to the bias of
+ *       the block's second convolution, whose residual out_ds is).
+ * Any other shape returns HDN_E_LIMIT (the caller keeps MIOpen for it).  fp32 accuracy from the bf16 pipe: activations and weights
+ * are split exactly into three bf16 pieces each and six piece products are accumulated in fp32 (conv3x3.hip); the result differs
+ * from an fp32 convolution by summation order and ~2^-23 relative per product.
+ * wpacked: the BatchNorm-folded weights split and laid out by the host (hdn_amd.trunk.pack_conv3x3 / pack_conv3x3s2_ds) as
+ *   [CO / BN][CI / (16 KS)][3 kernel rows][T taps][KS k steps][3 pieces][2 k halves][BN][8] bf16, input channel = chunk * 16 KS +
+ *   step * 16 + half * 8 + j, (BN, KS) = hdn_conv3x3_pack_info(S, CI, stride); T = 3, or 4 for the stride-2 form, whose 4th tap holds
+ *   the 1x1 weights in the middle kernel row (zeros in the other two); 16-byte aligned.
+ * Workspace: when the output tiles alone do not fill the chip (S = 4 at any batch size, every shape at small B) the K dimension is
+ * split over workgroups, the slices' partial sums go to `workspace` and a second launch adds them in slice order (deterministic)
+ * with the bias / residual / ReLU.  hdn_conv3x3_workspace_bytes(B, S, CI, stride): bytes needed, 0 = none (workspace may be NULL),
+ * negative = HDN_E_*.
+ * Replaces homo_estimator/Deep_homography/Oneline_DLTv1/backbone/resnet.py:78-94 and the downsample branch built at :162-169
+ * (eval mode only).
  */
-int hdn_conv3x3_pack_info(int S, int C, int* block_n, int* k_steps);
-/* Workspace: when the output tiles alone do not fill the chip (S = 4 at any batch size, every shape at small B) the K dimension is
- * split over workgroups, the slices' partial sums go to `workspace` ([slices][B,S,S,C] fp32) and a second launch adds them in slice
- * order (deterministic) with the bias / residual / ReLU.  hdn_conv3x3_workspace_bytes: bytes needed for (B, S, C), 0 = none
- * (workspace may then be NULL), negative = HDN_E_*. */
-long long hdn_conv3x3_workspace_bytes(int B, int S, int C);
+int hdn_conv3x3_pack_info(int S, int CI, int stride, int* block_n, int* k_steps);
+long long hdn_conv3x3_workspace_bytes(int B, int S, int CI, int stride);
 int hdn_conv3x3_bias_relu_f32(const float* x, const void* wpacked, const float* bias, const float* residual, float* out, float* workspace,
                               long long workspace_bytes, int B, int S, int C, void* stream);
+int hdn_conv3x3s2_ds_f32(const float* x, const void* wpacked, const float* bias, float* out, float* out_ds, float* workspace,
+                         long long workspace_bytes, int B, int S, int CI, void* stream);
 
 /*
  * Multi-GPU: template/search pairs are independent, so ranks own disjoint contiguous blocks of pairs

@@ -1038,6 +1038,36 @@ def test_conv3x3_matrix_core_vs_float64(dev, C, S, B):
         conv3x3_bias_relu(xd, wp[:-1], bd)
 
 
+@pytest.mark.parametrize("CI,S", [(64, 16), (128, 8), (256, 4)])
+@pytest.mark.parametrize("B", [1, 3, 64])
+def test_conv3x3s2_ds_matrix_core_vs_float64(dev, CI, S, B):
+    """hdn_conv3x3s2_ds_f32: the stride-2 convolution (+ bias, ReLU) and the block's 1x1 / stride-2 downsample branch from one
+    staged input, against float64 convolutions; same bound as the stride-1 kernel."""
+    import torch.nn.functional as F
+    from hdn_amd.trunk import pack_conv3x3s2_ds, conv3x3s2_ds
+    g = torch.Generator().manual_seed(CI + B)
+    CO = 2 * CI
+    w = torch.randn(CO, CI, 3, 3, generator=g) * (2.0 / (9 * CI)) ** 0.5
+    wd = torch.randn(CO, CI, 1, 1, generator=g) * (1.0 / CI) ** 0.5
+    b = torch.randn(CO, generator=g) * 0.1
+    x = torch.randn(B, CI, 2 * S, 2 * S, generator=g).clamp_min_(0)
+    cl = torch.channels_last
+    wp = pack_conv3x3s2_ds(w, wd).to(dev)
+    xd = x.to(dev).contiguous(memory_format=cl)
+    y, yd = conv3x3s2_ds(xd, wp, b.to(dev))
+    y2, yd2 = conv3x3s2_ds(xd, wp, b.to(dev))
+    assert torch.equal(y, y2) and torch.equal(yd, yd2) and y.shape == (B, CO, S, S) and yd.is_contiguous(memory_format=cl)
+    nb = min(B, 5)
+    for sl in (slice(0, nb), slice(B - nb, B)):
+        t = torch.relu(F.conv2d(x[sl].double(), w.double(), b.double(), stride=2, padding=1))
+        td = F.conv2d(x[sl].double(), wd.double(), None, stride=2)
+        ref = torch.relu(F.conv2d(x[sl], w, b, stride=2, padding=1))
+        refd = F.conv2d(x[sl], wd, None, stride=2)
+        for got, truth, r32 in ((y, t, ref), (yd, td, refd)):
+            e, e_ref, scale = float((got[sl].cpu().double() - truth).abs().max()), float((r32.double() - truth).abs().max()), float(truth.abs().max())
+            assert e <= 4 * e_ref + 1e-5 * scale, (e, e_ref, scale)
+
+
 def test_fused_epilogue_trunk_vs_unfused(dev):
     """The BN-folded trunk with FusedBasicBlock (bias-free MIOpen convolutions + hdn_bias_relu_f32) against the same folded
     trunk on PyTorch's own bias / add / relu kernels, NCHW and NHWC: the only arithmetic difference is (b2 + b_downsample)

@@ -57,9 +57,13 @@ def test_c_abi_argument_errors_need_no_gpu():
     assert lib.hdn_conv3x3_bias_relu_f32(one, one, one, None, None, None, 0, 1, 32, 64, None) == -1
     assert lib.hdn_conv3x3_bias_relu_f32(one, one, one, None, ctypes.c_void_p(32), None, 0, 1, 30, 64, None) == -3      # unsupported (S, C)
     assert lib.hdn_conv3x3_bias_relu_f32(one, one, one, None, ctypes.c_void_p(32), None, 0, 1, 32, 64, None) == -1      # needs a workspace at B = 1
-    assert lib.hdn_conv3x3_workspace_bytes(64, 32, 64) == 0 and lib.hdn_conv3x3_workspace_bytes(1, 32, 64) > 0 and lib.hdn_conv3x3_workspace_bytes(1, 5, 7) == -3
+    assert lib.hdn_conv3x3_workspace_bytes(64, 32, 64, 1) == 0 and lib.hdn_conv3x3_workspace_bytes(1, 32, 64, 1) > 0 and lib.hdn_conv3x3_workspace_bytes(1, 5, 7, 1) == -3
     bn, ks = ctypes.c_int(0), ctypes.c_int(0)
-    assert lib.hdn_conv3x3_pack_info(4, 512, ctypes.byref(bn), ctypes.byref(ks)) == 0 and bn.value == 64 and ks.value >= 1
+    assert lib.hdn_conv3x3_pack_info(4, 512, 1, ctypes.byref(bn), ctypes.byref(ks)) == 0 and bn.value == 64 and ks.value >= 1
+    assert lib.hdn_conv3x3_pack_info(16, 64, 2, ctypes.byref(bn), ctypes.byref(ks)) == 0 and lib.hdn_conv3x3_pack_info(16, 64, 3, None, None) == -3
+    assert lib.hdn_conv3x3s2_ds_f32(one, one, one, ctypes.c_void_p(32), None, None, 0, 1, 16, 64, None) == -1
+    assert lib.hdn_conv3x3s2_ds_f32(one, one, one, ctypes.c_void_p(32), ctypes.c_void_p(32), None, 0, 1, 16, 64, None) == -4
+    assert lib.hdn_conv3x3s2_ds_f32(one, one, one, ctypes.c_void_p(32), ctypes.c_void_p(48), None, 0, 64, 16, 96, None) == -3
     assert lib.hdn_similarity_translation_f32(one, one, one, one, one, None, 1, 25, 0.16, 8.0, 127.0, None) == -1
     assert lib.hdn_similarity_translation_f32(one, one, one, one, one, one, 1, 0, 0.16, 8.0, 127.0, None) == -2
     assert lib.hdn_similarity_logpolar_f32(one, one, None, one, one, 1, 13, 8.0, 0.03, 0.05, None) == -1

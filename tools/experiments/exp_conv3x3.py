@@ -48,3 +48,23 @@ for (C, S) in ((64, 32), (128, 16), (256, 8), (512, 4)):
             t_conv = timed(lambda: F.conv2d(xd, wd, None, 1, 1))
             fl = 2.0 * B * C * C * 9 * S * S
             print(f"   B={B:2d}: ours {t_ours:6.1f} us ({fl / t_ours / 1e6:6.1f} TFLOP/s fp32-equivalent) | MIOpen conv {t_conv:6.1f} us + epilogue = {t_lib:6.1f} us")
+
+# ---- the stride-2 convolution + downsample branch of the first block of layer2..4
+from hdn_amd.trunk import pack_conv3x3s2_ds, conv3x3s2_ds
+for (CI, S) in ((64, 16), (128, 8), (256, 4)):
+    CO = 2 * CI
+    g = torch.Generator().manual_seed(CI)
+    w = torch.randn(CO, CI, 3, 3, generator=g) * (2.0 / (9 * CI)) ** 0.5
+    wdn = torch.randn(CO, CI, 1, 1, generator=g) * (1.0 / CI) ** 0.5
+    b = torch.randn(CO, generator=g) * 0.1
+    wp = pack_conv3x3s2_ds(w, wdn).to(dev)
+    wd_, wdd, bd = w.to(dev).contiguous(memory_format=cl), wdn.to(dev).contiguous(memory_format=cl), b.to(dev)
+    for B in (64, 1):
+        xd = torch.randn(B, CI, 2 * S, 2 * S, generator=g).clamp_min_(0).to(dev).contiguous(memory_format=cl)
+        t_ours = timed(lambda: conv3x3s2_ds(xd, wp, bd))
+        def lib():
+            yy = F.conv2d(xd, wd_, None, 2, 1)
+            bias_relu_(yy, bd)
+            return F.conv2d(xd, wdd, None, 2)
+        t_lib = timed(lib)
+        print(f"s2 CI={CI} S={S} B={B:2d}: ours {t_ours:6.1f} us | MIOpen 3x3/s2 + epilogue + 1x1/s2 = {t_lib:6.1f} us")
