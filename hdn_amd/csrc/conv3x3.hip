@@ -18,9 +18,9 @@
 //                one conflict-free ds_read_b128, and a tap is a constant address offset.
 //   LDS W image: [tap of the stage][k step][piece][k half][cout] x 16 B, one STAGE = one kernel row (3 taps) of one chunk, double
 //                buffered, streamed from the host-packed layout (which is exactly this order).
-//   pipeline   : the next chunk's activations and the next stage's weights are in flight in registers (global loads) while the
-//                current stage runs on the matrix cores; inside a stage the next step's fragments are read from LDS before the
-//                current step's MFMAs are issued.
+//   pipeline   : A and W images are double buffered; the next chunk's activations and the next two stages' weights are in flight
+//                in registers (global loads) while the current stage runs on the matrix cores, their LDS stores are issued between
+//                its MFMAs, and the next step's fragments are read from LDS one step ahead: one barrier per stage.
 //   wave tile  : MT x NT MFMA tiles of 32 x 32; accumulators stay in registers over the whole K loop;
 //   epilogue   : + bias[cout] (+ residual) -> ReLU -> NHWC store, 128 contiguous bytes per pixel row and half wave.
 #include <cstdlib>
@@ -75,7 +75,7 @@ struct Cfg {
   static constexpr int WSTAGE_BYTES = NTAP * KS * WSTEP_BYTES;   // one kernel row of one chunk
   static constexpr int EPI_STRIDE = BN + 4;                      // floats per pixel row of the output staging (pad: bank spread of the two half waves)
   static constexpr int EPI_BYTES = BM * EPI_STRIDE * 4;
-  static constexpr int LDS_BYTES = (A_BYTES + 2 * WSTAGE_BYTES) > EPI_BYTES ? (A_BYTES + 2 * WSTAGE_BYTES) : EPI_BYTES;
+  static constexpr int LDS_BYTES = (2 * A_BYTES + 2 * WSTAGE_BYTES) > EPI_BYTES ? (2 * A_BYTES + 2 * WSTAGE_BYTES) : EPI_BYTES;   // A and W images double buffered
   static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit the LDS");
   static constexpr int NCHUNK = CI / (16 * KS), NB = CO / BN, NSTAGE = 3 * NCHUNK;
   static constexpr int W4 = WSTAGE_BYTES / 16;                   // 16-byte words of one stage's weights
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(HDN_BLOCK) void conv3x3_kernel(const float* __restr
   constexpr int S = Cf::S, SI = Cf::SI, CI = Cf::CI, C = Cf::CO, MT = Cf::MT, NT = Cf::NT, BM = Cf::BM, BN = Cf::BN, KS = Cf::KS, ST = Cf::STRIDE;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const sA = smem;
-  unsigned char* const sW = smem + Cf::A_BYTES;
+  unsigned char* const sW = smem + 2 * Cf::A_BYTES;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / Cf::WN, wn = wave % Cf::WN;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(HDN_BLOCK) void conv3x3_kernel(const float* __restr
       av[q][1] = ok ? src[1] : f4{0.f, 0.f, 0.f, 0.f};
     }
   };
-  auto store_a = [&]() {
+  auto store_a = [&](int ab) {
 #ifdef CV_EXP_NOSTAGE
     return;
 #endif
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(HDN_BLOCK) void conv3x3_kernel(const float* __restr
         split3x2(av[q][0].z, av[q][0].w, q0[1], q1[1], q2[1]);
         split3x2(av[q][1].x, av[q][1].y, q0[2], q1[2], q2[2]);
         split3x2(av[q][1].z, av[q][1].w, q0[3], q1[3], q2[3]);
-        unsigned char* dst = sA + sub * Cf::KG_BYTES + px * 16;
+        unsigned char* dst = sA + ab * Cf::A_BYTES + sub * Cf::KG_BYTES + px * 16;
         *reinterpret_cast<u32x4*>(dst) = u32x4{q0[0], q0[1], q0[2], q0[3]};
         *reinterpret_cast<u32x4*>(dst + Cf::PIECE_BYTES) = u32x4{q1[0], q1[1], q1[2], q1[3]};
         *reinterpret_cast<u32x4*>(dst + 2 * Cf::PIECE_BYTES) = u32x4{q2[0], q2[1], q2[2], q2[3]};
@@ -195,11 +195,11 @@ __global__ __launch_bounds__(HDN_BLOCK) void conv3x3_kernel(const float* __restr
     u32x4 a[MT][3], b[NT][3];
   };
   // fragments of step (tap t of the stage's kernel row ky, k step ks) from W buffer `buf`
-  auto read_frags = [&](Frags& f, int ky, int t, int ks, int buf) {
+  auto read_frags = [&](Frags& f, int ky, int t, int ks, int buf, int ab) {
 #ifdef CV_EXP_NOREAD
     if (ky + t + ks + buf >= 0) return;
 #endif
-    const int toff = (t == 3 ? 0 : ((ky - 1) * Cf::PW + (t - 1)) * 16) + ks * Cf::KSTEP_BYTES;   // (tap 3: the downsample branch reads the centre)
+    const int toff = (t == 3 ? 0 : ((ky - 1) * Cf::PW + (t - 1)) * 16) + ks * Cf::KSTEP_BYTES + ab * Cf::A_BYTES;   // (tap 3: the downsample branch reads the centre)
     const uint32_t wb = boff + buf * Cf::WSTAGE_BYTES + (t * KS + ks) * Cf::WSTEP_BYTES;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -238,21 +238,26 @@ __global__ __launch_bounds__(HDN_BLOCK) void conv3x3_kernel(const float* __restr
   load_a(0);
   load_w(0, P0{});
   load_w(1, P1{});
-  store_a();
+  store_a(0);
   store_w(P0{});
   __syncthreads();
-  auto run_stage = [&](int chunk, auto KY, auto P) {
-    constexpr int ky = decltype(KY)::value, p = decltype(P)::value;
+  // One stage = one kernel row of one chunk.  Everything that is not an MFMA is issued between the MFMAs of a stage: the next
+  // stage's weights go to the free W buffer after the first step, the next chunk's activations (loaded at the chunk's start) are
+  // split and written to the free A buffer in the last stage, the next step's fragments are read one step ahead.  A stage
+  // ends with ONE barrier (everything the next stage reads has been written; everything it overwrites has been read).
+  auto run_stage = [&](int chunk, auto KY, auto P, auto AB) {
+    constexpr int ky = decltype(KY)::value, p = decltype(P)::value, ab = decltype(AB)::value;
     constexpr int NSTEP = ((DS && ky == 1) ? 4 : 3) * KS;   // steps of this stage: (tap, k step); the middle row also feeds the downsample branch
     const int stage = chunk * 3 + ky;
-    if (ky == 0 && chunk + 1 < nchunk) load_a(chunk + 1);       // in flight during the whole chunk
+    if (ky == 0 && chunk + 1 < nchunk) load_a(chunk + 1);       // in flight until the middle stage
     if (stage + 2 < nstage) load_w(stage + 2, decltype(P){});   // in flight during this stage and the next
     Frags f[2];
-    read_frags(f[0], ky, 0, 0, p);
+    read_frags(f[0], ky, 0, 0, p, ab);
 #pragma unroll
     for (int st = 0; st < NSTEP; ++st) {
-      if (st + 1 < NSTEP) read_frags(f[(st + 1) & 1], ky, (st + 1) / KS, (st + 1) % KS, p);
-      // the fragments of step st have landed when at most the next step's reads are outstanding
+      if (st + 1 < NSTEP) read_frags(f[(st + 1) & 1], ky, (st + 1) / KS, (st + 1) % KS, p, ab);
+      // the fragments of step st have landed when at most the next step's reads are outstanding (LDS operations retire in
+      // order, so LDS stores issued in between only make this wait conservative)
       if (st + 1 < NSTEP) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((MT + NT) * 3) : "memory");
       else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -265,32 +270,30 @@ __global__ __launch_bounds__(HDN_BLOCK) void conv3x3_kernel(const float* __restr
         for (int s = 0; s < 3; ++s) asm volatile("" : "+v"(f[st & 1].b[nt][s]));
       if (DS && st / KS == 3) mma(f[st & 1], std::true_type{});   // (st is a constant after unrolling)
       else mma(f[st & 1], std::false_type{});
+      if (st == 0 && stage + 1 < nstage) store_w(std::integral_constant<int, 1 - p>{});   // (that buffer was read last in stage - 1: a barrier ago)
+      if (st == 0 && ky == 2 && chunk + 1 < nchunk) store_a(1 - ab);                       // (that image was read last in chunk - 1; its loads have had two stages)
     }
-    if (stage + 1 < nstage) {
-      if (ky == 2) {                                            // chunk boundary: the A image is rewritten as well
-        __syncthreads();                                        // everyone is done reading this chunk's A image
-        store_a();
-      }
-      store_w(std::integral_constant<int, 1 - p>{});           // stage + 1 -> the buffer read last during stage - 1: a barrier ago
-      __syncthreads();
-    }
+    if (stage + 1 < nstage) __syncthreads();
   };
-  // the stage loop is unrolled over two chunks (six stages) so that the register set / LDS buffer of a stage is static;
-  // an odd chunk count ends with one more chunk, which starts on buffer 0 again
+  // the stage loop is unrolled over two chunks (six stages) so that the register set / LDS buffers of a stage are static;
+  // an odd chunk count ends with one more chunk, which starts on buffers 0 again
+  using K0 = std::integral_constant<int, 0>;
+  using K1 = std::integral_constant<int, 1>;
+  using K2 = std::integral_constant<int, 2>;
   int c2 = 0;
 #pragma unroll 1
   for (; c2 + 1 < nchunk; c2 += 2) {
-    run_stage(c2, std::integral_constant<int, 0>{}, P0{});
-    run_stage(c2, std::integral_constant<int, 1>{}, P1{});
-    run_stage(c2, std::integral_constant<int, 2>{}, P0{});
-    run_stage(c2 + 1, std::integral_constant<int, 0>{}, P1{});
-    run_stage(c2 + 1, std::integral_constant<int, 1>{}, P0{});
-    run_stage(c2 + 1, std::integral_constant<int, 2>{}, P1{});
+    run_stage(c2, K0{}, P0{}, P0{});
+    run_stage(c2, K1{}, P1{}, P0{});
+    run_stage(c2, K2{}, P0{}, P0{});
+    run_stage(c2 + 1, K0{}, P1{}, P1{});
+    run_stage(c2 + 1, K1{}, P0{}, P1{});
+    run_stage(c2 + 1, K2{}, P1{}, P1{});
   }
   if (c2 < nchunk) {
-    run_stage(c2, std::integral_constant<int, 0>{}, P0{});
-    run_stage(c2, std::integral_constant<int, 1>{}, P1{});
-    run_stage(c2, std::integral_constant<int, 2>{}, P0{});
+    run_stage(c2, K0{}, P0{}, P0{});
+    run_stage(c2, K1{}, P1{}, P0{});
+    run_stage(c2, K2{}, P0{}, P0{});
   }
 
   // ---- epilogue.  C/D layout of v_mfma_f32_32x32x16_bf16: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
@@ -440,20 +443,21 @@ static int launch(const float* x, const void* wp, const float* bias, const float
 // Tile configurations.  When the output tiles alone do not fill the chip (the 4 x 4 stage at any batch size, every stage at the
 // tracker's B = 1) the K dimension is split over workgroups as well (k_slices) and a second launch reduces the slices.
 //                         S   CI   CO  ST  DS    WM WN MT NT KS
-using CV_L1  = hdn::cv::Cfg<32, 64, 64, 1, false, 4, 1, 1, 2, 1>;    // 128 pixels (4 rows) x 64 channels: 512 workgroups at B = 64, two per CU
+using CV_L1  = hdn::cv::Cfg<32, 64, 64, 1, false, 4, 1, 1, 2, 1>;    // 128 pixels (4 rows) x 64 channels: small batches
+using CV_L1B = hdn::cv::Cfg<32, 64, 64, 1, false, 4, 1, 2, 2, 1>;    // 256 pixels (8 rows) x 64 channels, 2 x 2 MFMA tiles per wave: B >= 32 (33.9 vs 38.8 us at B = 64); same weight packing
 using CV_L2  = hdn::cv::Cfg<16, 128, 128, 1, false, 4, 1, 1, 2, 1>;  // 128 pixels (8 rows) x 64 channels
 using CV_L3  = hdn::cv::Cfg<8, 256, 256, 1, false, 2, 2, 1, 1, 2>;   // 64 pixels (one image) x 64 channels
 using CV_L4  = hdn::cv::Cfg<4, 512, 512, 1, false, 4, 1, 2, 2, 1>;   // 256 pixels (16 images) x 64 channels, K split 8 ways at B = 64
 // first convolution of a stage (stride 2, channels doubled) together with the block's 1x1 / stride-2 downsample branch
-using CV_D2  = hdn::cv::Cfg<16, 64, 128, 2, true, 4, 1, 1, 2, 1>;    // 128 output pixels (8 rows of 16) x 64 channels
+using CV_D2  = hdn::cv::Cfg<16, 64, 128, 2, true, 2, 2, 1, 1, 1>;    // 64 output pixels (4 rows of 16) x 64 channels
 using CV_D3  = hdn::cv::Cfg<8, 128, 256, 2, true, 2, 2, 1, 1, 1>;    // 64 output pixels (one image) x 64 channels
 using CV_D4  = hdn::cv::Cfg<4, 256, 512, 2, true, 2, 2, 1, 1, 1>;    // 64 output pixels (4 images) x 64 channels
 
 // (S = output side, CI input channels, stride) -> configuration
 template <class F>
-static int cv_dispatch(int S, int CI, int stride, F&& f) {
+static int cv_dispatch(int S, int CI, int stride, int B, F&& f) {
   if (stride == 1) {
-    if (S == 32 && CI == 64) return f(CV_L1{});
+    if (S == 32 && CI == 64) return B >= 32 ? f(CV_L1B{}) : f(CV_L1{});
     if (S == 16 && CI == 128) return f(CV_L2{});
     if (S == 8 && CI == 256) return f(CV_L3{});
     if (S == 4 && CI == 512) return f(CV_L4{});
@@ -465,8 +469,10 @@ static int cv_dispatch(int S, int CI, int stride, F&& f) {
   return HDN_E_LIMIT;
 }
 
+static_assert(CV_L1::BN == CV_L1B::BN && CV_L1::KS == CV_L1B::KS, "both 64-channel configurations read one weight packing");
+
 extern "C" int hdn_conv3x3_pack_info(int S, int CI, int stride, int* block_n, int* k_steps) {
-  return cv_dispatch(S, CI, stride, [&](auto cfg) {
+  return cv_dispatch(S, CI, stride, 1, [&](auto cfg) {
     if (block_n) *block_n = decltype(cfg)::BN;
     if (k_steps) *k_steps = decltype(cfg)::KS;
     return HDN_OK;
@@ -477,7 +483,7 @@ extern "C" int hdn_conv3x3_pack_info(int S, int CI, int stride, int* block_n, in
 extern "C" long long hdn_conv3x3_workspace_bytes(int B, int S, int CI, int stride) {
   if (B <= 0) return HDN_E_SHAPE;
   long long out = 0;
-  const int rc = cv_dispatch(S, CI, stride, [&](auto cfg) {
+  const int rc = cv_dispatch(S, CI, stride, B, [&](auto cfg) {
     out = (long long)hdn::cv::workspace_bytes<decltype(cfg)>(B);
     return HDN_OK;
   });
@@ -499,7 +505,7 @@ extern "C" int hdn_conv3x3_bias_relu_f32(const float* x, const void* wpacked, co
   if (rc) return rc;
   if (residual && !hdn::aligned16(residual)) return HDN_E_LIMIT;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  return cv_dispatch(S, C, 1, [&](auto cfg) {
+  return cv_dispatch(S, C, 1, B, [&](auto cfg) {
     return hdn::cv::launch<decltype(cfg)>(x, wpacked, bias, residual, out, nullptr, workspace, workspace_bytes > 0 ? (size_t)workspace_bytes : 0, B, s);
   });
 }
@@ -513,7 +519,7 @@ extern "C" int hdn_conv3x3s2_ds_f32(const float* x, const void* wpacked, const f
   if (out_ds == out || out_ds == x) return HDN_E_ALIAS;
   if (!hdn::aligned16(out_ds)) return HDN_E_LIMIT;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  return cv_dispatch(S, CI, 2, [&](auto cfg) {
+  return cv_dispatch(S, CI, 2, B, [&](auto cfg) {
     return hdn::cv::launch<decltype(cfg)>(x, wpacked, bias, nullptr, out, out_ds, workspace, workspace_bytes > 0 ? (size_t)workspace_bytes : 0, B, s);
   });
 }
