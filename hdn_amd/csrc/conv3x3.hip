@@ -86,8 +86,11 @@ struct Cfg {
 // MODE 0: out = relu(conv + bias); 1: out = relu(conv + bias + res); 2: the K slice blockIdx.z of `cps` chunks, raw sums to
 // out[blockIdx.z][M][CO] (the workspace; conv3x3_reduce_kernel finishes).  Cf::DS: out2 = the downsample branch (raw sums, no
 // bias / ReLU; mode 2: out2[blockIdx.z][M][CO]).
-template <class Cf, int MODE>
-__global__ __launch_bounds__(HDN_BLOCK) void conv3x3_kernel(const float* __restrict__ x, const u32x4* __restrict__ wp, const float* __restrict__ bias,
+// SPEC: 8 waves, two per SIMD with separate roles: waves 0-3 only read fragments and issue MFMAs (consumers), waves 4-7 only
+// load from global memory, split to bf16 and fill the LDS images (producers).  A consumer then never waits for a global load or
+// for the operands of an LDS store; the two roles meet at the one barrier per stage.  SPEC = false: 4 waves doing both.
+template <class Cf, int MODE, bool SPEC>
+__global__ __launch_bounds__(SPEC ? 2 * HDN_BLOCK : HDN_BLOCK) void conv3x3_kernel(const float* __restrict__ x, const u32x4* __restrict__ wp, const float* __restrict__ bias,
                                                             const float* __restrict__ res, float* __restrict__ out, float* __restrict__ out2, int B,
                                                             int cps) {
   constexpr bool RES = MODE == 1, PARTIAL = MODE == 2, DS = Cf::DS;
@@ -95,8 +98,10 @@ __global__ __launch_bounds__(HDN_BLOCK) void conv3x3_kernel(const float* __restr
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const sA = smem;
   unsigned char* const sW = smem + 2 * Cf::A_BYTES;
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x & (HDN_BLOCK - 1), lane = tid & 63;   // index inside the role (or the workgroup)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int role = SPEC ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : -1;   // 0 consumer, 1 producer, -1 both
+  const bool consume = role != 1, produce = role != 0;
   const int wm = wave / Cf::WN, wn = wave % Cf::WN;
   const int li = lane & 31, g = lane >> 5;
   const long long m0 = (long long)blockIdx.x * BM;          // first output pixel of the tile, (b, y, x) order
@@ -235,43 +240,55 @@ __global__ __launch_bounds__(HDN_BLOCK) void conv3x3_kernel(const float* __restr
 
   using P0 = std::integral_constant<int, 0>;
   using P1 = std::integral_constant<int, 1>;
-  load_a(0);
-  load_w(0, P0{});
-  load_w(1, P1{});
-  store_a(0);
-  store_w(P0{});
+  if (produce) {
+    load_a(0);
+    load_w(0, P0{});
+    load_w(1, P1{});
+    store_a(0);
+    store_w(P0{});
+  }
   __syncthreads();
-  // One stage = one kernel row of one chunk.  Everything that is not an MFMA is issued between the MFMAs of a stage: the next
-  // stage's weights go to the free W buffer after the first step, the next chunk's activations (loaded at the chunk's start) are
-  // split and written to the free A buffer in the last stage, the next step's fragments are read one step ahead.  A stage
-  // ends with ONE barrier (everything the next stage reads has been written; everything it overwrites has been read).
+  // One stage = one kernel row of one chunk.  Producer side: the next stage's weights go to the free W buffer, the next chunk's
+  // activations (loaded at the chunk's start) are split and written to the free A buffer in the chunk's last stage; consumer side:
+  // the next step's fragments are read one step ahead of the MFMAs.  (SPEC = false: one wave does both, the stores issued between
+  // its MFMAs.)  A stage ends with ONE barrier: everything the next stage reads has been written, everything it overwrites read.
   auto run_stage = [&](int chunk, auto KY, auto P, auto AB) {
     constexpr int ky = decltype(KY)::value, p = decltype(P)::value, ab = decltype(AB)::value;
     constexpr int NSTEP = ((DS && ky == 1) ? 4 : 3) * KS;   // steps of this stage: (tap, k step); the middle row also feeds the downsample branch
     const int stage = chunk * 3 + ky;
-    if (ky == 0 && chunk + 1 < nchunk) load_a(chunk + 1);       // in flight until the middle stage
-    if (stage + 2 < nstage) load_w(stage + 2, decltype(P){});   // in flight during this stage and the next
-    Frags f[2];
-    read_frags(f[0], ky, 0, 0, p, ab);
+    if (produce) {
+      if (ky == 0 && chunk + 1 < nchunk) load_a(chunk + 1);       // in flight until the chunk's last stage
+      if (stage + 2 < nstage) load_w(stage + 2, decltype(P){});   // in flight during this stage and the next
+    }
+    if (SPEC && produce) {
+      if (stage + 1 < nstage) store_w(std::integral_constant<int, 1 - p>{});   // (that buffer was read last in stage - 1: a barrier ago)
+      if (ky == 2 && chunk + 1 < nchunk) store_a(1 - ab);                       // (that image was read last in chunk - 1)
+    }
+    if (consume) {
+      Frags f[2];
+      read_frags(f[0], ky, 0, 0, p, ab);
 #pragma unroll
-    for (int st = 0; st < NSTEP; ++st) {
-      if (st + 1 < NSTEP) read_frags(f[(st + 1) & 1], ky, (st + 1) / KS, (st + 1) % KS, p, ab);
-      // the fragments of step st have landed when at most the next step's reads are outstanding (LDS operations retire in
-      // order, so LDS stores issued in between only make this wait conservative)
-      if (st + 1 < NSTEP) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((MT + NT) * 3) : "memory");
-      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      for (int st = 0; st < NSTEP; ++st) {
+        if (st + 1 < NSTEP) read_frags(f[(st + 1) & 1], ky, (st + 1) / KS, (st + 1) % KS, p, ab);
+        // the fragments of step st have landed when at most the next step's reads are outstanding (LDS operations retire in
+        // order, so LDS stores issued in between only make this wait conservative)
+        if (st + 1 < NSTEP) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((MT + NT) * 3) : "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int s = 0; s < 3; ++s) asm volatile("" : "+v"(f[st & 1].a[mt][s]));
+          for (int s = 0; s < 3; ++s) asm volatile("" : "+v"(f[st & 1].a[mt][s]));
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int s = 0; s < 3; ++s) asm volatile("" : "+v"(f[st & 1].b[nt][s]));
-      if (DS && st / KS == 3) mma(f[st & 1], std::true_type{});   // (st is a constant after unrolling)
-      else mma(f[st & 1], std::false_type{});
-      if (st == 0 && stage + 1 < nstage) store_w(std::integral_constant<int, 1 - p>{});   // (that buffer was read last in stage - 1: a barrier ago)
-      if (st == 0 && ky == 2 && chunk + 1 < nchunk) store_a(1 - ab);                       // (that image was read last in chunk - 1; its loads have had two stages)
+          for (int s = 0; s < 3; ++s) asm volatile("" : "+v"(f[st & 1].b[nt][s]));
+        if (DS && st / KS == 3) mma(f[st & 1], std::true_type{});   // (st is a constant after unrolling)
+        else mma(f[st & 1], std::false_type{});
+        if (!SPEC) {
+          if (st == 0 && stage + 1 < nstage) store_w(std::integral_constant<int, 1 - p>{});
+          if (st == 0 && ky == 2 && chunk + 1 < nchunk) store_a(1 - ab);
+        }
+      }
     }
     if (stage + 1 < nstage) __syncthreads();
   };
@@ -301,29 +318,33 @@ __global__ __launch_bounds__(HDN_BLOCK) void conv3x3_kernel(const float* __restr
   // a pixel's BN channels (contiguous in NHWC) by BN / 4 consecutive lanes.
   __syncthreads();  // every wave is done with the A / W images
   float* const sO = reinterpret_cast<float*>(smem);
+  if (consume) {
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+      for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-        sO[row * Cf::EPI_STRIDE + (wn * NT + nt) * 32 + li] = acc[mt][nt][r];
-      }
+        for (int r = 0; r < 16; ++r) {
+          const int row = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+          sO[row * Cf::EPI_STRIDE + (wn * NT + nt) * 32 + li] = acc[mt][nt][r];
+        }
+  }
   __syncthreads();
-  constexpr int N4 = BN / 4, TOT4 = BM * N4, EITER = cdiv(TOT4, HDN_BLOCK);
+  constexpr int ETHREADS = SPEC ? 2 * HDN_BLOCK : HDN_BLOCK;   // every thread of the workgroup stores
+  const int etid = threadIdx.x;
+  constexpr int N4 = BN / 4, TOT4 = BM * N4, EITER = cdiv(TOT4, ETHREADS);
   f4 rv[EITER];
   if (RES) {
 #pragma unroll
     for (int q = 0; q < EITER; ++q) {
-      const int idx = tid + q * HDN_BLOCK, px = idx / N4, c4 = idx % N4;
+      const int idx = etid + q * ETHREADS, px = idx / N4, c4 = idx % N4;
       const long long m = min(m0 + px, M - 1);
       rv[q] = *reinterpret_cast<const f4*>(res + m * C + nb * BN + c4 * 4);
     }
   }
 #pragma unroll
   for (int q = 0; q < EITER; ++q) {
-    const int idx = tid + q * HDN_BLOCK, px = idx / N4, c4 = idx % N4;
+    const int idx = etid + q * ETHREADS, px = idx / N4, c4 = idx % N4;
     const long long m = m0 + px;
     if (idx < TOT4 && m < M) {
       f4 v = *reinterpret_cast<const f4*>(sO + px * Cf::EPI_STRIDE + c4 * 4);
@@ -339,19 +360,21 @@ __global__ __launch_bounds__(HDN_BLOCK) void conv3x3_kernel(const float* __restr
   }
   if (DS) {   // the downsample branch: raw sums (its bias travels with the block's second convolution)
     __syncthreads();
+    if (consume) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-          sO[row * Cf::EPI_STRIDE + (wn * NT + nt) * 32 + li] = accd[DS ? mt : 0][DS ? nt : 0][r];
-        }
+          for (int r = 0; r < 16; ++r) {
+            const int row = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+            sO[row * Cf::EPI_STRIDE + (wn * NT + nt) * 32 + li] = accd[DS ? mt : 0][DS ? nt : 0][r];
+          }
+    }
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < EITER; ++q) {
-      const int idx = tid + q * HDN_BLOCK, px = idx / N4, c4 = idx % N4;
+      const int idx = etid + q * ETHREADS, px = idx / N4, c4 = idx % N4;
       const long long m = m0 + px;
       if (idx < TOT4 && m < M)
         *reinterpret_cast<f4*>(out2 + ((PARTIAL ? (long long)blockIdx.z * M : 0) + m) * C + nb * BN + c4 * 4) =
@@ -409,11 +432,13 @@ static int launch(const float* x, const void* wp, const float* bias, const float
     if (!ws) return HDN_E_NULL;
     if (ws_bytes < workspace_bytes<Cf>(B) || !aligned16(ws)) return HDN_E_LIMIT;
   }
+  static const bool spec = [] { const char* e = getenv("HDN_CV_SPEC"); return !(e && e[0] == '0'); }();   // A/B switch: producer / consumer waves
   static PerDeviceOnce attr;
   const int dev_ = PerDeviceOnce::device();
   if (!attr.done(dev_)) {
-    for (const void* fn : {reinterpret_cast<const void*>(&conv3x3_kernel<Cf, 0>), reinterpret_cast<const void*>(&conv3x3_kernel<Cf, 1>),
-                           reinterpret_cast<const void*>(&conv3x3_kernel<Cf, 2>)}) {
+    for (const void* fn : {reinterpret_cast<const void*>(&conv3x3_kernel<Cf, 0, false>), reinterpret_cast<const void*>(&conv3x3_kernel<Cf, 1, false>),
+                           reinterpret_cast<const void*>(&conv3x3_kernel<Cf, 2, false>), reinterpret_cast<const void*>(&conv3x3_kernel<Cf, 0, true>),
+                           reinterpret_cast<const void*>(&conv3x3_kernel<Cf, 1, true>), reinterpret_cast<const void*>(&conv3x3_kernel<Cf, 2, true>)}) {
       hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS_BYTES);
       if (e != hipSuccess) return -(1000 + (int)e);
     }
@@ -421,13 +446,20 @@ static int launch(const float* x, const void* wp, const float* bias, const float
   }
   const dim3 grid((unsigned)((M + Cf::BM - 1) / Cf::BM), Cf::NB, z);
   const u32x4* w4 = (const u32x4*)wp;
+  const dim3 blk(spec ? 2 * HDN_BLOCK : HDN_BLOCK);
+#define HDN_CV_LAUNCH(MODE, OUT, OUT2, CPS)                                                                                                        \
+  do {                                                                                                                                            \
+    if (spec) hipLaunchKernelGGL((conv3x3_kernel<Cf, MODE, true>), grid, blk, Cf::LDS_BYTES, stream, x, w4, bias, res, OUT, OUT2, B, CPS);          \
+    else hipLaunchKernelGGL((conv3x3_kernel<Cf, MODE, false>), grid, blk, Cf::LDS_BYTES, stream, x, w4, bias, res, OUT, OUT2, B, CPS);               \
+  } while (0)
   if (z == 1) {
-    if (res) hipLaunchKernelGGL((conv3x3_kernel<Cf, 1>), grid, dim3(HDN_BLOCK), Cf::LDS_BYTES, stream, x, w4, bias, res, out, out2, B, Cf::NCHUNK);
-    else hipLaunchKernelGGL((conv3x3_kernel<Cf, 0>), grid, dim3(HDN_BLOCK), Cf::LDS_BYTES, stream, x, w4, bias, res, out, out2, B, Cf::NCHUNK);
+    if (res) HDN_CV_LAUNCH(1, out, out2, Cf::NCHUNK);
+    else HDN_CV_LAUNCH(0, out, out2, Cf::NCHUNK);
     return launch_status();
   }
   float* ws2 = ws + (size_t)z * M * Cf::CO;
-  hipLaunchKernelGGL((conv3x3_kernel<Cf, 2>), grid, dim3(HDN_BLOCK), Cf::LDS_BYTES, stream, x, w4, bias, res, ws, ws2, B, Cf::NCHUNK / z);
+  HDN_CV_LAUNCH(2, ws, ws2, Cf::NCHUNK / z);
+#undef HDN_CV_LAUNCH
   const unsigned n4 = (unsigned)(M * Cf::CO / 4);
   const int blocks = (int)((n4 + HDN_BLOCK - 1) / HDN_BLOCK < 1024 ? (n4 + HDN_BLOCK - 1) / HDN_BLOCK : 1024);
   const f4* b4 = (const f4*)bias;
