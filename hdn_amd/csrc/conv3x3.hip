@@ -25,6 +25,7 @@
 //   epilogue   : + bias[cout] (+ residual) -> ReLU -> NHWC store, 128 contiguous bytes per pixel row and half wave.
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 #include "hdn_common.h"
 
@@ -35,6 +36,16 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
+
+// compile-time loop: f(std::integral_constant<int, I>{}) for I = 0 .. N - 1
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
 
 __device__ __forceinline__ f32x16 mfma(const u32x4& a, const u32x4& b, const f32x16& c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
@@ -75,7 +86,7 @@ struct Cfg {
   static constexpr int WSTAGE_BYTES = NTAP * KS * WSTEP_BYTES;   // one kernel row of one chunk
   static constexpr int EPI_STRIDE = BN + 4;                      // floats per pixel row of the output staging (pad: bank spread of the two half waves)
   static constexpr int EPI_BYTES = BM * EPI_STRIDE * 4;
-  static constexpr int LDS_BYTES = (2 * A_BYTES + 2 * WSTAGE_BYTES) > EPI_BYTES ? (2 * A_BYTES + 2 * WSTAGE_BYTES) : EPI_BYTES;   // A and W images double buffered
+  static constexpr int LDS_BYTES = (2 * A_BYTES + 3 * WSTAGE_BYTES) > EPI_BYTES ? (2 * A_BYTES + 3 * WSTAGE_BYTES) : EPI_BYTES;   // two A images, a ring of three W stages
   static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit the LDS");
   static constexpr int NCHUNK = CI / (16 * KS), NB = CO / BN, NSTAGE = 3 * NCHUNK;
   static constexpr int W4 = WSTAGE_BYTES / 16;                   // 16-byte words of one stage's weights
@@ -86,11 +97,12 @@ struct Cfg {
 // MODE 0: out = relu(conv + bias); 1: out = relu(conv + bias + res); 2: the K slice blockIdx.z of `cps` chunks, raw sums to
 // out[blockIdx.z][M][CO] (the workspace; conv3x3_reduce_kernel finishes).  Cf::DS: out2 = the downsample branch (raw sums, no
 // bias / ReLU; mode 2: out2[blockIdx.z][M][CO]).
-// SPEC: 8 waves, two per SIMD with separate roles: waves 0-3 only read fragments and issue MFMAs (consumers), waves 4-7 only
-// load from global memory, split to bf16 and fill the LDS images (producers).  A consumer then never waits for a global load or
-// for the operands of an LDS store; the two roles meet at the one barrier per stage.  SPEC = false: 4 waves doing both.
-template <class Cf, int MODE, bool SPEC>
-__global__ __launch_bounds__(SPEC ? 2 * HDN_BLOCK : HDN_BLOCK) void conv3x3_kernel(const float* __restrict__ x, const u32x4* __restrict__ wp, const float* __restrict__ bias,
+// 8 waves, two per SIMD, with separate roles: waves 0-3 only read fragments and issue MFMAs (consumers), waves 4-7 only load from
+// global memory, split to bf16 and fill the LDS images (producers).  A consumer never waits for a global load or for the operands
+// of an LDS store; the two roles meet at the one barrier per stage, and the producers run TWO stages ahead, so that a consumer can
+// read the first fragments of stage s + 1 while it still issues the MFMAs of stage s.
+template <class Cf, int MODE>
+__global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __restrict__ x, const u32x4* __restrict__ wp, const float* __restrict__ bias,
                                                             const float* __restrict__ res, float* __restrict__ out, float* __restrict__ out2, int B,
                                                             int cps) {
   constexpr bool RES = MODE == 1, PARTIAL = MODE == 2, DS = Cf::DS;
@@ -100,8 +112,7 @@ __global__ __launch_bounds__(SPEC ? 2 * HDN_BLOCK : HDN_BLOCK) void conv3x3_kern
   unsigned char* const sW = smem + 2 * Cf::A_BYTES;
   const int tid = threadIdx.x & (HDN_BLOCK - 1), lane = tid & 63;   // index inside the role (or the workgroup)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int role = SPEC ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : -1;   // 0 consumer, 1 producer, -1 both
-  const bool consume = role != 1, produce = role != 0;
+  const bool produce = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) != 0, consume = !produce;
   const int wm = wave / Cf::WN, wn = wave % Cf::WN;
   const int li = lane & 31, g = lane >> 5;
   const long long m0 = (long long)blockIdx.x * BM;          // first output pixel of the tile, (b, y, x) order
@@ -139,19 +150,19 @@ __global__ __launch_bounds__(SPEC ? 2 * HDN_BLOCK : HDN_BLOCK) void conv3x3_kern
   // this channel block's packed weights: [chunk][kernel row][tap in row][k step][piece][k half][n][8 bf16] = [stage][W4 words]
   const int chunk0 = PARTIAL ? (int)blockIdx.z * cps : 0, nchunk = PARTIAL ? cps : Cf::NCHUNK, nstage = 3 * nchunk;   // this launch's K range
   const u32x4* wblock = wp + ((size_t)nb * Cf::NSTAGE + (size_t)chunk0 * 3) * Cf::W4;
-  u32x4 wr[2][Cf::WITER];   // two stages in flight: stage s travels in wr[s & 1] from the start of stage s - 2 to the end of stage s - 1
+  u32x4 wr[2][Cf::WITER];   // two stages in flight: stage t travels in wr[t & 1] from stage t - 4 (load) to stage t - 2 (LDS store)
   auto load_w = [&](int stage, auto P) {
     constexpr int p = decltype(P)::value;
 #ifdef CV_EXP_NOWLOAD
-    if (stage > 1) return;
+    if (stage > 3) return;
 #endif
     const u32x4* src = wblock + (size_t)stage * Cf::W4;
 #pragma unroll
     for (int q = 0; q < Cf::WITER; ++q) wr[p][q] = src[min(tid + q * HDN_BLOCK, Cf::W4 - 1)];
   };
-  auto store_w = [&](auto P) {
+  auto store_w = [&](auto P, int buf) {
     constexpr int p = decltype(P)::value;
-    u32x4* dst = reinterpret_cast<u32x4*>(sW + p * Cf::WSTAGE_BYTES);
+    u32x4* dst = reinterpret_cast<u32x4*>(sW + buf * Cf::WSTAGE_BYTES);
 #pragma unroll
     for (int q = 0; q < Cf::WITER; ++q)
       if (tid + q * HDN_BLOCK < Cf::W4) dst[tid + q * HDN_BLOCK] = wr[p][q];
@@ -240,77 +251,82 @@ __global__ __launch_bounds__(SPEC ? 2 * HDN_BLOCK : HDN_BLOCK) void conv3x3_kern
 
   using P0 = std::integral_constant<int, 0>;
   using P1 = std::integral_constant<int, 1>;
+  // Stage t = chunk t / 3, kernel row t % 3 of this launch's K range.  Schedule (producers two stages ahead of the consumers):
+  //   W(t): global load at stage t - 4 into wr[t & 1], LDS store at stage t - 2 into ring slot t % 3, read at stage t
+  //         (and its first step already at the end of stage t - 1);
+  //   A(c): global load at stage (c - 1, row 1), split + LDS store at stage (c, row 1)... into image c & 1, i.e. a chunk is
+  //         complete two stages before its first read; a slot / image is rewritten at the earliest one barrier after its last read.
+  // The loop is unrolled over two chunks = six stages, so that register sets (t & 1), ring slots (t % 3) and images are static.
+  constexpr int NSTEP_ROW[3] = {3 * KS, (DS ? 4 : 3) * KS, 3 * KS};   // steps (tap, k step) per kernel row; the middle row also feeds the downsample branch
+  // The two roles run separate loops with the same barrier sequence (so that neither role's registers are live in the other's code).
+  // J = position of a stage in the six-stage period, `base` = the period's first chunk.
   if (produce) {
     load_a(0);
     load_w(0, P0{});
     load_w(1, P1{});
     store_a(0);
-    store_w(P0{});
-  }
-  __syncthreads();
-  // One stage = one kernel row of one chunk.  Producer side: the next stage's weights go to the free W buffer, the next chunk's
-  // activations (loaded at the chunk's start) are split and written to the free A buffer in the chunk's last stage; consumer side:
-  // the next step's fragments are read one step ahead of the MFMAs.  (SPEC = false: one wave does both, the stores issued between
-  // its MFMAs.)  A stage ends with ONE barrier: everything the next stage reads has been written, everything it overwrites read.
-  auto run_stage = [&](int chunk, auto KY, auto P, auto AB) {
-    constexpr int ky = decltype(KY)::value, p = decltype(P)::value, ab = decltype(AB)::value;
-    constexpr int NSTEP = ((DS && ky == 1) ? 4 : 3) * KS;   // steps of this stage: (tap, k step); the middle row also feeds the downsample branch
-    const int stage = chunk * 3 + ky;
-    if (produce) {
-      if (ky == 0 && chunk + 1 < nchunk) load_a(chunk + 1);       // in flight until the chunk's last stage
-      if (stage + 2 < nstage) load_w(stage + 2, decltype(P){});   // in flight during this stage and the next
-    }
-    if (SPEC && produce) {
-      if (stage + 1 < nstage) store_w(std::integral_constant<int, 1 - p>{});   // (that buffer was read last in stage - 1: a barrier ago)
-      if (ky == 2 && chunk + 1 < nchunk) store_a(1 - ab);                       // (that image was read last in chunk - 1)
-    }
-    if (consume) {
-      Frags f[2];
-      read_frags(f[0], ky, 0, 0, p, ab);
-#pragma unroll
-      for (int st = 0; st < NSTEP; ++st) {
-        if (st + 1 < NSTEP) read_frags(f[(st + 1) & 1], ky, (st + 1) / KS, (st + 1) % KS, p, ab);
-        // the fragments of step st have landed when at most the next step's reads are outstanding (LDS operations retire in
-        // order, so LDS stores issued in between only make this wait conservative)
-        if (st + 1 < NSTEP) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((MT + NT) * 3) : "memory");
+    store_w(P0{}, 0);
+    store_w(P1{}, 1);
+    if (nchunk > 1) load_a(1);
+    if (2 < nstage) load_w(2, P0{});
+    if (3 < nstage) load_w(3, P1{});
+    __syncthreads();
+    auto stage_p = [&](int base, auto Jc) {
+      constexpr int J = decltype(Jc)::value, ky = J % 3, ab = (J / 3) & 1;
+      const int chunk = base + J / 3, stage = chunk * 3 + ky;
+      if (stage + 2 < nstage) store_w(std::integral_constant<int, J & 1>{}, (J + 2) % 3);   // W(stage + 2): that slot was read last in stage - 1
+      if (stage + 4 < nstage) load_w(stage + 4, std::integral_constant<int, J & 1>{});
+      if (ky == 1 && chunk + 1 < nchunk) {
+        store_a(1 - ab);                                   // A(chunk + 1): that image was read last in chunk - 1
+        if (chunk + 2 < nchunk) load_a(chunk + 2);
+      }
+      if (stage + 1 < nstage) __syncthreads();
+    };
+    int c2 = 0;
+#pragma unroll 1
+    for (; c2 + 1 < nchunk; c2 += 2) static_for<6>([&](auto Jc) { stage_p(c2, Jc); });
+    if (c2 < nchunk) static_for<3>([&](auto Jc) { stage_p(c2, Jc); });   // an odd chunk count: one more chunk, at position 0 of the period again
+  } else {
+    __syncthreads();
+    Frags f[2];
+    read_frags(f[0], 0, 0, 0, 0, 0);   // the very first fragments
+    auto stage_c = [&](int base, auto Jc) {
+      constexpr int J = decltype(Jc)::value, ky = J % 3, slot = J % 3, ab = (J / 3) & 1;
+      constexpr int NSTEP = NSTEP_ROW[ky];
+      // parity of the fragment set of this stage's first step: the steps of a period alternate sets without a break
+      constexpr int fp0 = ((J >= 1 ? NSTEP_ROW[0] : 0) + (J >= 2 ? NSTEP_ROW[1] : 0) + (J >= 3 ? NSTEP_ROW[2] : 0) + (J >= 4 ? NSTEP_ROW[0] : 0) +
+                           (J >= 5 ? NSTEP_ROW[1] : 0)) & 1;
+      const int chunk = base + J / 3, stage = chunk * 3 + ky;
+      static_for<NSTEP>([&](auto STc) {
+        constexpr int st = decltype(STc)::value, cur = (fp0 + st) & 1;
+        constexpr bool more = st + 1 < NSTEP;
+        bool issued = more;
+        if constexpr (more) {
+          read_frags(f[1 - cur], ky, (st + 1) / KS, (st + 1) % KS, slot, ab);
+        } else if (stage + 1 < nstage) {                   // first step of the next stage: its images were complete a barrier ago
+          read_frags(f[1 - cur], (ky + 1) % 3, 0, 0, (slot + 1) % 3, ky == 2 ? 1 - ab : ab);
+          issued = true;
+        }
+        // the fragments of this step have landed when at most the reads just issued are outstanding (LDS operations retire in order)
+        if (issued) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((MT + NT) * 3) : "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int s = 0; s < 3; ++s) asm volatile("" : "+v"(f[st & 1].a[mt][s]));
+          for (int s_ = 0; s_ < 3; ++s_) asm volatile("" : "+v"(f[cur].a[mt][s_]));
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-          for (int s = 0; s < 3; ++s) asm volatile("" : "+v"(f[st & 1].b[nt][s]));
-        if (DS && st / KS == 3) mma(f[st & 1], std::true_type{});   // (st is a constant after unrolling)
-        else mma(f[st & 1], std::false_type{});
-        if (!SPEC) {
-          if (st == 0 && stage + 1 < nstage) store_w(std::integral_constant<int, 1 - p>{});
-          if (st == 0 && ky == 2 && chunk + 1 < nchunk) store_a(1 - ab);
-        }
-      }
-    }
-    if (stage + 1 < nstage) __syncthreads();
-  };
-  // the stage loop is unrolled over two chunks (six stages) so that the register set / LDS buffers of a stage are static;
-  // an odd chunk count ends with one more chunk, which starts on buffers 0 again
-  using K0 = std::integral_constant<int, 0>;
-  using K1 = std::integral_constant<int, 1>;
-  using K2 = std::integral_constant<int, 2>;
-  int c2 = 0;
+          for (int s_ = 0; s_ < 3; ++s_) asm volatile("" : "+v"(f[cur].b[nt][s_]));
+        if constexpr (DS && st / KS == 3) mma(f[cur], std::true_type{});
+        else mma(f[cur], std::false_type{});
+      });
+      if (stage + 1 < nstage) __syncthreads();
+    };
+    int c2 = 0;
 #pragma unroll 1
-  for (; c2 + 1 < nchunk; c2 += 2) {
-    run_stage(c2, K0{}, P0{}, P0{});
-    run_stage(c2, K1{}, P1{}, P0{});
-    run_stage(c2, K2{}, P0{}, P0{});
-    run_stage(c2 + 1, K0{}, P1{}, P1{});
-    run_stage(c2 + 1, K1{}, P0{}, P1{});
-    run_stage(c2 + 1, K2{}, P1{}, P1{});
-  }
-  if (c2 < nchunk) {
-    run_stage(c2, K0{}, P0{}, P0{});
-    run_stage(c2, K1{}, P1{}, P0{});
-    run_stage(c2, K2{}, P0{}, P0{});
+    for (; c2 + 1 < nchunk; c2 += 2) static_for<6>([&](auto Jc) { stage_c(c2, Jc); });
+    if (c2 < nchunk) static_for<3>([&](auto Jc) { stage_c(c2, Jc); });
   }
 
   // ---- epilogue.  C/D layout of v_mfma_f32_32x32x16_bf16: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
@@ -330,7 +346,7 @@ __global__ __launch_bounds__(SPEC ? 2 * HDN_BLOCK : HDN_BLOCK) void conv3x3_kern
         }
   }
   __syncthreads();
-  constexpr int ETHREADS = SPEC ? 2 * HDN_BLOCK : HDN_BLOCK;   // every thread of the workgroup stores
+  constexpr int ETHREADS = 2 * HDN_BLOCK;   // every thread of the workgroup stores
   const int etid = threadIdx.x;
   constexpr int N4 = BN / 4, TOT4 = BM * N4, EITER = cdiv(TOT4, ETHREADS);
   f4 rv[EITER];
@@ -432,34 +448,25 @@ static int launch(const float* x, const void* wp, const float* bias, const float
     if (!ws) return HDN_E_NULL;
     if (ws_bytes < workspace_bytes<Cf>(B) || !aligned16(ws)) return HDN_E_LIMIT;
   }
-  static const bool spec = [] { const char* e = getenv("HDN_CV_SPEC"); return !(e && e[0] == '0'); }();   // A/B switch: producer / consumer waves
   static PerDeviceOnce attr;
   const int dev_ = PerDeviceOnce::device();
   if (!attr.done(dev_)) {
-    for (const void* fn : {reinterpret_cast<const void*>(&conv3x3_kernel<Cf, 0, false>), reinterpret_cast<const void*>(&conv3x3_kernel<Cf, 1, false>),
-                           reinterpret_cast<const void*>(&conv3x3_kernel<Cf, 2, false>), reinterpret_cast<const void*>(&conv3x3_kernel<Cf, 0, true>),
-                           reinterpret_cast<const void*>(&conv3x3_kernel<Cf, 1, true>), reinterpret_cast<const void*>(&conv3x3_kernel<Cf, 2, true>)}) {
+    for (const void* fn : {reinterpret_cast<const void*>(&conv3x3_kernel<Cf, 0>), reinterpret_cast<const void*>(&conv3x3_kernel<Cf, 1>),
+                           reinterpret_cast<const void*>(&conv3x3_kernel<Cf, 2>)}) {
       hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS_BYTES);
       if (e != hipSuccess) return -(1000 + (int)e);
     }
     attr.set(dev_);
   }
-  const dim3 grid((unsigned)((M + Cf::BM - 1) / Cf::BM), Cf::NB, z);
+  const dim3 grid((unsigned)((M + Cf::BM - 1) / Cf::BM), Cf::NB, z), blk(2 * HDN_BLOCK);
   const u32x4* w4 = (const u32x4*)wp;
-  const dim3 blk(spec ? 2 * HDN_BLOCK : HDN_BLOCK);
-#define HDN_CV_LAUNCH(MODE, OUT, OUT2, CPS)                                                                                                        \
-  do {                                                                                                                                            \
-    if (spec) hipLaunchKernelGGL((conv3x3_kernel<Cf, MODE, true>), grid, blk, Cf::LDS_BYTES, stream, x, w4, bias, res, OUT, OUT2, B, CPS);          \
-    else hipLaunchKernelGGL((conv3x3_kernel<Cf, MODE, false>), grid, blk, Cf::LDS_BYTES, stream, x, w4, bias, res, OUT, OUT2, B, CPS);               \
-  } while (0)
   if (z == 1) {
-    if (res) HDN_CV_LAUNCH(1, out, out2, Cf::NCHUNK);
-    else HDN_CV_LAUNCH(0, out, out2, Cf::NCHUNK);
+    if (res) hipLaunchKernelGGL((conv3x3_kernel<Cf, 1>), grid, blk, Cf::LDS_BYTES, stream, x, w4, bias, res, out, out2, B, Cf::NCHUNK);
+    else hipLaunchKernelGGL((conv3x3_kernel<Cf, 0>), grid, blk, Cf::LDS_BYTES, stream, x, w4, bias, res, out, out2, B, Cf::NCHUNK);
     return launch_status();
   }
   float* ws2 = ws + (size_t)z * M * Cf::CO;
-  HDN_CV_LAUNCH(2, ws, ws2, Cf::NCHUNK / z);
-#undef HDN_CV_LAUNCH
+  hipLaunchKernelGGL((conv3x3_kernel<Cf, 2>), grid, blk, Cf::LDS_BYTES, stream, x, w4, bias, res, ws, ws2, B, Cf::NCHUNK / z);
   const unsigned n4 = (unsigned)(M * Cf::CO / 4);
   const int blocks = (int)((n4 + HDN_BLOCK - 1) / HDN_BLOCK < 1024 ? (n4 + HDN_BLOCK - 1) / HDN_BLOCK : 1024);
   const f4* b4 = (const f4*)bias;
@@ -479,7 +486,7 @@ using CV_L1  = hdn::cv::Cfg<32, 64, 64, 1, false, 4, 1, 1, 2, 1>;    // 128 pixe
 using CV_L1B = hdn::cv::Cfg<32, 64, 64, 1, false, 4, 1, 2, 2, 1>;    // 256 pixels (8 rows) x 64 channels, 2 x 2 MFMA tiles per wave: B >= 32 (33.9 vs 38.8 us at B = 64); same weight packing
 using CV_L2  = hdn::cv::Cfg<16, 128, 128, 1, false, 4, 1, 1, 2, 1>;  // 128 pixels (8 rows) x 64 channels
 using CV_L3  = hdn::cv::Cfg<8, 256, 256, 1, false, 2, 2, 1, 1, 2>;   // 64 pixels (one image) x 64 channels
-using CV_L4  = hdn::cv::Cfg<4, 512, 512, 1, false, 4, 1, 2, 2, 1>;   // 256 pixels (16 images) x 64 channels, K split 8 ways at B = 64
+using CV_L4  = hdn::cv::Cfg<4, 512, 512, 1, false, 4, 1, 1, 2, 1>;   // 128 pixels (8 images) x 64 channels, K split 4 ways at B = 64
 // first convolution of a stage (stride 2, channels doubled) together with the block's 1x1 / stride-2 downsample branch
 using CV_D2  = hdn::cv::Cfg<16, 64, 128, 2, true, 2, 2, 1, 1, 1>;    // 64 output pixels (4 rows of 16) x 64 channels
 using CV_D3  = hdn::cv::Cfg<8, 128, 256, 2, true, 2, 2, 1, 1, 1>;    // 64 output pixels (one image) x 64 channels
