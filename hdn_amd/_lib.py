@@ -45,6 +45,8 @@ SIGNATURES = {
     "hdn_remap_linear_f32": (_i, [_c_float_p] * 4 + [_i] * 5 + [ctypes.c_void_p]),
     "hdn_similarity_translation_f32": (_i, [_c_float_p] * 6 + [_i, _i, ctypes.c_double, ctypes.c_float, ctypes.c_double, ctypes.c_void_p]),
     "hdn_similarity_logpolar_f32": (_i, [_c_float_p] * 5 + [_i, _i, ctypes.c_float, ctypes.c_double, ctypes.c_float, ctypes.c_void_p]),
+    "hdn_track_prepare_f64": (_i, [_c_float_p] * 3 + [_i, ctypes.c_void_p]),
+    "hdn_track_accumulate_f64": (_i, [_c_float_p] * 6 + [_i] + [_c_float_p] * 2 + [_i, ctypes.c_void_p]),
     "hdn_trunk_stem_f32": (_i, [_c_float_p] * 4 + [_i] * 4 + [ctypes.c_void_p]),
     "hdn_bias_relu_f32": (_i, [_c_float_p] * 3 + [_i] * 4 + [ctypes.c_void_p]),
     "hdn_conv3x3_pack_info": (_i, [_i, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i)]),

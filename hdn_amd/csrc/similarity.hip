@@ -136,6 +136,83 @@ __global__ __launch_bounds__(HDN_WAVE) void similarity_logpolar_kernel(const flo
   }
 }
 
+// ---- the tracker's 3x3 bookkeeping (hdn_tracker_proj_e2e.py:150-155 and :251-272), one lane per sequence ----------------------
+
+__device__ __forceinline__ double det3(const double* m) {
+  return (m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6])) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+}
+
+__global__ __launch_bounds__(HDN_WAVE) void track_prepare_kernel(const double* __restrict__ H_total, double* __restrict__ Ht,
+                                                                 double* __restrict__ Hinv, int B) {
+  const int b = blockIdx.x * HDN_WAVE + threadIdx.x;
+  if (b >= B) return;
+  double m[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) m[q] = H_total[9 * b + q];
+  double det = det3(m);
+  if (det == 0.0) {   // :150-153  "we will do inv after, so make sure H_total is non-singular"
+#pragma unroll
+    for (int q = 0; q < 9; ++q) m[q] = (q % 4 == 0) ? 1.0 : 0.0;
+    det = 1.0;
+  }
+  const double adj[9] = {m[4] * m[8] - m[5] * m[7], m[2] * m[7] - m[1] * m[8], m[1] * m[5] - m[2] * m[4],
+                         m[5] * m[6] - m[3] * m[8], m[0] * m[8] - m[2] * m[6], m[2] * m[3] - m[0] * m[5],
+                         m[3] * m[7] - m[4] * m[6], m[1] * m[6] - m[0] * m[7], m[0] * m[4] - m[1] * m[3]};
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    Ht[9 * b + q] = m[q];
+    Hinv[9 * b + q] = adj[q] / det;
+  }
+}
+
+__global__ __launch_bounds__(HDN_WAVE) void track_accumulate_kernel(const double* __restrict__ Ht, const double* __restrict__ sim_state,
+                                                                    const double* __restrict__ H_comp, const float* __restrict__ homo_score,
+                                                                    const double* __restrict__ consts, const double* __restrict__ init_points,
+                                                                    int n_points, double* __restrict__ H_out, float* __restrict__ out, int B) {
+  const int b = blockIdx.x * HDN_WAVE + threadIdx.x;
+  if (b >= B) return;
+  const double* k = consts + size_t(b) * HDN_TRACK_CONST_DOUBLES;
+  double t0[9], t1[9], H[9];
+  // :251-258  H_homo = inv(shift_H) @ (inv(scale_H_1) @ H_hm_comp @ scale_H_1) @ shift_H, left to right as numpy evaluates it
+  mat3_mul(k, H_comp + 9 * b, t0);
+  mat3_mul(t0, k + 9, t1);
+  mat3_mul(k + 18, t1, t0);
+  mat3_mul(t0, k + 27, t1);                       // t1 = H_homo
+  // :261-264  H = H_total @ H_sim  (@ H_homo unless homo_score > gate)
+  if (sim_state) {
+    mat3_mul(Ht + 9 * b, sim_state + size_t(b) * HDN_SIM_STATE_DOUBLES + 20, t0);
+  } else {
+#pragma unroll
+    for (int q = 0; q < 9; ++q) t0[q] = Ht[9 * b + q];
+  }
+  if ((double)homo_score[b] > k[36]) {
+#pragma unroll
+    for (int q = 0; q < 9; ++q) H[q] = t0[q];
+  } else {
+    mat3_mul(t0, t1, H);
+  }
+  const double inv22 = 1.0 / H[8];                // :265  H = (1.0 / H.item(8)) * H
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    H[q] = inv22 * H[q];
+    H_out[9 * b + q] = H[q];
+  }
+  // :272  cv2.perspectiveTransform(init_points (float32), H_total): double arithmetic, w = 1 / w, zero output for w == 0
+  float* o = out + size_t(b) * (2 * n_points + 1);
+  for (int i = 0; i < n_points; ++i) {
+    const double x = (double)(float)init_points[(size_t(b) * n_points + i) * 2], y = (double)(float)init_points[(size_t(b) * n_points + i) * 2 + 1];
+    double w = (x * H[6] + y * H[7]) + H[8];
+    if (fabs(w) > 2.220446049250313e-16) {
+      w = 1.0 / w;
+      o[2 * i] = (float)(((x * H[0] + y * H[1]) + H[2]) * w);
+      o[2 * i + 1] = (float)(((x * H[3] + y * H[4]) + H[5]) * w);
+    } else {
+      o[2 * i] = o[2 * i + 1] = 0.f;
+    }
+  }
+  o[2 * n_points] = sim_state ? (float)sim_state[size_t(b) * HDN_SIM_STATE_DOUBLES + 5] : 0.f;   // best_score, as track_new returns it
+}
+
 }  // namespace hdn
 
 extern "C" int hdn_similarity_translation_f32(const float* cls, const float* loc_c, const double* window, const float* points,
@@ -156,5 +233,24 @@ extern "C" int hdn_similarity_logpolar_f32(const float* cls_lp, const float* loc
   if (S > 1024) return HDN_E_LIMIT;
   hipLaunchKernelGGL(hdn::similarity_logpolar_kernel, dim3(B), dim3(HDN_WAVE), 0, (hipStream_t)stream, cls_lp, loc_lp, points_lp, seq, state, S,
                      stride_lp, mag, rot_unit);
+  return hdn::launch_status();
+}
+
+extern "C" int hdn_track_prepare_f64(const double* H_total, double* Ht, double* Hinv, int B, void* stream) {
+  if (!H_total || !Ht || !Hinv) return HDN_E_NULL;
+  if (B <= 0) return HDN_E_SHAPE;
+  if (Hinv == H_total || Hinv == Ht) return HDN_E_ALIAS;
+  hipLaunchKernelGGL(hdn::track_prepare_kernel, dim3(hdn::cdiv(B, HDN_WAVE)), dim3(HDN_WAVE), 0, (hipStream_t)stream, H_total, Ht, Hinv, B);
+  return hdn::launch_status();
+}
+
+extern "C" int hdn_track_accumulate_f64(const double* Ht, const double* sim_state, const double* H_comp, const float* homo_score,
+                                        const double* consts, const double* init_points, int n_points, double* H_out, float* out, int B,
+                                        void* stream) {
+  if (!Ht || !H_comp || !homo_score || !consts || !init_points || !H_out || !out) return HDN_E_NULL;
+  if (B <= 0 || n_points <= 0) return HDN_E_SHAPE;
+  if (n_points > 4096) return HDN_E_LIMIT;
+  hipLaunchKernelGGL(hdn::track_accumulate_kernel, dim3(hdn::cdiv(B, HDN_WAVE)), dim3(HDN_WAVE), 0, (hipStream_t)stream, Ht, sim_state, H_comp,
+                     homo_score, consts, init_points, n_points, H_out, out, B);
   return hdn::launch_status();
 }

@@ -18,7 +18,7 @@ reference's ModelBuilder interface).  Without one the similarity estimate is the
 
 What the reference does on the host per frame — cv2 warps of the full frame, numpy crops, three crop uploads, numpy decodes of the
 head maps and six .cpu().numpy() syncs — is here ONE upload of the uint8 frame, kernels (hdn_amd.frame, .similarity, .refine) and
-3x3 float64 bookkeeping on the device; the only host read is the 4 projected corners + best_score the caller asks for
+two one-lane kernels for the 3x3 float64 bookkeeping (hdn_track_prepare_f64 / hdn_track_accumulate_f64); the only host read is the 4 projected corners + best_score the caller asks for
 (`sync=True`).  Nothing in the body depends on host values, so it replays as one hipGraph (`graph=True`) with or without the
 similarity branch.  Sequences are independent: N GPUs run N sequences (replicas only, no collective).
 """
@@ -29,9 +29,12 @@ import os
 import numpy as np
 import torch
 
+from . import _lib
 from . import frame as FR
 from .refine import homo_refine
 from .similarity import DeviceSimilarity, TrackerConfig
+
+TRACK_CONST_DOUBLES = 40     # HDN_TRACK_CONST_DOUBLES
 
 
 class HomoTracker:
@@ -45,7 +48,6 @@ class HomoTracker:
         self.cfg = cfg or (similarity.cfg if similarity is not None and hasattr(similarity, "cfg") else TrackerConfig())
         self.use_graph = bool(graph)
         self._graph = None
-        self._capturing = False
         self.iterations = int(iterations)
         self.similarity = similarity
         self.score_gate = float(score_gate)
@@ -73,73 +75,61 @@ class HomoTracker:
         self.init_homo_tmp = FR.get_search_info(frame, self.center_pos, self.init_s_z_sm, self.channel_average, model_sz=c.exemplar_size)
         if self.similarity is not None:
             self.similarity.init(frame, self.init_pos, self.init_s_z, self.init_s_z_sm, self.channel_average)   # model.template(z_crop), :99-107
-        self.init_points = torch.tensor(np.asarray(gt_points, np.float64).reshape(-1, 2), dtype=torch.float64, device=self.dev)
-        self._init_points_h = torch.cat([self.init_points, torch.ones_like(self.init_points[:, :1])], dim=1)
+        self.init_points = torch.tensor(np.asarray(gt_points, np.float64).reshape(1, -1, 2), dtype=torch.float64, device=self.dev).contiguous()
         self.H_total = torch.eye(3, dtype=torch.float64, device=self.dev)
-        self._eye = torch.eye(3, dtype=torch.float64, device=self.dev)
-        self._zero = torch.zeros((), dtype=torch.float64, device=self.dev)
+        self._Ht, self._Hinv, self._H_next = (torch.empty((3, 3), dtype=torch.float64, device=self.dev) for _ in range(3))
+        self._out = torch.empty((1, 2 * self.init_points.shape[1] + 1), dtype=torch.float32, device=self.dev)
         self._const_params = FR._dev_f64([self.init_pos[0], self.init_pos[1], self.init_s_z_sm] + [float(a) for a in self.channel_average], self.dev)
         self._graph = None
-        # un-scale / un-shift of the residual (:251-258) are constants of the sequence: H_homo = A @ H_hm_comp @ B
+        # un-scale / un-shift of the residual (:251-258): the four matrices are constants of the sequence (float32 as the reference
+        # builds them, their inverses float32 by numpy's dtype rule), handed to hdn_track_accumulate_f64 with the gate
         cw = self.z_crop_points_sm[2] - self.z_crop_points_sm[0] + 1
         ch = self.z_crop_points_sm[3] - self.z_crop_points_sm[1] + 1
         E = c.exemplar_size
-        S = np.diag([E / cw, E / ch, 1.0]).astype(np.float32)          # float32, as :251-257 build them
+        S = np.diag([E / cw, E / ch, 1.0]).astype(np.float32)
         Sh = np.array([[1, 0, -self.z_crop_points_sm[0]], [0, 1, -self.z_crop_points_sm[1]], [0, 0, 1]], np.float32)
-        A = np.linalg.inv(Sh).astype(np.float64) @ np.linalg.inv(S).astype(np.float64)           # (float32 inverses, numpy's dtype rule)
-        self._A = torch.tensor(A, dtype=torch.float64, device=self.dev)
-        self._B = torch.tensor(S.astype(np.float64) @ Sh.astype(np.float64), dtype=torch.float64, device=self.dev)
+        consts = np.zeros(TRACK_CONST_DOUBLES, np.float64)
+        consts[0:9], consts[9:18] = np.linalg.inv(S).astype(np.float64).reshape(-1), S.astype(np.float64).reshape(-1)
+        consts[18:27], consts[27:36] = np.linalg.inv(Sh).astype(np.float64).reshape(-1), Sh.astype(np.float64).reshape(-1)
+        consts[36] = self.score_gate
+        self._consts = torch.from_numpy(consts).to(self.dev)
 
     # -------------------------------------------------------------------------------------------------- one frame
-    @staticmethod
-    def _det3(m):
-        return (m[0, 0] * (m[1, 1] * m[2, 2] - m[1, 2] * m[2, 1]) - m[0, 1] * (m[1, 0] * m[2, 2] - m[1, 2] * m[2, 0])
-                + m[0, 2] * (m[1, 0] * m[2, 1] - m[1, 1] * m[2, 0]))
-
     def _body(self, frame):
         """Everything of a frame that runs on the device, from the uploaded frame to the 4 projected corners; no host
         reads, no allocations that depend on data: capturable in a hipGraph when the frame is a static buffer.
-        -> (H_total', out float32 [9] = 4 corners (x, y) + best_score, homo_score)."""
+        -> (H_total' [3,3] float64 (a buffer of this object), out float32 [9] = 4 corners (x, y) + best_score, homo_score)."""
+        lib, st = _lib.load(), _lib.stream_ptr(self.dev)
         # :150-155  undo the accumulated motion (a singular H_total is reset to the identity, as the reference does).
-        # hdn_frame_warp_perspective_u8 inverts its matrix itself (cv2 semantics), so it is handed inv(H_total) = adj / det.
-        det = self._det3(self.H_total)
-        Ht = torch.where(det == 0, self._eye, self.H_total)
-        frame = FR.warp_perspective(frame, torch.linalg.inv(Ht).reshape(-1) if not self._capturing else self._inv3(Ht).reshape(-1))
+        # hdn_frame_warp_perspective_u8 inverts its matrix itself (cv2 semantics), so it is handed inv(H_total).
+        with torch.cuda.device(self.dev):
+            _lib.check(lib.hdn_track_prepare_f64(_lib.ptr(self.H_total), _lib.ptr(self._Ht), _lib.ptr(self._Hinv), 1, st), "track prepare")
+        frame = FR.warp_perspective(frame, self._Hinv.view(-1))
+        sim_state = None
         if self.similarity is not None:
             # :157-214 on the STABILISED frame; :223 rotate back by -rot_delta about the new centre (bicubic; rot 0 = identity)
             sim = self.similarity(frame)
-            H_sim, params, best_score = sim["H_sim"], sim["params_homo"], sim["best_score"]
+            sim_state, params = self.similarity.state, sim["params_homo"]
             rot_img = FR.warp_affine_cubic(frame, sim["rot_matrix"])
         else:
-            H_sim, params, best_score, rot_img = self._eye, self._const_params, self._zero, frame
+            params, rot_img = self._const_params, frame
         # :224-239  cut the homography crop, normalise
         search = FR.get_search_info(rot_img, None, None, None, model_sz=self.cfg.exemplar_size, params=params)
         # :242-250  refinement loop around track_proj
         H_comp, homo_score, _ = homo_refine(self.net, self.init_homo_tmp, search, iterations=self.iterations)
-        # :251-266  un-scale, un-shift, gate, accumulate
-        H_homo = self._A @ H_comp[0] @ self._B
-        base = Ht @ H_sim
-        H = torch.where(homo_score.to(torch.float64) > self.score_gate, base, base @ H_homo)
-        H = H / H[2, 2]
-        # :272  cv2.perspectiveTransform(init_points, H_total)
-        p = self._init_points_h @ H.T
-        pts = (p[:, :2] / p[:, 2:3]).to(torch.float32)
-        out = torch.cat([pts.reshape(-1), best_score.to(torch.float32).reshape(1)])
-        return H, out, homo_score
-
-    def _inv3(self, m):
-        """Closed-form 3x3 inverse from elementwise ops (graph capture cannot hold the solver call of torch.linalg.inv)."""
-        a, b, c, d, e, f, g, h, i = (m[0, 0], m[0, 1], m[0, 2], m[1, 0], m[1, 1], m[1, 2], m[2, 0], m[2, 1], m[2, 2])
-        adj = torch.stack([torch.stack([e * i - f * h, c * h - b * i, b * f - c * e]),
-                           torch.stack([f * g - d * i, a * i - c * g, c * d - a * f]),
-                           torch.stack([d * h - e * g, b * g - a * h, a * e - b * d])])
-        return adj / self._det3(m)
+        # :251-272  un-scale, un-shift, gate, accumulate, project the initial corners
+        score = homo_score.detach().reshape(-1).to(torch.float32).contiguous()
+        with torch.cuda.device(self.dev):
+            _lib.check(lib.hdn_track_accumulate_f64(_lib.ptr(self._Ht), _lib.ptr(sim_state) if sim_state is not None else None, _lib.ptr(H_comp),
+                                                    _lib.ptr(score), _lib.ptr(self._consts), _lib.ptr(self.init_points),
+                                                    self.init_points.shape[1], _lib.ptr(self._H_next), _lib.ptr(self._out), 1, st),
+                       "track accumulate")
+        return self._H_next, self._out.view(-1), homo_score
 
     def _capture(self, frame_shape):
         """hipGraph of the whole per-frame body.  The frame lands in a static device buffer; H_total is carried in a static
         tensor updated by the graph itself; the similarity state record is a static tensor of the DeviceSimilarity."""
         self._static_frame = torch.empty(frame_shape, dtype=torch.uint8, device=self.dev)
-        self._capturing = True
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         H0 = self.H_total.clone()
@@ -153,7 +143,6 @@ class HomoTracker:
             self.H_total.copy_(H)            # the recurrence lives inside the graph
             self._g_out, self._g_score = out, score
         self.H_total.copy_(H0)
-        self._capturing = False
 
     def track_new(self, fr_idx, img, gt_box=None, gt_poly=None, gt_points=None, sync: bool = True):
         if self.use_graph:
@@ -169,7 +158,8 @@ class HomoTracker:
                 out, homo_score = out.clone(), homo_score.clone()
         else:
             H, out, homo_score = self._body(FR.upload(img))
-            self.H_total = H
+            self.H_total.copy_(H)
+            out = out.clone()
         pts = out[:8].view(4, 2)
         self.last_points, self.last_score = pts, homo_score
         if not sync:

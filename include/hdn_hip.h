@@ -253,6 +253,30 @@ int hdn_similarity_logpolar_f32(const float* cls_lp, const float* loc_lp, const 
                                 int S, float stride_lp, double mag, float rot_unit, void* stream);
 
 /*
+ * The tracker's 3x3 float64 bookkeeping, one lane per sequence (BASELINE configs[3]): the numpy lines of
+ * hdnTrackerHomo.track_new either side of the networks, hdn/tracker/hdn_tracker_proj_e2e.py.
+ *
+ * hdn_track_prepare_f64 (:150-155): Ht = H_total, or the identity when det(H_total) == 0; Hinv = inv(Ht) = adj(Ht) / det(Ht)
+ * (closed form; the reference calls np.linalg.inv) — the matrix handed to cv2.warpPerspective, i.e. to
+ * hdn_frame_warp_perspective_u8.  H_total, Ht, Hinv: [B][9] row major; Ht may alias H_total.
+ *
+ * hdn_track_accumulate_f64 (:251-272): H_homo = inv(shift_H) @ (inv(scale_H_1) @ H_comp @ scale_H_1) @ shift_H;
+ * H = Ht @ H_sim if homo_score > gate else Ht @ H_sim @ H_homo; H *= 1 / H[8]; out = cv2.perspectiveTransform(init_points, H)
+ * (restated from OpenCV's published algorithm: double arithmetic on float32 points, multiplication by 1 / w, zeros when
+ * |w| <= DBL_EPSILON) followed by best_score.
+ *   consts[B][HDN_TRACK_CONST_DOUBLES]: [0..8] inv(scale_H_1) [9..17] scale_H_1 [18..26] inv(shift_H) [27..35] shift_H
+ *                                       [36] the gate (2.5 in the reference), rest unused
+ *   sim_state: the similarity record (HDN_SIM_STATE_DOUBLES per sequence; H_sim at [20..28], best_score at [5]) or NULL
+ *              (H_sim = identity, best_score = 0)
+ *   H_comp [B][9] float64 (hdn_refine_warp_f32's product), homo_score [B] float32, init_points [B][n_points][2] float64 (rounded to
+ *   float32 as the reference's .astype(np.float32) does), H_out [B][9] (may alias H_total, not Ht), out [B][2 * n_points + 1] float32.
+ */
+#define HDN_TRACK_CONST_DOUBLES 40
+int hdn_track_prepare_f64(const double* H_total, double* Ht, double* Hinv, int B, void* stream);
+int hdn_track_accumulate_f64(const double* Ht, const double* sim_state, const double* H_comp, const float* homo_score, const double* consts,
+                             const double* init_points, int n_points, double* H_out, float* out, int B, void* stream);
+
+/*
  * First stage of the homography regressor's trunk, fused:
  *   out = maxpool3x3/s2/p1( relu( conv7x7/s2/p3(x, w) + b ) ),  x [B,2,H,W] (NCHW) -> out [B,64,Hp,Wp],
  *   Hc = (H-1)/2 + 1, Hp = (Hc-1)/2 + 1 (127 -> 64 -> 32); 2 <= W <= 128 (else HDN_E_LIMIT).

@@ -134,6 +134,32 @@ class SimilarityOracle:
                 "rot_delta": lp["rot_delta"], "best_score": float(tr["best_score"]), "H_sim": H_sim}
 
 
+def track_prepare(H_total):
+    """hdn_tracker_proj_e2e.py:150-155: a singular H_total is reset to the identity; -> (H_total, the matrix handed to cv2.warpPerspective)."""
+    if np.linalg.det(H_total) == 0:
+        H_total = np.eye(3, dtype=np.float32)
+    return H_total, np.linalg.inv(H_total)
+
+
+def track_accumulate(H_total, H_sim, H_hm_comp, score, z_crop_points_sm, init_points, score_gate=2.5):
+    """hdn_tracker_proj_e2e.py:251-272: un-scale / un-shift the residual, gate it, accumulate, project the initial corners
+    (cv2.perspectiveTransform restated: double arithmetic on the float32 points, multiplied by 1 / w)."""
+    cw = z_crop_points_sm[2] - z_crop_points_sm[0] + 1
+    ch = z_crop_points_sm[3] - z_crop_points_sm[1] + 1
+    S = np.array([[127 / cw, 0, 0], [0, 127 / ch, 0], [0, 0, 1]]).astype(np.float32)
+    H_hm_comp = np.linalg.inv(S) @ H_hm_comp @ S
+    Sh = np.array([[1, 0, -z_crop_points_sm[0]], [0, 1, -z_crop_points_sm[1]], [0, 0, 1]]).astype(np.float32)
+    H_homo = np.linalg.inv(Sh) @ H_hm_comp @ Sh
+    H = H_total @ H_sim if float(score) > score_gate else H_total @ H_sim @ H_homo
+    H = (1.0 / H.item(8)) * H
+    q = np.asarray(init_points, np.float32).reshape(-1, 2).astype(np.float64)
+    w = q[:, 0] * H[2, 0] + q[:, 1] * H[2, 1] + H[2, 2]
+    ok = np.abs(w) > np.finfo(np.float64).eps
+    w = np.where(ok, 1.0 / np.where(ok, w, 1.0), 0.0)
+    pts = np.stack([(q[:, 0] * H[0, 0] + q[:, 1] * H[0, 1] + H[0, 2]) * w, (q[:, 0] * H[1, 0] + q[:, 1] * H[1, 1] + H[1, 2]) * w], 1)
+    return H, pts.astype(np.float32)
+
+
 class HomoTrackerOracle:
     def __init__(self, sf_sd: dict, regress, iterations: int = 1, score_gate: float = 2.5, similarity: SimilarityOracle = None):
         self.sf_sd, self.regress, self.iterations, self.score_gate = sf_sd, regress, iterations, score_gate
@@ -160,9 +186,8 @@ class HomoTrackerOracle:
         self.H_total = np.eye(3, dtype=np.float32)
 
     def track_new(self, fr_idx, img):
-        if np.linalg.det(self.H_total) == 0:
-            self.H_total = np.eye(3, dtype=np.float32)
-        img = F.warp_perspective_u8(img, np.linalg.inv(self.H_total))
+        self.H_total, H_inv = track_prepare(self.H_total)
+        img = F.warp_perspective_u8(img, H_inv)
         cx, cy = self.init_pos
         H_sim, scale_delta, best_score, sim = np.eye(3), 1.0, 0.0, None
         rot_img = img   # rot_delta = 0: img_rot_around_center is the bicubic identity
@@ -176,16 +201,6 @@ class HomoTrackerOracle:
         srch = torch.from_numpy(search).float().unsqueeze(0)
         with torch.no_grad():
             H_comp, score, _, _ = O.homo_refine(tmpl, srch, self.sf_sd, self.regress, self.iterations)
-        H_hm_comp = H_comp[0]
-        cw = self.z_crop_points_sm[2] - self.z_crop_points_sm[0] + 1
-        ch = self.z_crop_points_sm[3] - self.z_crop_points_sm[1] + 1
-        S = np.array([[127 / cw, 0, 0], [0, 127 / ch, 0], [0, 0, 1]]).astype(np.float32)
-        H_hm_comp = np.linalg.inv(S) @ H_hm_comp @ S
-        Sh = np.array([[1, 0, -self.z_crop_points_sm[0]], [0, 1, -self.z_crop_points_sm[1]], [0, 0, 1]]).astype(np.float32)
-        H_homo = np.linalg.inv(Sh) @ H_hm_comp @ Sh
-        H = self.H_total @ H_sim if float(score) > self.score_gate else self.H_total @ H_sim @ H_homo
-        H = (1.0 / H.item(8)) * H
+        H, pts = track_accumulate(self.H_total, H_sim, H_comp[0], score, self.z_crop_points_sm, self.init_points, self.score_gate)
         self.H_total = H
-        p = np.concatenate([self.init_points.astype(np.float64), np.ones((len(self.init_points), 1))], 1) @ H.T
-        pts = (p[:, :2] / p[:, 2:3]).astype(np.float32)
         return {"points": pts, "polygon": pts, "score": float(score), "best_score": best_score, "similarity": sim}

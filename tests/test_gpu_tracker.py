@@ -154,6 +154,56 @@ def test_similarity_decode_batch_and_errors(dev):
         dec.translation(T("cls").cpu(), T("loc_c").cpu(), seq_d, state)
 
 
+def test_track_bookkeeping_kernels_vs_restatement(dev):
+    """hdn_track_prepare_f64 / hdn_track_accumulate_f64 against oracle.tracker_oracle.track_prepare / track_accumulate
+    (hdn_tracker_proj_e2e.py:150-155, :251-272): several sequences per launch, a singular H_total, scores either side of the gate,
+    with and without a similarity record."""
+    from hdn_amd import _lib
+    from hdn_amd.similarity import STATE_DOUBLES
+    from hdn_amd.tracker import TRACK_CONST_DOUBLES
+    from oracle.tracker_oracle import track_accumulate, track_prepare
+    rng = np.random.default_rng(7)
+    B, n = 6, 4
+    Ht = np.eye(3)[None] + rng.normal(0, 0.05, (B, 3, 3)); Ht[:, 2, :2] *= 1e-3; Ht[:, :2, 2] *= 100
+    Ht[2] = 0.0; Ht[2, 0, 0] = 1.0                                     # singular -> identity
+    lib, st = _lib.load(), _lib.stream_ptr(dev)
+    d = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dt)
+    H_total, H_keep, H_inv = d(Ht), torch.empty((B, 9), dtype=torch.float64, device=dev), torch.empty((B, 9), dtype=torch.float64, device=dev)
+    _lib.check(lib.hdn_track_prepare_f64(_lib.ptr(H_total), _lib.ptr(H_keep), _lib.ptr(H_inv), B, st), "prepare")
+    prep = [track_prepare(Ht[b]) for b in range(B)]
+    for b in range(B):
+        np.testing.assert_array_equal(H_keep[b].cpu().numpy().reshape(3, 3), np.asarray(prep[b][0], np.float64))
+        np.testing.assert_allclose(H_inv[b].cpu().numpy().reshape(3, 3), prep[b][1], rtol=1e-11, atol=1e-13)
+    assert lib.hdn_track_prepare_f64(_lib.ptr(H_total), _lib.ptr(H_keep), _lib.ptr(H_total), B, st) == -4      # HDN_E_ALIAS
+    # accumulate
+    H_comp = np.eye(3)[None] + rng.normal(0, 0.02, (B, 3, 3)); H_comp[:, 2, :2] *= 1e-2
+    H_sim = np.eye(3)[None] + rng.normal(0, 0.03, (B, 3, 3)); H_sim[:, 2] = [0, 0, 1]; H_sim[:, :2, 2] *= 200
+    score = np.array([0.3, 2.4999, 2.5, 2.5001, 9.0, 1.0], np.float32)
+    zc = [np.array([100.0 + 3 * b, 50.0 + b, 300.0 + 5 * b, 180.0 + 2 * b]) for b in range(B)]
+    pts = rng.uniform(0, 700, (B, n, 2))
+    consts = np.zeros((B, TRACK_CONST_DOUBLES))
+    for b in range(B):
+        S = np.diag([127 / (zc[b][2] - zc[b][0] + 1), 127 / (zc[b][3] - zc[b][1] + 1), 1.0]).astype(np.float32)
+        Sh = np.array([[1, 0, -zc[b][0]], [0, 1, -zc[b][1]], [0, 0, 1]], np.float32)
+        consts[b, 0:9], consts[b, 9:18] = np.linalg.inv(S).reshape(-1), S.reshape(-1)
+        consts[b, 18:27], consts[b, 27:36], consts[b, 36] = np.linalg.inv(Sh).reshape(-1), Sh.reshape(-1), 2.5
+    state = np.zeros((B, STATE_DOUBLES)); state[:, 20:29] = H_sim.reshape(B, 9); state[:, 5] = rng.uniform(0, 1, B)
+    H_out, out = torch.empty((B, 9), dtype=torch.float64, device=dev), torch.empty((B, 2 * n + 1), dtype=torch.float32, device=dev)
+    for with_sim in (True, False):
+        keep = [d(state), d(H_comp), d(score, torch.float32), d(consts), d(pts)]   # (alive until the launch has run)
+        args = (_lib.ptr(H_keep), _lib.ptr(keep[0]) if with_sim else None, _lib.ptr(keep[1]), _lib.ptr(keep[2]), _lib.ptr(keep[3]), _lib.ptr(keep[4]))
+        _lib.check(lib.hdn_track_accumulate_f64(*args, n, _lib.ptr(H_out), _lib.ptr(out), B, st), "accumulate")
+        torch.cuda.synchronize()
+        for b in range(B):
+            H_ref, p_ref = track_accumulate(np.asarray(prep[b][0], np.float64), H_sim[b] if with_sim else np.eye(3), H_comp[b], score[b], zc[b],
+                                            pts[b], 2.5)
+            np.testing.assert_allclose(H_out[b].cpu().numpy().reshape(3, 3), H_ref, rtol=1e-12, atol=1e-12 * np.abs(H_ref).max())
+            got = out[b].cpu().numpy()
+            np.testing.assert_allclose(got[:2 * n].reshape(n, 2), p_ref, rtol=3e-7, atol=1e-4)
+            assert got[2 * n] == (np.float32(state[b, 5]) if with_sim else 0.0)
+    assert lib.hdn_track_accumulate_f64(None, None, None, None, None, None, n, None, None, B, st) != 0
+
+
 def _similarity_pair(dev, fc_bias_scale=1.0, **standin_kw):
     import standin_model as SM
     from test_gpu_parity import _seeded_net
