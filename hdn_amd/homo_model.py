@@ -123,22 +123,34 @@ class HomoModelBuilder(nn.Module):
     def forward(self, data):
         """Inference-mode forward with the reference's output keys (homo_model_builder.py:212-215).
 
-        if_pos / if_unsup / search_window follow the reference's defaults (all ones; the 'search_windowx'
-        typo at :122 means the window is always ones there too).  The negative-sample branch (if_pos == 0)
-        is training-only and not implemented.
+        if_pos / if_unsup default to ones as in the reference (:125-132; the 'search_windowx' typo at :122 means the window is
+        always ones there too).  With per-sample flags (the training set's, unconstrained_v2_dataset.py:310-312) the
+        negative-sample branch (:172-205) runs: the triplet term over the samples with if_pos * if_unsup == 1 only, normalised
+        by their count, and homo_neg_loss = mean L2 norm of the predicted offsets of the if_pos == 0 samples.  Losses are
+        computed without autograd (this package is the inference path).
         """
-        if "if_pos" in data and bool((data["if_pos"] == 0).any()):
-            raise NotImplementedError("negative samples (if_pos == 0) are a training-only branch")
         st = homo_stages(self, data)
         p1, p2, pf, pred, x = st["patch_1"], st["patch_2"], st["pred_feat"], st["pred_I2"], st["x"]
         B = x.shape[0]
+        homo_neg_loss = torch.zeros((), device=x.device)
         with torch.no_grad():
+            n_pos = B * p1.shape[2] * p1.shape[3]          # default flags [B,1,127,127] of ones: nonzero() has one row per pixel
+            if "if_pos" in data or "if_unsup" in data:
+                ones = torch.ones((B, 1, 127, 127), dtype=torch.float32, device=x.device)
+                if_pos, if_unsup = data.get("if_pos", ones).to(x.device), data.get("if_unsup", ones).to(x.device)
+                neg_ids = if_pos.eq(0).nonzero().squeeze(1)
+                pos_ids = (if_pos * if_unsup).eq(1).nonzero().squeeze(1)
+                n_pos = pos_ids.shape[0]
+                if neg_ids.shape[0] != 0:
+                    p1, p2, pf = p1[pos_ids], p2[pos_ids], pf[pos_ids]
+                    homo_neg_loss = torch.sum(torch.norm(x[neg_ids, :], p=2, dim=1)) / neg_ids.shape[0]
             # TripletMarginLoss(margin=1, p=1, reduce=False): pairwise L1 over the last dim, eps 1e-6
             d_ap = ((p2 - pf) + 1e-6).abs().sum(-1)
             d_an = ((p2 - p1) + 1e-6).abs().sum(-1)
             loss_mat = (d_ap - d_an + 1.0).clamp_min(0.0)
-            n_pos = B * p1.shape[2] * p1.shape[3]
             feature_loss = (loss_mat.sum() / n_pos / (127 * 127)).reshape(1)
+        p2 = st["patch_2"]
+        pf = st["pred_feat"]
         return {
             "feature_loss": feature_loss,
             "pred_I2_d": pred[:1],
@@ -146,5 +158,5 @@ class HomoModelBuilder(nn.Module):
             "H_mat": st["H_mat"],
             "patch_2_res_d": p2[:1],
             "pred_I2_CnnFeature_d": pf[:1],
-            "homo_neg_loss": torch.zeros((), device=x.device),
+            "homo_neg_loss": homo_neg_loss,
         }

@@ -338,6 +338,31 @@ def gen_homo_model(ref_hmb, ref_gi):
         fc_b=m.fc.bias.data.numpy(),
         **sf,
     )
+    # the negative-sample branch (homo_model_builder.py:172-205): per-sample if_pos / if_unsup flags as the training set hands
+    # them over (hdn/datasets/dataset/unconstrained_v2_dataset.py:310-312,401-404), B = 3 = the two pairs above + their swap
+    idx = [0, 1, 0]
+    data3 = {k: v[idx].clone() for k, v in data.items()}
+    data3["input_tensors"][2] = data3["input_tensors"][2].flip(0)
+    data3["org_imgs"][2] = data3["org_imgs"][2].flip(0)
+    flags = {"if_pos": torch.tensor([1.0, 0.0, 1.0]), "if_unsup": torch.tensor([1.0, 1.0, 0.0])}
+    with torch.no_grad():
+        out3 = m({**data3, **flags})
+        out3b = m({**data3, "if_pos": torch.tensor([0.0, 1.0, 1.0]), "if_unsup": torch.ones(3)})
+    save(
+        "homo_forward_neg",
+        org_imgs=data3["org_imgs"].numpy(),
+        input_tensors=data3["input_tensors"].numpy(),
+        patch_indices=data3["patch_indices"].numpy(),
+        h4p=data3["h4p"].numpy(),
+        if_pos=flags["if_pos"].numpy(),
+        if_unsup=flags["if_unsup"].numpy(),
+        x=out3["x"].numpy(),
+        H_mat=out3["H_mat"].numpy(),
+        feature_loss=out3["feature_loss"].numpy(),
+        homo_neg_loss=np.array(float(out3["homo_neg_loss"])),
+        feature_loss_b=out3b["feature_loss"].numpy(),
+        homo_neg_loss_b=np.array(float(out3b["homo_neg_loss"])),
+    )
     return m, data
 
 
@@ -626,7 +651,7 @@ def main():
         gen_dlt(ref_utils)
     if want("transform", "transformer"):
         gen_transform(ref_utils)
-    if want("homo_forward", "track_proj"):
+    if want("homo_forward", "homo_forward_neg", "track_proj"):
         hm_seeded, hm_data = gen_homo_model(ref_hmb, ref_gi)
         import hdn.models.model_builder_e2e_unconstrained_v2 as ref_mb
         gen_track_proj(ref_mb, hm_seeded, hm_data)

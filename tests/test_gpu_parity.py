@@ -761,6 +761,33 @@ def test_homo_forward_golden_post_trunk(dev):
     assert float(out["homo_neg_loss"]) == 0.0
 
 
+def test_homo_forward_negative_sample_branch_golden(dev):
+    """HomoModelBuilder.forward with per-sample if_pos / if_unsup flags (homo_model_builder.py:172-205): feature_loss over the
+    positive unsupervised samples only, homo_neg_loss over the negatives, against the reference's own output
+    (tests/golden/homo_forward_neg.npz; trunk output injected)."""
+    g, gn = load_golden("homo_forward"), load_golden("homo_forward_neg")
+    net = hdn_amd.HomoModelBuilder().eval()
+    net.ShareFeature.load_state_dict(share_sd(g, "sf__"))
+    net = net.to(dev)
+    xfix = T(gn["x"]).to(dev)
+    net.fc = torch.nn.Identity()
+    net.avgpool = torch.nn.Identity()
+
+    class Inject(torch.nn.Module):
+        def forward(self, feats):
+            return xfix
+
+    net.backbone = Inject()
+    data = {k: T(gn[k]).to(dev) for k in ("org_imgs", "input_tensors", "h4p", "patch_indices")}
+    out = net({**data, "if_pos": T(gn["if_pos"]).to(dev), "if_unsup": T(gn["if_unsup"]).to(dev)})
+    np.testing.assert_allclose(out["H_mat"].cpu().numpy(), gn["H_mat"], atol=1e-5)
+    np.testing.assert_allclose(out["feature_loss"].cpu().numpy(), gn["feature_loss"], rtol=1e-3, atol=1e-8)
+    np.testing.assert_allclose(float(out["homo_neg_loss"]), float(gn["homo_neg_loss"]), rtol=1e-6)
+    out = net({**data, "if_pos": torch.tensor([0.0, 1.0, 1.0], device=dev), "if_unsup": torch.ones(3, device=dev)})
+    np.testing.assert_allclose(out["feature_loss"].cpu().numpy(), gn["feature_loss_b"], rtol=1e-3, atol=1e-8)
+    np.testing.assert_allclose(float(out["homo_neg_loss"]), float(gn["homo_neg_loss_b"]), rtol=1e-6)
+
+
 def test_track_proj_golden_tuple(dev):
     """(H_mat, similarity_norm, similarity_norm_simi) against the tuple the reference's ModelBuilder.track_proj returned
     (tests/golden/track_proj.npz; trunk output injected), in both batch orders: the scores read sample 0 only."""
