@@ -69,8 +69,9 @@ def parse():
     ap.add_argument("--no-breakdown", action="store_true", help="skip the per-kernel breakdown after the timed region")
     ap.add_argument("--no-full-head", action="store_true", help="skip the full_head block (configs[2] per-GPU workload)")
     ap.add_argument("--full-head-steps", type=int, default=30)
-    ap.add_argument("--collective", choices=["c_abi", "torch"], default="c_abi",
-                    help="N > 1: hdn_allgather_offsets of the C ABI (default) or torch.distributed.all_gather_into_tensor")
+    ap.add_argument("--collective", choices=["c_abi", "torch", "oneshot"], default="c_abi",
+                    help="N > 1: hdn_allgather_offsets of the C ABI on RCCL (default), torch.distributed.all_gather_into_tensor, or the "
+                         "direct-write hdn_gather_offsets_oneshot (hipIpc windows; validated on one device only)")
     ap.add_argument("--only-north", action="store_true", help="step = the north-star correlation only (profiling aid)")
     ap.add_argument("--head-stream", choices=["inline", "after-north", "parallel"], default="parallel",
                     help="where the homography head runs in the TIMED region: in line with the correlations; on its own stream beside "
@@ -154,6 +155,8 @@ def main():
     comm = None
     if world > 1 and not one_device and args.collective == "c_abi":
         comm = hdist.RcclComm.from_process_group(dev)
+    elif world > 1 and args.collective == "oneshot":     # (works between processes sharing a device too)
+        comm = hdist.OneShotGather.from_process_group(PAIRS, dev)
     from hdn_amd import homography as G
     from hdn_amd import share_feature as SF
     from hdn_amd import xcorr as X
@@ -330,7 +333,7 @@ def main():
             "workload": ("north-star correlation only" if args.only_north else
                          "BASELINE configs[1]: batch=64 synthetic 127/255 pairs per GPU, 256-ch features; HIP kernels only: "
                          "1x xcorr 31x31(x)61x61 + 6x xcorr 5x5(x)29x29 + 6x circular xcorr 13x13(x)13x13 + "
-                         "3x PreShareFeature 127x127 + fused DLT/warp + the 2 L1 scores (one launch)" + (" + RCCL all-gather of [64,8] offsets" if world > 1 else "")),
+                         "3x PreShareFeature 127x127 + fused DLT/warp + the 2 L1 scores (one launch)" + ((" + direct-write all-gather of [64,8] offsets (hdn_gather_offsets_oneshot)" if args.collective == "oneshot" else " + RCCL all-gather of [64,8] offsets") if world > 1 else "")),
             "pairs_per_gpu": PAIRS,
             "channels": C,
             "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective except the offsets all-gather",

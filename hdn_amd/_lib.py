@@ -58,6 +58,12 @@ SIGNATURES = {
     "hdn_rccl_unique_id": (_i, [ctypes.c_void_p]),
     "hdn_rccl_comm_create": (_i, [ctypes.POINTER(ctypes.c_void_p), _i, _i, ctypes.c_void_p]),
     "hdn_rccl_comm_destroy": (_i, [ctypes.c_void_p]),
+    "hdn_gather_create": (_i, [ctypes.POINTER(ctypes.c_void_p), _i, _i, ctypes.c_longlong]),
+    "hdn_gather_handle": (_i, [ctypes.c_void_p, ctypes.c_void_p]),
+    "hdn_gather_connect": (_i, [ctypes.c_void_p, ctypes.c_void_p]),
+    "hdn_gather_offsets_oneshot": (_i, [ctypes.c_void_p, _c_float_p, _c_float_p, _i, ctypes.c_void_p]),
+    "hdn_gather_status": (_i, [ctypes.c_void_p]),
+    "hdn_gather_destroy": (_i, [ctypes.c_void_p]),
     "hdn_logpolar_sample_f32": (_i, [_c_float_p] * 7 + [_i] * 5 + [ctypes.c_void_p]),
 }
 

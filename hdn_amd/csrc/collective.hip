@@ -59,6 +59,81 @@ const Rccl& rccl() {
 }
 
 inline int rccl_status(ncclResult_t e) { return e == 0 ? HDN_OK : -(2000 + (int)e); }
+inline int hip_status(hipError_t e) { return e == hipSuccess ? HDN_OK : -(1000 + (int)e); }
+
+// ---- one-shot direct-write gather --------------------------------------------------------------------------------------------
+// A ring (or any RCCL algorithm) pays several hops and a proxy hand-off for a payload of 2 KB per rank; on a fully connected
+// xGMI node every rank can instead STORE its slice straight into every peer's window and raise a flag there: one kernel per
+// rank, one hop, no host thread in the data path.  Each rank owns a window of uncached device memory, exported by
+// hipIpcGetMemHandle and mapped by the peers:
+//
+//   [ control: epoch, done, pad ]  [ flags[2][world] (u64) ]  [ slots[2][world][slot_bytes] ]
+//
+// Call e (device-resident counter, so a hipGraph replay is a valid call) uses parity e & 1.  Workgroup p of rank r: store the
+// local slice into peer p's slots[parity][r], release-store e into peer p's flags[parity][r]; spin (acquire, system scope)
+// on the own flags[parity][p] until it holds e, copy the own slots[parity][p] to the output.  Two parities suffice: a rank
+// reaches call e + 2 only after every peer raised its flag for e + 1, which a peer does after its call e has left the stream.
+constexpr int kGatherMaxWorld = 16;
+constexpr unsigned long long kGatherSpinLimit = 200000000ull;   // 2 s of the 100 MHz wall clock, then status |= 1 and give up
+
+struct GatherPeers {
+  char* win[kGatherMaxWorld];
+};
+
+struct GatherCtx {
+  int world = 0, rank = 0, device = 0;
+  size_t slot_bytes = 0, window_bytes = 0;
+  char* window = nullptr;              // own window (device, uncached)
+  GatherPeers peers{};                 // [rank] = window, others = hipIpcOpenMemHandle mappings
+  bool connected = false;
+  unsigned* status = nullptr;          // pinned host word the kernel ORs error bits into
+};
+
+__host__ __device__ inline size_t gather_flags_off() { return 64; }
+__host__ __device__ inline size_t gather_slots_off(int world) { return 64 + round_up(2 * world * 8, 64); }
+
+__global__ __launch_bounds__(HDN_BLOCK) void gather_oneshot_kernel(const float4* __restrict__ local, float4* __restrict__ all, GatherPeers peers,
+                                                                   int world, int rank, int n16, unsigned long long slot_bytes,
+                                                                   unsigned* status) {
+  const int p = blockIdx.x, tid = threadIdx.x;
+  char* mine = peers.win[rank];
+  unsigned long long* ctl = reinterpret_cast<unsigned long long*>(mine);
+  const unsigned long long epoch = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;   // the same for every workgroup
+  const int parity = (int)(epoch & 1);
+  // push
+  char* theirs = peers.win[p];
+  float4* dst = reinterpret_cast<float4*>(theirs + gather_slots_off(world) + (size_t(parity) * world + rank) * slot_bytes);
+  for (int i = tid; i < n16; i += HDN_BLOCK) dst[i] = local[i];
+  __atomic_thread_fence(__ATOMIC_RELEASE);   // (clang: system scope)
+  __syncthreads();
+  if (tid == 0) {
+    unsigned long long* f = reinterpret_cast<unsigned long long*>(theirs + gather_flags_off()) + (parity * world + rank);
+    __hip_atomic_store(f, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // wait for peer p's slice in the own window
+    unsigned long long* g = reinterpret_cast<unsigned long long*>(mine + gather_flags_off()) + (parity * world + p);
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(g, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+      if (wall_clock64() - t0 > kGatherSpinLimit) {
+        __hip_atomic_fetch_or(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  __syncthreads();
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  const float4* src = reinterpret_cast<const float4*>(mine + gather_slots_off(world) + (size_t(parity) * world + p) * slot_bytes);
+  for (int i = tid; i < n16; i += HDN_BLOCK) all[size_t(p) * n16 + i] = src[i];
+  // the last workgroup to finish publishes the epoch for the next call (stream order makes it visible to that launch)
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned long long d = __hip_atomic_fetch_add(ctl + 1, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (d + 1 == (unsigned long long)world) {
+      __hip_atomic_store(ctl + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ctl, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
 
 }  // namespace
 }  // namespace hdn
@@ -110,6 +185,98 @@ int hdn_allgather_offsets(const float* local, float* all, int Bl, void* rccl_com
   const float* mine = all + (size_t)rank * Bl * 8;
   if (local != mine && local < all + (size_t)world * Bl * 8 && all < local + (size_t)Bl * 8) return HDN_E_ALIAS;
   return hdn::rccl_status(r.AllGather(local, all, (size_t)Bl * 8, hdn::kNcclFloat32, c, static_cast<hipStream_t>(stream)));
+}
+
+
+int hdn_gather_create(void** ctx_out, int world, int rank, long long slot_bytes) {
+  if (!ctx_out) return HDN_E_NULL;
+  if (world <= 0 || rank < 0 || rank >= world || slot_bytes <= 0 || slot_bytes % 16 != 0) return HDN_E_SHAPE;
+  if (world > hdn::kGatherMaxWorld || slot_bytes > (1ll << 26)) return HDN_E_LIMIT;
+  hdn::GatherCtx* c = new hdn::GatherCtx;
+  c->world = world; c->rank = rank; c->slot_bytes = (size_t)slot_bytes;
+  (void)hipGetDevice(&c->device);
+  c->window_bytes = hdn::gather_slots_off(world) + 2 * (size_t)world * c->slot_bytes;
+  hipError_t e = hipExtMallocWithFlags(reinterpret_cast<void**>(&c->window), c->window_bytes, hipDeviceMallocUncached);
+  if (e == hipSuccess) e = hipMemset(c->window, 0, c->window_bytes);
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->status), sizeof(unsigned), hipHostMallocMapped);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) {
+    if (c->window) (void)hipFree(c->window);
+    if (c->status) (void)hipHostFree(c->status);
+    delete c;
+    return hdn::hip_status(e);
+  }
+  *c->status = 0;
+  c->peers.win[rank] = c->window;
+  *ctx_out = c;
+  return HDN_OK;
+}
+
+int hdn_gather_handle(void* ctx, void* handle64) {
+  if (!ctx || !handle64) return HDN_E_NULL;
+  hdn::GatherCtx* c = static_cast<hdn::GatherCtx*>(ctx);
+  static_assert(sizeof(hipIpcMemHandle_t) == HDN_IPC_HANDLE_BYTES, "hipIpcMemHandle_t is 64 bytes");
+  hipIpcMemHandle_t h;
+  const hipError_t e = hipIpcGetMemHandle(&h, c->window);
+  if (e != hipSuccess) return hdn::hip_status(e);
+  memcpy(handle64, &h, sizeof h);
+  return HDN_OK;
+}
+
+int hdn_gather_connect(void* ctx, const void* handles) {
+  if (!ctx || !handles) return HDN_E_NULL;
+  hdn::GatherCtx* c = static_cast<hdn::GatherCtx*>(ctx);
+  if (c->connected) return HDN_E_SHAPE;
+  for (int p = 0; p < c->world; ++p) {
+    if (p == c->rank) continue;
+    hipIpcMemHandle_t h;
+    memcpy(&h, static_cast<const char*>(handles) + (size_t)p * HDN_IPC_HANDLE_BYTES, sizeof h);
+    void* ptr = nullptr;
+    const hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      for (int q = 0; q < p; ++q)
+        if (q != c->rank && c->peers.win[q]) { (void)hipIpcCloseMemHandle(c->peers.win[q]); c->peers.win[q] = nullptr; }
+      return hdn::hip_status(e);
+    }
+    c->peers.win[p] = static_cast<char*>(ptr);
+  }
+  c->connected = true;
+  return HDN_OK;
+}
+
+int hdn_gather_offsets_oneshot(void* ctx, const float* local, float* all, int Bl, void* stream) {
+  if (!ctx || !local || !all) return HDN_E_NULL;
+  hdn::GatherCtx* c = static_cast<hdn::GatherCtx*>(ctx);
+  if (Bl <= 0 || !c->connected) return HDN_E_SHAPE;
+  const size_t bytes = (size_t)Bl * 8 * sizeof(float);
+  if (bytes > c->slot_bytes) return HDN_E_LIMIT;
+  if (!hdn::aligned16(local) || !hdn::aligned16(all)) return HDN_E_SHAPE;
+  if (local < all + (size_t)c->world * Bl * 8 && all < local + (size_t)Bl * 8) return HDN_E_ALIAS;
+  hipLaunchKernelGGL(hdn::gather_oneshot_kernel, dim3(c->world), dim3(HDN_BLOCK), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const float4*>(local), reinterpret_cast<float4*>(all), c->peers, c->world, c->rank, (int)(bytes / 16),
+                     (unsigned long long)c->slot_bytes, c->status);
+  return hdn::launch_status();
+}
+
+int hdn_gather_status(void* ctx) {
+  if (!ctx) return HDN_E_NULL;
+  return (int)__atomic_load_n(static_cast<hdn::GatherCtx*>(ctx)->status, __ATOMIC_ACQUIRE);
+}
+
+int hdn_gather_destroy(void* ctx) {
+  if (!ctx) return HDN_E_NULL;
+  hdn::GatherCtx* c = static_cast<hdn::GatherCtx*>(ctx);
+  hipError_t e = hipSuccess;
+  for (int p = 0; p < c->world; ++p)
+    if (p != c->rank && c->peers.win[p]) {
+      const hipError_t e2 = hipIpcCloseMemHandle(c->peers.win[p]);
+      if (e == hipSuccess) e = e2;
+    }
+  const hipError_t e3 = hipFree(c->window);
+  if (e == hipSuccess) e = e3;
+  (void)hipHostFree(c->status);
+  delete c;
+  return hdn::hip_status(e);
 }
 
 }  // extern "C"

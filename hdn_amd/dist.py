@@ -83,12 +83,78 @@ class RcclComm:
                 _lib.check(_lib.load().hdn_rccl_comm_destroy(h), "hdn_rccl_comm_destroy")
 
 
-def all_gather_offsets(x_local: torch.Tensor, n_pairs: int = None, group=None, comm: RcclComm = None,
+class OneShotGather:
+    """The same exchange without RCCL: a direct-write gather through hipIpc-mapped windows (hdn_gather_* of the C ABI,
+    include/hdn_hip.h) — one kernel per rank, one xGMI hop, no host state per call (capturable in a hipGraph).  For the 2 KB per
+    rank of this path a ring's hops and proxy hand-offs are all latency; SURVEY.md §5 asks for exactly this form.
+
+    OneShotGather.from_process_group(max_rows, device) exchanges the 64-byte window handles over an initialised
+    torch.distributed group (any backend); OneShotGather(world, rank, max_rows, exchange=...) over anything else, where
+    exchange(my_handle: bytes) -> list of every rank's handle in rank order.  Drop-in for RcclComm in all_gather_offsets /
+    sharded_offsets (`comm=`).  Needs every pair of ranks to have peer access (one xGMI node)."""
+
+    def __init__(self, world: int, rank: int, max_rows: int, exchange, device=None):
+        self.world, self.rank, self.max_rows = int(world), int(rank), int(max_rows)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        h = ctypes.c_void_p()
+        lib = _lib.load()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.hdn_gather_create(ctypes.byref(h), self.world, self.rank, self.max_rows * 32), "hdn_gather_create")
+            self._h = h
+            mine = ctypes.create_string_buffer(64)
+            _lib.check(lib.hdn_gather_handle(h, mine), "hdn_gather_handle")
+            handles = exchange(mine.raw)
+            if len(handles) != self.world or any(len(x) != 64 for x in handles):
+                raise ValueError("exchange() must return one 64-byte handle per rank")
+            _lib.check(lib.hdn_gather_connect(h, ctypes.c_char_p(b"".join(handles))), "hdn_gather_connect")
+
+    @classmethod
+    def from_process_group(cls, max_rows: int, device=None, group=None):
+        if dist.is_available() and dist.is_initialized():
+            world, rank = dist.get_world_size(group), dist.get_rank(group)
+
+            def exchange(mine):
+                box = [None] * world
+                dist.all_gather_object(box, mine, group=group)
+                return box
+        else:
+            world, rank, exchange = 1, 0, (lambda mine: [mine])
+        return cls(world, rank, max_rows, exchange, device)
+
+    def all_gather(self, local: torch.Tensor) -> torch.Tensor:
+        """local [Bl, 8] on this object's device -> [world * Bl, 8]; asynchronous on torch's current stream."""
+        dev = _lib.require_device(local)
+        if dev != self.device:
+            raise _lib.HdnHipError(f"gather window bound to {self.device}, tensor on {dev}")
+        if local.dim() != 2 or local.shape[1] != 8 or local.shape[0] == 0 or local.shape[0] > self.max_rows:
+            raise ValueError(f"expected [1..{self.max_rows}, 8] corner offsets, got {tuple(local.shape)}")
+        if self._h is None:
+            raise _lib.HdnHipError("gather window destroyed")
+        loc = local.detach().to(torch.float32).contiguous()
+        out = torch.empty((self.world * loc.shape[0], 8), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.load().hdn_gather_offsets_oneshot(self._h, _lib.ptr(loc), _lib.ptr(out), loc.shape[0], _lib.stream_ptr(dev))
+        _lib.check(rc, "hdn_gather_offsets_oneshot")
+        return out
+
+    def status(self) -> int:
+        """0, or non-zero once a call gave up waiting for a peer (read it after the stream has drained)."""
+        return int(_lib.load().hdn_gather_status(self._h)) if self._h is not None else 0
+
+    def destroy(self):
+        if self._h is not None:
+            h, self._h = self._h, None
+            with torch.cuda.device(self.device):
+                _lib.check(_lib.load().hdn_gather_destroy(h), "hdn_gather_destroy")
+
+
+def all_gather_offsets(x_local: torch.Tensor, n_pairs: int = None, group=None, comm=None,
                        always_collective: bool = False) -> torch.Tensor:
     """Gather every rank's [B_local, 8] offsets into [n_pairs, 8] on every rank, in pair order.
 
     Equal shards are one all-gather; ragged shards (n_pairs % world != 0) pad to the largest shard so that it is
-    still a single collective.  With `comm` the collective is hdn_allgather_offsets of the C ABI (RCCL directly);
+    still a single collective.  With `comm` (an RcclComm or a OneShotGather) the collective is the C ABI's (hdn_allgather_offsets on RCCL, or the
+    direct-write hdn_gather_offsets_oneshot);
     otherwise torch.distributed's all_gather_into_tensor on `group` (backend "nccl" = RCCL on ROCm, "gloo" in the
     CPU tests).  A world of one returns x_local unless `always_collective` (tests: run RCCL on a one-GPU box).
     """
@@ -130,7 +196,7 @@ def all_gather_offsets(x_local: torch.Tensor, n_pairs: int = None, group=None, c
     return torch.cat([out[r * cap: r * cap + (e - s)] for r, (s, e) in enumerate(sizes)], dim=0)
 
 
-def sharded_offsets(net, data: dict, group=None, comm: RcclComm = None, always_collective: bool = False) -> torch.Tensor:
+def sharded_offsets(net, data: dict, group=None, comm=None, always_collective: bool = False) -> torch.Tensor:
     """Run the homography head on this rank's shard of `data` (dict of [B, ...] tensors, all ranks hold
     the same global batch) and return the gathered [B, 8] corner offsets."""
     from .homo_model import homo_stages

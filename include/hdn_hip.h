@@ -350,6 +350,30 @@ int hdn_rccl_unique_id(void* id128);
 int hdn_rccl_comm_create(void** comm_out, int world, int rank, const void* id128);
 int hdn_rccl_comm_destroy(void* comm);
 
+/*
+ * The same exchange as ONE kernel per rank and one xGMI hop, for a fully connected node (for 2 KB per rank a
+ * direct one-shot gather beats a ring): every rank owns a window of uncached device memory that its peers map through
+ * hipIpc handles; a call stores the local slice straight into every peer's window, raises a flag there, waits for the peers'
+ * flags in its own window and copies the slices out.  No RCCL, no host thread in the data path, no host state per call
+ * (the call counter lives in the window), so the launch can sit inside a hipGraph.
+ *   hdn_gather_create   window on the CURRENT device: world <= 16 ranks, slot_bytes (multiple of 16) = the largest local slice
+ *   hdn_gather_handle   this rank's 64-byte hipIpcMemHandle_t; ship all of them to all ranks (any means), in rank order
+ *   hdn_gather_connect  maps the peers' windows (handles[world][64]; the own entry is ignored); collective, once
+ *   hdn_gather_offsets_oneshot  local[Bl,8] -> all[world*Bl,8], same contract as hdn_allgather_offsets (Bl equal on all ranks,
+ *                       Bl*32 <= slot_bytes, 16-byte aligned pointers, no overlap); asynchronous on `stream`.  A peer that does
+ *                       not show up within 2 s makes the kernel give up: hdn_gather_status() != 0 after the stream has drained.
+ *   hdn_gather_destroy  unmaps and frees; the peers must have stopped calling.
+ * Every rank must make the same sequence of calls.  Validated with two processes sharing one device (tests/test_gpu_dist.py);
+ * across devices it needs peer access over xGMI (hipIpcMemLazyEnablePeerAccess) and has not been run.
+ */
+#define HDN_IPC_HANDLE_BYTES 64
+int hdn_gather_create(void** ctx_out, int world, int rank, long long slot_bytes);
+int hdn_gather_handle(void* ctx, void* handle64);
+int hdn_gather_connect(void* ctx, const void* handles);
+int hdn_gather_offsets_oneshot(void* ctx, const float* local, float* all, int Bl, void* stream);
+int hdn_gather_status(void* ctx);
+int hdn_gather_destroy(void* ctx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -149,7 +149,7 @@ def test_sharded_offsets_two_ranks_on_one_gpu(dev, pairs):
     assert res == {0: ok, 1: ok}, "\n----\n".join(o[-2000:] for o in outs)
 
 
-@pytest.mark.parametrize("workload", ["full", "kernels"])
+@pytest.mark.parametrize("workload", ["full", "kernels", "kernels-oneshot"])
 def test_bench_two_ranks_one_device_json_contract(dev, workload):
     """bench.py's N > 1 path (`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...`) on the one-GPU box:
     HDN_BENCH_ONE_DEVICE=1 puts both ranks on GPU 0 over gloo (RCCL refuses two ranks on a device).  Rank 0 prints ONE JSON
@@ -162,6 +162,8 @@ def test_bench_two_ranks_one_device_json_contract(dev, workload):
            "--no-cpu-baseline", "--no-breakdown", "--no-full-head", "--roofline-steps", "2"]
     if workload == "full":
         cmd += ["--workload", "full"]
+    if workload == "kernels-oneshot":      # the exchange as the direct-write gather between the two processes
+        cmd += ["--collective", "oneshot"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-3000:]
@@ -172,5 +174,97 @@ def test_bench_two_ranks_one_device_json_contract(dev, workload):
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["unit"] == "frames/s" and d["dtype"] == "f32"
     assert abs(d["value"] - 2 * 64 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]      # whole-job aggregate over both ranks
     assert "workload" in d["config"] and "model" not in d["config"]
-    if workload == "kernels":
+    if workload.startswith("kernels"):
         assert "roofline" in d and d["roofline"]["bound"] == "hbm" and "all-gather" in d["config"]["workload"]
+        assert ("hdn_gather_offsets_oneshot" in d["config"]["workload"]) == (workload == "kernels-oneshot")
+
+
+def test_oneshot_gather_world_of_one(dev):
+    """hdn_gather_* on a single rank: the kernel pushes into its own window; argument errors come back as HDN_E_*."""
+    from hdn_amd import _lib
+    from hdn_amd import dist as hdist
+    g = hdist.OneShotGather.from_process_group(64, dev)
+    try:
+        for Bl in (64, 1, 17, 64):
+            x = torch.randn(Bl, 8, device=dev)
+            y = g.all_gather(x)
+            torch.cuda.synchronize()
+            assert torch.equal(y, x) and g.status() == 0
+        z = hdist.all_gather_offsets(x, 64, comm=g, always_collective=True)
+        assert torch.equal(z, x)
+        with pytest.raises(ValueError):
+            g.all_gather(torch.zeros(65, 8, device=dev))
+        buf = torch.zeros(16, 8, device=dev)
+        assert _lib.load().hdn_gather_offsets_oneshot(g._h, _lib.ptr(buf), _lib.ptr(buf), 16, _lib.stream_ptr(dev)) == -4
+    finally:
+        g.destroy()
+    with pytest.raises(_lib.HdnHipError):
+        g.all_gather(torch.zeros(4, 8, device=dev))
+
+
+_ONESHOT_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+from hdn_amd import dist as hdist
+g = hdist.OneShotGather.from_process_group(64, dev)
+def rows(it, r, Bl):
+    return torch.randn(Bl, 8, generator=torch.Generator().manual_seed(1000 * it + r))
+res = {"eager": True, "graph": True, "ragged": True}
+for it, Bl in enumerate([64, 1, 33, 64, 64, 7, 64, 64]):            # more calls than parities, sizes changing between calls
+    out = g.all_gather(rows(it, rank, Bl).to(dev))
+    torch.cuda.synchronize()
+    res["eager"] &= bool(torch.equal(out.cpu(), torch.cat([rows(it, r, Bl) for r in range(world)])))
+# ragged shards through the wrapper (pads to the largest shard, one call)
+n = 2 * 20 + 1
+s, e = hdist.shard_range(n, rank, world)
+full = rows(77, 0, n)
+got = hdist.all_gather_offsets(full[s:e].to(dev), n, comm=g, always_collective=True)
+torch.cuda.synchronize()
+res["ragged"] = bool(torch.equal(got.cpu(), full))
+# the launch inside a hipGraph: the call counter lives in the window, so a replay is a valid call
+static = torch.zeros(32, 8, device=dev)
+torch.cuda.synchronize(); dist.barrier()
+graph = torch.cuda.CUDAGraph()
+with torch.cuda.graph(graph):
+    gout = g.all_gather(static)
+for it in range(3):
+    static.copy_(rows(200 + it, rank, 32).to(dev))
+    graph.replay()
+    torch.cuda.synchronize()
+    res["graph"] &= bool(torch.equal(gout.cpu(), torch.cat([rows(200 + it, r, 32) for r in range(world)])))
+res["status"] = g.status()
+dist.barrier()
+g.destroy()
+print("RESULT", rank, json.dumps(res), flush=True)
+dist.destroy_process_group()
+"""
+
+
+def test_oneshot_gather_two_processes_one_device(dev):
+    """The direct-write gather between two PROCESSES (hipIpc-mapped windows, flags, parities), both on GPU 0 — the only peer
+    topology a one-GPU box offers; across devices the same code needs xGMI peer access and is unmeasured."""
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", _ONESHOT_WORKER % {"root": ROOT}], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+            o += "\nTIMEOUT"
+        outs.append(o)
+    res = _results(outs)
+    assert set(res) == {0, 1}, "\n".join(outs)
+    for r in (0, 1):
+        assert res[r] == {"eager": True, "graph": True, "ragged": True, "status": 0}, (res, outs[r][-2000:])
