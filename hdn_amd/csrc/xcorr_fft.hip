@@ -625,8 +625,14 @@ NF_DEV constexpr int bfly_mode(int s, int x, int h) {
 
 // In-register radix-2 DIT FFT of 2^LOGN points, direction SIGN.  Entry: v[p] = input bitrev(p) (inputs >= NZ are zero
 // and need not be stored); exit: v[f] = bin f for f < NOUT.
-template <int LOGN, int SIGN, int NZ, int NOUT>
-NF_DEV void fft(cf (&v)[1 << LOGN]) {
+// `between(integral_constant<int, i>)` runs after the i-th pair of butterflies (i < LOGN * n / 4): a place to issue memory
+// instructions one at a time inside the arithmetic instead of as a burst beside it.
+struct NoHook {
+  template <class I>
+  NF_DEV void operator()(I) const {}
+};
+template <int LOGN, int SIGN, int NZ, int NOUT, class Hook = NoHook>
+NF_DEV void fft(cf (&v)[1 << LOGN], Hook between = Hook{}) {
   constexpr int n = 1 << LOGN;
   sfor<0, LOGN>([&](auto S) NF2_LAMBDA {
     constexpr int s = decltype(S)::value, h = 1 << s, G = n / (2 * h);
@@ -638,6 +644,7 @@ NF_DEV void fft(cf (&v)[1 << LOGN]) {
       constexpr int M0 = (SIGN > 0 ? 2 * e0 : 128 - 2 * e0) % 128, M1 = (SIGN > 0 ? 2 * e1 : 128 - 2 * e1) % 128;
       constexpr int m0 = bfly_mode<LOGN, NZ, NOUT>(s, x0, h), m1 = bfly_mode<LOGN, NZ, NOUT>(s, x1, h);
       bfly2<M0, M1, m0, m1>(v[x0], v[x0 + h], v[x1], v[x1 + h]);
+      between(std::integral_constant<int, s * (n / 4) + decltype(Q)::value>{});
     });
   });
 }
@@ -1076,6 +1083,12 @@ __global__ __launch_bounds__(64 * WPG) void xcorr_north_fft2_kernel(const float*
 // v4: v2 on the TRANSPOSED problem ("column first"): see the comment at its loads.  Same passes, same arithmetic per plane
 // pair up to the transposition (the summation order inside a plane differs from v2's: row and column transforms swap).
 // =======================================================================================
+#ifndef NF4_SPREAD_LOADS
+#define NF4_SPREAD_LOADS 1
+#endif
+#ifndef NF4_STAGGER
+#define NF4_STAGGER 4000
+#endif
 template <int WPG>
 __global__ __launch_bounds__(64 * WPG) void xcorr_north_fft4_kernel(const float* __restrict__ x, const float* __restrict__ k,
                                                                     float* __restrict__ out, int npairs, int nmain, int planes,
@@ -1091,6 +1104,9 @@ __global__ __launch_bounds__(64 * WPG) void xcorr_north_fft4_kernel(const float*
     if (worker == tail_worker) north_fft_v1_body(smem, x, k, out, planes, npairs, 0, 1, tab, lane);
     return;  // (a surplus wave of the last workgroup)
   }
+#ifdef NF4_EXP_SOLO   // measurement only: NF4_EXP_SOLO of a workgroup's 4 waves work, the others leave (their pairs are skipped)
+  if (wave >= NF4_EXP_SOLO) return;
+#endif
   const uint32_t sb = lds_addr(smem);
 
   const int fc = lane & 31;
@@ -1153,11 +1169,23 @@ __global__ __launch_bounds__(64 * WPG) void xcorr_north_fft4_kernel(const float*
 
   int p = worker;
   if (p >= npairs) return;
+#if NF4_STAGGER > 0
+  // Wave w of a workgroup asks for its first pair w * NF4_STAGGER shader clocks after wave 0.  All 1,024 workers fetching their
+  // first 45 KB at once is 46 MB that HBM serves in ~10 us anyway, so the later start costs little; what it buys is that the four
+  // waves of a CU no longer reach their LDS-heavy stretches (32 KB of spectrum writes, the transposed reads) in lock-step.
+  if (WPG > 1 && wave > 0 && npairs >= 4 * nmain) {   // (only where a worker has several pairs to win it back on)
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    while (__builtin_readcyclecounter() - t0 < (unsigned long long)wave * NF4_STAGGER) __builtin_amdgcn_s_sleep(16);
+  }
+#endif
   fetch_x(p);
   fetch_k(p);
   wait_vm0();
+  NFFT_DBG_BEGIN(worker)
+  NFFT_DBG_ITER_DECL()
   for (; p < npairs; p += nmain) {
     const int pn = min(p + nmain, npairs - 1);  // (the last iteration re-fetches its own pair: harmless)
+    NFFT_DBG_MARK(0)
     // ---- first pass: lane = column of the planes; samples from the AGPRs, which are refilled with the next pair at once.
     //      (The loads were waited for before the previous pair's stores were issued: nobody ever waits for a store.)
     {
@@ -1167,7 +1195,20 @@ __global__ __launch_bounds__(64 * WPG) void xcorr_north_fft4_kernel(const float*
         ra[m] = cf{acc_read(AX[0][2 * m]), 2 * m + 1 < HX ? acc_read(AX[0][2 * m + 1 < HX ? 2 * m + 1 : 0]) : 0.f};
         rb[m] = cf{acc_read(AX[1][2 * m]), 2 * m + 1 < HX ? acc_read(AX[1][2 * m + 1 < HX ? 2 * m + 1 : 0]) : 0.f};
       });
+#if NF4_SPREAD_LOADS
+      // the next pair's 122 row loads, ONE at a time between the packed ops of this pass (31 in the twiddle loop, 91 in the FFT):
+      // as a burst the four waves of a CU fill the vector-memory queue together and stall on it (phase clocks 7.2 k vs 5.5 k alone)
+      const char* const xbn = reinterpret_cast<const char*>(x + (long long)pn * (2 * XPL));
+      auto fetch_x1 = [&](auto Qi) NF2_LAMBDA {
+        constexpr int q = decltype(Qi)::value;
+        if constexpr (q < 2 * HX) {
+          constexpr int P = q / HX, r = q % HX;
+          gload32_to_agpr<(r % 16) * (HX * 4)>(AX[P][r], vx, xbn + P * (XPL * 4) + (r / 16) * (16 * HX * 4));
+        }
+      };
+#else
       fetch_x(pn);
+#endif
       cf v[64];
       sfor<0, 31>([&](auto Mi) NF2_LAMBDA {
         constexpr int j = 2 * decltype(Mi)::value;
@@ -1176,8 +1217,15 @@ __global__ __launch_bounds__(64 * WPG) void xcorr_north_fft4_kernel(const float*
         twiddle_in2<-j, -(j + 1), (j + 1 < HX)>(A, B, lo, hi);
         v[bitrev(j, 6)] = lo;
         if constexpr (j + 1 < HX) v[bitrev(j + 1, 6)] = hi;
+#if NF4_SPREAD_LOADS
+        fetch_x1(Mi);
+#endif
       });
+#if NF4_SPREAD_LOADS
+      fft<6, -1, HX, 64>(v, [&](auto I) NF2_LAMBDA { fetch_x1(std::integral_constant<int, 31 + decltype(I)::value>{}); });
+#else
       fft<6, -1, HX, 64>(v);
+#endif
       {
         cf sa[32], sb2[32];  // C(f) + conj C(63-f),  C(f) - conj C(63-f); each write trails its split by one element
         sfor<0, 33>([&](auto F) NF2_LAMBDA {
@@ -1194,11 +1242,14 @@ __global__ __launch_bounds__(64 * WPG) void xcorr_north_fft4_kernel(const float*
         });
       }
     }
+    NFFT_DBG_MARK(1)
     // ---- column pass: lane = (plane, half-bin column); straight into X
     cf X[64];
     sfor<0, HX>([&](auto R) NF2_LAMBDA { constexpr int r = decltype(R)::value; X[bitrev(r, 6)] = lr64<r * RS * 8>(a_col); });
     wait_lgkm<0>();
+    NFFT_DBG_MARK(2)
     fft<6, -1, HX, 64>(X);
+    NFFT_DBG_MARK(3)
 
     // ---- kernel row pass, pruned: even bins = FFT32(c * e^{-i*pi*j/64}) on lanes 0..30, odd bins =
     //      FFT32(c * e^{-3i*pi*j/64}) on lanes 32..62, in ONE pass; raw spectra to LDS (the real/imaginary split needs an
@@ -1210,7 +1261,18 @@ __global__ __launch_bounds__(64 * WPG) void xcorr_north_fft4_kernel(const float*
         ka[m] = cf{acc_read(AK[0][2 * m]), 2 * m + 1 < HK ? acc_read(AK[0][2 * m + 1 < HK ? 2 * m + 1 : 0]) : 0.f};
         kb[m] = cf{acc_read(AK[1][2 * m]), 2 * m + 1 < HK ? acc_read(AK[1][2 * m + 1 < HK ? 2 * m + 1 : 0]) : 0.f};
       });
+#if NF4_SPREAD_LOADS
+      const char* const kbn = reinterpret_cast<const char*>(k + (long long)pn * (2 * KPL));
+      auto fetch_k1 = [&](auto Qi) NF2_LAMBDA {      // the next kernel pair's 62 row loads, one between every pair of butterflies
+        constexpr int q = decltype(Qi)::value;
+        if constexpr (q < 2 * HK) {
+          constexpr int P = q / HK, r = q % HK;
+          gload32_to_agpr<r * (HK * 4)>(AK[P][r], vk, kbn + P * (KPL * 4));
+        }
+      };
+#else
       fetch_k(pn);
+#endif
       cf v[32];
       constexpr int TCH = 4;  // twiddles arrive in chunks of 4 (two ds_read2_b64), one chunk ahead of their use
       cf tq[2][TCH];
@@ -1250,12 +1312,18 @@ __global__ __launch_bounds__(64 * WPG) void xcorr_north_fft4_kernel(const float*
           if constexpr (j + 1 < HK) v[bitrev(j + 1, 5)] = hi;
         });
       });
+#if NF4_SPREAD_LOADS
+      fft<5, -1, HK, 32>(v, fetch_k1);          // 5 x 8 = 40 places
+      sfor<40, 2 * HK>(fetch_k1);               // the other 22 beside the spectrum writes
+#else
       fft<5, -1, HK, 32>(v);
+#endif
       sfor<0, 16>([&](auto Gi) NF2_LAMBDA {
         constexpr int g = 2 * decltype(Gi)::value;
         lw2x64<2 * g, 2 * g + 2>(a_rowk, v[g], v[g + 1]);  // bins 2g + hl, 2(g + 1) + hl
       });
     }
+    NFFT_DBG_MARK(4)
     // ---- kernel column pass (pruned halves; split by a per-lane sign while reading) and product X * conj(K)
     sfor<0, 2>([&](auto Hf) NF2_LAMBDA {
       constexpr int half = decltype(Hf)::value;
@@ -1310,6 +1378,7 @@ __global__ __launch_bounds__(64 * WPG) void xcorr_north_fft4_kernel(const float*
         X[2 * g1 + half] = x1;
       });
     });
+    NFFT_DBG_MARK(5)
     // ---- inverse column pass (rows 0..30 needed), to LDS
     {
       cf V[64];
@@ -1317,6 +1386,7 @@ __global__ __launch_bounds__(64 * WPG) void xcorr_north_fft4_kernel(const float*
       fft<6, +1, 64, HO>(V);
       sfor<0, HO>([&](auto R) NF2_LAMBDA { constexpr int r = decltype(R)::value; lw64<r * RS * 8>(a_col, V[r]); });
     }
+    NFFT_DBG_MARK(6)
     // ---- inverse row pass: lane = (output row, parity of the bins it inverts); Hermitian re-packing of the pair,
     //      32-point inverse FFT, un-shift, cross-half sum
     {
@@ -1377,6 +1447,7 @@ __global__ __launch_bounds__(64 * WPG) void xcorr_north_fft4_kernel(const float*
         add2(ox[kk], oy[kk], ox[kk + 16], oy[kk + 16]);
       });
       // register kk = output row kk (lanes < 32) / kk + 16 (lanes >= 32), lane = output column: one contiguous row each.
+      NFFT_DBG_MARK(7)
       wait_vm0();  // the next pair's loads (issued most of an iteration ago) have landed; the stores below stay in flight
       char* const ob = reinterpret_cast<char*>(out + (long long)p * (2 * OPL));
       sfor<0, 15>([&](auto Ki) NF2_LAMBDA {
@@ -1387,7 +1458,10 @@ __global__ __launch_bounds__(64 * WPG) void xcorr_north_fft4_kernel(const float*
       gstore32_low_half<15 * (HO * 4)>(vo, ox[15], ob);            // row 31 does not exist: lanes 0..31 only
       gstore32_low_half<15 * (HO * 4)>(vo, oy[15], ob + OPL * 4);
     }
+    NFFT_DBG_MARK(8)
+    NFFT_DBG_ITER()
   }
+  NFFT_DBG_END()
 }
 
 
