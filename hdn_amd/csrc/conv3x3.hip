@@ -78,8 +78,17 @@ struct Cfg {
   static_assert((BM % S == 0) && ((S * S) % BM == 0 || BM % (S * S) == 0), "a tile is whole rows of one image, or whole images");
   static constexpr int IMGS = BM > S * S ? BM / (S * S) : 1;      // images per tile
   static constexpr int R = BM / (S * IMGS);                      // output rows per image in the tile
-  static constexpr int PW = SI + 2, PH = STRIDE == 1 ? R + 2 : 2 * R + 1;   // halo'ed input patch
-  static constexpr int LP = IMGS * PH * PW;                      // LDS pixels
+  static constexpr int PWV = SI + 2, PH = STRIDE == 1 ? R + 2 : 2 * R + 1;  // halo'ed input patch
+  // Pitches of the LDS image.  A ds_read_b128 is served in groups of 16 lanes ({0-3,12-15,20-27}, {4-11,16-19,28-31} of a half
+  // wave), which must fall on 16 different 16-byte columns of the 256-byte bank row.  With image rows shorter than 16 pixels that
+  // takes a row pitch of 12 pixels at S = 8 and an image pitch of 40 at S = 4, together with the lane -> pixel order of
+  // mrow_to_pixel() below (40 % of the LDS cycles of those stages were bank conflicts before).
+  static constexpr int PW = (STRIDE == 1 && S == 8) ? 12 : PWV;
+  static constexpr int IPITCH = PH * PW + ((STRIDE == 1 && S == 4) ? 4 : 0);
+  // ... and the producers' ds_write_b128 (8 consecutive lanes = 8 / (2 KS) pixels x the 2 KS (k step, k half) sub-images of a pixel, one
+  // 128-byte bank row) needs the sub-images 128 / (2 KS) bytes apart modulo 128: LP = 8 / (2 KS) modulo 8.
+  static constexpr int LPV = IMGS * IPITCH;                      // LDS pixels that exist
+  static constexpr int LP = LPV + ((8 / (2 * KS) - LPV % 8) + 8) % 8;
   static constexpr int KG_BYTES = LP * 16, KSTEP_BYTES = 2 * KG_BYTES, PIECE_BYTES = KS * KSTEP_BYTES, A_BYTES = 3 * PIECE_BYTES;
   static constexpr int WKG_BYTES = BN * 16, WPIECE_BYTES = 2 * WKG_BYTES, WSTEP_BYTES = 3 * WPIECE_BYTES;   // one (tap, k step)
   static constexpr int NTAP = DS ? 4 : 3;                        // taps of a stage: a kernel row (+ the downsample tap, used in the middle row)
@@ -93,6 +102,21 @@ struct Cfg {
   static constexpr int WITER = cdiv(W4, HDN_BLOCK);
   static constexpr int AITEMS = LP * 2 * KS, AITER = cdiv(AITEMS, HDN_BLOCK);   // (pixel, k step, k half) items of 8 channels
 };
+
+// Row i (0..31) of an MFMA tile -> pixel of the tile's 32-pixel block, (image, y, x) order.  Stride-1 tiles with rows shorter than
+// 32 pixels hand the two 16-lane access groups of a fragment read pixel sets that are 16 distinct columns of the bank row:
+// group = which of the two, k = rank inside it; S = 16: group = row; S = 8: rows (0, 2) | (1, 3); S = 4: even | odd rows of two images.
+template <class Cf>
+__device__ __forceinline__ int mrow_to_pixel(int i) {
+  if constexpr (Cf::STRIDE != 1 || Cf::S >= 32) {
+    return i;
+  } else {
+    const int q = i >> 2, grp = (0x96 >> q) & 1, k = ((q >> 1) << 2) | (i & 3);
+    if constexpr (Cf::S == 16) return grp * 16 + k;
+    else if constexpr (Cf::S == 8) return (2 * (k >> 3) + grp) * 8 + (k & 7);
+    else return (k >> 3) * 16 + (2 * ((k >> 2) & 1) + grp) * 4 + (k & 3);
+  }
+}
 
 // MODE 0: out = relu(conv + bias); 1: out = relu(conv + bias + res); 2: the K slice blockIdx.z of `cps` chunks, raw sums to
 // out[blockIdx.z][M][CO] (the workspace; conv3x3_reduce_kernel finishes).  Cf::DS: out2 = the downsample branch (raw sums, no
@@ -124,9 +148,9 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __r
   uint32_t aoff[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    const int i = (wm * MT + mt) * 32 + li;                  // pixel inside the tile
+    const int i = (wm * MT + mt) * 32 + mrow_to_pixel<Cf>(li);   // pixel inside the tile
     const int img = i / (Cf::R * S), yy = (i / S) % Cf::R, xx = i % S;
-    aoff[mt] = lds_addr(sA) + g * Cf::KG_BYTES + (img * (Cf::PH * Cf::PW) + (ST * yy + 1) * Cf::PW + (ST * xx + 1)) * 16;
+    aoff[mt] = lds_addr(sA) + g * Cf::KG_BYTES + (img * Cf::IPITCH + (ST * yy + 1) * Cf::PW + (ST * xx + 1)) * 16;
   }
   const uint32_t boff = lds_addr(sW) + g * Cf::WKG_BYTES + (wn * NT * 32 + li) * 16;
 
@@ -177,9 +201,9 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __r
     for (int q = 0; q < Cf::AITER; ++q) {
       const int item = tid + q * HDN_BLOCK;
       const int px = min(item / (2 * KS), Cf::LP - 1), sub = item % (2 * KS);
-      const int img = px / (Cf::PH * Cf::PW), ry = (px / Cf::PW) % Cf::PH, rx = px % Cf::PW;
+      const int img = px / Cf::IPITCH, ry = (px % Cf::IPITCH) / Cf::PW, rx = px % Cf::IPITCH % Cf::PW;   // (pad pixels: zeros)
       const int b = b0 + img, y = ST * y0 + ry - 1, xx = rx - 1;
-      const bool ok = item < Cf::AITEMS && b < B && y >= 0 && y < SI && xx >= 0 && xx < SI;
+      const bool ok = item < Cf::AITEMS && img < Cf::IMGS && b < B && ry < Cf::PH && y >= 0 && y < SI && xx >= 0 && xx < SI;
       const f4* src = reinterpret_cast<const f4*>(x + (((size_t)b * SI + y) * SI + xx) * CI + (chunk0 + chunk) * (16 * KS) + sub * 8);
       av[q][0] = ok ? src[0] : f4{0.f, 0.f, 0.f, 0.f};
       av[q][1] = ok ? src[1] : f4{0.f, 0.f, 0.f, 0.f};
@@ -288,27 +312,41 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __r
     if (c2 < nchunk) static_for<3>([&](auto Jc) { stage_p(c2, Jc); });   // an odd chunk count: one more chunk, at position 0 of the period again
   } else {
     __syncthreads();
-    Frags f[2];
+    // Fragment sets: a step's fragments are read AHEAD steps before its MFMAs (across stage boundaries too: the next stage's
+    // images were complete a barrier ago).  The sets rotate with the step number; a period's step count must be a multiple of
+    // NSETS for the indices to be static.  One step ahead is what fits: with three sets (two steps ahead) the consumers spill
+    // (256 registers per wave at two waves per SIMD) and nothing is gained (measured: 30.0 / 31.6 vs 28.7 / 30.2 us at 128 / 256 channels).
+    constexpr int NSETS = 2, AHEAD = NSETS - 1;
+    constexpr int PERIOD_STEPS = 2 * (NSTEP_ROW[0] + NSTEP_ROW[1] + NSTEP_ROW[2]);
+    static_assert(PERIOD_STEPS % NSETS == 0, "fragment sets must line up with the period");
+    Frags f[NSETS];
+    // the step AHEAD steps after (J, st): position in the period (may run into the next period: taken modulo 6 by the caller), step
+    auto ahead = [](int J, int st, int d) constexpr {
+      for (; d > 0; --d) {
+        if (st + 1 < NSTEP_ROW[J % 3]) ++st;
+        else { ++J; st = 0; }
+      }
+      return std::pair<int, int>(J, st);
+    };
     read_frags(f[0], 0, 0, 0, 0, 0);   // the very first fragments
+    if constexpr (AHEAD > 1) read_frags(f[1], 0, 1 / KS, 1 % KS, 0, 0);
     auto stage_c = [&](int base, auto Jc) {
-      constexpr int J = decltype(Jc)::value, ky = J % 3, slot = J % 3, ab = (J / 3) & 1;
+      constexpr int J = decltype(Jc)::value, ky = J % 3;
       constexpr int NSTEP = NSTEP_ROW[ky];
-      // parity of the fragment set of this stage's first step: the steps of a period alternate sets without a break
+      // set of this stage's first step: the steps of a period rotate through the sets without a break
       constexpr int fp0 = ((J >= 1 ? NSTEP_ROW[0] : 0) + (J >= 2 ? NSTEP_ROW[1] : 0) + (J >= 3 ? NSTEP_ROW[2] : 0) + (J >= 4 ? NSTEP_ROW[0] : 0) +
-                           (J >= 5 ? NSTEP_ROW[1] : 0)) & 1;
+                           (J >= 5 ? NSTEP_ROW[1] : 0)) % NSETS;
       const int chunk = base + J / 3, stage = chunk * 3 + ky;
       static_for<NSTEP>([&](auto STc) {
-        constexpr int st = decltype(STc)::value, cur = (fp0 + st) & 1;
-        constexpr bool more = st + 1 < NSTEP;
-        bool issued = more;
-        if constexpr (more) {
-          read_frags(f[1 - cur], ky, (st + 1) / KS, (st + 1) % KS, slot, ab);
-        } else if (stage + 1 < nstage) {                   // first step of the next stage: its images were complete a barrier ago
-          read_frags(f[1 - cur], (ky + 1) % 3, 0, 0, (slot + 1) % 3, ky == 2 ? 1 - ab : ab);
-          issued = true;
-        }
-        // the fragments of this step have landed when at most the reads just issued are outstanding (LDS operations retire in order)
-        if (issued) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((MT + NT) * 3) : "memory");
+        constexpr int st = decltype(STc)::value, cur = (fp0 + st) % NSETS;
+        constexpr std::pair<int, int> tg = ahead(J, st, AHEAD);
+        constexpr int Jn = tg.first, stn = tg.second, kyn = Jn % 3, slotn = Jn % 3, abn = ((Jn % 6) / 3) & 1;
+        const bool issue = stage + (Jn - J) < nstage;
+        if (issue) read_frags(f[(cur + AHEAD) % NSETS], kyn, stn / KS, stn % KS, slotn, abn);
+        // the fragments of this step have landed when at most the AHEAD sets read after them are outstanding (LDS operations retire in
+        // order; the counter holds 15 at most: waiting for a few reads of the next step as well is harmless)
+        constexpr int OUTSTANDING = AHEAD * (MT + NT) * 3 < 15 ? AHEAD * (MT + NT) * 3 : 15;
+        if (issue) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(OUTSTANDING) : "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -341,7 +379,7 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __r
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+          const int row = (wm * MT + mt) * 32 + mrow_to_pixel<Cf>((r & 3) + 8 * (r >> 2) + 4 * g);
           sO[row * Cf::EPI_STRIDE + (wn * NT + nt) * 32 + li] = acc[mt][nt][r];
         }
   }
@@ -383,7 +421,7 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __r
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int row = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+            const int row = (wm * MT + mt) * 32 + mrow_to_pixel<Cf>((r & 3) + 8 * (r >> 2) + 4 * g);
             sO[row * Cf::EPI_STRIDE + (wn * NT + nt) * 32 + li] = accd[DS ? mt : 0][DS ? nt : 0][r];
           }
     }
