@@ -76,17 +76,19 @@ __device__ __forceinline__ void sfor7(F&& f) {
     sfor7<I + 1>(static_cast<F&&>(f));
   }
 }
-constexpr int PR = 4, NR = 2 * PR + 1;  // pooled rows per strip; conv rows a strip computes: 2 pa - 1 .. 2 pa + 7
+// PR = pooled rows per strip (template parameter of the kernel: 4, or 1 for small batches where 4-row strips leave the chip empty);
+// NR = 2 PR + 1 conv rows a strip computes: 2 pa - 1 .. 2 pa + 2 PR - 1
 }  // namespace stem
 
 // The loop nest is (input channel, ky) [runtime, 14 trips] x kx [7] x conv row [9]: a tap's 16 weights are loaded ONCE
 // (s_load_dwordx16, the next tap's in flight meanwhile) and feed 9 x 8 packed FMAs; the 9 input rows a (ci, ky) touches are
 // loaded as one 8-byte pair per lane each and expanded to the 7 horizontal taps by DPP.
-template <bool NHWC>
+template <bool NHWC, int PR>
 __global__ __launch_bounds__(HDN_BLOCK, 2) void trunk_stem_kernel(const float* __restrict__ x, const float* __restrict__ wT,
                                                                   const float* __restrict__ bias, float* __restrict__ out, int H, int W,
                                                                   int Hc, int Wc, int Hp, int Wp, int strips_per_img, int total_waves) {
   using namespace stem;
+  constexpr int NR = 2 * PR + 1;
   const int lane = threadIdx.x & 63;
   const int g = __builtin_amdgcn_readfirstlane(blockIdx.x * (HDN_BLOCK / 64) + (threadIdx.x >> 6));
   if (g >= total_waves) return;
@@ -198,12 +200,20 @@ extern "C" int hdn_trunk_stem_f32(const float* x, const float* wT, const float* 
   const int Hc = (H - 1) / 2 + 1, Wc = (W - 1) / 2 + 1, Hp = (Hc - 1) / 2 + 1, Wp = (Wc - 1) / 2 + 1;
   if (W < 2 || Wc > 64 || B > 65535 || (long long)H * W > (1LL << 24)) return HDN_E_LIMIT;  // a lane reads its columns as a pair; one lane per conv column
   if (out == x) return HDN_E_ALIAS;
-  const int strips = hdn::cdiv(Hp, hdn::stem::PR);  // a wave: 4 pooled rows x 16 channels x the full width
+  // a wave: PR pooled rows x 16 channels x the full width.  4-row strips share most of their input rows (9 conv rows for 4 pooled
+  // ones); below ~1,000 waves (B < 32 at 127 px) the chip is better filled by 1-row strips (3 conv rows each: 1.3 x the arithmetic,
+  // 4 x the waves, a quarter of the chain per wave) - the tracker's B = 1 call drops from 35 to ~12 us
+  const bool small = (long long)B * 4 * hdn::cdiv(Hp, 4) < 1024;
+  const int pr = small ? 1 : 4;
+  const int strips = hdn::cdiv(Hp, pr);
   const long long total = (long long)B * 4 * strips;
   if (total > 0x7fffffffLL) return HDN_E_LIMIT;
   const dim3 grid((unsigned)((total + 3) / 4)), block(HDN_BLOCK);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (nhwc) hipLaunchKernelGGL(hdn::trunk_stem_kernel<true>, grid, block, 0, st, x, wT, bias, out, H, W, Hc, Wc, Hp, Wp, strips, (int)total);
-  else hipLaunchKernelGGL(hdn::trunk_stem_kernel<false>, grid, block, 0, st, x, wT, bias, out, H, W, Hc, Wc, Hp, Wp, strips, (int)total);
+#define HDN_STEM_LAUNCH(NHWC_, PR_) \
+  hipLaunchKernelGGL((hdn::trunk_stem_kernel<NHWC_, PR_>), grid, block, 0, st, x, wT, bias, out, H, W, Hc, Wc, Hp, Wp, strips, (int)total)
+  if (nhwc) { if (small) HDN_STEM_LAUNCH(true, 1); else HDN_STEM_LAUNCH(true, 4); }
+  else { if (small) HDN_STEM_LAUNCH(false, 1); else HDN_STEM_LAUNCH(false, 4); }
+#undef HDN_STEM_LAUNCH
   return hdn::launch_status();
 }

@@ -958,7 +958,9 @@ def test_graphed_track_proj_matches_eager(dev):
 
 
 # --------------------------------------------------------------------------- trunk, first stage
-@pytest.mark.parametrize("shape", [(2, 127, 127), (1, 9, 13), (3, 64, 128), (2, 5, 7), (1, 126, 125), (1, 2, 2), (1, 4, 1), (1, 3, 130)])
+# (batches below ~1,000 waves take the 1-row-strip kernel, the two large ones the 4-row-strip kernel)
+@pytest.mark.parametrize("shape", [(2, 127, 127), (1, 9, 13), (3, 64, 128), (2, 5, 7), (1, 126, 125), (1, 2, 2), (1, 4, 1), (1, 3, 130), (33, 127, 127),
+                                   (130, 31, 29)])
 def test_trunk_fused_stem_vs_torch(dev, shape):
     """hdn_trunk_stem_f32 (conv 7x7/s2 + folded BN + ReLU + maxpool 3x3/s2 in one kernel) against the same stage of the folded trunk
     in PyTorch on the CPU; both memory layouts; widths outside the kernel's range take the library path inside FusedStem."""
