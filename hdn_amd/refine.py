@@ -13,7 +13,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib
-from .homo_model import track_proj
+from .homo_model import track_proj, track_proj_pair
 
 
 def refine_warp(H_mat: torch.Tensor, search: torch.Tensor, H_comp: torch.Tensor = None):
@@ -48,7 +48,8 @@ def _constants(dev, B, H, W):
             _CONST.clear()
         h4p = torch.tensor([[0, 0, 0, H, W, H, W, 0]], dtype=torch.float32, device=dev).repeat(B, 1)
         pidx = torch.arange(H * W, dtype=torch.float32, device=dev).repeat(B, 1)
-        _CONST[key] = (h4p, pidx)
+        eye = torch.eye(3, dtype=torch.float64, device=dev).repeat(B, 1, 1).contiguous()
+        _CONST[key] = (h4p, pidx, eye)
     return _CONST[key]
 
 
@@ -62,14 +63,17 @@ def homo_refine(net, template: torch.Tensor, search: torch.Tensor, iterations: i
         raise ValueError("iterations must be >= 1")
     B, _, H, W = template.shape
     dev = _lib.require_device(template, search)
-    h4p, pidx = _constants(dev, B, H, W)
-    H_comp = torch.eye(3, dtype=torch.float64, device=dev).repeat(B, 1, 1).contiguous()
+    h4p, pidx, eye = _constants(dev, B, H, W)
+    H_comp = eye.clone()
     cur = search
     p1 = net.ShareFeature(template) if cache_template else None
     score = score_simi = None
     for _ in range(iterations):
-        imgs = torch.cat((template, cur), dim=1)
-        data = {"org_imgs": imgs, "input_tensors": imgs, "h4p": h4p, "patch_indices": pidx}
-        H_mat, score, score_simi = track_proj(net, data, None, cached_patch_1=p1)
+        if p1 is not None:
+            H_mat, score, score_simi = track_proj_pair(net, template, cur, h4p, p1)
+        else:
+            imgs = torch.cat((template, cur), dim=1)
+            data = {"org_imgs": imgs, "input_tensors": imgs, "h4p": h4p, "patch_indices": pidx}
+            H_mat, score, score_simi = track_proj(net, data, None)
         cur = refine_warp(H_mat, cur, H_comp)
     return H_comp, score, score_simi

@@ -77,7 +77,7 @@ class HomoTracker:
             self.similarity.init(frame, self.init_pos, self.init_s_z, self.init_s_z_sm, self.channel_average)   # model.template(z_crop), :99-107
         self.init_points = torch.tensor(np.asarray(gt_points, np.float64).reshape(1, -1, 2), dtype=torch.float64, device=self.dev).contiguous()
         self.H_total = torch.eye(3, dtype=torch.float64, device=self.dev)
-        self._Ht, self._Hinv, self._H_next = (torch.empty((3, 3), dtype=torch.float64, device=self.dev) for _ in range(3))
+        self._Ht, self._Hinv = (torch.empty((3, 3), dtype=torch.float64, device=self.dev) for _ in range(2))
         self._out = torch.empty((1, 2 * self.init_points.shape[1] + 1), dtype=torch.float32, device=self.dev)
         self._const_params = FR._dev_f64([self.init_pos[0], self.init_pos[1], self.init_s_z_sm] + [float(a) for a in self.channel_average], self.dev)
         self._graph = None
@@ -122,9 +122,9 @@ class HomoTracker:
         with torch.cuda.device(self.dev):
             _lib.check(lib.hdn_track_accumulate_f64(_lib.ptr(self._Ht), _lib.ptr(sim_state) if sim_state is not None else None, _lib.ptr(H_comp),
                                                     _lib.ptr(score), _lib.ptr(self._consts), _lib.ptr(self.init_points),
-                                                    self.init_points.shape[1], _lib.ptr(self._H_next), _lib.ptr(self._out), 1, st),
-                       "track accumulate")
-        return self._H_next, self._out.view(-1), homo_score
+                                                    self.init_points.shape[1], _lib.ptr(self.H_total), _lib.ptr(self._out), 1, st),
+                       "track accumulate")     # (in place: the kernel reads Ht, the copy hdn_track_prepare_f64 made)
+        return self.H_total, self._out.view(-1), homo_score
 
     def _capture(self, frame_shape):
         """hipGraph of the whole per-frame body.  The frame lands in a static device buffer; H_total is carried in a static
@@ -139,8 +139,7 @@ class HomoTracker:
         torch.cuda.current_stream().wait_stream(side)
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
-            H, out, score = self._body(self._static_frame)
-            self.H_total.copy_(H)            # the recurrence lives inside the graph
+            H, out, score = self._body(self._static_frame)      # (H_total is updated in place: the recurrence lives inside the graph)
             self._g_out, self._g_score = out, score
         self.H_total.copy_(H0)
 
@@ -158,7 +157,6 @@ class HomoTracker:
                 out, homo_score = out.clone(), homo_score.clone()
         else:
             H, out, homo_score = self._body(FR.upload(img))
-            self.H_total.copy_(H)
             out = out.clone()
         pts = out[:8].view(4, 2)
         self.last_points, self.last_score = pts, homo_score
