@@ -443,16 +443,23 @@ template <bool RES, bool ACT>
 __global__ __launch_bounds__(HDN_BLOCK) void conv3x3_reduce_kernel(const f4* __restrict__ ws, const f4* __restrict__ bias, const f4* __restrict__ res,
                                                                    f4* __restrict__ out, unsigned n4, unsigned c4n, int slices) {
   for (unsigned i = blockIdx.x * HDN_BLOCK + threadIdx.x; i < n4; i += gridDim.x * HDN_BLOCK) {
-    f4 v = ws[i];
-    int z = 1;
-    for (; z + 3 < slices; z += 4) {   // four slices in flight; the additions stay in slice order
-      const f4 a0 = ws[(size_t)z * n4 + i], a1 = ws[(size_t)(z + 1) * n4 + i], a2 = ws[(size_t)(z + 2) * n4 + i], a3 = ws[(size_t)(z + 3) * n4 + i];
-      v = (((v + a0) + a1) + a2) + a3;
+    // up to 16 slices in flight at once (at B = 1 the launch is a handful of workgroups and nothing but load latency: one round
+    // trip instead of one per four slices); the additions stay in slice order, so the sum is the same for any grouping
+    f4 v = f4{0.f, 0.f, 0.f, 0.f}, bv = v, rv = v;
+    if (ACT) bv = bias[i % c4n];     // (asked for together with the slices, not after them)
+    if (ACT && RES) rv = res[i];
+    for (int z0 = 0; z0 < slices; z0 += 16) {
+      f4 a[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (z0 + j < slices) a[j] = ws[(size_t)(z0 + j) * n4 + i];
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (z0 + j < slices) v = (z0 + j == 0) ? a[j] : v + a[j];
     }
-    for (; z < slices; ++z) v = v + ws[(size_t)z * n4 + i];
     if (ACT) {
-      v = v + bias[i % c4n];
-      if (RES) v = v + res[i];
+      v = v + bv;
+      if (RES) v = v + rv;
       v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
     }
     out[i] = v;

@@ -170,6 +170,11 @@ class HomoTracker:
         return {"bbox_aligned": bbox, "best_score": best_score, "polygon": pn, "points": pn, "bbox": bbox}
 
 
+    def track(self, img):
+        """BaseTracker.track (hdn/tracker/base_tracker.py:28-37, abstract there): the next frame, nothing else known."""
+        return self.track_new(None, img)
+
+
 class DeviceTrackerHomo(HomoTracker):
     """Drop-in for hdnTrackerHomo (hdn_tracker_proj_e2e.py:22-285) behind build_tracker(model)
     (hdn/tracker/tracker_builder.py:18-19): same constructor argument, same init / track_new signatures and result keys.
