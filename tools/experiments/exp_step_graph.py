@@ -1,0 +1,50 @@
+"""The configs[1] step (bench.py's kernels workload, parallel schedule) launched eagerly on two streams vs replayed as ONE hipGraph
+(two parallel branches): how much of the step is launch path / cross-stream event hand-off?   python tools/experiments/exp_step_graph.py"""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+import torch
+import bench
+import hdn_amd
+from hdn_amd import homography as G, share_feature as SF, xcorr as X
+dev = torch.device("cuda:0")
+d = bench.make_inputs(dev, 0)
+torch.manual_seed(bench.SEED)
+sf = hdn_amd.PreShareFeature().eval().to(dev)
+folded = sf.folded(dev)
+P = bench.PAIRS
+imgs2 = d["imgs"].reshape(P * 2, 1, 127, 127); tmpl = d["imgs"][:, :1].contiguous()
+head_stream = torch.cuda.Stream(device=dev)
+
+def head():
+    feats = SF.share_feature(imgs2, folded).reshape(P, 2, 127, 127)
+    Hm, warped = G.dlt_warp(d["h4p"], d["off"], tmpl)
+    pf = SF.share_feature(warped, folded)
+    G.l1_score2(feats[0, 1], pf[0, 0], feats[0, 0], 1.0 / (127 * 127))
+
+def step():
+    main = torch.cuda.current_stream()
+    head_stream.wait_stream(main)
+    with torch.cuda.stream(head_stream):
+        head()
+    X.xcorr_depthwise(d["north_x"], d["north_k"])
+    X.xcorr_depthwise_multi(d["circ_x"], d["circ_k"], circular=True)
+    X.xcorr_depthwise_multi(d["prod_x"], d["prod_k"])
+    main.wait_stream(head_stream)
+
+def timed(fn, n=200):
+    for _ in range(300): fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+side = torch.cuda.Stream()
+with torch.cuda.stream(side):
+    for _ in range(5): step()
+torch.cuda.synchronize()
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g):
+    step()
+for rep in range(3):
+    print(f"eager two streams {timed(step):.4f} ms/step   one hipGraph per step {timed(g.replay):.4f} ms/step")
