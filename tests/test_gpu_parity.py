@@ -938,6 +938,14 @@ def test_homo_refine_two_iterations_config5(dev):
     assert float((Hb[:8] - Hb[248:]).abs().max()) <= 1e-4
     H8, _, _ = hdn_amd.homo_refine(netd, t8, s8, iterations=2)
     assert float((Hb[:8] - H8).abs().max()) <= 2e-4
+    # the two forms of the loop body: separate crops + cached ShareFeature(template) (track_proj_pair, the tracker's path) and the
+    # reference-shaped data dictionary without the cache give the same H and scores
+    Hp, sp, ssp = hdn_amd.homo_refine(netd, t8, s8, iterations=2, cache_template=True)
+    Hd, sd_, ssd = hdn_amd.homo_refine(netd, t8, s8, iterations=2, cache_template=False)
+    assert float((Hp - Hd).abs().max()) <= 2e-4 and abs(float(sp) - float(sd_)) <= 1e-5 and abs(float(ssp) - float(ssd)) <= 1e-6
+    from hdn_amd.homo_model import track_proj_pair
+    with pytest.raises(ValueError):
+        track_proj_pair(netd, t8, s8[:, :, :100], None, None)
 
 
 def test_graphed_track_proj_matches_eager(dev):

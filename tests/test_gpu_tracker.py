@@ -53,6 +53,9 @@ def test_sequence_stream_device_loop_vs_cpu_restatement(dev):
     # without the host read nothing synchronises: the same frame again, asynchronously, gives device tensors
     out = trk.track_new(99, frames[-1], sync=False)
     assert out["points"].is_cuda and trk.host_syncs == len(frames)
+    # BaseTracker.track(img) (base_tracker.py:28): the next frame with nothing else known
+    out = trk.track(frames[-1])
+    assert set(out) == {"bbox_aligned", "best_score", "polygon", "points", "bbox"} and trk.host_syncs == len(frames) + 1
 
 
 def test_graphed_tracker_loop_matches_eager(dev):
