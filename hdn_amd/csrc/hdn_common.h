@@ -65,6 +65,29 @@ __device__ __forceinline__ void copy_l2g(const float* src, float* __restrict__ d
   }
 }
 
+// Streaming hints for data that is touched exactly once (the correlation kernels' planes): nontemporal 16-byte loads / stores.
+// tools/experiments/ubench_stream.hip: the 5x5 (x) 35x35 traffic shape 156.8 -> 148.5 us, the 5x5 (x) 29x29 shape 98.9 -> 75-89 us.
+// HDN_STREAM_HINT: bit 0 = loads, bit 1 = stores (A/B switch; default both).
+#ifndef HDN_STREAM_HINT
+#define HDN_STREAM_HINT 3
+#endif
+typedef float hdn_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_stream(const float4* p) {
+#if HDN_STREAM_HINT & 1
+  const hdn_f4v v = __builtin_nontemporal_load(reinterpret_cast<const hdn_f4v*>(p));
+  return float4{v.x, v.y, v.z, v.w};
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ void st_stream(float4* p, const float4& v) {
+#if HDN_STREAM_HINT & 2
+  __builtin_nontemporal_store(hdn_f4v{v.x, v.y, v.z, v.w}, reinterpret_cast<hdn_f4v*>(p));
+#else
+  *p = v;
+#endif
+}
+
 // Same copy for a compile-time float count when the workgroup owns a full plane group: every thread issues ALL of
 // its 16-byte loads before the first LDS write, so one HBM round trip covers the whole group (the runtime-count
 // loop above gets serialised load -> wait -> write by the compiler).
@@ -77,7 +100,7 @@ __device__ __forceinline__ void copy_g2l_full(const float* __restrict__ src, flo
   float4* d4 = reinterpret_cast<float4*>(dst);
   float4 r[ITER];
 #pragma unroll
-  for (int q = 0; q < ITER; ++q) r[q] = s4[min(tid + q * HDN_BLOCK, N4 - 1)];  // unconditional: stays in registers
+  for (int q = 0; q < ITER; ++q) r[q] = ld_stream(s4 + min(tid + q * HDN_BLOCK, N4 - 1));  // unconditional: stays in registers
 #pragma unroll
   for (int q = 0; q < ITER; ++q) {
     const int i = tid + q * HDN_BLOCK;
@@ -95,7 +118,7 @@ __device__ __forceinline__ void copy_l2g_full(const float* src, float* __restric
 #pragma unroll
   for (int q = 0; q < ITER; ++q) {
     const int i = tid + q * HDN_BLOCK;
-    if (i < N4) d4[i] = s4[i];
+    if (i < N4) st_stream(d4 + i, s4[i]);
   }
 }
 

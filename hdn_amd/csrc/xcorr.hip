@@ -81,7 +81,7 @@ __global__ __launch_bounds__(HDN_BLOCK) void xcorr_prod29_kernel(XcorrPtrs P, in
     const float4* s4 = reinterpret_cast<const float4*>(xg);
     float4 r[ITER];
 #pragma unroll
-    for (int q = 0; q < ITER; ++q) r[q] = s4[min(tid + q * HDN_BLOCK, N4 - 1)];
+    for (int q = 0; q < ITER; ++q) r[q] = ld_stream(s4 + min(tid + q * HDN_BLOCK, N4 - 1));
 #pragma unroll
     for (int q = 0; q < ITER; ++q) {
       const int i4 = tid + q * HDN_BLOCK;
@@ -846,7 +846,9 @@ struct PlaneRegs {
 };
 __device__ __forceinline__ void planes_load(PlaneRegs& r, const float* __restrict__ g, const Moves& m, int np, int lane) {
 #pragma unroll
-  for (int rd = 0; rd < Moves::ROUNDS; ++rd) r.v[rd] = *reinterpret_cast<const f4u*>(g + max(m.g[rd], 0));  // all in flight at once
+  // all in flight at once.  (No streaming hint here: with nontemporal loads / stores this kernel is 8 % SLOWER, 42-45 vs 38-41 us -
+  // its 16-byte accesses are only 4-byte aligned - while the 5x5 kernels and the 31x31 kernel gain 3-9 %.)
+  for (int rd = 0; rd < Moves::ROUNDS; ++rd) r.v[rd] = *reinterpret_cast<const f4u*>(g + max(m.g[rd], 0));
   r.last = g[min(lane, np - 1) * PL + 168];
 }
 __device__ __forceinline__ void planes_store(float* lds, const PlaneRegs& r, const Moves& m, int np, int lane) {

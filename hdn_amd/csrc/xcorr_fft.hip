@@ -478,13 +478,24 @@ template <int OFF>
 NF_DEV void lw32(uint32_t a, float v) { asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(a), "v"(v), "n"(OFF)); }
 template <int OFF>
 NF_DEV void lw128_from_agpr(uint32_t a, const f4v& v) { asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(a), "a"(v), "n"(OFF)); }
+// streaming hints (hdn_common.h, HDN_STREAM_HINT): the planes are read once and the outputs written once
+#if HDN_STREAM_HINT & 1
+#define NF_NT_LD " nt"
+#else
+#define NF_NT_LD ""
+#endif
+#if HDN_STREAM_HINT & 2
+#define NF_NT_ST " nt"
+#else
+#define NF_NT_ST ""
+#endif
 template <int OFF>
 NF_DEV void gload128_to_agpr(f4v& v, uint32_t voff, const void* sbase) {
-  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=a"(v) : "v"(voff), "s"(sbase), "n"(OFF));
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" NF_NT_LD : "=a"(v) : "v"(voff), "s"(sbase), "n"(OFF));
 }
 template <int OFF>
 NF_DEV void gload32_to_agpr(float& v, uint32_t voff, const void* sbase) {
-  asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=a"(v) : "v"(voff), "s"(sbase), "n"(OFF));
+  asm volatile("global_load_dword %0, %1, %2 offset:%3" NF_NT_LD : "=a"(v) : "v"(voff), "s"(sbase), "n"(OFF));
 }
 NF_DEV float acc_read(const float& a) {
   float r;
@@ -493,12 +504,12 @@ NF_DEV float acc_read(const float& a) {
 }
 template <int OFF>
 NF_DEV void gstore32(uint32_t voff, float v, void* sbase) {
-  asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(voff), "v"(v), "s"(sbase), "n"(OFF) : "memory");
+  asm volatile("global_store_dword %0, %1, %2 offset:%3" NF_NT_ST ::"v"(voff), "v"(v), "s"(sbase), "n"(OFF) : "memory");
 }
 template <int OFF>  // the same from lanes 0..31 only
 NF_DEV void gstore32_low_half(uint32_t voff, float v, void* sbase) {
   uint64_t keep;
-  asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 0xffffffff\n\tglobal_store_dword %1, %2, %3 offset:%4\n\ts_mov_b64 exec, %0"
+  asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 0xffffffff\n\tglobal_store_dword %1, %2, %3 offset:%4" NF_NT_ST "\n\ts_mov_b64 exec, %0"
                : "=&s"(keep) : "v"(voff), "v"(v), "s"(sbase), "n"(OFF) : "memory");
 }
 template <int CNT>

@@ -5,9 +5,12 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <algorithm>
+#include <type_traits>
 
 // one-shot: group g = blockIdx.x; loads -> LDS -> barrier -> LDS -> stores (the structure of the correlation kernels)
-template <int R4, int W4>
+typedef float f4n __attribute__((ext_vector_type(4)));
+// NT: 1 = nontemporal loads, 2 = nontemporal stores, 3 = both (streaming hints: the data is touched once)
+template <int R4, int W4, int NT = 0>
 __global__ __launch_bounds__(256) void oneshot(const float4* __restrict__ in, float4* __restrict__ out, int groups, int lds_pad) {
   extern __shared__ float4 sm[];
   const int tid = threadIdx.x;
@@ -17,12 +20,19 @@ __global__ __launch_bounds__(256) void oneshot(const float4* __restrict__ in, fl
     constexpr int RI = (R4 + 255) / 256, WI = (W4 + 255) / 256;
     float4 r[RI];
 #pragma unroll
-    for (int q = 0; q < RI; ++q) r[q] = s[min(tid + q * 256, R4 - 1)];
+    for (int q = 0; q < RI; ++q) {
+      if constexpr (NT & 1) { const f4n v = __builtin_nontemporal_load(reinterpret_cast<const f4n*>(s) + min(tid + q * 256, R4 - 1)); r[q] = float4{v.x, v.y, v.z, v.w}; }
+      else r[q] = s[min(tid + q * 256, R4 - 1)];
+    }
 #pragma unroll
     for (int q = 0; q < RI; ++q) if (tid + q * 256 < R4) sm[tid + q * 256] = r[q];
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < WI; ++q) if (tid + q * 256 < W4) d[tid + q * 256] = sm[tid + q * 256];
+    for (int q = 0; q < WI; ++q) if (tid + q * 256 < W4) {
+      const float4 v = sm[tid + q * 256];
+      if constexpr (NT & 2) __builtin_nontemporal_store(f4n{v.x, v.y, v.z, v.w}, reinterpret_cast<f4n*>(d) + tid + q * 256);
+      else d[tid + q * 256] = v;
+    }
     __syncthreads();
   }
 }
@@ -82,6 +92,21 @@ int main() {
   }
   { double t = timed([&] { read4<<<4096, 256>>>(in, out, n4); }); printf("read  only: %.1f us = %.0f GB/s\n", t, 1.0 * n4 * 16 / t / 1e3); }
   { double t = timed([&] { write4<<<4096, 256>>>(out, n4); }); printf("write only: %.1f us = %.0f GB/s\n", t, 1.0 * n4 * 16 / t / 1e3); }
+  {   // streaming hints on the two production shapes at their kernels' occupancy (cfg5: 20 KB -> 8 WG/CU; prod29: 27 KB -> 5 WG/CU)
+    auto nt = [&](auto NTc, const char* tag) {
+      constexpr int N = decltype(NTc)::value;
+      hipFuncSetAttribute((const void*)oneshot<1225, 961, N>, hipFuncAttributeMaxDynamicSharedMemorySize, 20 * 1024);
+      hipFuncSetAttribute((const void*)oneshot<841, 625, N>, hipFuncAttributeMaxDynamicSharedMemorySize, 27 * 1024);
+      const double t5 = timed([&] { oneshot<1225, 961, N><<<groups, 256, 20 * 1024>>>(in, out, groups, 0); });
+      const double t9 = timed([&] { oneshot<841, 625, N><<<groups, 256, 27 * 1024>>>(in, out, groups, 0); });
+      printf("hints %-22s cfg5 shape %.1f us = %.0f GB/s | prod29 shape %.1f us = %.0f GB/s\n", tag, t5, (double)groups * (1225 + 961) * 16 / t5 / 1e3, t9,
+             (double)groups * (841 + 625) * 16 / t9 / 1e3);
+    };
+    nt(std::integral_constant<int, 0>{}, "none");
+    nt(std::integral_constant<int, 1>{}, "nontemporal loads");
+    nt(std::integral_constant<int, 2>{}, "nontemporal stores");
+    nt(std::integral_constant<int, 3>{}, "both");
+  }
   shape<1225, 961>("cfg5 35x35 -> 31x31 (4 pl)", in, out, groups);
   shape<841, 625>("prod 29x29 -> 25x25 (4 pl)", in, out, groups);
   shape<2450, 1922>("cfg5 (8 planes / WG)", in, out, groups / 2);
