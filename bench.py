@@ -19,8 +19,9 @@ Before the W warm-up steps the GPU is kept busy for --prewarm-ms (150 ms, untime
 ~40 ms of sustained load to reach steady clocks, and the first ~80 steps would otherwise be timed on the ramp.
 
 The JSON line also carries
-    "roofline"      for the dominant kernel (the 31x31 (x) 61x61 correlation), measured with events on the launch stream in
-                    --roofline-steps separate steps after the timed region (mean / min / median), schedule after-north
+    "roofline"      for the dominant kernel (the 31x31 (x) 61x61 correlation), measured with events on the launch stream around every
+                    launch of the TIMED region (mean / min / median); with a --head-stream other than the default, in
+                    --roofline-steps separate after-north steps behind it
     "cpu_baseline"  the CPU oracle (PyTorch-CPU restatement of the reference path) timed on this box's host cores:
                     all 64 pairs, warm-up 3, 5 passes, at 1 thread pinned to one core (the reference's own setting,
                     tools/test.py:51) and at all cores; headline = the better of the two, best and median of both listed
@@ -73,11 +74,12 @@ def parse():
                     help="N > 1: hdn_allgather_offsets of the C ABI on RCCL (default), torch.distributed.all_gather_into_tensor, or the "
                          "direct-write hdn_gather_offsets_oneshot (hipIpc windows; validated on one device only)")
     ap.add_argument("--only-north", action="store_true", help="step = the north-star correlation only (profiling aid)")
-    ap.add_argument("--head-stream", choices=["inline", "after-north", "parallel"], default="parallel",
+    ap.add_argument("--head-stream", choices=["inline", "after-north", "parallel"], default="after-north",
                     help="where the homography head runs in the TIMED region: in line with the correlations; on its own stream beside "
-                         "the 13x13 and 5x5 launches only; or on its own stream from the start of the step (default: the fastest "
-                         "schedule).  The roofline block times the 31x31 kernel in --roofline-steps separate steps of the after-north "
-                         "schedule, where that launch has the chip to itself")
+                         "the 13x13 and 5x5 launches only (default: the fastest schedule since the streaming hints, and the 31x31 "
+                         "launch has the chip to itself, so the roofline brackets ARE the timed region's); or on its own stream from "
+                         "the start of the step (then the roofline block times the 31x31 kernel in --roofline-steps separate "
+                         "after-north steps)")
     ap.add_argument("--roofline-steps", type=int, default=30, help="untimed steps after the timed region in which the 31x31 launch is bracketed")
     ap.add_argument("--north", choices=["fft", "fftr", "fft2w", "direct", "dense", "mfma"], default=None,
                     help="kernel for the 31x31 (x) 61x61 correlation (default: the library's default, fft = the column-first FFT kernel; fftr = the row-first one); A/B runs")
@@ -215,9 +217,10 @@ def main():
                     hdist.all_gather_offsets(d["off"], PAIRS * world, comm=comm)
 
         # The step's two branches are independent, as in the tracker (similarity-branch correlations | homography head).
-        # tools/experiments/exp_streams2.py: one stream 0.324 ms; head beside the 13x13 and 5x5 launches 0.317; head from the start
-        # of the step 0.301 (it fills the SIMDs the persistent 31x31 workers leave as they retire) - but then the roofline
-        # block times the 31x31 kernel while it shares the chip (125-131 us instead of 110), so that is not the default.
+        # Rounds 2-3 (tools/experiments/exp_streams2.py): one stream 0.324 ms; head beside the 13x13 and 5x5 launches 0.317; head from
+        # the start of the step 0.301.  Since the correlation kernels use nontemporal loads / stores the order is the other way
+        # round (tools/experiments/ab_head_stream.sh, three alternations on one box): after-north 0.2778-0.2783 ms, parallel
+        # 0.2830-0.2852 ms - the issue-bound 31x31 kernel is best left alone, the head hides behind the bandwidth-bound launches.
         mode = "inline" if args.only_north else (mode or args.head_stream)
         if mode == "parallel":
             fork_head()
@@ -280,14 +283,19 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
-    # Roofline of the 31x31 (x) 61x61 kernel: bracketed on its launch stream inside whole steps of the after-north schedule
-    # (the launch has the chip to itself, the clocks / power state are the step's), in a separate short loop so that the timed
-    # region above can run the fastest schedule.  The brackets taken inside the timed region are reported beside it.
+    # Roofline of the 31x31 (x) 61x61 kernel: HIP events on its launch stream around the launch.  Under the default schedule
+    # (after-north: the head stream is forked behind that launch, which therefore has the chip to itself) the brackets of the
+    # TIMED region are the measurement.  Under another schedule the timed region's brackets are reported beside a short separate
+    # loop of after-north steps.
+    timed_is_clean = args.only_north or args.head_stream == "after-north"
     solo_ev = []
-    for _ in range(3):
-        step(False, collective=False, mode="inline" if args.only_north else "after-north")
-    for _ in range(max(1, args.roofline_steps)):
-        step(True, collective=False, mode="inline" if args.only_north else "after-north", sink=solo_ev)
+    if timed_is_clean:
+        solo_ev = list(north_ev)
+    else:
+        for _ in range(3):
+            step(False, collective=False, mode="after-north")
+        for _ in range(max(1, args.roofline_steps)):
+            step(True, collective=False, mode="after-north", sink=solo_ev)
     torch.cuda.synchronize()
     solo = np.array([a.elapsed_time(b) for a, b in solo_ev])
     in_region = np.array([a.elapsed_time(b) for a, b in north_ev])
@@ -358,13 +366,16 @@ def main():
             "avg_launch_ms": north_ms,
             "min_launch_ms": float(solo.min()),
             "median_launch_ms": float(np.median(solo)),
-            "timing": "in-step, %d brackets: HIP events on the launch stream around the 31x31 launch in %d separate steps run after the "
-                      "timed region with the head stream forked AFTER that launch (it has the chip to itself); achieved / frac use the mean"
-                      % (len(solo), len(solo)),
+            "timing": ("in-step, %d brackets: HIP events on the launch stream around every 31x31 launch of the timed region (after-north "
+                       "schedule: the head stream is forked behind that launch, it has the chip to itself); achieved / frac use the mean"
+                       % len(solo)) if timed_is_clean else
+                      ("in-step, %d brackets: HIP events on the launch stream around the 31x31 launch in %d separate steps run after the "
+                       "timed region with the head stream forked AFTER that launch (it has the chip to itself); achieved / frac use the mean"
+                       % (len(solo), len(solo))),
             "timed_region_launch_ms": {"schedule": "inline" if args.only_north else args.head_stream, "mean": float(in_region.mean()),
                                        "min": float(in_region.min()), "median": float(np.median(in_region)),
-                                       "note": "the same brackets inside the timed region; under the parallel schedule the kernel "
-                                               "shares the chip with the homography head there"},
+                                       "note": "the brackets inside the timed region (identical to the above under the default schedule; under "
+                                               "the parallel schedule the kernel shares the chip with the homography head there)"},
         },
     }
     if north_variant.startswith("north_fft"):

@@ -410,7 +410,8 @@ def test_committed_bench_line_follows_the_contract(name):
         assert "xcorr_north_fft4_kernel" in d["roofline"]["kernel"]
     if name.startswith("round3"):
         r3 = d["roofline"]
-        assert r3["min_launch_ms"] <= r3["median_launch_ms"] and "in-step" in r3["timing"] and r3["timed_region_launch_ms"]["schedule"] == "parallel"
+        assert r3["min_launch_ms"] <= r3["median_launch_ms"] and "in-step" in r3["timing"] and r3["timed_region_launch_ms"]["schedule"] == "after-north"
+        assert abs(r3["timed_region_launch_ms"]["mean"] - r3["avg_launch_ms"]) <= 1e-9      # default schedule: the brackets ARE the timed region's
         assert "gpu_over_cpu" not in d and "median_of_5" in d["cpu_baseline"]["frames_per_s_1_thread"]
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
