@@ -98,6 +98,11 @@ __global__ __launch_bounds__(HDN_BLOCK) void subwindow_kernel(const uint8_t* __r
 }
 
 // ---- cv2.warpPerspective, 8U, INTER_LINEAR, BORDER_REPLICATE ----------------------------------------------------------
+// A pixel of the BGR frame is 3 bytes at a byte-aligned address; neighbouring taps of a row are contiguous.  One byte-aligned 4-byte
+// load (global memory takes them) per 4 bytes instead of one byte load per sample: the warps are bound by the number of loads.
+typedef uint32_t u32u __attribute__((aligned(1)));
+__device__ __forceinline__ uint32_t ld4(const uint8_t* p) { return *reinterpret_cast<const u32u*>(p); }
+__device__ __forceinline__ int byte_of(uint32_t w, int i) { return (int)((w >> (8 * i)) & 0xffu); }
 __device__ __forceinline__ void inv3(const double* m, double* o) {
   const double d = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
   const double id = d != 0.0 ? 1.0 / d : 0.0;
@@ -114,7 +119,9 @@ __global__ __launch_bounds__(HDN_BLOCK) void frame_warp_perspective_kernel(const
   for (int q = 0; q < 9; ++q) m[q] = M[q];
   inv3(m, mi);
   const size_t n = size_t(H) * W;
-  for (size_t pix = size_t(blockIdx.x) * HDN_BLOCK + threadIdx.x; pix < n; pix += size_t(gridDim.x) * HDN_BLOCK) {
+  for (size_t base = size_t(blockIdx.x) * HDN_BLOCK; base < n; base += size_t(gridDim.x) * HDN_BLOCK) {
+    const bool valid = base + threadIdx.x < n;
+    const size_t pix = valid ? base + threadIdx.x : n - 1;
     const int y = (int)(pix / W), x = (int)(pix - size_t(y) * W);
     const int bx = (x / bw) * bw, x1 = x - bx;
     const double X0 = mi[0] * bx + mi[1] * y + mi[2], Y0 = mi[3] * bx + mi[4] * y + mi[5], W0 = mi[6] * bx + mi[7] * y + mi[8];
@@ -129,10 +136,26 @@ __global__ __launch_bounds__(HDN_BLOCK) void frame_warp_perspective_kernel(const
     const uint8_t* p01 = src + (size_t(y0) * W + x1c) * C;
     const uint8_t* p10 = src + (size_t(y1c) * W + x0) * C;
     const uint8_t* p11 = src + (size_t(y1c) * W + x1c) * C;
-    for (int q = 0; q < C; ++q) {
-      const int acc = p00[q] * w00 + p01[q] * w01 + p10[q] * w10 + p11[q] * w11;
-      dst[pix * C + q] = (uint8_t)min(max((acc + (1 << 14)) >> 15, 0), 255);
+    int res[FR_MAXC] = {0, 0, 0, 0};
+    if (C == 3 && x1c == x0 + 1 && size_t(y1c) * W + x0 + 2 < n) {
+      // the two taps of a row are 6 contiguous bytes: two 4-byte loads per row (the last two bytes read belong to the next pixel,
+      // which exists); same integer sums as the byte path below
+      const uint32_t a0 = ld4(p00), a1 = ld4(p00 + 4), b0 = ld4(p10), b1 = ld4(p10 + 4);
+      const int t00[3] = {byte_of(a0, 0), byte_of(a0, 1), byte_of(a0, 2)}, t01[3] = {byte_of(a0, 3), byte_of(a1, 0), byte_of(a1, 1)};
+      const int t10[3] = {byte_of(b0, 0), byte_of(b0, 1), byte_of(b0, 2)}, t11[3] = {byte_of(b0, 3), byte_of(b1, 0), byte_of(b1, 1)};
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int acc = t00[q] * w00 + t01[q] * w01 + t10[q] * w10 + t11[q] * w11;
+        res[q] = min(max((acc + (1 << 14)) >> 15, 0), 255);
+      }
+    } else {
+      for (int q = 0; q < C; ++q) {
+        const int acc = p00[q] * w00 + p01[q] * w01 + p10[q] * w10 + p11[q] * w11;
+        res[q] = min(max((acc + (1 << 14)) >> 15, 0), 255);
+      }
     }
+    if (valid)
+      for (int q = 0; q < C; ++q) dst[pix * C + q] = (uint8_t)res[q];
   }
 }
 
@@ -150,7 +173,9 @@ __global__ __launch_bounds__(HDN_BLOCK) void frame_warp_affine_cubic_kernel(cons
   const double b1 = -m00 * m02 - m01 * m12, b2 = -m10 * m02 - m11 * m12;
   m02 = b1; m12 = b2;
   const size_t n = size_t(H) * W;
-  for (size_t pix = size_t(blockIdx.x) * HDN_BLOCK + threadIdx.x; pix < n; pix += size_t(gridDim.x) * HDN_BLOCK) {
+  for (size_t base = size_t(blockIdx.x) * HDN_BLOCK; base < n; base += size_t(gridDim.x) * HDN_BLOCK) {
+    const bool valid = base + threadIdx.x < n;
+    const size_t pix = valid ? base + threadIdx.x : n - 1;
     const int y = (int)(pix / W), x = (int)(pix - size_t(y) * W);
     const long long adelta = llrint(m00 * x * 1024.0), bdelta = llrint(m10 * x * 1024.0);
     const long long X0 = llrint((m01 * y + m02) * 1024.0) + 16, Y0 = llrint((m11 * y + m12) * 1024.0) + 16;
@@ -158,18 +183,36 @@ __global__ __launch_bounds__(HDN_BLOCK) void frame_warp_affine_cubic_kernel(cons
     const long long sx = (X >> 5) - 1, sy = (Y >> 5) - 1;
     const short* tab = g_cubic_itab + (((int)(Y & 31) * 32 + (int)(X & 31)) << 4);
     int acc[FR_MAXC] = {0, 0, 0, 0};
+    if (C == 3 && sx >= 0 && sx + 3 <= (long long)W - 1) {
+      // interior columns: the four taps of a row are 12 contiguous bytes = three 4-byte loads (the sums are integer: any order)
 #pragma unroll
-    for (int k1 = 0; k1 < 4; ++k1) {
-      const int yy = (int)min(max(sy + k1, 0LL), (long long)H - 1);
+      for (int k1 = 0; k1 < 4; ++k1) {
+        const int yy = (int)min(max(sy + k1, 0LL), (long long)H - 1);
+        const uint8_t* p = src + (size_t(yy) * W + (size_t)sx) * 3;
+        const uint32_t u0 = ld4(p), u1 = ld4(p + 4), u2 = ld4(p + 8);
+        const int w0 = tab[k1 * 4], w1 = tab[k1 * 4 + 1], w2 = tab[k1 * 4 + 2], w3 = tab[k1 * 4 + 3];
+        acc[0] += byte_of(u0, 0) * w0 + byte_of(u0, 3) * w1 + byte_of(u1, 2) * w2 + byte_of(u2, 1) * w3;
+        acc[1] += byte_of(u0, 1) * w0 + byte_of(u1, 0) * w1 + byte_of(u1, 3) * w2 + byte_of(u2, 2) * w3;
+        acc[2] += byte_of(u0, 2) * w0 + byte_of(u1, 1) * w1 + byte_of(u2, 0) * w2 + byte_of(u2, 3) * w3;
+      }
+    } else {
 #pragma unroll
-      for (int k2 = 0; k2 < 4; ++k2) {
-        const int xx = (int)min(max(sx + k2, 0LL), (long long)W - 1);
-        const int w = tab[k1 * 4 + k2];
-        const uint8_t* p = src + (size_t(yy) * W + xx) * C;
-        for (int q = 0; q < C; ++q) acc[q] += p[q] * w;
+      for (int k1 = 0; k1 < 4; ++k1) {
+        const int yy = (int)min(max(sy + k1, 0LL), (long long)H - 1);
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) {
+          const int xx = (int)min(max(sx + k2, 0LL), (long long)W - 1);
+          const int w = tab[k1 * 4 + k2];
+          const uint8_t* p = src + (size_t(yy) * W + xx) * C;
+          for (int q = 0; q < C; ++q) acc[q] += p[q] * w;
+        }
       }
     }
-    for (int q = 0; q < C; ++q) dst[pix * C + q] = (uint8_t)min(max((acc[q] + (1 << 14)) >> 15, 0), 255);
+    int res[FR_MAXC];
+#pragma unroll
+    for (int q = 0; q < FR_MAXC; ++q) res[q] = min(max((acc[q] + (1 << 14)) >> 15, 0), 255);
+    if (valid)
+      for (int q = 0; q < C; ++q) dst[pix * C + q] = (uint8_t)res[q];
   }
 }
 

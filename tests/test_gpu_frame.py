@@ -71,6 +71,22 @@ def test_frame_warps_vs_oracle(dev):
     for (cx, cy, rot) in ((160.0, 90.0, 0.3), (10.0, 170.0, -1.2), (400.0, -20.0, 3.0)):
         got = FR.rot_around_center(fr, cx, cy, rot).cpu().numpy()
         np.testing.assert_array_equal(got, F.warp_affine_cubic_u8(im, F.rot_matrix_2x3(cx, cy, rot)))
+    # sizes whose pixel count is not a multiple of 4 (the last pixels leave as bytes, the rest as packed 4-byte stores), images narrower
+    # than the 4-tap window, a single pixel; and 1- / 4-channel frames (byte path throughout)
+    for (h, w) in ((7, 5), (33, 31), (1, 1), (2, 3), (5, 127), (257, 3)):
+        im2 = r.integers(0, 256, (h, w, 3)).astype(np.uint8)
+        f2 = FR.upload(im2)
+        M = np.array([[0.97, 0.05, 0.7], [-0.04, 1.03, -0.4], [1e-4, -2e-4, 1.0]])
+        np.testing.assert_array_equal(FR.warp_perspective(f2, M).cpu().numpy(), F.warp_perspective_u8(im2, M), err_msg=str((h, w)))
+        A = F.rot_matrix_2x3(w / 2.0, h / 3.0, 0.4)
+        np.testing.assert_array_equal(FR.warp_affine_cubic(f2, A).cpu().numpy(), F.warp_affine_cubic_u8(im2, A), err_msg=str((h, w)))
+    for c in (1, 4):
+        im2 = r.integers(0, 256, (21, 19, c)).astype(np.uint8)
+        f2 = FR.upload(im2)
+        M = np.array([[1.01, 0.02, -1.3], [0.03, 0.98, 2.2], [0, 0, 1.0]])
+        np.testing.assert_array_equal(FR.warp_perspective(f2, M).cpu().numpy(), F.warp_perspective_u8(im2, M))
+        A = F.rot_matrix_2x3(9.0, 11.0, -0.2)
+        np.testing.assert_array_equal(FR.warp_affine_cubic(f2, A).cpu().numpy(), F.warp_affine_cubic_u8(im2, A))
     with pytest.raises(Exception):
         FR.get_subwindow(torch.zeros(4, 4, 3, dtype=torch.uint8), [1, 1], 3, 3, [0, 0, 0])
 
