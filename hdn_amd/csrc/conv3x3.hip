@@ -12,17 +12,18 @@
 // ~2^-23 relative per product.  The weights are split once on the host (hdn_amd.trunk.pack_conv3x3), the activations while they
 // are staged into LDS.
 //
-// Workgroup = 4 waves, tile = BM output pixels (consecutive in (b, y, x) order: whole image rows) x BN output channels.
+// Workgroup = 8 waves (4 consumers issuing MFMAs + 4 producers staging operands, see conv3x3_kernel), tile = BM output pixels
+// (consecutive in (b, y, x) order: whole image rows) x BN output channels.
 //   LDS A image: the tile's input pixels with a one-pixel halo (zeros outside the image), one K chunk of 16 * KS input channels at
 //                a time, as [piece][k step][k half][pixel] x 16 B: an MFMA A fragment (lane = (pixel row i, k half g), 8 bf16) is
-//                one conflict-free ds_read_b128, and a tap is a constant address offset.
-//   LDS W image: [tap of the stage][k step][piece][k half][cout] x 16 B, one STAGE = one kernel row (3 taps) of one chunk, double
-//                buffered, streamed from the host-packed layout (which is exactly this order).
-//   pipeline   : A and W images are double buffered; the next chunk's activations and the next two stages' weights are in flight
-//                in registers (global loads) while the current stage runs on the matrix cores, their LDS stores are issued between
-//                its MFMAs, and the next step's fragments are read from LDS one step ahead: one barrier per stage.
+//                one ds_read_b128 and a tap is a constant address offset; conflict-free through the row / image pitches of Cfg and
+//                the lane -> pixel order of mrow_to_pixel().  Two images (double buffer).
+//   LDS W image: [tap of the stage][k step][piece][k half][cout] x 16 B, one STAGE = one kernel row (3 taps) of one chunk, a ring
+//                of three stages, streamed from the host-packed layout (which is exactly this order).
+//   pipeline   : the producers run two stages ahead of the consumers (weights in registers two more stages ahead of that); the
+//                consumers read a step's fragments one step ahead, across stage boundaries too: one barrier per stage.
 //   wave tile  : MT x NT MFMA tiles of 32 x 32; accumulators stay in registers over the whole K loop;
-//   epilogue   : + bias[cout] (+ residual) -> ReLU -> NHWC store, 128 contiguous bytes per pixel row and half wave.
+//   epilogue   : the tile goes through LDS once, then + bias[cout] (+ residual) -> ReLU -> NHWC store, 16 bytes per lane, by all 512 threads.
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
