@@ -775,8 +775,12 @@ __global__ __launch_bounds__(HDN_BLOCK, 2) void xcorr_north_mfma_kernel(XcorrPtr
 namespace circ13f {
 constexpr int N = 13, PL = N * N, NF = 7, PPW = 9, WAVES = HDN_BLOCK / 64;
 constexpr int XS = 172;                    // floats per plane in the LDS input / output images (43 16-byte words)
-constexpr int TS = 184;                    // floats per plane in the spectra and Z images: 7 x 13 complex, padded
-constexpr int REGION = PPW * TS;           // 1,656 floats: a region holds 9 input planes, or 9 spectra, or Z, or the output rows
+// floats per plane in the spectra and Z images: 7 x 13 complex = 91 float2, NOT padded: 91 = 27 (mod 32) is the plane pitch that
+// spreads the 8-byte slots of a 32-lane access best for the (plane, frequency) and (plane, column) lane orders of stages 2 and 3
+// (brute force over pitches and row strides, round 3: 175 LDS cycles per wave against 257 at the former pitch of 92; SQ_LDS_BANK_CONFLICT
+// was 45 % of the kernel's LDS cycles)
+constexpr int TS = 182;
+constexpr int REGION = round_up(PPW * TS, 4);   // 1,640 floats: a region holds 9 input planes, or 9 spectra, or Z, or the output rows (16-byte aligned)
 constexpr int WAVE_FLOATS = 2 * REGION;    // 13.2 KB per wave: 12 waves per CU
 static_assert(PPW * XS <= REGION, "inputs fit");
 
