@@ -110,20 +110,24 @@ __global__ __launch_bounds__(HDN_BLOCK, 2) void trunk_stem_kernel(const float* _
 #pragma unroll
     for (int k = 0; k < NPAIR; ++k) acc[i][k] = float2v{0.f, 0.f};
 
-#pragma unroll 1
-  for (int t = 0; t < 2 * KS; ++t) {
+  // the NR input rows of step t = (input channel, ky): iy = 2 (r0 + i) - 3 + ky, each as the four pairs its 7 taps come from:
+  //   kx: 0 -> (c-2).y   1, 2 -> (c-1).x, .y   3, 4 -> own .x, .y   5, 6 -> (c+1).x, .y
+  // All NR loads in flight at once, branch-free: rows beyond the image re-read row 0 and are dropped.  The rows of step t + 1 are
+  // asked for before step t's FMAs: with few waves per SIMD (the tracker's B = 1 call) a step would otherwise begin with a full
+  // HBM / L2 round trip, fourteen times over.
+  auto load_rows = [&](int t, float2v (&raw)[NR], bool (&rk)[NR]) {
     const int ci = t >= KS ? 1 : 0, ky = t - KS * ci;
-    // the 9 input rows iy = 2 (r0 + i) - 3 + ky, each as the four pairs its 7 taps come from:
-    //   kx: 0 -> (c-2).y   1, 2 -> (c-1).x, .y   3, 4 -> own .x, .y   5, 6 -> (c+1).x, .y
-    float2v raw[NR];
-    bool rk[NR];
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {  // all 9 loads in flight at once: branch-free, rows beyond the image re-read row 0 and are dropped
+    for (int i = 0; i < NR; ++i) {
       const int iy = 2 * (r0 + i) - 3 + ky;          // wave-uniform
       const bool rok = iy >= 0 && iy < H;
       rk[i] = rok;
       raw[i] = *reinterpret_cast<const f2u*>(reinterpret_cast<const char*>(xb + ci * HW + (rok ? iy : 0) * W) + ix0);
     }
+  };
+  // one step: the 7 taps of (input channel, ky) on the NR rows
+  auto do_step = [&](int t, const float2v (&raw)[NR], const bool (&rk)[NR]) {
+    const int ci = t >= KS ? 1 : 0, ky = t - KS * ci;
     const cfloat* wr = opaque(wT + cb * CB + (ci * KS + ky) * KS * CO);
     f16v w = sload16<0>(wr);
     float2v xv[NR][4];
@@ -151,6 +155,30 @@ __global__ __launch_bounds__(HDN_BLOCK, 2) void trunk_stem_kernel(const float* _
         w = wn;
       }
     });
+  };
+  if constexpr (PR == 1) {
+    // small batches (few waves per SIMD, nothing to hide a round trip behind): ALL 14 x 3 input rows are asked for up front
+    // (84 registers), the loop is unrolled
+    float2v raw[2 * KS][NR];
+    bool rk[2 * KS][NR];
+#pragma unroll
+    for (int t = 0; t < 2 * KS; ++t) load_rows(t, raw[t], rk[t]);
+#pragma unroll
+    for (int t = 0; t < 2 * KS; ++t) do_step(t, raw[t], rk[t]);
+  } else {
+    float2v raw[NR], rawn[NR];
+    bool rk[NR], rkn[NR];
+    load_rows(0, raw, rk);
+#pragma unroll 1
+    for (int t = 0; t < 2 * KS; ++t) {
+      load_rows(min(t + 1, 2 * KS - 1), rawn, rkn);
+      do_step(t, raw, rk);
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        raw[i] = rawn[i];
+        rk[i] = rkn[i];
+      }
+    }
   }
 
   // + bias, ReLU; conv rows / columns that do not exist are 0 (they never win a maximum: every window has a real element >= 0)
