@@ -230,7 +230,7 @@ extern "C" int hdn_trunk_stem_f32(const float* x, const float* wT, const float* 
   if (out == x) return HDN_E_ALIAS;
   // a wave: PR pooled rows x 16 channels x the full width.  4-row strips share most of their input rows (9 conv rows for 4 pooled
   // ones); below ~1,000 waves (B < 32 at 127 px) the chip is better filled by 1-row strips (3 conv rows each: 1.3 x the arithmetic,
-  // 4 x the waves, a quarter of the chain per wave) - the tracker's B = 1 call drops from 35 to ~12 us
+  // 4 x the waves, a quarter of the chain per wave) - the tracker's B = 1 call drops from 35 to 27 us, and to 12 us with all of a wave's 42 input rows asked for up front (see the kernel)
   const bool small = (long long)B * 4 * hdn::cdiv(Hp, 4) < 1024;
   const int pr = small ? 1 : 4;
   const int strips = hdn::cdiv(Hp, pr);
