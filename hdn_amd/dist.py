@@ -101,12 +101,17 @@ class OneShotGather:
         with torch.cuda.device(self.device):
             _lib.check(lib.hdn_gather_create(ctypes.byref(h), self.world, self.rank, self.max_rows * 32), "hdn_gather_create")
             self._h = h
-            mine = ctypes.create_string_buffer(64)
-            _lib.check(lib.hdn_gather_handle(h, mine), "hdn_gather_handle")
-            handles = exchange(mine.raw)
-            if len(handles) != self.world or any(len(x) != 64 for x in handles):
-                raise ValueError("exchange() must return one 64-byte handle per rank")
-            _lib.check(lib.hdn_gather_connect(h, ctypes.c_char_p(b"".join(handles))), "hdn_gather_connect")
+            try:
+                mine = ctypes.create_string_buffer(64)
+                _lib.check(lib.hdn_gather_handle(h, mine), "hdn_gather_handle")
+                handles = exchange(mine.raw)
+                if len(handles) != self.world or any(len(x) != 64 for x in handles):
+                    raise ValueError("exchange() must return one 64-byte handle per rank")
+                _lib.check(lib.hdn_gather_connect(h, ctypes.c_char_p(b"".join(handles))), "hdn_gather_connect")
+            except Exception:
+                self._h = None                     # (the window is freed; peers that already mapped it must not use it)
+                lib.hdn_gather_destroy(h)
+                raise
 
     @classmethod
     def from_process_group(cls, max_rows: int, device=None, group=None):
