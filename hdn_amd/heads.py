@@ -4,8 +4,11 @@
     DepthwiseXCorrCirc / DepthwiseCircBAN / MultiCircBAN <- hdn/models/head/ban_lp.py:14-92
 
 Same module / parameter names as the reference, so its snapshots load.  The 3x3 / 1x1 convolutions stay on
-PyTorch-ROCm (MIOpen); what changes is the schedule of a frame:
+PyTorch-ROCm (MIOpen / hipBLASLt); what changes is the schedule of a frame:
   * all 3 levels x {cls, loc} correlations of a head are ONE launch (hdn_xcorr_depthwise_multi_f32);
+  * at the tracker's B = 1 everything around the correlations is packed (_PackedHead: BatchNorm folded, the two branches of a
+    level as one convolution, the 1x1 convolutions of all levels and the weighted sum as two batched matrix products): ~15 launches
+    per head instead of ~70;
   * the template branch conv_kernel(z_f) is computed once per template (the reference recomputes it every
     frame although self.zf only changes in template(), model_builder_e2e_unconstrained_v2.py:87-96, ban.py:74).
 `fused_forward` works on any object with the reference's attribute layout, so install() can bind it onto the
@@ -17,7 +20,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .xcorr import xcorr_depthwise, xcorr_depthwise_circular, xcorr_depthwise_multi
+from .xcorr import out_shape, xcorr_depthwise, xcorr_depthwise_circular, xcorr_depthwise_multi
 
 
 def _conv_bn_relu(cin, cout, k):
@@ -89,12 +92,30 @@ class _TemplateCache:
                 and _param_versions(branches) == self.param_versions)
 
 
+def _tensor_refs(modules):
+    """(dict, name) of every parameter / buffer below `modules`: walking Module.parameters() costs ~1 us per tensor and frame in
+    the eager loop; a held reference to the owning module's _parameters / _buffers dict is a plain lookup.  (Replacing a whole
+    sub-module afterwards is not seen: invalidate_template_cache() drops the references.)"""
+    refs = []
+    for m in modules:
+        for sub in m.modules():
+            refs += [(sub._parameters, n) for n, t in sub._parameters.items() if t is not None]
+            refs += [(sub._buffers, n) for n, t in sub._buffers.items() if t is not None]
+    return refs
+
+
+def _versions(refs):
+    return tuple((id(t), t.data_ptr(), t._version) for t in (d[n] for d, n in refs))
+
+
 def _param_versions(branches):
-    out = []
-    for br in branches:
-        for t in list(br.conv_kernel.parameters()) + list(br.conv_kernel.buffers()):
-            out.append((id(t), t.data_ptr(), t._version))
-    return tuple(out)
+    head = getattr(branches[0], "_hdn_owner", None)
+    refs = getattr(head, "_hdn_refs_template", None) if head is not None else None
+    if refs is None:
+        refs = _tensor_refs([br.conv_kernel for br in branches])
+        if head is not None:
+            object.__setattr__(head, "_hdn_refs_template", refs)
+    return _versions(refs)
 
 
 def invalidate_template_cache(head):
@@ -102,6 +123,123 @@ def invalidate_template_cache(head):
     every new template calls this for both heads; call it yourself after mutating weights through .data (which bypasses the
     version counters the cache is keyed on) without re-running template()."""
     object.__setattr__(head, "_hdn_template_cache", None)
+    object.__setattr__(head, "_hdn_packed_head", None)
+    object.__setattr__(head, "_hdn_refs_template", None)
+    object.__setattr__(head, "_hdn_refs_head", None)
+    object.__setattr__(head, "_hdn_packable", None)
+
+
+class _PackedHead:
+    """Everything of a head behind the correlations, packed for the tracker's B = 1 call (launch-bound: ~70 small kernels per
+    forward in the module-by-module form, 313 us under a hipGraph at 256 channels; packed ~15):
+      * conv_search of a level: BatchNorm folded into the weights, the cls and loc branches (same input) as ONE convolution with
+        2 x hidden output channels, bias + ReLU in one pass (hdn_bias_relu_f32);
+      * the first 1x1 convolution + BatchNorm of all 2n (level, branch) heads: one batched matrix product;
+      * the second 1x1 convolution, loc_scale and the (softmax-)weighted sum over the levels are linear: one batched matrix
+        product with the weights [cw_0 W_0 | cw_1 W_1 | ...] per branch.
+    Keyed on the version counters of every tensor it was built from (as _TemplateCache is)."""
+
+    __slots__ = ("key", "ws", "bs", "w1", "b1", "wf", "bf", "oc", "ol", "hidden")
+
+
+def _head_key(self, boxes):
+    refs = getattr(self, "_hdn_refs_head", None)
+    if refs is None:
+        refs = _tensor_refs([m for box in boxes for br in (box.cls, box.loc) for m in (br.conv_search, br.head)])
+        refs += [(self._parameters, n) for n in ("loc_scale", "cls_weight", "loc_weight") if self._parameters.get(n) is not None]
+        object.__setattr__(self, "_hdn_refs_head", refs)
+    return _versions(refs)
+
+
+def _packable(self, boxes, x_fs):
+    """The packed path covers the reference's configuration: B = 1 on a GPU, every level with the same channel counts and the
+    module layout of DepthwiseXCorr (conv3x3 no bias + BN + ReLU; conv1x1 no bias + BN + ReLU + conv1x1)."""
+    x0 = x_fs[0]
+    if not x0.is_cuda or x0.shape[0] != 1 or x0.dtype != torch.float32 or any(x.shape != x0.shape for x in x_fs):
+        return False
+    ref = None
+    for box in boxes:
+        for br in (box.cls, box.loc):
+            cs, hd = br.conv_search, br.head
+            if not (isinstance(cs, nn.Sequential) and len(cs) == 3 and isinstance(cs[0], nn.Conv2d) and isinstance(cs[1], nn.BatchNorm2d)
+                    and isinstance(hd, nn.Sequential) and len(hd) == 4 and isinstance(hd[0], nn.Conv2d) and isinstance(hd[1], nn.BatchNorm2d)
+                    and isinstance(hd[3], nn.Conv2d)):
+                return False
+            c0, h0, h3 = cs[0], hd[0], hd[3]
+            if (c0.bias is not None or c0.stride != (1, 1) or c0.padding != (0, 0) or c0.dilation != (1, 1) or c0.groups != 1
+                    or h0.bias is not None or h0.kernel_size != (1, 1) or h3.kernel_size != (1, 1) or h3.bias is None):
+                return False
+            sig = (tuple(c0.weight.shape), tuple(h0.weight.shape))
+            if ref is None:
+                ref = sig
+            elif sig != ref:
+                return False
+        if box.cls.head[3].weight.shape[1:] != box.loc.head[3].weight.shape[1:]:
+            return False
+    return all(tuple(box.cls.head[3].weight.shape) == tuple(boxes[0].cls.head[3].weight.shape)
+               and tuple(box.loc.head[3].weight.shape) == tuple(boxes[0].loc.head[3].weight.shape) for box in boxes)
+
+
+def _fold_bn(conv, bn):
+    s = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    return conv.weight * s.reshape(-1, 1, 1, 1), bn.bias - bn.running_mean * s
+
+
+def _pack_head(self, boxes):
+    n = len(boxes)
+    pk = _PackedHead()
+    pk.key = _head_key(self, boxes)
+    pk.ws, pk.bs = [], []
+    for box in boxes:
+        wc, bc = _fold_bn(box.cls.conv_search[0], box.cls.conv_search[1])
+        wl, bl = _fold_bn(box.loc.conv_search[0], box.loc.conv_search[1])
+        pk.ws.append(torch.cat([wc, wl], 0).contiguous())
+        pk.bs.append(torch.cat([bc, bl], 0).contiguous())
+    pk.hidden = hidden = boxes[0].cls.head[0].weight.shape[0]
+    order = [box.cls for box in boxes] + [box.loc for box in boxes]          # stacked order: cls of every level, then loc
+    w1, b1 = zip(*[_fold_bn(br.head[0], br.head[1]) for br in order])
+    pk.w1 = torch.stack([w.reshape(hidden, -1) for w in w1]).contiguous()      # [2n, hidden, hidden]
+    pk.b1 = torch.stack(b1).reshape(2 * n, hidden, 1).contiguous()
+    dev, dt = pk.w1.device, pk.w1.dtype
+    if self.weighted:
+        cw, lw = F.softmax(self.cls_weight, 0), F.softmax(self.loc_weight, 0)
+    else:
+        cw = lw = torch.full((n,), 1.0 / n, device=dev, dtype=dt)
+    lw = lw * self.loc_scale
+    pk.oc, pk.ol = boxes[0].cls.head[3].weight.shape[0], boxes[0].loc.head[3].weight.shape[0]
+    om = max(pk.oc, pk.ol)
+    pk.wf = torch.zeros((2, om, n * hidden), device=dev, dtype=dt)
+    pk.bf = torch.zeros((2, om, 1), device=dev, dtype=dt)
+    for i, box in enumerate(boxes):
+        pk.wf[0, :pk.oc, i * hidden:(i + 1) * hidden] = cw[i] * box.cls.head[3].weight.reshape(pk.oc, hidden)
+        pk.wf[1, :pk.ol, i * hidden:(i + 1) * hidden] = lw[i] * box.loc.head[3].weight.reshape(pk.ol, hidden)
+        pk.bf[0, :pk.oc, 0] += cw[i] * box.cls.head[3].bias
+        pk.bf[1, :pk.ol, 0] += lw[i] * box.loc.head[3].bias
+    return pk
+
+
+def _packed_forward(self, boxes, kern, x_fs, circular):
+    from .trunk import bias_relu_
+    n = len(boxes)
+    pk = getattr(self, "_hdn_packed_head", None)
+    key = _head_key(self, boxes)
+    if pk is None or pk.key != key:
+        pk = _pack_head(self, boxes)
+        object.__setattr__(self, "_hdn_packed_head", pk)
+    h = pk.hidden
+    s_cls, s_loc = [], []
+    for l in range(n):
+        y = F.conv2d(x_fs[l], pk.ws[l])                  # [1, 2 hidden, Ho, Wo]: both branches of the level
+        bias_relu_(y, pk.bs[l])
+        s_cls.append(y[:, :h])
+        s_loc.append(y[:, h:])
+    k_cls, k_loc = kern[0::2], kern[1::2]                 # the template cache holds (cls, loc) per level
+    shape = out_shape(s_cls[0].shape, k_cls[0].shape, circular)
+    feats = torch.empty((2 * n, h, shape[2], shape[3]), dtype=torch.float32, device=y.device)
+    xcorr_depthwise_multi(s_cls + s_loc, list(k_cls) + list(k_loc), circular=circular, outs=[feats[i:i + 1] for i in range(2 * n)])
+    hid = torch.baddbmm(pk.b1, pk.w1, feats.view(2 * n, h, -1)).relu_()
+    out = torch.baddbmm(pk.bf, pk.wf, hid.view(2, n * h, -1))
+    return (out[0, :pk.oc].reshape(1, pk.oc, shape[2], shape[3]), out[1, :pk.ol].reshape(1, pk.ol, shape[2], shape[3]))
 
 
 def fused_forward(self, z_fs, x_fs, circular=None):
@@ -120,6 +258,8 @@ def fused_forward(self, z_fs, x_fs, circular=None):
     n = len(z_fs)
     boxes = [getattr(self, "box" + str(i + 2)) for i in range(n)]
     branches = [br for box in boxes for br in (box.cls, box.loc)]
+    if getattr(branches[0], "_hdn_owner", None) is not self:
+        object.__setattr__(branches[0], "_hdn_owner", self)       # (plain attribute, not a registered sub-module: where _param_versions keeps its references)
     if circular is None:
         circular = bool(getattr(boxes[0].cls, "_circular", False)) or type(boxes[0].cls).__name__.endswith("Circ")
     with torch.no_grad():
@@ -129,6 +269,14 @@ def fused_forward(self, z_fs, x_fs, circular=None):
             cache = _TemplateCache(z_fs, branches, False, kern)
             object.__setattr__(self, "_hdn_template_cache", cache)
         kern = cache.kern
+        pv = getattr(self, "_hdn_packable", None)
+        sig = (tuple(x_fs[0].shape), x_fs[0].device, x_fs[0].dtype)
+        if pv is None or pv[0] != sig:
+            pv = (sig, 2 * n <= 8 and _packable(self, boxes, x_fs))
+            object.__setattr__(self, "_hdn_packable", pv)
+        if (pv[1] and all(x.shape == x_fs[0].shape for x in x_fs) and all(k.shape == kern[0].shape for k in kern)
+                and not getattr(self, "_hdn_no_packed_head", False)):
+            return _packed_forward(self, boxes, kern, x_fs, circular)
         srch = [br.conv_search(x) for box, x in zip(boxes, x_fs) for br in (box.cls, box.loc)]
         same = all(k.shape == kern[0].shape for k in kern) and all(s.shape == srch[0].shape for s in srch)
         if same and len(kern) <= 8:

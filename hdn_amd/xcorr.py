@@ -63,8 +63,10 @@ def xcorr_depthwise_circular(x: torch.Tensor, kernel: torch.Tensor) -> torch.Ten
     return _xcorr(x, kernel, True)
 
 
-def xcorr_depthwise_multi(xs: Sequence[torch.Tensor], kernels: Sequence[torch.Tensor], circular: bool = False) -> List[torch.Tensor]:
-    """n same-shaped correlations in one launch (n <= 8)."""
+def xcorr_depthwise_multi(xs: Sequence[torch.Tensor], kernels: Sequence[torch.Tensor], circular: bool = False,
+                          outs: Sequence[torch.Tensor] = None) -> List[torch.Tensor]:
+    """n same-shaped correlations in one launch (n <= 8).  `outs`: n preallocated contiguous float32 result tensors (e.g. the
+    slices of one stacked buffer) instead of fresh ones."""
     if len(xs) != len(kernels) or not xs:
         raise ValueError("xs and kernels must be non-empty and of equal length")
     n = len(xs)
@@ -83,7 +85,13 @@ def xcorr_depthwise_multi(xs: Sequence[torch.Tensor], kernels: Sequence[torch.Te
         xcs.append(xc)
         kcs.append(kc)
     lib = _lib.load()
-    outs = [torch.empty(shape, dtype=torch.float32, device=dev) for _ in range(n)]
+    if outs is None:
+        outs = [torch.empty(shape, dtype=torch.float32, device=dev) for _ in range(n)]
+    else:
+        outs = list(outs)
+        if len(outs) != n or any(tuple(o.shape) != tuple(shape) or o.dtype != torch.float32 or o.device != dev or not o.is_contiguous()
+                                 for o in outs):
+            raise ValueError(f"outs must be {n} contiguous float32 tensors of shape {tuple(shape)} on {dev}")
     arr = ctypes.c_void_p * n
     B, C, Hx, Wx = xcs[0].shape
     Hk, Wk = kcs[0].shape[2:]
