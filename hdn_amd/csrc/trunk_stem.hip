@@ -112,9 +112,9 @@ __global__ __launch_bounds__(HDN_BLOCK, 2) void trunk_stem_kernel(const float* _
 
   // the NR input rows of step t = (input channel, ky): iy = 2 (r0 + i) - 3 + ky, each as the four pairs its 7 taps come from:
   //   kx: 0 -> (c-2).y   1, 2 -> (c-1).x, .y   3, 4 -> own .x, .y   5, 6 -> (c+1).x, .y
-  // All NR loads in flight at once, branch-free: rows beyond the image re-read row 0 and are dropped.  The rows of step t + 1 are
-  // asked for before step t's FMAs: with few waves per SIMD (the tracker's B = 1 call) a step would otherwise begin with a full
-  // HBM / L2 round trip, fourteen times over.
+  // All NR loads in flight at once, branch-free: rows beyond the image re-read row 0 and are dropped.  With few waves per SIMD (the
+  // tracker's B = 1 call) a step would begin with a full HBM / L2 round trip, fourteen times over: the small-batch form below asks for
+  // every step's rows before the first FMA.
   auto load_rows = [&](int t, float2v (&raw)[NR], bool (&rk)[NR]) {
     const int ci = t >= KS ? 1 : 0, ky = t - KS * ci;
 #pragma unroll
@@ -166,18 +166,14 @@ __global__ __launch_bounds__(HDN_BLOCK, 2) void trunk_stem_kernel(const float* _
 #pragma unroll
     for (int t = 0; t < 2 * KS; ++t) do_step(t, raw[t], rk[t]);
   } else {
-    float2v raw[NR], rawn[NR];
-    bool rk[NR], rkn[NR];
-    load_rows(0, raw, rk);
+    // large batches: enough waves per SIMD to hide the rows' round trip; asking for step t + 1's rows a step ahead costs registers
+    // and measured 48 -> 53 us at B = 64
 #pragma unroll 1
     for (int t = 0; t < 2 * KS; ++t) {
-      load_rows(min(t + 1, 2 * KS - 1), rawn, rkn);
+      float2v raw[NR];
+      bool rk[NR];
+      load_rows(t, raw, rk);
       do_step(t, raw, rk);
-#pragma unroll
-      for (int i = 0; i < NR; ++i) {
-        raw[i] = rawn[i];
-        rk[i] = rkn[i];
-      }
     }
   }
 
