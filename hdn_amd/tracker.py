@@ -133,21 +133,31 @@ class HomoTracker:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         H0 = self.H_total.clone()
-        with torch.cuda.stream(side):
-            for _ in range(3):  # warm-up on the side stream (MIOpen find, lazy initialisations) without touching the state
-                self._body(self._static_frame)
-        torch.cuda.current_stream().wait_stream(side)
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
-            H, out, score = self._body(self._static_frame)      # (H_total is updated in place: the recurrence lives inside the graph)
-            self._g_out, self._g_score = out, score
-        self.H_total.copy_(H0)
+        try:
+            with torch.cuda.stream(side):
+                for _ in range(3):  # warm-up on the side stream (MIOpen find, lazy initialisations); H_total is put back below
+                    self._body(self._static_frame)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                H, out, score = self._body(self._static_frame)      # (H_total is updated in place: the recurrence lives inside the graph)
+                self._g_out, self._g_score = out, score
+            self._graph = graph
+        finally:
+            torch.cuda.current_stream().wait_stream(side)
+            self.H_total.copy_(H0)
 
     def track_new(self, fr_idx, img, gt_box=None, gt_poly=None, gt_points=None, sync: bool = True):
         if self.use_graph:
             t = img if isinstance(img, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(img))
             if self._graph is None:
-                self._capture(tuple(t.shape))
+                try:
+                    self._capture(tuple(t.shape))
+                except Exception as e:      # e.g. a model whose forward makes host round trips: the same kernels, launched one by one
+                    import warnings
+                    warnings.warn(f"hdn_amd: the per-frame body could not be captured as a hipGraph ({type(e).__name__}: {e}); running it eagerly")
+                    self.use_graph, self._graph = False, None
+                    return self.track_new(fr_idx, img, gt_box, gt_poly, gt_points, sync=sync)
             if tuple(t.shape) != tuple(self._static_frame.shape) or t.dtype != torch.uint8:
                 raise ValueError(f"graph mode was captured for uint8 frames of shape {tuple(self._static_frame.shape)}, got {t.dtype} {tuple(t.shape)}")
             self._static_frame.copy_(t, non_blocking=True)

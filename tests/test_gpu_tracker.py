@@ -300,3 +300,35 @@ def test_long_sequence_720p_graph_loop_vs_cpu(dev):
     assert trk._graph is not None and trk.host_syncs - syncs0 == len(frames) - 1
     assert errs[0] <= 1e-3 and max(errs[:10]) <= 1e-2, errs[:10]
     assert max(errs) <= 0.25, errs
+
+
+def test_graph_capture_failure_falls_back_to_eager(dev):
+    """A model whose forward cannot be captured (a host read inside it) makes graph mode warn and run eagerly, with the state intact."""
+    from synth_sequence import make_sequence
+    from test_gpu_parity import _seeded_net
+    from hdn_amd.tracker import HomoTracker
+    frames, corners, init = make_sequence(n_frames=4, frame_hw=(180, 320), target_wh=(80, 60), seed=5)
+    net = _seeded_net().to(dev)
+
+    class HostRead(torch.nn.Module):       # stands for reference-side code that synchronises
+        def __init__(self, inner):
+            super().__init__()
+            self.inner = inner
+
+        def forward(self, x):
+            float(x.sum())                 # device -> host read: illegal during capture
+            return self.inner(x)
+
+    good = HomoTracker(net, graph=False)
+    good.init(frames[0], init["bbox"], init["poly"], init["gt_points"], init["first_point"])
+    want = [good.track_new(t, frames[t])["points"] for t in range(1, 4)]
+    net2 = _seeded_net().to(dev)
+    net2.ShareFeature = HostRead(net2.ShareFeature)
+    trk = HomoTracker(net2, graph=True)
+    trk.init(frames[0], init["bbox"], init["poly"], init["gt_points"], init["first_point"])
+    with pytest.warns(UserWarning, match="could not be captured"):
+        got0 = trk.track_new(1, frames[1])["points"]
+    assert trk.use_graph is False
+    got = [got0] + [trk.track_new(t, frames[t])["points"] for t in (2, 3)]
+    for a, b in zip(got, want):
+        np.testing.assert_allclose(a, b, rtol=0, atol=2e-3)
