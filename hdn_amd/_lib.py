@@ -141,9 +141,35 @@ def require_device(*tensors: torch.Tensor) -> torch.device:
     return dev
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr(device: torch.device) -> ctypes.c_void_p:
-    """The hipStream_t torch is currently issuing work on for `device`."""
+    """The hipStream_t torch is currently issuing work on for `device` (the raw handle: no Stream object per launch)."""
+    if _raw_stream is not None:
+        idx = device.index
+        return ctypes.c_void_p(_raw_stream(idx if idx is not None else torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class _NoGuard:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def device_guard(device: torch.device):
+    """`with device_guard(dev):` = `with torch.cuda.device(dev):`, free when `dev` already is the current device (the one-process-per-GPU
+    case: a launch wrapper should not pay two device switches of bookkeeping per kernel)."""
+    idx = device.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _NO_GUARD
+    return torch.cuda.device(device)
 
 
 def ptr(t: torch.Tensor) -> ctypes.c_void_p:

@@ -38,7 +38,7 @@ class RcclComm:
         self.world, self.rank = int(world), int(rank)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         h = ctypes.c_void_p()
-        with torch.cuda.device(self.device):
+        with _lib.device_guard(self.device):
             rc = _lib.load().hdn_rccl_comm_create(ctypes.byref(h), self.world, self.rank, ctypes.c_char_p(uid))
         _lib.check(rc, "hdn_rccl_comm_create")
         self._h = h
@@ -71,7 +71,7 @@ class RcclComm:
             raise _lib.HdnHipError("communicator destroyed")
         loc = local.detach().contiguous()
         out = torch.empty((self.world * loc.shape[0], 8), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             rc = _lib.load().hdn_allgather_offsets(_lib.ptr(loc), _lib.ptr(out), loc.shape[0], self._h, _lib.stream_ptr(dev))
         _lib.check(rc, "hdn_allgather_offsets")
         return out
@@ -79,7 +79,7 @@ class RcclComm:
     def destroy(self):
         if self._h is not None:
             h, self._h = self._h, None
-            with torch.cuda.device(self.device):
+            with _lib.device_guard(self.device):
                 _lib.check(_lib.load().hdn_rccl_comm_destroy(h), "hdn_rccl_comm_destroy")
 
 
@@ -98,7 +98,7 @@ class OneShotGather:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         h = ctypes.c_void_p()
         lib = _lib.load()
-        with torch.cuda.device(self.device):
+        with _lib.device_guard(self.device):
             _lib.check(lib.hdn_gather_create(ctypes.byref(h), self.world, self.rank, self.max_rows * 32), "hdn_gather_create")
             self._h = h
             try:
@@ -137,7 +137,7 @@ class OneShotGather:
             raise _lib.HdnHipError("gather window destroyed")
         loc = local.detach().to(torch.float32).contiguous()
         out = torch.empty((self.world * loc.shape[0], 8), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             rc = _lib.load().hdn_gather_offsets_oneshot(self._h, _lib.ptr(loc), _lib.ptr(out), loc.shape[0], _lib.stream_ptr(dev))
         _lib.check(rc, "hdn_gather_offsets_oneshot")
         return out
@@ -149,7 +149,7 @@ class OneShotGather:
     def destroy(self):
         if self._h is not None:
             h, self._h = self._h, None
-            with torch.cuda.device(self.device):
+            with _lib.device_guard(self.device):
                 _lib.check(_lib.load().hdn_gather_destroy(h), "hdn_gather_destroy")
 
 

@@ -79,7 +79,7 @@ def _subwindow(frame, pos, model_sz, original_sz, avg_chans, mode, params=None):
         raise ValueError(f"params must be [cx, cy, original_sz, avg x {C}]")
     m = int(model_sz)
     out = torch.empty((1, 1 if mode else C, m, m), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         rc = _lib.load().hdn_subwindow_f32(_lib.ptr(frame), _lib.ptr(params), _lib.ptr(out), H, W, C, m, mode, _lib.stream_ptr(dev))
     _lib.check(rc, "get_subwindow")
     return out
@@ -128,7 +128,7 @@ def get_polar_img(patch: torch.Tensor, original=None) -> torch.Tensor:
     mx, my = _polar_maps[key]
     src = patch.detach().contiguous()
     out = torch.empty_like(src)
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         rc = _lib.load().hdn_remap_linear_f32(_lib.ptr(src), _lib.ptr(mx), _lib.ptr(my), _lib.ptr(out), C, H, W, H, W, _lib.stream_ptr(dev))
     _lib.check(rc, "get_polar_img")
     return out
@@ -152,7 +152,7 @@ def warp_perspective(frame, M):
     if m.numel() != 9:
         raise ValueError("M must be 3x3")
     out = torch.empty_like(frame)
-    with torch.cuda.device(frame.device):
+    with _lib.device_guard(frame.device):
         rc = _lib.load().hdn_frame_warp_perspective_u8(_lib.ptr(frame), _lib.ptr(m), _lib.ptr(out), H, W, C, _lib.stream_ptr(frame.device))
     _lib.check(rc, "warp_perspective")
     return out
@@ -165,7 +165,7 @@ def warp_affine_cubic(frame, M):
     if m.numel() != 6:
         raise ValueError("M must be 2x3")
     out = torch.empty_like(frame)
-    with torch.cuda.device(frame.device):
+    with _lib.device_guard(frame.device):
         rc = _lib.load().hdn_frame_warp_affine_cubic_u8(_lib.ptr(frame), _lib.ptr(m), _lib.ptr(out), H, W, C, _lib.stream_ptr(frame.device))
     _lib.check(rc, "warp_affine_cubic")
     return out

@@ -28,7 +28,7 @@ def DLT_solve(src_p: torch.Tensor, off_set: torch.Tensor) -> torch.Tensor:
     if B == 0:
         raise ValueError("empty batch")
     H = torch.empty((B, 9), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         rc = _lib.load().hdn_dlt_solve_f32(_lib.ptr(s), _lib.ptr(o), _lib.ptr(H), B, _lib.stream_ptr(dev))
     _lib.check(rc, "DLT_solve")
     return H.view(B, 1, 3, 3)
@@ -53,7 +53,7 @@ def transformer(U: torch.Tensor, theta: torch.Tensor, out_size, want_condition: 
     img = U.detach().contiguous()
     out = torch.empty((B, H, W, C), dtype=torch.float32, device=dev)
     count = torch.empty((1,), dtype=torch.int32, device=dev) if want_condition else None  # zeroed by the call
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         rc = _lib.load().hdn_warp_count_f32(_lib.ptr(img), _lib.ptr(th), _lib.ptr(out),
                                             _lib.ptr(count) if want_condition else None, B, C, H, W, _lib.stream_ptr(dev))
     _lib.check(rc, "transformer")
@@ -101,7 +101,7 @@ def dlt_warp(h4p: torch.Tensor, off_set: torch.Tensor, img: torch.Tensor):
     p, o, im = h4p.detach().contiguous(), off_set.detach().contiguous(), img.detach().contiguous()
     Hm = torch.empty((B, 9), dtype=torch.float32, device=dev)
     warped = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         rc = _lib.load().hdn_dlt_warp_f32(_lib.ptr(p), _lib.ptr(o), _lib.ptr(im), _lib.ptr(Hm), _lib.ptr(warped), B, H, W,
                                           _lib.stream_ptr(dev))
     _lib.check(rc, "dlt_warp")
@@ -115,7 +115,7 @@ def l1_score(a: torch.Tensor, b: torch.Tensor, scale: float) -> torch.Tensor:
         raise ValueError("l1_score needs two non-empty tensors of equal size")
     ac, bc = a.detach().contiguous(), b.detach().contiguous()
     out = torch.empty((1,), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         rc = _lib.load().hdn_l1_score_f32(_lib.ptr(ac), _lib.ptr(bc), _lib.ptr(out), ac.numel(), float(scale), _lib.stream_ptr(dev))
     _lib.check(rc, "l1_score")
     return out[0]
@@ -129,7 +129,7 @@ def l1_score2(a: torch.Tensor, b0: torch.Tensor, b1: torch.Tensor, scale: float)
         raise ValueError("l1_score2 needs three non-empty tensors of equal size")
     ac, b0c, b1c = a.detach().contiguous(), b0.detach().contiguous(), b1.detach().contiguous()
     out = torch.empty((2,), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         rc = _lib.load().hdn_l1_score2_f32(_lib.ptr(ac), _lib.ptr(b0c), _lib.ptr(b1c), _lib.ptr(out), ac.numel(), float(scale),
                                            _lib.stream_ptr(dev))
     _lib.check(rc, "l1_score2")

@@ -38,7 +38,7 @@ def logpolar_sample(x: torch.Tensor, polar: torch.Tensor, tabs, want_grid: bool 
     xc, pc = x.detach().contiguous(), polar.detach().contiguous()
     out = torch.empty((B, C, S, S), dtype=torch.float32, device=dev)
     grid = torch.empty((B, S, S, 2), dtype=torch.float32, device=dev) if want_grid else None
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         rc = _lib.load().hdn_logpolar_sample_f32(
             _lib.ptr(xc), _lib.ptr(pc), _lib.ptr(rho), _lib.ptr(c), _lib.ptr(s), _lib.ptr(out),
             _lib.ptr(grid) if want_grid else None, B, C, H, W, S, _lib.stream_ptr(dev))

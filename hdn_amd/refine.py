@@ -29,7 +29,7 @@ def refine_warp(H_mat: torch.Tensor, search: torch.Tensor, H_comp: torch.Tensor 
             raise ValueError("H_comp must be a contiguous float64 [B,3,3] tensor on the same device")
     hm, sc = H_mat.detach().reshape(B, 9).contiguous(), search.detach().contiguous()
     out = torch.empty_like(sc)
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         rc = _lib.load().hdn_refine_warp_f32(_lib.ptr(hm), _lib.ptr(sc), _lib.ptr(out),
                                              _lib.ptr(H_comp) if H_comp is not None else None, B, H, W, _lib.stream_ptr(dev))
     _lib.check(rc, "refine_warp")

@@ -57,7 +57,7 @@ def share_feature(x: torch.Tensor, folded: torch.Tensor) -> torch.Tensor:
     if B == 0:
         raise ValueError("empty batch")
     out = torch.empty_like(xc)
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         rc = _lib.load().hdn_share_feature_f32(_lib.ptr(xc), _lib.ptr(folded), _lib.ptr(out), B, H, W, _lib.stream_ptr(dev))
     _lib.check(rc, "PreShareFeature")
     return out
@@ -87,10 +87,15 @@ class PreShareFeature(nn.Module):
         self._folded_key = None
 
     def _param_key(self, device):
-        key = [str(device)]
-        for name, t in self.ShareFeature.state_dict().items():
-            key.append((name, t.data_ptr(), t._version))
-        return tuple(key)
+        # (references to the owning modules' parameter / buffer dictionaries: a state_dict() walk per call is ~15 us of Python)
+        refs = self.__dict__.get("_key_refs")
+        if refs is None:
+            refs = []
+            for sub in self.ShareFeature.modules():
+                refs += [(sub._parameters, n) for n, t in sub._parameters.items() if t is not None]
+                refs += [(sub._buffers, n) for n, t in sub._buffers.items() if t is not None]
+            self.__dict__["_key_refs"] = refs
+        return (str(device),) + tuple((id(t), t.data_ptr(), t._version) for t in (d[n] for d, n in refs))
 
     def folded(self, device) -> torch.Tensor:
         """Folded parameter block on `device`, rebuilt when any parameter / buffer changed."""

@@ -104,7 +104,7 @@ class SimilarityDecoder:
         cls, loc_c = self._maps(cls, 2, self.S, "cls"), self._maps(loc_c, 2, self.S, "loc_c")
         self._records(seq, state, B)
         c = self.cfg
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             rc = _lib.load().hdn_similarity_translation_f32(_lib.ptr(cls), _lib.ptr(loc_c), _lib.ptr(self.window), _lib.ptr(self.points),
                                                             _lib.ptr(seq), _lib.ptr(state), B, self.S, c.window_influence, 8.0,
                                                             float(c.exemplar_size), _lib.stream_ptr(dev))   # (_convert_c hard-codes 8)
@@ -116,7 +116,7 @@ class SimilarityDecoder:
         B = cls_lp.shape[0]
         cls_lp, loc_lp = self._maps(cls_lp, 2, self.S_lp, "cls_lp"), self._maps(loc_lp, 4, self.S_lp, "loc_lp")
         self._records(seq, state, B)
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             rc = _lib.load().hdn_similarity_logpolar_f32(_lib.ptr(cls_lp), _lib.ptr(loc_lp), _lib.ptr(self.points_lp), _lib.ptr(seq),
                                                          _lib.ptr(state), B, self.S_lp, float(self.cfg.stride_lp), self.mag, self.rot_unit,
                                                          _lib.stream_ptr(dev))

@@ -102,7 +102,7 @@ class HomoTracker:
         lib, st = _lib.load(), _lib.stream_ptr(self.dev)
         # :150-155  undo the accumulated motion (a singular H_total is reset to the identity, as the reference does).
         # hdn_frame_warp_perspective_u8 inverts its matrix itself (cv2 semantics), so it is handed inv(H_total).
-        with torch.cuda.device(self.dev):
+        with _lib.device_guard(self.dev):
             _lib.check(lib.hdn_track_prepare_f64(_lib.ptr(self.H_total), _lib.ptr(self._Ht), _lib.ptr(self._Hinv), 1, st), "track prepare")
         frame = FR.warp_perspective(frame, self._Hinv.view(-1))
         sim_state = None
@@ -119,7 +119,7 @@ class HomoTracker:
         H_comp, homo_score, _ = homo_refine(self.net, self.init_homo_tmp, search, iterations=self.iterations)
         # :251-272  un-scale, un-shift, gate, accumulate, project the initial corners
         score = homo_score.detach().reshape(-1).to(torch.float32).contiguous()
-        with torch.cuda.device(self.dev):
+        with _lib.device_guard(self.dev):
             _lib.check(lib.hdn_track_accumulate_f64(_lib.ptr(self._Ht), _lib.ptr(sim_state) if sim_state is not None else None, _lib.ptr(H_comp),
                                                     _lib.ptr(score), _lib.ptr(self._consts), _lib.ptr(self.init_points),
                                                     self.init_points.shape[1], _lib.ptr(self.H_total), _lib.ptr(self._out), 1, st),

@@ -99,7 +99,7 @@ class FusedStem(nn.Module):
 
         out = torch.empty((B, 64, Hp, Wp), dtype=x.dtype, device=dev,
                           memory_format=torch.channels_last if self.channels_last else torch.contiguous_format)
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             rc = _lib.load().hdn_trunk_stem_f32(_lib.ptr(xs), _lib.ptr(self.wT), _lib.ptr(self.b), _lib.ptr(out), B, H, W,
                                                 1 if self.channels_last else 0, _lib.stream_ptr(dev))
         _lib.check(rc, "trunk_stem")
@@ -125,7 +125,7 @@ def bias_relu_(y, bias, residual=None):
         raise ValueError("bias_relu_: y must be NCHW-contiguous or channels-last")
     if residual is not None and not (residual.is_contiguous(memory_format=torch.channels_last) if nhwc else residual.is_contiguous()):
         residual = residual.contiguous(memory_format=torch.channels_last if nhwc else torch.contiguous_format)
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         rc = _lib.load().hdn_bias_relu_f32(_lib.ptr(y), _lib.ptr(bias), _lib.ptr(residual) if residual is not None else None, B, C, H * W,
                                            nhwc, _lib.stream_ptr(dev))
     _lib.check(rc, "bias_relu")
@@ -204,7 +204,7 @@ def conv3x3_bias_relu(x, wpacked, bias, residual=None):
     if nws < 0:
         _lib.check(int(nws), "conv3x3_bias_relu")
     ws = torch.empty(nws // 4, dtype=torch.float32, device=dev) if nws else None   # (from torch's caching allocator: no sync, graph-safe)
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         rc = lib.hdn_conv3x3_bias_relu_f32(_lib.ptr(x), _lib.ptr(wpacked), _lib.ptr(bias), _lib.ptr(residual) if residual is not None else None,
                                            _lib.ptr(out), _lib.ptr(ws) if ws is not None else None, nws, B, S, C, _lib.stream_ptr(dev))
     _lib.check(rc, "conv3x3_bias_relu")
@@ -238,7 +238,7 @@ def conv3x3s2_ds(x, wpacked, bias):
     if nws < 0:
         _lib.check(int(nws), "conv3x3s2_ds")
     ws = torch.empty(nws // 4, dtype=torch.float32, device=dev) if nws else None
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         rc = lib.hdn_conv3x3s2_ds_f32(_lib.ptr(x), _lib.ptr(wpacked), _lib.ptr(bias), _lib.ptr(out), _lib.ptr(out_ds),
                                       _lib.ptr(ws) if ws is not None else None, nws, B, S, CI, _lib.stream_ptr(dev))
     _lib.check(rc, "conv3x3s2_ds")

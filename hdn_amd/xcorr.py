@@ -47,7 +47,7 @@ def _xcorr(x: torch.Tensor, kernel: torch.Tensor, circular: bool) -> torch.Tenso
     B, C, Hx, Wx = xc.shape
     Hk, Wk = kc.shape[2:]
     fn = lib.hdn_xcorr_depthwise_circ_f32 if circular else lib.hdn_xcorr_depthwise_f32
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         rc = fn(_lib.ptr(xc), _lib.ptr(kc), _lib.ptr(out), B, C, Hx, Wx, Hk, Wk, _lib.stream_ptr(dev))
     _lib.check(rc, "xcorr_depthwise_circular" if circular else "xcorr_depthwise")
     return out
@@ -95,7 +95,7 @@ def xcorr_depthwise_multi(xs: Sequence[torch.Tensor], kernels: Sequence[torch.Te
     arr = ctypes.c_void_p * n
     B, C, Hx, Wx = xcs[0].shape
     Hk, Wk = kcs[0].shape[2:]
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         rc = lib.hdn_xcorr_depthwise_multi_f32(
             arr(*[t.data_ptr() for t in xcs]), arr(*[t.data_ptr() for t in kcs]), arr(*[t.data_ptr() for t in outs]),
             n, int(bool(circular)), B, C, Hx, Wx, Hk, Wk, _lib.stream_ptr(dev),
@@ -120,7 +120,7 @@ def xcorr_fast(x: torch.Tensor, kernel: torch.Tensor) -> torch.Tensor:
         raise ValueError(f"kernel {Hk}x{Wk} does not fit the search plane {Hx}x{Wx}")
     dev, xc, kc = _prep(x, kernel)
     out = torch.empty((B, O, Hx - Hk + 1, Wx - Wk + 1), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         rc = _lib.load().hdn_xcorr_fast_f32(_lib.ptr(xc), _lib.ptr(kc), _lib.ptr(out), B, C, O, Hx, Wx, Hk, Wk,
                                             _lib.stream_ptr(dev))
     _lib.check(rc, "xcorr_fast")
