@@ -165,6 +165,10 @@ def _packable(self, boxes, x_fs):
                     and isinstance(hd, nn.Sequential) and len(hd) == 4 and isinstance(hd[0], nn.Conv2d) and isinstance(hd[1], nn.BatchNorm2d)
                     and isinstance(hd[3], nn.Conv2d)):
                 return False
+            if not (isinstance(cs[2], nn.ReLU) and isinstance(hd[2], nn.ReLU)):
+                return False
+            if any(bn.training or not bn.track_running_stats or not bn.affine or bn.running_mean is None for bn in (cs[1], hd[1])):
+                return False          # _fold_bn folds the running statistics and the affine weights: eval-mode BatchNorm only
             c0, h0, h3 = cs[0], hd[0], hd[3]
             if (c0.bias is not None or c0.stride != (1, 1) or c0.padding != (0, 0) or c0.dilation != (1, 1) or c0.groups != 1
                     or h0.bias is not None or h0.kernel_size != (1, 1) or h3.kernel_size != (1, 1) or h3.bias is None):

@@ -153,7 +153,10 @@ class HomoTracker:
             if self._graph is None:
                 try:
                     self._capture(tuple(t.shape))
-                except Exception as e:      # e.g. a model whose forward makes host round trips: the same kernels, launched one by one
+                except RuntimeError as e:
+                    # stream capture reports what it cannot hold (e.g. a model whose forward makes host round trips) as a
+                    # RuntimeError; the same kernels are then launched one by one.  Anything else is a real error and propagates,
+                    # as does whatever the eager retry raises.
                     import warnings
                     warnings.warn(f"hdn_amd: the per-frame body could not be captured as a hipGraph ({type(e).__name__}: {e}); running it eagerly")
                     self.use_graph, self._graph = False, None
@@ -168,13 +171,14 @@ class HomoTracker:
         else:
             H, out, homo_score = self._body(FR.upload(img))
             out = out.clone()
-        pts = out[:8].view(4, 2)
+        n = self.init_points.shape[1]          # any number of initial points (cv2.perspectiveTransform takes any; POT gives 4)
+        pts = out[:2 * n].view(n, 2)
         self.last_points, self.last_score = pts, homo_score
         if not sync:
-            return {"points": pts, "polygon": pts, "best_score": out[8]}
+            return {"points": pts, "polygon": pts, "best_score": out[2 * n]}
         host = out.cpu().numpy()
         self.host_syncs += 1
-        pn, best_score = host[:8].reshape(4, 2), host[8]
+        pn, best_score = host[:2 * n].reshape(n, 2), host[2 * n]
         mx, mn = pn.max(0), pn.min(0)
         bbox = [mn[0], mn[1], mx[0] - mn[0], mx[1] - mn[1]]
         return {"bbox_aligned": bbox, "best_score": best_score, "polygon": pn, "points": pn, "bbox": bbox}
@@ -184,6 +188,20 @@ class HomoTracker:
         """BaseTracker.track (hdn/tracker/base_tracker.py:28-37, abstract there): the next frame, nothing else known."""
         return self.track_new(None, img)
 
+    def similarity_state(self) -> dict:
+        """The last frame's similarity record read back to the host (one extra device->host read, counted): centre, deltas,
+        scale / rotation increments, scores.  The reference keeps `center_pos`, `rot`, `scale` as host attributes updated every
+        frame (hdn_tracker_proj_e2e.py:185,215-216); nothing outside the tracker reads them and here they live on the device
+        only, so they are produced on demand instead of costing every frame a synchronisation."""
+        if self.similarity is None or self.similarity.state is None:
+            return {}
+        from .similarity import state_fields
+        row = self.similarity.state.view(-1).cpu()
+        self.host_syncs += 1
+        f = {k: v.numpy().copy() for k, v in state_fields(row).items()}
+        self.center_pos = f["center"].astype(np.float64).copy()
+        return f
+
 
 class DeviceTrackerHomo(HomoTracker):
     """Drop-in for hdnTrackerHomo (hdn_tracker_proj_e2e.py:22-285) behind build_tracker(model)
@@ -191,13 +209,20 @@ class DeviceTrackerHomo(HomoTracker):
     `model` is the reference's ModelBuilder (hm_net = the homography estimator, template / track_new / track_new_lp = the
     similarity branch).  HDN_TRACKER_GRAPH=1 replays each frame as one hipGraph."""
 
-    def __init__(self, model, graph: bool = None, iterations: int = 1):
-        cfg = TrackerConfig()
-        try:
-            from hdn.core.config import cfg as ref_cfg     # the reference's node, after tools/test.py merged the YAML
-            cfg = TrackerConfig.from_reference(ref_cfg)
-        except ImportError:
-            pass
+    def __init__(self, model, graph: bool = None, iterations: int = 1, cfg: TrackerConfig = None):
+        cls_out = 2
+        if cfg is None:
+            cfg = TrackerConfig()
+            try:
+                from hdn.core.config import cfg as ref_cfg     # the reference's node, after tools/test.py merged the YAML
+                cfg = TrackerConfig.from_reference(ref_cfg)
+                cls_out = int(ref_cfg.BAN.KWARGS.cls_out_channels)
+            except ImportError:
+                pass
+        if cls_out != 2:
+            # hdnTracker._convert_score's sigmoid branch (hdn_tracker.py:85-87); the shipped configurations use the 2-class softmax
+            raise NotImplementedError("hdn_amd's device decode implements cfg.BAN.KWARGS.cls_out_channels == 2 (softmax); run the "
+                                      "reference's host tracker for the 1-channel sigmoid head (python -m hdn_amd.run --host-tracker ...)")
         if graph is None:
             graph = os.environ.get("HDN_TRACKER_GRAPH", "0") not in ("", "0")
         model.eval()

@@ -111,21 +111,23 @@ class SimilarityOracle:
     Call: (stabilised frame uint8 [H,W,3], init_pos, init_s_z, channel_average) -> dict(dcx, dcy, cx, cy, scale_delta,
     rot_delta, best_score, H_sim)."""
 
-    def __init__(self, model, window_influence=WINDOW_INFLUENCE):
-        self.model, self.window_influence = model, window_influence
-        score_size = (INSTANCE_SIZE - EXEMPLAR_SIZE) // STRIDE + 1 + BASE_SIZE
+    def __init__(self, model, window_influence=WINDOW_INFLUENCE, instance_size=INSTANCE_SIZE):
+        """instance_size: cfg.TRACK.INSTANCE_SIZE (255 shipped; 303 = BASELINE configs[4], score map 31 x 31, :24-25)."""
+        self.model, self.window_influence, self.instance_size = model, window_influence, int(instance_size)
+        score_size = (self.instance_size - EXEMPLAR_SIZE) // STRIDE + 1 + BASE_SIZE
+        self.score_size = score_size
         self.window = hanning_window(score_size)
         self.points = generate_points(STRIDE, score_size)
         self.points_lp = generate_points(STRIDE_LP, OUTPUT_SIZE_LP)
 
     def __call__(self, img, init_pos, init_s_z, channel_average):
-        s_x = np.floor(init_s_z * np.round(INSTANCE_SIZE / EXEMPLAR_SIZE))
-        x_crop = F.get_subwindow(img, init_pos, INSTANCE_SIZE, s_x, channel_average)
+        s_x = np.floor(init_s_z * np.round(self.instance_size / EXEMPLAR_SIZE))
+        x_crop = F.get_subwindow(img, init_pos, self.instance_size, s_x, channel_average)
         with torch.no_grad():
             out = self.model.track_new(torch.from_numpy(x_crop))
         tr = decode_translation(out["cls"], out["loc_c"], self.window, self.points, init_s_z, self.window_influence)
         cx, cy = tr["center"][0] + init_pos[0], tr["center"][1] + init_pos[1]
-        x_moved = F.get_subwindow(img, np.array([cx, cy]), INSTANCE_SIZE, s_x, channel_average)
+        x_moved = F.get_subwindow(img, np.array([cx, cy]), self.instance_size, s_x, channel_average)
         with torch.no_grad():
             out = self.model.track_new_lp(torch.from_numpy(x_moved), [0, 0])
         lp = decode_logpolar(out["cls_lp"], out["loc_lp"], self.points_lp, tr["stop"], init_s_z, init_s_z)

@@ -47,10 +47,12 @@ def seeded_head256(tag):
     fixture's `param_sum` detects a drift).  Returns (module, z_fs, x_fs)."""
     import torch
     from hdn_amd import heads
-    cls, zsz, xsz = (heads.MultiBAN, 7, 31) if tag == "ban" else (heads.MultiCircBAN, 15, 15)
-    torch.manual_seed(SEED + (13 if tag == "ban" else 14))
+    # tag "ban_cfg5": heads256_cfg5.npz, the MultiBAN of BASELINE configs[4] (37 x 37 search features -> 31 x 31 maps)
+    cls, zsz, xsz, seed, gtag = {"ban": (heads.MultiBAN, 7, 31, 13, 810), "circ": (heads.MultiCircBAN, 15, 15, 14, 811),
+                                 "ban_cfg5": (heads.MultiBAN, 7, 37, 15, 812)}[tag]
+    torch.manual_seed(SEED + seed)
     m = cls([256, 256, 256], 2, weighted=True).eval()
-    g = golden_rng(810 if tag == "ban" else 811)
+    g = golden_rng(gtag)
     for mod in m.modules():
         if isinstance(mod, torch.nn.BatchNorm2d):
             seeded_bn_(mod, g)

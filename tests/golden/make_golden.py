@@ -620,6 +620,144 @@ def gen_similarity(ref_te, cfg):
     save("similarity", **out)
 
 
+def gen_config5(ref_te, ref_ban, ref_bt, cfg):
+    """BASELINE configs[4] at the tracker level: cfg.TRACK.INSTANCE_SIZE = 303 (score map 31 x 31, hdn_tracker_proj_e2e.py:24-25;
+    37 x 37 search features -> conv_search 35 x 35 -> 31 x 31, ban.py:73-78).
+      similarity303.npz  the decode of gen_similarity on a REAL hdnTrackerHomo built under INSTANCE_SIZE = 303 (31 x 31 window /
+                         anchor points from its constructor); the log-polar maps stay 13 x 13 (cfg.TRAIN.OUTPUT_SIZE_LP)
+      heads256_cfg5.npz  the 256-channel MultiBAN on 37 x 37 search features (modules re-created from the seed in the tests)
+      frame303.npz       SiameseTracker.get_subwindow with model_sz = original_sz = 303 (crop / pad arithmetic; no cv2 call reached)"""
+    import hdn.utils.transform as ref_tf
+
+    class _NoModel(torch.nn.Module):
+        pass
+
+    old = cfg.TRACK.INSTANCE_SIZE
+    cfg.TRACK.INSTANCE_SIZE = 303
+    try:
+        trk = ref_te.hdnTrackerHomo(_NoModel())
+        assert trk.score_size == 31
+        g = rng(1100)
+        wi_prod = float(cfg.TRACK.WINDOW_INFLUENCE)
+        S = trk.score_size
+
+        def maps(peak=None, peak_lp=None, cls_bias=0.0, lp_bias=0.0, loc_sigma=0.4, lp_sigma=0.3):
+            cls = g.standard_normal((1, 2, S, S)).astype(np.float32)
+            cls[0, 1] += np.float32(cls_bias)
+            loc = (loc_sigma * g.standard_normal((1, 2, S, S))).astype(np.float32)
+            cls_lp = g.standard_normal((1, 2, 13, 13)).astype(np.float32)
+            cls_lp[0, 1] += np.float32(lp_bias)
+            loc_lp = (lp_sigma * g.standard_normal((1, 4, 13, 13))).astype(np.float32)
+            if peak is not None:
+                cls[0, 1, peak[0], peak[1]] += np.float32(6.0)
+            if peak_lp is not None:
+                cls_lp[0, 1, peak_lp[0], peak_lp[1]] += np.float32(6.0)
+            return cls, loc, cls_lp, loc_lp
+
+        cases = []
+        # 0: peaks near the centre; 1: a peak in the outermost ring (a 64-px displacement: what the wider window is for)
+        cases.append(dict(m=maps((16, 14), (6, 7)), size=(150.0, 100.0), pos=(320.0, 180.0), wi=wi_prod))
+        cases.append(dict(m=maps((1, 29), (2, 10), loc_sigma=1.5, lp_sigma=1.0), size=(201.0, 77.0), pos=(611.5, 402.25), wi=wi_prod))
+        # 2: translation gate fires; 3: log-polar gate fires
+        cases.append(dict(m=maps(None, (5, 5), cls_bias=-8.0), size=(150.0, 100.0), pos=(300.0, 200.0), wi=0.0))
+        cases.append(dict(m=maps((15, 15), None, lp_bias=-9.0), size=(90.0, 120.0), pos=(100.0, 80.0), wi=wi_prod))
+        # 4: exact argmax tie at (i, j) / (j, i) (the window is symmetric bit for bit)
+        c4 = maps(None, None)
+        for (i, j) in ((11, 19), (19, 11)):
+            c4[0][0, 0, i, j], c4[0][0, 1, i, j] = np.float32(-2.0), np.float32(5.0)
+        cases.append(dict(m=c4, size=(150.0, 100.0), pos=(320.0, 180.0), wi=wi_prod))
+
+        out = {"window": trk.window, "points": trk.points, "points_lp": trk.points_lp, "n_cases": np.array(len(cases)),
+               "score_size": np.array(S), "window_influence_production": np.array(wi_prod)}
+        for n, cs in enumerate(cases):
+            cls, loc_c, cls_lp, loc_lp = cs["m"]
+            size = np.array(cs["size"])
+            cfg.TRACK.WINDOW_INFLUENCE = cs["wi"]
+            w_z = size[0] + cfg.TRACK.CONTEXT_AMOUNT * np.sum(size)
+            h_z = size[1] + cfg.TRACK.CONTEXT_AMOUNT * np.sum(size)
+            init_s_z = np.floor(np.sqrt(w_z * h_z))
+            center_pos = np.array(cs["pos"])
+            s_z = init_s_z
+            cur_sz = init_s_z
+            INS_EXAM_RATIO = np.round(cfg.TRACK.INSTANCE_SIZE / cfg.TRACK.EXEMPLAR_SIZE)      # :159 (= 2 at 303 as well)
+            scale_z = cfg.TRACK.EXEMPLAR_SIZE / s_z
+            s_x = np.floor(s_z * INS_EXAM_RATIO)
+            outputs = {"cls": t(cls), "loc_c": t(loc_c.copy())}
+            score = trk._convert_score(outputs["cls"])
+            pred_c = trk._convert_c(outputs["loc_c"], trk.points)
+            pscore = score
+            pscore = pscore * (1 - cfg.TRACK.WINDOW_INFLUENCE) + trk.window * cfg.TRACK.WINDOW_INFLUENCE
+            best_idx = np.argmax(pscore)
+            stop_update_flag = 0
+            if pscore[best_idx] < 0.05:
+                center = [0, 0]
+                stop_update_flag = 1
+            else:
+                center = pred_c[:, best_idx] / scale_z
+            cx = center[0] + center_pos[0]
+            cy = center[1] + center_pos[1]
+            delta_cx = center[0]
+            delta_cy = center[1]
+            outputs = {"cls_lp": t(cls_lp), "loc_lp": t(loc_lp.copy())}
+            score_lp = trk._convert_score(outputs["cls_lp"])
+            peak_idx = np.argmax(score_lp.copy())
+            pred_center_lp = trk._convert_logpolar_simi(outputs["loc_lp"], trk.points_lp, peak_idx, 1)
+            pscore_lp = score_lp
+            best_idx_lp = np.argmax(pscore_lp)
+            sim_lp = pred_center_lp[:, best_idx_lp]
+            if stop_update_flag or pscore_lp[best_idx_lp] < 0.25:
+                sim_lp = [1, 1, 0, 0]
+            best_score = score[best_idx]
+            scale_delta = sim_lp[0] * cur_sz / init_s_z
+            rot_delta = sim_lp[2]
+            H_sim = ref_tf.rot_scale_around_center_shift_tran(cx, cy, rot_delta, scale_delta, delta_cx, delta_cy)
+            k = f"c{n}__"
+            out.update({k + "cls": cls, k + "loc_c": loc_c, k + "cls_lp": cls_lp, k + "loc_lp": loc_lp, k + "size": size,
+                        k + "center_pos": center_pos, k + "window_influence": np.array(cs["wi"]), k + "init_s_z": np.array(init_s_z),
+                        k + "s_x": np.array(s_x), k + "score": score, k + "pred_c": pred_c, k + "pscore": pscore,
+                        k + "best_idx": np.array(best_idx), k + "stop": np.array(stop_update_flag), k + "center": np.array(center, np.float64),
+                        k + "cxcy": np.array([cx, cy], np.float64), k + "score_lp": score_lp, k + "pred_center_lp": pred_center_lp,
+                        k + "best_idx_lp": np.array(best_idx_lp), k + "sim_lp": np.array(sim_lp, np.float64),
+                        k + "best_score": np.array(best_score), k + "scale_delta": np.array(scale_delta, np.float64),
+                        k + "rot_delta": np.array(rot_delta, np.float64), k + "H_sim": H_sim})
+        cfg.TRACK.WINDOW_INFLUENCE = wi_prod
+        save("similarity303", **out)
+    finally:
+        cfg.TRACK.INSTANCE_SIZE = old
+
+    # 256-channel MultiBAN on 37 x 37 search features (7 x 7 template): conv_search -> 35 x 35, 5 x 5 kernel -> 31 x 31
+    torch.manual_seed(SEED + 15)
+    m = ref_ban.MultiBAN([256, 256, 256], 2, weighted=True).eval()
+    g = rng(812)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            seeded_bn_(mod, g)
+    m.cls_weight.data = t(g.standard_normal(3).astype(np.float32))
+    m.loc_weight.data = t(g.standard_normal(3).astype(np.float32))
+    m.loc_scale.data = t(g.uniform(0.5, 1.5, 3).astype(np.float32))
+    zfs = [t(g.standard_normal((1, 256, 7, 7), dtype=np.float32)) for _ in range(3)]
+    xfs = [t(g.standard_normal((1, 256, 37, 37), dtype=np.float32)) for _ in range(3)]
+    with torch.no_grad():
+        c, l = m(zfs, xfs)
+    assert tuple(c.shape) == (1, 2, 31, 31) and tuple(l.shape) == (1, 2, 31, 31)
+    save("heads256_cfg5", ban__cls=c.numpy(), ban__loc=l.numpy(),
+         ban__param_sum=np.array(sum(float(v.double().sum()) for v in m.state_dict().values())))
+
+    # get_subwindow / get_subwindow_for_homo at model_sz = original_sz = 303: every padding side, odd / fractional centres
+    g = rng(901)
+    im = g.integers(0, 256, (331, 417, 3)).astype(np.uint8)
+    avg = np.mean(im, axis=(0, 1))
+    cases = [((208.0, 165.0), 303), ((20.3, 300.7), 303), ((410.5, 10.5), 303)]
+    out = {"im": im, "avg": avg, "pos": np.array([c[0] for c in cases]), "sz": np.array([c[1] for c in cases])}
+    for i, (pos, sz) in enumerate(cases):
+        a = ref_bt.SiameseTracker.get_subwindow(None, im, np.array(pos), sz, sz, avg)
+        b, pts = ref_bt.SiameseTracker.get_subwindow_for_homo(None, im, np.array(pos), sz, sz, avg)
+        assert torch.equal(a, b)
+        out[f"crop{i}"] = a.numpy().astype(np.uint8)
+        out[f"pts{i}"] = np.array(pts, np.float64)
+    save("frame303", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
@@ -668,6 +806,11 @@ def main():
     if want("similarity"):
         import hdn.tracker.hdn_tracker_proj_e2e as ref_te
         gen_similarity(ref_te, cfg)
+    if want("similarity303", "heads256_cfg5", "frame303"):
+        import hdn.models.head.ban as ref_ban
+        import hdn.tracker.base_tracker as ref_bt
+        import hdn.tracker.hdn_tracker_proj_e2e as ref_te
+        gen_config5(ref_te, ref_ban, ref_bt, cfg)
     print("torch", torch.__version__, "numpy", np.__version__)
 
 

@@ -7,8 +7,12 @@ from oracle import frame_oracle as F
 from oracle import hdn_oracle as O
 
 
-def test_get_subwindow_matches_reference_crops_and_padding():
-    g = load_golden("frame")
+import pytest
+
+
+@pytest.mark.parametrize("fixture", ["frame", "frame303"])     # frame303: model_sz = 303, the search crop of BASELINE configs[4]
+def test_get_subwindow_matches_reference_crops_and_padding(fixture):
+    g = load_golden(fixture)
     im, avg = g["im"], g["avg"]
     for i, (pos, sz) in enumerate(zip(g["pos"], g["sz"])):
         sz = int(sz)

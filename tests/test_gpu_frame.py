@@ -21,6 +21,24 @@ def dev():
 from hdn_amd import frame as FR  # noqa: E402
 
 
+def test_get_subwindow_golden_config5_crop_size(dev):
+    """hdn_subwindow_f32 at model_sz = 303 (the search crop of BASELINE configs[4]) against the reference's own get_subwindow /
+    get_subwindow_for_homo (tests/golden/frame303.npz): crop position, every padding side, uint8(avg) fill — bit-exact."""
+    g = load_golden("frame303")
+    fr = FR.upload(g["im"])
+    for i, (pos, sz) in enumerate(zip(g["pos"], g["sz"])):
+        sz = int(sz)
+        assert sz == 303
+        a = FR.get_subwindow(fr, pos, sz, sz, g["avg"])
+        assert a.shape == (1, 3, 303, 303)
+        np.testing.assert_array_equal(a.cpu().numpy()[0].astype(np.uint8), g[f"crop{i}"][0], err_msg=f"case {i}")
+        _, pts = FR.get_subwindow_for_homo(fr, pos, sz, sz, g["avg"])
+        np.testing.assert_array_equal(np.array(pts, np.float64), g[f"pts{i}"])
+    # with the resize in front (s_x != 303), against the oracle's restated cv2.resize (parity-unpinned)
+    for pos, osz in (((208.0, 165.0), 380.0), ((20.3, 300.7), 251.0)):
+        np.testing.assert_array_equal(FR.get_subwindow(fr, pos, 303, osz, g["avg"]).cpu().numpy(), F.get_subwindow(g["im"], pos, 303, osz, g["avg"]))
+
+
 def test_get_subwindow_golden(dev):
     g = load_golden("frame")
     fr = FR.upload(g["im"])

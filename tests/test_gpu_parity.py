@@ -616,6 +616,27 @@ def test_multi_ban_fused_forward_production_width(dev, tag, circular):
     np.testing.assert_allclose(l.cpu().numpy(), g[tag + "__loc"], rtol=0, atol=2e-4)
 
 
+def test_multi_ban_fused_forward_config5_search_size(dev):
+    """BASELINE configs[4] through the head: 37 x 37 search features (INSTANCE_SIZE = 303) -> conv_search 35 x 35 -> the
+    xcorr_cfg5_kernel (6 problems, one launch) -> 31 x 31 maps, against the reference's MultiBAN output
+    (tests/golden/heads256_cfg5.npz); packed (B = 1) and module-by-module forms."""
+    from conftest import seeded_head256
+    g = load_golden("heads256_cfg5")
+    m, zfs, xfs = seeded_head256("ban_cfg5")
+    psum = sum(float(v.double().sum()) for v in m.state_dict().values())
+    assert abs(psum - float(g["ban__param_sum"])) <= 1e-6 * abs(psum), "torch's init stream drifted: regenerate heads256_cfg5.npz"
+    m = m.to(dev)
+    zd, xd = [z.to(dev) for z in zfs], [x.to(dev) for x in xfs]
+    for packed in (True, False):
+        object.__setattr__(m, "_hdn_no_packed_head", not packed)
+        c, l = m(zd, xd)
+        assert X.last_variant() == "cfg5_35x35_5x5"
+        assert c.shape == (1, 2, 31, 31) and l.shape == (1, 2, 31, 31)
+        np.testing.assert_allclose(c.cpu().numpy(), g["ban__cls"], rtol=0, atol=2e-4)
+        np.testing.assert_allclose(l.cpu().numpy(), g["ban__loc"], rtol=0, atol=2e-4)
+    assert getattr(m, "_hdn_packed_head", None) is not None
+
+
 @pytest.mark.parametrize("tag,circular", [("ban", False), ("circ", True)])
 def test_packed_head_matches_module_by_module_form(dev, tag, circular):
     """The tracker's B = 1 call takes the packed path of heads.fused_forward (BatchNorm folded, the two branches of a level as one

@@ -79,12 +79,12 @@ def test_graphed_tracker_loop_matches_eager(dev):
 
 
 # ------------------------------------------------------------------------------------------ similarity half (configs[3])
-def _decode_case(dev, g, n, dec_cache):
+def _decode_case(dev, g, n, dec_cache, instance_size=255):
     from hdn_amd.similarity import SimilarityDecoder, TrackerConfig, sequence_constants, state_fields
     k = f"c{n}__"
     wi = float(g[k + "window_influence"])
     if wi not in dec_cache:
-        dec_cache[wi] = SimilarityDecoder(dev, TrackerConfig(window_influence=wi))
+        dec_cache[wi] = SimilarityDecoder(dev, TrackerConfig(window_influence=wi, instance_size=instance_size))
     dec = dec_cache[wi]
     size = g[k + "size"]
     seq = sequence_constants(g[k + "center_pos"], float(g[k + "init_s_z"]), float(np.floor(np.sqrt(size[0] * size[1]))), [10.0, 20.0, 30.0], dec.cfg)
@@ -96,17 +96,22 @@ def _decode_case(dev, g, n, dec_cache):
     return {kk: v.cpu().numpy() for kk, v in state_fields(state.view(-1)).items()}, seq
 
 
-def test_similarity_decode_golden(dev):
+@pytest.mark.parametrize("fixture,instance_size,S", [("similarity", 255, 25), ("similarity303", 303, 31)])
+def test_similarity_decode_golden(dev, fixture, instance_size, S):
     """hdn_similarity_translation_f32 / hdn_similarity_logpolar_f32 against the reference's own decode
-    (tests/golden/similarity.npz: hdn_tracker_proj_e2e.py:169-214 on seeded head maps, both gates, exact argmax ties).
+    (tests/golden/similarity.npz: hdn_tracker_proj_e2e.py:169-214 on seeded head maps, both gates, exact argmax ties;
+    similarity303.npz: the same from a tracker the reference built under INSTANCE_SIZE = 303 — BASELINE configs[4], S = 31).
     Indices, gates and the centre are exact; scores / scale / rotation within 1e-6 (expf / exp of the device library vs the
     host's: at most an ulp of float32); H_sim within 1e-9 relative to its largest entry."""
     from conftest import load_golden
-    g = load_golden("similarity")
+    g = load_golden(fixture)
     cache = {}
     for n in range(int(g["n_cases"])):
         k = f"c{n}__"
-        st, seq = _decode_case(dev, g, n, cache)
+        st, seq = _decode_case(dev, g, n, cache, instance_size)
+        assert next(iter(cache.values())).S == S
+        if fixture == "similarity303":
+            assert seq[3] == float(g[k + "s_x"])             # s_x = floor(s_z * round(303 / 127)), :159-161
         assert int(st["best_idx"]) == int(g[k + "best_idx"]), n
         assert int(st["stop"]) == int(g[k + "stop"]), n
         assert int(st["best_idx_lp"]) == int(g[k + "best_idx_lp"]), n
@@ -332,3 +337,102 @@ def test_graph_capture_failure_falls_back_to_eager(dev):
     got = [got0] + [trk.track_new(t, frames[t])["points"] for t in (2, 3)]
     for a, b in zip(got, want):
         np.testing.assert_allclose(a, b, rtol=0, atol=2e-3)
+
+
+# ------------------------------------------------------------------- production shapes (configs[3]) and configs[4] at the tracker level
+def _production_pair(dev, frames, init, instance_size=255, iterations=1, fc_bias_scale=0.1):
+    """(CPU restatement of the loop, GPU stand-in model) around tests/production_standin.py: ResNet-50 / stride 8 / dilated
+    backbone, 1x1 necks to 256 channels, 256-channel heads — the shapes of the shipped configuration, seeded weights."""
+    import production_standin as PS
+    from test_gpu_parity import _seeded_net
+    from oracle.tracker_oracle import HomoTrackerOracle, SimilarityOracle
+    net = _seeded_net()
+    net.fc.bias.data.mul_(fc_bias_scale)
+    net_cpu = copy.deepcopy(net)
+    twin = PS.ProductionStandIn(net, instance_size=instance_size)
+    twin.calibrate(*PS.calibration_crops(frames, init))
+    cpu = PS.ProductionStandInCPU(twin)
+    sd = {k: v.clone() for k, v in net_cpu.ShareFeature.state_dict().items()}
+    ref = HomoTrackerOracle(sd, lambda f: net_cpu.fc(net_cpu.avgpool(net_cpu.backbone(f)).flatten(1)), iterations,
+                            similarity=SimilarityOracle(cpu, instance_size=instance_size))
+    return ref, twin.to(dev).eval()
+
+
+def test_device_tracker_homo_runs_production_shaped_model(dev, monkeypatch):
+    """The exact object install(tracker=True) registers — DeviceTrackerHomo(model), constructed as build_tracker(model) constructs
+    it (hdn/tracker/tracker_builder.py:18-19) — around a model with the production shapes and the reference's ModelBuilder
+    interface (template / track_new / track_new_lp / hm_net / logpolar_instance): eager, and with HDN_TRACKER_GRAPH=1 as ONE
+    hipGraph per frame, against the CPU restatement of the loop on every frame.  prod29 / circ13 kernels at 256 channels, packed
+    heads, device decode and crops all run inside the loop."""
+    from synth_sequence import make_sequence, success_4pts_error
+    from hdn_amd.tracker import DeviceTrackerHomo
+    from hdn_amd import xcorr as X
+    frames, corners, init = make_sequence(n_frames=13, frame_hw=(720, 1280), target_wh=(300, 200), seed=20260928)
+    ref, model = _production_pair(dev, frames, init)
+    eager = DeviceTrackerHomo(model)
+    monkeypatch.setenv("HDN_TRACKER_GRAPH", "1")
+    graphed = DeviceTrackerHomo(model)
+    assert eager.use_graph is False and graphed.use_graph is True and eager.cfg.score_size == 25
+    ref.init(frames[0], init["bbox"], init["poly"], init["gt_points"], init["first_point"])
+    for t in (eager, graphed):
+        t.init(frames[0], init["bbox"], init["poly"], init["gt_points"], init["first_point"])
+    assert [tuple(z.shape) for z in model.zf] == [(1, 256, 7, 7)] * 3 and [tuple(z.shape) for z in model.zf_lp] == [(1, 256, 15, 15)] * 3
+    for a, b in zip(model.zf + model.zf_lp, ref.similarity.model.zf + ref.similarity.model.zf_lp):
+        assert float((a.cpu() - b).abs().max()) <= 2e-3 * float(b.abs().max())      # 50 fp32 convolution layers, MIOpen vs oneDNN
+    errs_e, errs_g, moved = [], [], 0
+    for t in range(1, len(frames)):
+        a = eager.track_new(t, frames[t])
+        g = graphed.track_new(t, frames[t])
+        b = ref.track_new(t, frames[t])
+        s = b["similarity"]
+        moved += int(abs(s["dcx"]) + abs(s["dcy"]) > 0.05 and abs(s["scale_delta"] - 1) > 1e-4 and abs(s["rot_delta"]) > 1e-6)
+        assert set(a) == {"bbox_aligned", "best_score", "polygon", "points", "bbox"} and a["points"].shape == (4, 2)
+        errs_e.append(success_4pts_error(a["points"], b["points"]))
+        errs_g.append(success_4pts_error(g["points"], b["points"]))
+    print("production-shaped DeviceTrackerHomo, corner error vs CPU loop (px): eager", " ".join(f"{e:.1e}" for e in errs_e))
+    print("                                                               hipGraph", " ".join(f"{e:.1e}" for e in errs_g))
+    assert graphed._graph is not None, "the production-shaped frame body was not captured"
+    assert moved == len(frames) - 1, "the stand-in's similarity estimate must be non-trivial in every component"
+    assert errs_e[0] <= 2e-2 and errs_g[0] <= 2e-2, (errs_e, errs_g)
+    assert max(errs_e) <= 0.25 and max(errs_g) <= 0.25, (errs_e, errs_g)
+    f = eager.similarity_state()
+    assert abs(float(f["center"][0]) - s["cx"]) <= 5e-2 and abs(float(f["center"][1]) - s["cy"]) <= 5e-2
+    model.track_new(torch.zeros((1, 3, 255, 255), device=dev))
+    assert X.last_variant() == "prod_29x29_5x5"
+
+
+def test_config5_tracker_loop_303_two_iterations_vs_cpu(dev):
+    """BASELINE configs[4] at the tracker level: TrackerConfig(instance_size = 303) — 303-px search crops, 37 x 37 head input, the
+    xcorr_cfg5_kernel inside the loop, 31 x 31 decode — and a refinement loop of two iterations
+    (hdn_tracker_proj_e2e.py:24-25,159-166,242-250), device loop vs the CPU restatement frame by frame."""
+    from synth_sequence import make_sequence, success_4pts_error
+    from hdn_amd import xcorr as X
+    from hdn_amd.similarity import DeviceSimilarity, TrackerConfig
+    from hdn_amd.tracker import HomoTracker
+    frames, corners, init = make_sequence(n_frames=9, frame_hw=(360, 640), target_wh=(150, 100), seed=7)
+    cfg = TrackerConfig(instance_size=303)
+    assert cfg.score_size == 31
+    ref, model = _production_pair(dev, frames, init, instance_size=303, iterations=2)
+    trk = HomoTracker(model.hm_net, iterations=2, similarity=DeviceSimilarity(model, cfg), cfg=cfg)
+    ref.init(frames[0], init["bbox"], init["poly"], init["gt_points"], init["first_point"])
+    trk.init(frames[0], init["bbox"], init["poly"], init["gt_points"], init["first_point"])
+    errs = []
+    for t in range(1, len(frames)):
+        a = trk.track_new(t, frames[t])
+        b = ref.track_new(t, frames[t])
+        s, st = b["similarity"], trk.similarity.state.view(-1).cpu().numpy()
+        assert abs(st[0] - s["dcx"]) <= 5e-2 and abs(st[1] - s["dcy"]) <= 5e-2, (t, st[:2], s["dcx"], s["dcy"])
+        assert abs(st[16] - s["scale_delta"]) <= 1e-3 and abs(st[17] - s["rot_delta"]) <= 1e-3, (t, st[16:18], s)
+        errs.append(success_4pts_error(a["points"], b["points"]))
+    print("config 5 tracker loop (303 px, 2 iterations), corner error vs CPU loop (px):", " ".join(f"{e:.1e}" for e in errs))
+    assert errs[0] <= 2e-2 and max(errs) <= 0.25, errs
+    out = model.track_new(torch.zeros((1, 3, 303, 303), device=dev))
+    assert X.last_variant() == "cfg5_35x35_5x5" and tuple(out["cls"].shape) == (1, 2, 31, 31)
+    # and as one hipGraph per frame
+    g = HomoTracker(model.hm_net, iterations=2, similarity=DeviceSimilarity(model, cfg), cfg=cfg, graph=True)
+    g.init(frames[0], init["bbox"], init["poly"], init["gt_points"], init["first_point"])
+    e = HomoTracker(model.hm_net, iterations=2, similarity=DeviceSimilarity(model, cfg), cfg=cfg)
+    e.init(frames[0], init["bbox"], init["poly"], init["gt_points"], init["first_point"])
+    for t in range(1, 5):
+        assert success_4pts_error(g.track_new(t, frames[t])["points"], e.track_new(t, frames[t])["points"]) <= 2e-2
+    assert g._graph is not None

@@ -242,6 +242,20 @@ def test_multi_ban_heads_production_width(tag, circular):
     np.testing.assert_allclose(l.numpy(), g[tag + "__loc"], rtol=0, atol=2e-5)
 
 
+def test_multi_ban_head_config5_search_size():
+    """BASELINE configs[4]: the 256-channel MultiBAN on 37 x 37 search features (INSTANCE_SIZE = 303) -> 31 x 31 maps, against
+    the reference's output (tests/golden/heads256_cfg5.npz)."""
+    from conftest import seeded_head256
+    g = load_golden("heads256_cfg5")
+    m, zfs, xfs = seeded_head256("ban_cfg5")
+    psum = sum(float(v.double().sum()) for v in m.state_dict().values())
+    assert abs(psum - float(g["ban__param_sum"])) <= 1e-6 * abs(psum), "torch's init stream drifted: regenerate heads256_cfg5.npz"
+    c, l = O.multi_ban(zfs, xfs, m.state_dict(), False)
+    assert c.shape == (1, 2, 31, 31) and l.shape == (1, 2, 31, 31)
+    np.testing.assert_allclose(c.numpy(), g["ban__cls"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(l.numpy(), g["ban__loc"], rtol=0, atol=2e-5)
+
+
 def test_xcorr_fast_and_slow():
     g = load_golden("xcorr_fast")
     for n in ("cls_o2", "loc_o4"):
@@ -291,19 +305,22 @@ def test_refine_step_composes_normalised_inverse():
     np.testing.assert_array_equal(w[:, :4], np.repeat(img[:, :1], 4, axis=1))
 
 
-def test_similarity_decode_oracle_vs_reference():
+@pytest.mark.parametrize("fixture,S,n_expected", [("similarity", 25, 7), ("similarity303", 31, 5)])
+def test_similarity_decode_oracle_vs_reference(fixture, S, n_expected):
     """oracle.tracker_oracle's restatement of hdn_tracker_proj_e2e.py:164-214 against tests/golden/similarity.npz (the
     reference's own _convert_score / _convert_c / _convert_logpolar_simi / window / rot_scale_around_center_shift_tran on
-    seeded head maps: both gates, exact argmax ties, the identity branches of H_sim).  Same numpy / ATen calls in the same
+    seeded head maps: both gates, exact argmax ties, the identity branches of H_sim) and similarity303.npz (the same on a
+    tracker built under INSTANCE_SIZE = 303: 31 x 31 score map, BASELINE configs[4]).  Same numpy / ATen calls in the same
     order: bit-exact."""
     from oracle import tracker_oracle as TO
-    g = load_golden("similarity")
-    np.testing.assert_array_equal(TO.hanning_window(25), g["window"])
-    np.testing.assert_array_equal(TO.generate_points(8, 25), g["points"])
+    g = load_golden(fixture)
+    np.testing.assert_array_equal(TO.hanning_window(S), g["window"])
+    np.testing.assert_array_equal(TO.generate_points(8, S), g["points"])
     np.testing.assert_array_equal(TO.generate_points(8, 13), g["points_lp"])
     assert float(g["window_influence_production"]) == TO.WINDOW_INFLUENCE
     n_cases = int(g["n_cases"])
-    assert n_cases == 7
+    assert n_cases == n_expected
+    assert TO.SimilarityOracle(None, instance_size={25: 255, 31: 303}[S]).score_size == S
     fired = {"stop": 0, "lp_gate": 0}
     for n in range(n_cases):
         k = f"c{n}__"
