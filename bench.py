@@ -26,7 +26,9 @@ The JSON line also carries
                     all 64 pairs, warm-up 3, 5 passes, at 1 thread pinned to one core (the reference's own setting,
                     tools/test.py:51) and at all cores; headline = the better of the two, best and median of both listed
     "full_head"     BASELINE configs[2] per GPU, timed after the headline region: the whole HomoModelBuilder head incl. the
-                    PyTorch-ROCm ResNet-34 trunk on the same 64 pairs (the trunk is >90 % of it), with its own CPU figure
+                    ResNet-34 trunk on the same 64 pairs (the trunk is >90 % of it), with its own CPU figure
+    "sequence"      BASELINE configs[3] (N = 1): the end-to-end tracker loop over a 501-frame synthetic 1280x720 sequence with a
+                    production-shaped model — ms per frame, frames/s, per-component table, share owned by the hand-written kernels
 """
 from __future__ import annotations
 
@@ -70,6 +72,9 @@ def parse():
     ap.add_argument("--no-breakdown", action="store_true", help="skip the per-kernel breakdown after the timed region")
     ap.add_argument("--no-full-head", action="store_true", help="skip the full_head block (configs[2] per-GPU workload)")
     ap.add_argument("--full-head-steps", type=int, default=30)
+    ap.add_argument("--no-sequence", action="store_true", help="skip the `sequence` block (BASELINE configs[3]: the end-to-end tracker loop "
+                                                               "with a production-shaped model, N = 1 only)")
+    ap.add_argument("--sequence-frames", type=int, default=501, help="frames of the synthetic 1280x720 sequence (POT: 501, hdn/core/config.py:285)")
     ap.add_argument("--collective", choices=["c_abi", "torch", "oneshot"], default="c_abi",
                     help="N > 1: hdn_allgather_offsets of the C ABI on RCCL (default), torch.distributed.all_gather_into_tensor, or the "
                          "direct-write hdn_gather_offsets_oneshot (hipIpc windows; validated on one device only)")
@@ -309,19 +314,20 @@ def main():
     north_variant = X.last_variant()
     north_kernel = {"north_fft_61x61_31x31": "xcorr_north_fft2_kernel", "north_fft2w_61x61_31x31": "xcorr_north_fft3_kernel", "north_fftc_61x61_31x31": "xcorr_north_fft4_kernel",
                     "north_61x61_31x31": "xcorr_north_kernel", "north_mfma_61x61_31x31": "xcorr_north_mfma_kernel"}[north_variant]
-    traffic, traffic_note = None, "no committed PMC measurement found for " + north_kernel
-    try:
-        for rnd in ("round3", "round2", "round1"):  # the newest committed PMC measurement of this kernel
-            path = os.path.join(ROOT, "profiles", rnd + "_pmc_hbm_traffic.json")
-            if not os.path.exists(path):
-                continue
-            with open(path) as f:
-                for name, rec in json.load(f).items():
-                    if north_kernel in name and "traffic_calibrated_bytes" in rec and traffic is None:
-                        traffic = rec["traffic_calibrated_bytes"]
-                        traffic_note = rec.get("how", "profiles/%s_pmc_hbm_traffic.txt" % rnd)
-    except (OSError, ValueError):
-        pass
+    traffic, traffic_note = None, None
+    for rnd in ("round4", "round3", "round2", "round1"):  # the newest committed PMC measurement of this kernel
+        path = os.path.join(ROOT, "profiles", rnd + "_pmc_hbm_traffic.json")
+        if not os.path.exists(path) or traffic is not None:
+            continue
+        with open(path) as f:
+            for name, rec in json.load(f).items():
+                if north_kernel in name and "traffic_calibrated_bytes" in rec and traffic is None:
+                    traffic = rec["traffic_calibrated_bytes"]
+                    traffic_note = rec.get("how", "profiles/%s_pmc_hbm_traffic.txt" % rnd)
+    if traffic is None:
+        # a renamed / replaced kernel must not silently carry `traffic: null` (or a stale figure): re-run tools/profile_round.sh
+        raise SystemExit("bench.py: no committed PMC traffic measurement under profiles/*_pmc_hbm_traffic.json names the kernel the "
+                         "roofline block times (" + north_kernel + "); run tools/profile_round.sh and commit its output")
 
     result = {
         "metric": "frames/sec on 127/255 template/search pairs",
@@ -417,6 +423,8 @@ def main():
         }
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             result["full_head"]["cpu_baseline"] = cpu_full_head(d, full_cpu_sd)
+    if rank == 0 and world == 1 and not args.no_sequence and not args.only_north:
+        result["sequence"] = sequence_block(args.sequence_frames, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(d, sf_cpu_sd)
     if world > 1:
@@ -507,18 +515,47 @@ def run_config5(args, dev, rank, world, dist, hdist, comm, sf, folded):
                          "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms}}), flush=True)
 
 
-def breakdown(d, imgs2, tmpl, folded, X, SF, G, iters=20):
-    """Per-kernel event timing outside the timed region (informational; algorithmic GB/s per kernel)."""
+def sequence_block(n_frames, dev):
+    """BASELINE configs[3]: the end-to-end per-frame loop — hdn_amd.tracker.DeviceTrackerHomo(model), the object
+    install(tracker=True) registers, one hipGraph per frame, the host reading the 4 corners every frame — over a synthetic
+    1280x720 sequence of `n_frames` frames with a PRODUCTION-SHAPED model (tests/production_standin.py: ResNet-50 / stride-8
+    dilated backbone twice per frame on PyTorch-ROCm / MIOpen, 1x1 necks, 256-channel heads, ResNet-34 homography estimator;
+    seeded weights, fp32).  Sequences are independent (H_total recurrence): replicas only, N = 1.  Parity of the same loop against
+    the CPU restatement: tests/test_gpu_tracker.py and `tests/tools/sequence_bench.py --production-shape --parity 61`
+    (profiles/round4_sequence.txt); nothing under oracle/ is touched here."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    import sequence_bench as SB
+    t0 = time.perf_counter()
+    res = SB.run_production(n_frames=n_frames, n_parity=0, components=True, dev=dev, quiet=True)
+    res["wall_s_incl_generation_and_miopen_find"] = time.perf_counter() - t0
+    res["metric"], res["unit"], res["value"] = "end-to-end frames/sec, tracker.track() loop, 1280x720 frames, 127/255 crops", "frames/s", res["fps"]
+    return res
+
+
+def breakdown(d, imgs2, tmpl, folded, X, SF, G, iters=50):
+    """Per-kernel timing outside the timed region (informational; algorithmic GB/s per kernel): each launch captured as a
+    hipGraph and replayed back to back between two events, so the host side of a call (output allocations, pointer tables of
+    the multi-problem launches) is not in the figure."""
     def timed(fn):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            keep = fn()
         for _ in range(3):
-            fn()
+            g.replay()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(iters):
-            fn()
+            g.replay()
         e1.record()
         torch.cuda.synchronize()
+        del keep
         return e0.elapsed_time(e1) / iters
 
     warped = G.dlt_warp(d["h4p"], d["off"], tmpl)[1]

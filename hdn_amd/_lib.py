@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libhdn_hip.so"
 LIB_PATH = os.environ.get("HDN_LIB_PATH", os.path.join(_HERE, LIB_NAME))  # override: A/B builds of the kernels
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _c_float_p = ctypes.c_void_p  # device pointers travel as integers
 _i = ctypes.c_int

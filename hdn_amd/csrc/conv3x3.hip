@@ -5,17 +5,20 @@
 // (C, S) = (64, 32), (128, 16), (256, 8), (512, 4) for 127-px crops).
 //
 // GEMM view (NHWC): D[pixel][cout] = sum over (tap, cin) A_tap[pixel][cin] * W[tap][cin][cout], A_tap = the input shifted by the tap.
-// fp32 in, fp32 out, but the products run on the bf16 matrix pipe at 16x the fp32 MFMA rate: every fp32 value is split EXACTLY into
-// three bf16 pieces x = x0 + x1 + x2 (8 + 8 + 8 significand bits) and six piece products are accumulated in fp32
-// (x0 w0, x0 w1, x1 w0, x1 w1, x0 w2, x2 w0; the three dropped ones are below 2^-24 of the product): 6 x 32 clk per K = 16
-// against 8 x 64 clk on v_mfma_f32_32x32x2_f32, with a result that differs from an fp32 convolution by summation order and
-// ~2^-23 relative per product.  The weights are split once on the host (hdn_amd.trunk.pack_conv3x3), the activations while they
-// are staged into LDS.
+// fp32 in, fp32 out, but the products run on the 16-bit matrix pipe at 16x the fp32 MFMA rate.  Round 4: every fp32 value is split
+// into TWO fp16 pieces, x = h0 + 2^-11 h1 with h0 = fp16(x) and h1 = fp16((x - h0) * 2^11) (the residual is exact in fp32; scaling
+// it by 2^11 keeps it in fp16's normal range whenever x is: 11 + 11 significand bits, |x - h0 - 2^-11 h1| <= 2^-23 |x|), and THREE
+// piece products are accumulated in fp32 in two accumulator sets: hi += x0 w0, lo += x0 w1 + x1 w0, result = hi + 2^-11 lo (the
+// dropped x1 w1 is below 2^-22 of the product).  3 x 32 clk per K = 16 against 8 x 64 clk on v_mfma_f32_32x32x2_f32 and against
+// the 6 x 32 clk of round 3's three-bf16-piece form; measured against float64 the result has the error of an fp32 convolution
+// (rms 6.6e-8 of the output scale on K = 2,304 sums, fp32 sgemm: 6.6e-8, the bf16 form: 2.8e-8).  Range: |x| < 65,504 (fp16);
+// the trunk's activations (BatchNorm-folded, ReLU) are O(10).  The weights are split once on the host
+// (hdn_amd.trunk.pack_conv3x3), the activations while they are staged into LDS.
 //
 // Workgroup = 8 waves (4 consumers issuing MFMAs + 4 producers staging operands, see conv3x3_kernel), tile = BM output pixels
 // (consecutive in (b, y, x) order: whole image rows) x BN output channels.
 //   LDS A image: the tile's input pixels with a one-pixel halo (zeros outside the image), one K chunk of 16 * KS input channels at
-//                a time, as [piece][k step][k half][pixel] x 16 B: an MFMA A fragment (lane = (pixel row i, k half g), 8 bf16) is
+//                a time, as [piece][k step][k half][pixel] x 16 B: an MFMA A fragment (lane = (pixel row i, k half g), 8 fp16) is
 //                one ds_read_b128 and a tap is a constant address offset; conflict-free through the row / image pitches of Cfg and
 //                the lane -> pixel order of mrow_to_pixel().  Two images (double buffer).
 //   LDS W image: [tap of the stage][k step][piece][k half][cout] x 16 B, one STAGE = one kernel row (3 taps) of one chunk, a ring
@@ -33,7 +36,7 @@
 namespace hdn {
 namespace cv {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -49,20 +52,20 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 __device__ __forceinline__ f32x16 mfma(const u32x4& a, const u32x4& b, const f32x16& c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-// two fp32 values -> their three bf16 pieces (round-to-nearest-even by v_cvt_pk_bf16_f32), packed (lo = first value):
-// x = p0 + p1 + p2 up to 2^-24 |x|; each residual is exact in fp32
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// two fp32 values -> their two fp16 pieces (round-to-nearest-even by v_cvt_pk_f16_f32), packed (lo = first value):
+// x = p0 + 2^-11 p1 up to 2^-23 |x|; the residual x - p0 is exact in fp32, and so is its product with 2^11 (6 VALU ops per pair)
+constexpr float LO_SCALE = 2048.f, LO_UNSCALE = 1.f / 2048.f;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split3x2(float x, float y, unsigned& p0, unsigned& p1, unsigned& p2) {
+__device__ __forceinline__ void split2x2(float x, float y, unsigned& p0, unsigned& p1) {
   const f2 v = {x, y};
-  p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-  const f2 r1 = v - f2{__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xffff0000u)};
-  p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
-  const f2 r2 = r1 - f2{__uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u)};
-  p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+  const f16x2 h = __builtin_convertvector(v, f16x2);
+  p0 = __builtin_bit_cast(unsigned, h);
+  const f2 r = (v - __builtin_convertvector(h, f2)) * LO_SCALE;
+  p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
 }
 
 // S = OUTPUT side, CI -> CO channels, STRIDE 1 or 2 (input side S * STRIDE); DS: the block's 1x1 / stride-2 downsample branch is
@@ -90,8 +93,9 @@ struct Cfg {
   // 128-byte bank row) needs the sub-images 128 / (2 KS) bytes apart modulo 128: LP = 8 / (2 KS) modulo 8.
   static constexpr int LPV = IMGS * IPITCH;                      // LDS pixels that exist
   static constexpr int LP = LPV + ((8 / (2 * KS) - LPV % 8) + 8) % 8;
-  static constexpr int KG_BYTES = LP * 16, KSTEP_BYTES = 2 * KG_BYTES, PIECE_BYTES = KS * KSTEP_BYTES, A_BYTES = 3 * PIECE_BYTES;
-  static constexpr int WKG_BYTES = BN * 16, WPIECE_BYTES = 2 * WKG_BYTES, WSTEP_BYTES = 3 * WPIECE_BYTES;   // one (tap, k step)
+  static constexpr int NP = 2;                                   // fp16 pieces per value
+  static constexpr int KG_BYTES = LP * 16, KSTEP_BYTES = 2 * KG_BYTES, PIECE_BYTES = KS * KSTEP_BYTES, A_BYTES = NP * PIECE_BYTES;
+  static constexpr int WKG_BYTES = BN * 16, WPIECE_BYTES = 2 * WKG_BYTES, WSTEP_BYTES = NP * WPIECE_BYTES;   // one (tap, k step)
   static constexpr int NTAP = DS ? 4 : 3;                        // taps of a stage: a kernel row (+ the downsample tap, used in the middle row)
   static constexpr int WSTAGE_BYTES = NTAP * KS * WSTEP_BYTES;   // one kernel row of one chunk
   static constexpr int EPI_STRIDE = BN + 4;                      // floats per pixel row of the output staging (pad: bank spread of the two half waves)
@@ -123,7 +127,7 @@ __device__ __forceinline__ int mrow_to_pixel(int i) {
 // out[blockIdx.z][M][CO] (the workspace; conv3x3_reduce_kernel finishes).  Cf::DS: out2 = the downsample branch (raw sums, no
 // bias / ReLU; mode 2: out2[blockIdx.z][M][CO]).
 // 8 waves, two per SIMD, with separate roles: waves 0-3 only read fragments and issue MFMAs (consumers), waves 4-7 only load from
-// global memory, split to bf16 and fill the LDS images (producers).  A consumer never waits for a global load or for the operands
+// global memory, split to fp16 pieces and fill the LDS images (producers).  A consumer never waits for a global load or for the operands
 // of an LDS store; the two roles meet at the one barrier per stage, and the producers run TWO stages ahead, so that a consumer can
 // read the first fragments of stage s + 1 while it still issues the MFMAs of stage s.
 template <class Cf, int MODE>
@@ -155,30 +159,30 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __r
   }
   const uint32_t boff = lds_addr(sW) + g * Cf::WKG_BYTES + (wn * NT * 32 + li) * 16;
 
-  f32x16 acc[MT][NT];
+  f32x16 acc[MT][NT], accl[MT][NT];        // hi: x0 w0; lo: x0 w1 + x1 w0 (scaled by 2^11)
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-  f32x16 accd[DS ? MT : 1][DS ? NT : 1];   // the downsample branch
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = accl[mt][nt][r] = 0.f;
+  f32x16 accd[DS ? MT : 1][DS ? NT : 1], accdl[DS ? MT : 1][DS ? NT : 1];   // the downsample branch
   if (DS) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) accd[mt][nt][r] = 0.f;
+        for (int r = 0; r < 16; ++r) accd[mt][nt][r] = accdl[mt][nt][r] = 0.f;
   }
 
-  // this channel block's packed weights: [chunk][kernel row][tap in row][k step][piece][k half][n][8 bf16] = [stage][W4 words]
+  // this channel block's packed weights: [chunk][kernel row][tap in row][k step][piece][k half][n][8 fp16] = [stage][W4 words]
   const int chunk0 = PARTIAL ? (int)blockIdx.z * cps : 0, nchunk = PARTIAL ? cps : Cf::NCHUNK, nstage = 3 * nchunk;   // this launch's K range
   const u32x4* wblock = wp + ((size_t)nb * Cf::NSTAGE + (size_t)chunk0 * 3) * Cf::W4;
   u32x4 wr[2][Cf::WITER];   // two stages in flight: stage t travels in wr[t & 1] from stage t - 4 (load) to stage t - 2 (LDS store)
   auto load_w = [&](int stage, auto P) {
     constexpr int p = decltype(P)::value;
-#ifdef CV_EXP_NOWLOAD
+#if defined(HDN_ABLATION) && defined(CV_EXP_NOWLOAD)   // measurement build only: tools/build_variant.sh -DHDN_ABLATION -DCV_EXP_NOWLOAD
     if (stage > 3) return;
 #endif
     const u32x4* src = wblock + (size_t)stage * Cf::W4;
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __r
   // input chunk: (pixel, k step, k half) items of 8 channels = 32 bytes
   f4 av[Cf::AITER][2];
   auto load_a = [&](int chunk) {
-#ifdef CV_EXP_NOALOAD
+#if defined(HDN_ABLATION) && defined(CV_EXP_NOALOAD)   // measurement build only: tools/build_variant.sh -DHDN_ABLATION -DCV_EXP_NOALOAD
     if (chunk > 0) return;
 #endif
 #pragma unroll
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __r
     }
   };
   auto store_a = [&](int ab) {
-#ifdef CV_EXP_NOSTAGE
+#if defined(HDN_ABLATION) && defined(CV_EXP_NOSTAGE)   // measurement build only: tools/build_variant.sh -DHDN_ABLATION -DCV_EXP_NOSTAGE
     return;
 #endif
 #pragma unroll
@@ -219,25 +223,24 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __r
       const int item = tid + q * HDN_BLOCK;
       if (item < Cf::AITEMS) {
         const int px = item / (2 * KS), sub = item % (2 * KS);   // sub = k step * 2 + k half
-        unsigned q0[4], q1[4], q2[4];
-        split3x2(av[q][0].x, av[q][0].y, q0[0], q1[0], q2[0]);
-        split3x2(av[q][0].z, av[q][0].w, q0[1], q1[1], q2[1]);
-        split3x2(av[q][1].x, av[q][1].y, q0[2], q1[2], q2[2]);
-        split3x2(av[q][1].z, av[q][1].w, q0[3], q1[3], q2[3]);
+        unsigned q0[4], q1[4];
+        split2x2(av[q][0].x, av[q][0].y, q0[0], q1[0]);
+        split2x2(av[q][0].z, av[q][0].w, q0[1], q1[1]);
+        split2x2(av[q][1].x, av[q][1].y, q0[2], q1[2]);
+        split2x2(av[q][1].z, av[q][1].w, q0[3], q1[3]);
         unsigned char* dst = sA + ab * Cf::A_BYTES + sub * Cf::KG_BYTES + px * 16;
         *reinterpret_cast<u32x4*>(dst) = u32x4{q0[0], q0[1], q0[2], q0[3]};
         *reinterpret_cast<u32x4*>(dst + Cf::PIECE_BYTES) = u32x4{q1[0], q1[1], q1[2], q1[3]};
-        *reinterpret_cast<u32x4*>(dst + 2 * Cf::PIECE_BYTES) = u32x4{q2[0], q2[1], q2[2], q2[3]};
       }
     }
   };
 
   struct Frags {
-    u32x4 a[MT][3], b[NT][3];
+    u32x4 a[MT][Cf::NP], b[NT][Cf::NP];
   };
   // fragments of step (tap t of the stage's kernel row ky, k step ks) from W buffer `buf`
   auto read_frags = [&](Frags& f, int ky, int t, int ks, int buf, int ab) {
-#ifdef CV_EXP_NOREAD
+#if defined(HDN_ABLATION) && defined(CV_EXP_NOREAD)   // measurement build only: tools/build_variant.sh -DHDN_ABLATION -DCV_EXP_NOREAD
     if (ky + t + ks + buf >= 0) return;
 #endif
     const int toff = (t == 3 ? 0 : ((ky - 1) * Cf::PW + (t - 1)) * 16) + ks * Cf::KSTEP_BYTES + ab * Cf::A_BYTES;   // (tap 3: the downsample branch reads the centre)
@@ -245,16 +248,16 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __r
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int s = 0; s < 3; ++s)
+      for (int s = 0; s < Cf::NP; ++s)
         asm volatile("ds_read_b128 %0, %1" : "=v"(f.a[mt][s]) : "v"(aoff[mt] + toff + s * Cf::PIECE_BYTES));
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int s = 0; s < 3; ++s)
+      for (int s = 0; s < Cf::NP; ++s)
         asm volatile("ds_read_b128 %0, %1" : "=v"(f.b[nt][s]) : "v"(wb + s * Cf::WPIECE_BYTES + nt * 32 * 16));
   };
   auto mma = [&](const Frags& f, auto TODS) {
-#ifdef CV_EXP_NOMFMA
+#if defined(HDN_ABLATION) && defined(CV_EXP_NOMFMA)   // measurement build only: tools/build_variant.sh -DHDN_ABLATION -DCV_EXP_NOMFMA
     return;
 #endif
     constexpr bool tods = decltype(TODS)::value;
@@ -262,15 +265,13 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __r
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        f32x16 c = tods ? accd[DS ? mt : 0][DS ? nt : 0] : acc[mt][nt];
-        c = mfma(f.a[mt][2], f.b[nt][0], c);  // smallest terms first
-        c = mfma(f.a[mt][0], f.b[nt][2], c);
-        c = mfma(f.a[mt][1], f.b[nt][1], c);
-        c = mfma(f.a[mt][1], f.b[nt][0], c);
-        c = mfma(f.a[mt][0], f.b[nt][1], c);
-        c = mfma(f.a[mt][0], f.b[nt][0], c);
-        if (tods) accd[DS ? mt : 0][DS ? nt : 0] = c;
-        else acc[mt][nt] = c;
+        f32x16 h = tods ? accd[DS ? mt : 0][DS ? nt : 0] : acc[mt][nt];
+        f32x16 l = tods ? accdl[DS ? mt : 0][DS ? nt : 0] : accl[mt][nt];
+        l = mfma(f.a[mt][1], f.b[nt][0], l);
+        h = mfma(f.a[mt][0], f.b[nt][0], h);
+        l = mfma(f.a[mt][0], f.b[nt][1], l);
+        if (tods) accd[DS ? mt : 0][DS ? nt : 0] = h, accdl[DS ? mt : 0][DS ? nt : 0] = l;
+        else acc[mt][nt] = h, accl[mt][nt] = l;
       }
   };
 
@@ -316,7 +317,8 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __r
     // Fragment sets: a step's fragments are read AHEAD steps before its MFMAs (across stage boundaries too: the next stage's
     // images were complete a barrier ago).  The sets rotate with the step number; a period's step count must be a multiple of
     // NSETS for the indices to be static.  One step ahead is what fits: with three sets (two steps ahead) the consumers spill
-    // (256 registers per wave at two waves per SIMD) and nothing is gained (measured: 30.0 / 31.6 vs 28.7 / 30.2 us at 128 / 256 channels).
+    // (256 registers per wave at two waves per SIMD) and nothing is gained (measured with round 3's bf16 form: 30.0 / 31.6 vs
+    // 28.7 / 30.2 us at 128 / 256 channels).
     constexpr int NSETS = 2, AHEAD = NSETS - 1;
     constexpr int PERIOD_STEPS = 2 * (NSTEP_ROW[0] + NSTEP_ROW[1] + NSTEP_ROW[2]);
     static_assert(PERIOD_STEPS % NSETS == 0, "fragment sets must line up with the period");
@@ -346,17 +348,17 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __r
         if (issue) read_frags(f[(cur + AHEAD) % NSETS], kyn, stn / KS, stn % KS, slotn, abn);
         // the fragments of this step have landed when at most the AHEAD sets read after them are outstanding (LDS operations retire in
         // order; the counter holds 15 at most: waiting for a few reads of the next step as well is harmless)
-        constexpr int OUTSTANDING = AHEAD * (MT + NT) * 3 < 15 ? AHEAD * (MT + NT) * 3 : 15;
+        constexpr int OUTSTANDING = AHEAD * (MT + NT) * Cf::NP < 15 ? AHEAD * (MT + NT) * Cf::NP : 15;
         if (issue) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(OUTSTANDING) : "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int s_ = 0; s_ < 3; ++s_) asm volatile("" : "+v"(f[cur].a[mt][s_]));
+          for (int s_ = 0; s_ < Cf::NP; ++s_) asm volatile("" : "+v"(f[cur].a[mt][s_]));
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-          for (int s_ = 0; s_ < 3; ++s_) asm volatile("" : "+v"(f[cur].b[nt][s_]));
+          for (int s_ = 0; s_ < Cf::NP; ++s_) asm volatile("" : "+v"(f[cur].b[nt][s_]));
         if constexpr (DS && st / KS == 3) mma(f[cur], std::true_type{});
         else mma(f[cur], std::false_type{});
       });
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __r
     if (c2 < nchunk) static_for<3>([&](auto Jc) { stage_c(c2, Jc); });
   }
 
-  // ---- epilogue.  C/D layout of v_mfma_f32_32x32x16_bf16: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+  // ---- epilogue.  C/D layout of v_mfma_f32_32x32x16_f16: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
   // The tile goes through LDS once ([pixel][BN] fp32) so that the residual is read and the result written as 16 bytes per lane,
   // a pixel's BN channels (contiguous in NHWC) by BN / 4 consecutive lanes.
   __syncthreads();  // every wave is done with the A / W images
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __r
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = (wm * MT + mt) * 32 + mrow_to_pixel<Cf>((r & 3) + 8 * (r >> 2) + 4 * g);
-          sO[row * Cf::EPI_STRIDE + (wn * NT + nt) * 32 + li] = acc[mt][nt][r];
+          sO[row * Cf::EPI_STRIDE + (wn * NT + nt) * 32 + li] = acc[mt][nt][r] + accl[mt][nt][r] * LO_UNSCALE;
         }
   }
   __syncthreads();
@@ -423,7 +425,7 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __r
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int row = (wm * MT + mt) * 32 + mrow_to_pixel<Cf>((r & 3) + 8 * (r >> 2) + 4 * g);
-            sO[row * Cf::EPI_STRIDE + (wn * NT + nt) * 32 + li] = accd[DS ? mt : 0][DS ? nt : 0][r];
+            sO[row * Cf::EPI_STRIDE + (wn * NT + nt) * 32 + li] = accd[DS ? mt : 0][DS ? nt : 0][r] + accdl[DS ? mt : 0][DS ? nt : 0][r] * LO_UNSCALE;
           }
     }
     __syncthreads();

@@ -132,19 +132,23 @@ def bias_relu_(y, bias, residual=None):
     return y
 
 
-def _split_bf16(w):
-    """fp32 -> three bf16 pieces, w = p0 + p1 + p2 (round-to-nearest-even each; the residuals are exact in fp32)."""
+SPLIT_PIECES = 2
+
+
+def _split_f16(w):
+    """fp32 -> two fp16 pieces, w = p0 + 2^-11 p1 (round-to-nearest-even each; the residual w - p0 and its product with 2^11 are
+    exact in fp32): the split the kernel applies to the activations (conv3x3.hip, split2x2)."""
     import torch
 
-    p0 = w.to(torch.bfloat16)
-    r1 = w - p0.float()
-    p1 = r1.to(torch.bfloat16)
-    p2 = (r1 - p1.float()).to(torch.bfloat16)
-    return torch.stack([p0, p1, p2])
+    if float(w.abs().max()) >= 65504.0:
+        raise ValueError("conv3x3 matrix-core kernel: weights beyond the fp16 range")
+    p0 = w.to(torch.float16)
+    p1 = ((w - p0.float()) * 2048.0).to(torch.float16)
+    return torch.stack([p0, p1])
 
 
 def _pack(w4, S, CI, stride):
-    """w4 [CO, CI, 3, T] fp32 (T taps per kernel row) -> [CO / BN][CI / (16 KS)][3][T][KS][3 pieces][2][BN][8] int16 bit patterns."""
+    """w4 [CO, CI, 3, T] fp32 (T taps per kernel row) -> [CO / BN][CI / (16 KS)][3][T][KS][2 pieces][2][BN][8] int16 bit patterns (fp16)."""
     import ctypes
 
     import torch
@@ -156,8 +160,8 @@ def _pack(w4, S, CI, stride):
         raise ValueError(f"no matrix-core kernel for {CI} input channels at output side {S}, stride {stride}")
     BN, KS = bn.value, ks.value
     CO, T = w4.shape[0], w4.shape[3]
-    pieces = _split_bf16(w4.detach().to(torch.float32).cpu())           # [3, CO, CI, ky, t]
-    t = pieces.permute(0, 1, 3, 4, 2).reshape(3, CO // BN, BN, 3, T, CI // (16 * KS), KS, 2, 8)   # [piece, nb, n, ky, t, chunk, ks, g, 8]
+    pieces = _split_f16(w4.detach().to(torch.float32).cpu())            # [2, CO, CI, ky, t]
+    t = pieces.permute(0, 1, 3, 4, 2).reshape(SPLIT_PIECES, CO // BN, BN, 3, T, CI // (16 * KS), KS, 2, 8)   # [piece, nb, n, ky, t, chunk, ks, g, 8]
     t = t.permute(1, 5, 3, 4, 6, 0, 7, 2, 8).contiguous()               # [nb, chunk, ky, t, ks, piece, g, n, 8]
     return t.view(torch.int16)
 
@@ -196,7 +200,7 @@ def conv3x3_bias_relu(x, wpacked, bias, residual=None):
     cl = torch.channels_last
     if S != S2 or not x.is_contiguous(memory_format=cl) or (residual is not None and (residual.shape != x.shape or not residual.is_contiguous(memory_format=cl))):
         raise ValueError("conv3x3_bias_relu: square channels-last inputs of equal shape")
-    if wpacked.dtype != torch.int16 or wpacked.device != dev or wpacked.numel() != 27 * C * C or bias.numel() != C:
+    if wpacked.dtype != torch.int16 or wpacked.device != dev or wpacked.numel() != 9 * SPLIT_PIECES * C * C or bias.numel() != C:
         raise ValueError("conv3x3_bias_relu: weights must come from pack_conv3x3 for this channel count, on the input's device")
     out = torch.empty_like(x, memory_format=cl)
     lib = _lib.load()
@@ -229,7 +233,7 @@ def conv3x3s2_ds(x, wpacked, bias):
     if H != W or H % 2 or not x.is_contiguous(memory_format=cl):
         raise ValueError("conv3x3s2_ds: square, even-sided channels-last input")
     S, CO = H // 2, 2 * CI
-    if wpacked.dtype != torch.int16 or wpacked.device != dev or wpacked.numel() != 3 * 3 * 4 * CI * CO or bias.numel() != CO:
+    if wpacked.dtype != torch.int16 or wpacked.device != dev or wpacked.numel() != SPLIT_PIECES * 3 * 4 * CI * CO or bias.numel() != CO:
         raise ValueError("conv3x3s2_ds: weights must come from pack_conv3x3s2_ds for this channel count, on the input's device")
     out = torch.empty((B, CO, S, S), dtype=torch.float32, device=dev, memory_format=cl)
     out_ds = torch.empty_like(out, memory_format=cl)
@@ -247,7 +251,7 @@ def conv3x3s2_ds(x, wpacked, bias):
 
 class FusedBasicBlock(nn.Module):
     """BasicBlock.forward (backbone/resnet.py:78-94) of the BN-folded trunk with its elementwise tail fused.  Stride-1 3x3
-    convolutions of MATRIX_CORE_CHANNELS run, bias / residual / ReLU included, as ONE launch of the split-bf16 matrix-core kernel
+    convolutions of MATRIX_CORE_CHANNELS run, bias / residual / ReLU included, as ONE launch of the split-fp16 matrix-core kernel
     (hdn_conv3x3_bias_relu_f32, channels-last only); every other convolution runs bias-free on MIOpen with `relu(y + b1)` /
     `relu(y + b2 + residual)` as one HIP pass each (hdn_bias_relu_f32).  A folded downsample branch contributes its bias to b2 and
     its raw convolution as the residual.  GPU / eval only."""
@@ -271,7 +275,7 @@ class FusedBasicBlock(nn.Module):
         else:
             self.wd = None
         self.register_buffer("b2", b2)
-        # packed split-bf16 weights for the matrix-core kernel (stride 1, C -> C only)
+        # packed split-fp16 weights for the matrix-core kernel (stride 1, C -> C only)
         dev = self.w1.device
         cin, cout = self.w1.shape[1], self.w1.shape[0]
         use1 = matrix_core and self.stride == (1, 1) and cin == cout and cout in MATRIX_CORE_CHANNELS
@@ -312,7 +316,7 @@ def fold_for_inference(net: HomoResNet, channels_last: bool = True, fused_stem: 
     fused_stem: replace conv1 / relu / maxpool by FusedStem (GPU only, W <= 128).
     fused_epilogue: replace every BasicBlock by FusedBasicBlock (GPU only): 83 elementwise launches per forward -> 32.
     matrix_core (default: fused_epilogue and channels_last): the stride-1 3x3 convolutions of MATRIX_CORE_CHANNELS as one launch of
-    the split-bf16 matrix-core kernel each, epilogue included."""
+    the split-fp16 matrix-core kernel each, epilogue included."""
     import copy
 
     import torch

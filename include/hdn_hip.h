@@ -32,7 +32,7 @@ extern "C" {
 /* RCCL failures are returned as -(2000 + ncclResult_t). */
 
 /* ABI version of this header; hdn_abi_version() of the loaded library must match. */
-#define HDN_ABI_VERSION 4
+#define HDN_ABI_VERSION 5
 int hdn_abi_version(void);
 
 /* Name of the kernel variant the last hdn_xcorr_* call on this thread dispatched to
@@ -307,11 +307,13 @@ int hdn_bias_relu_f32(float* y, const float* bias, const float* residual, int B,
  *       x [B,2S,2S,CI] -> out / out_ds [B,S,S,2 CI], (S, CI) = (16, 64), (8, 128), (4, 256): conv1 + bn1 + relu and the `downsample`
  *       branch of the first block of layer2..4 (out_ds carries no bias: the caller adds the folded downsample shift to the bias of
  *       the block's second convolution, whose residual out_ds is).
- * Any other shape returns HDN_E_LIMIT (the caller keeps MIOpen for it).  fp32 accuracy from the bf16 pipe: activations and weights
- * are split exactly into three bf16 pieces each and six piece products are accumulated in fp32 (conv3x3.hip); the result differs
- * from an fp32 convolution by summation order and ~2^-23 relative per product.
+ * Any other shape returns HDN_E_LIMIT (the caller keeps MIOpen for it).  fp32 accuracy from the 16-bit matrix pipe (ABI 5): activations
+ * and weights are split into two fp16 pieces each, v = p0 + 2^-11 p1 with p0 = fp16(v), p1 = fp16((v - p0) * 2^11) (22 significand
+ * bits), and three piece products are accumulated in fp32 (x0 w0 in one accumulator set, x0 w1 + x1 w0 in a second one that is
+ * added with the factor 2^-11; conv3x3.hip); against float64 the result has the error of an fp32 convolution.  Values must lie in
+ * fp16's range, |v| < 65,504 (the packer checks the weights; the trunk's activations are O(10)).
  * wpacked: the BatchNorm-folded weights split and laid out by the host (hdn_amd.trunk.pack_conv3x3 / pack_conv3x3s2_ds) as
- *   [CO / BN][CI / (16 KS)][3 kernel rows][T taps][KS k steps][3 pieces][2 k halves][BN][8] bf16, input channel = chunk * 16 KS +
+ *   [CO / BN][CI / (16 KS)][3 kernel rows][T taps][KS k steps][2 pieces][2 k halves][BN][8] fp16, input channel = chunk * 16 KS +
  *   step * 16 + half * 8 + j, (BN, KS) = hdn_conv3x3_pack_info(S, CI, stride); T = 3, or 4 for the stride-2 form, whose 4th tap holds
  *   the 1x1 weights in the middle kernel row (zeros in the other two); 16-byte aligned.
  * Workspace: when the output tiles alone do not fill the chip (S = 4 at any batch size, every shape at small B) the K dimension is

@@ -1,51 +1,290 @@
 #!/usr/bin/env python3
 """BASELINE configs[3] on the synthetic sequence of tools/synth_sequence.py (no POT data, no cv2 here): a 1280x720
-planar-target sequence streamed through the device-resident tracker loop (hdn_amd.tracker.HomoTracker: upload the uint8
-frame once, full-frame warp, crop + normalise, track_proj, 3x3 bookkeeping, ONE host read of the 4 corners per frame).
+planar-target sequence streamed through the device-resident tracker loop (hdn_amd.tracker: upload the uint8 frame once,
+full-frame warp, crops, networks, decodes, track_proj, 3x3 bookkeeping, ONE host read of the 4 corners per frame).
 
-Reported: wall time per frame with the host reading the corners EVERY frame (what tools/test.py's loop sees, :115-174),
-host syncs per frame, the same loop without the per-frame read (pipelined), corner error (success_4pts_error) of the device
-loop against the CPU restatement of the same loop on the first --parity frames, and — for the B=1 head alone — eager vs
-hipGraph replay, each synchronised per frame.
---similarity runs the loop WITH the similarity branch (crop, heads, device decode, moved crop, log-polar heads, decode, H_sim,
-rotate-back) around tests/standin_model.py's seeded stand-in for the reference's ModelBuilder: the ResNet-50 backbone of the
-deployment is PyTorch-ROCm's and is not shipped here, so these times cover everything of a frame EXCEPT two backbone passes.
-    python tests/tools/sequence_bench.py [--frames 200] [--parity 12] [--similarity]
+Three model choices for the similarity branch:
+    (default)            none: the similarity estimate is the identity (the homography half of a frame alone)
+    --similarity         tests/standin_model.py: a 16-channel, one-convolution-per-level toy (everything of a frame EXCEPT the networks)
+    --production-shape   tests/production_standin.py: ResNet-50 / stride 8 / dilated backbone, 1x1 necks, 256-channel heads — the
+                         shapes of the shipped configuration with seeded weights, driven through DeviceTrackerHomo(model), the
+                         object install(tracker=True) registers.  This is the honest end-to-end frame: two backbone passes
+                         (PyTorch-ROCm / MIOpen, as north_star assigns them) + everything hand-written around them.
+
+Reported: wall time per frame with the host reading the corners EVERY frame (what tools/test.py's loop sees, :115-174), eager
+and as one hipGraph per frame; with --production-shape also a per-component table (every stage of the frame body captured as
+its own hipGraph and replayed) and the share of the frame the hand-written kernels own; corner error (success_4pts_error) of
+the device loop against the CPU restatement of the same loop on the first --parity frames, free-running and with the
+recurrence state (H_total) re-synchronised to the CPU loop's before every frame.
+
+    python tests/tools/sequence_bench.py --production-shape [--frames 501] [--parity 61] [--nchw]
 """
 import argparse, copy, json, os, sys, time
 import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+for p in (ROOT, os.path.join(ROOT, "tools"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
 import hdn_amd
-from hdn_amd.graph import GraphedTrackProj
-from hdn_amd.tracker import HomoTracker
-from oracle.tracker_oracle import HomoTrackerOracle, SimilarityOracle
-from synth_sequence import make_sequence, success_4pts_error
+from hdn_amd import _lib, frame as FR
+from hdn_amd.tracker import DeviceTrackerHomo, HomoTracker
+from synth_sequence import LONG_WALK, make_sequence, success_4pts_error
 
 
-def seeded_net():
+def seeded_net(fc_bias_scale=1.0):
     torch.manual_seed(1)
     net = hdn_amd.HomoModelBuilder().eval()
     for m in net.modules():
         if isinstance(m, torch.nn.BatchNorm2d):
             m.running_mean.uniform_(-0.2, 0.2); m.running_var.uniform_(0.8, 1.2)
     net.fc.weight.data.mul_(0.01)
+    net.fc.bias.data.mul_(fc_bias_scale)
     return net
 
 
+# --------------------------------------------------------------------------------------------------- timing helpers
+def graph_ms(fn, reps=200, warm=3):
+    """fn() captured as ONE hipGraph (static inputs), replayed `reps` times back to back: mean ms per replay."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(warm):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        keep = fn()
+    for _ in range(5):
+        g.replay()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); a.record()
+    for _ in range(reps):
+        g.replay()
+    b.record(); torch.cuda.synchronize()
+    del keep
+    return a.elapsed_time(b) / reps
+
+
+def stream_loop(new_tracker, frames, sync, graph=False, warm=6):
+    """The tracker over the whole sequence: ms per frame (wall), host syncs per frame, p99 per-frame latency."""
+    t = new_tracker(graph)
+    for i in range(1, warm):
+        t.track_new(i, frames[i])                    # warm-up (MIOpen find, clocks, graph capture)
+    t.H_total.copy_(torch.eye(3, dtype=torch.float64, device=t.dev)); torch.cuda.synchronize(); s0 = t.host_syncs
+    t0 = time.perf_counter(); per = []
+    n = len(frames)
+    for i in range(1, n):
+        a = time.perf_counter(); t.track_new(i, frames[i], sync=sync); per.append(time.perf_counter() - a)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / (n - 1) * 1e3, (t.host_syncs - s0) / (n - 1), float(np.percentile(per, 99) * 1e3), t
+
+
+# --------------------------------------------------------------------------------------------------- production-shaped model
+def build_production_model(frames, init, dev, nchw=False, instance_size=255, crops="product"):
+    """tests/production_standin.ProductionStandIn on `dev`, BatchNorm statistics calibrated on crops of the first frames.
+    crops="product": the calibration crops are cut by hdn_amd.frame on the device (bench.py: no oracle outside its cpu_baseline
+    leg); "oracle": by oracle/frame_oracle.py (bit-identical crops; the CPU twin is then built from the same weights)."""
+    import production_standin as PS
+    net = seeded_net(0.1)
+    twin = PS.ProductionStandIn(net, instance_size=instance_size)
+    if crops == "oracle":
+        c255, c127 = PS.calibration_crops(frames, init)
+    else:
+        poly = init["poly"]
+        s_z = float(np.floor(np.sqrt((poly[2] + 0.5 * (poly[2] + poly[3])) * (poly[3] + 0.5 * (poly[2] + poly[3])))))
+        c255, c127 = [], []
+        for f in frames[:3]:
+            fr, avg = FR.upload(f), np.mean(f, axis=(0, 1))
+            c255.append(FR.get_subwindow(fr, poly[:2], 255, float(np.floor(2 * s_z)), avg)[0].cpu())
+            c127.append(FR.get_subwindow(fr, poly[:2], 127, s_z, avg)[0].cpu())
+        c255, c127 = torch.stack(c255), torch.stack(c127)
+    twin.calibrate(c255, c127)
+    cpu_twin_src = copy.deepcopy(twin) if crops == "oracle" else None
+    twin = twin.to(dev).eval()
+    twin.hm_net.optimize_for_inference(channels_last=True)
+    if not nchw:
+        twin.backbone.to(memory_format=torch.channels_last)
+        twin.neck.to(memory_format=torch.channels_last); twin.neck_lp.to(memory_format=torch.channels_last)
+    return twin, cpu_twin_src
+
+
+def component_table(trk, frame_u8, reps=200):
+    """Every stage of DeviceTrackerHomo's frame body as its own hipGraph on static inputs (the outputs of the stages before it,
+    computed once), replayed `reps` times: (name, ms, owner) rows.  owner: 'hip' = hand-written kernels of this repo only,
+    'rocm' = PyTorch-ROCm / MIOpen / hipBLASLt only, 'mixed' = the packed heads (library convolutions + matrix products around the
+    HIP correlation launch; the correlation launch is timed again on its own in the row below each head)."""
+    from hdn_amd.refine import homo_refine
+    from hdn_amd.xcorr import xcorr_depthwise_multi
+    sim, model, c, dev = trk.similarity, trk.model, trk.cfg, trk.dev
+    lib, st = _lib.load(), (lambda: _lib.stream_ptr(dev))
+    dec = sim.decoder(dev)
+    static = torch.empty_like(FR.upload(frame_u8)); static.copy_(FR.upload(frame_u8))
+    rows = []
+
+    def add(name, fn, owner):
+        with torch.no_grad():
+            rows.append((name, graph_ms(fn, reps), owner))
+
+    # host -> device copy of the frame and device -> host read of the result (eager, synchronised: PCIe, not kernels)
+    host = torch.from_numpy(np.ascontiguousarray(frame_u8))
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(50):
+        static.copy_(host, non_blocking=True); torch.cuda.synchronize()
+    rows.append(("frame upload (2.76 MB pageable, synchronised)", (time.perf_counter() - t0) / 50 * 1e3, "pcie"))
+
+    def prepare_and_warp():
+        _lib.check(lib.hdn_track_prepare_f64(_lib.ptr(trk.H_total), _lib.ptr(trk._Ht), _lib.ptr(trk._Hinv), 1, st()), "prepare")
+        return FR.warp_perspective(static, trk._Hinv.view(-1))
+    add("singular check + inverse, stabilising full-frame warp", prepare_and_warp, "hip")
+    stab = prepare_and_warp()
+    add("search crop 255 px (crop + pad + resize)", lambda: FR.get_subwindow(stab, None, c.instance_size, None, None, params=sim._params0), "hip")
+    x_crop = FR.get_subwindow(stab, None, c.instance_size, None, None, params=sim._params0)
+    add("backbone (ResNet-50, 255 px) + necks", lambda: model.neck(model.feature_extractor(x_crop)), "rocm")
+    with torch.no_grad():
+        xf = model.neck(model.feature_extractor(x_crop))
+        out = model.track_new(x_crop)
+    add("MultiBAN head, packed (2 x 3 levels)", lambda: model.head(model.zf, xf), "mixed")
+    s6 = [torch.randn(1, 256, 29, 29, device=dev).relu_() for _ in range(6)]
+    k6 = [torch.randn(1, 256, 5, 5, device=dev).relu_() for _ in range(6)]
+    o6 = [torch.empty(1, 256, 25, 25, device=dev) for _ in range(6)]
+    add("  of which: the 6 correlations 5x5 (x) 29x29 (one launch)", lambda: xcorr_depthwise_multi(s6, k6, circular=False, outs=o6), "hip")
+    add("translation decode (softmax, window, argmax, gate)", lambda: dec.translation(out["cls"], out["loc_c"], sim.seq, sim.state), "hip")
+    row = sim.state.view(-1)
+    add("moved crop 255 px", lambda: FR.get_subwindow(stab, None, c.instance_size, None, None, params=row[8:14]), "hip")
+    x_moved = FR.get_subwindow(stab, None, c.instance_size, None, None, params=row[8:14])
+    polar = torch.zeros((1, 2), dtype=torch.float32, device=dev)
+    add("log-polar sampler 255 -> 127 px", lambda: model.logpolar_instance(x_moved, polar, [0, 0]), "hip")
+    x_lp, _ = model.logpolar_instance(x_moved, polar, [0, 0])
+    add("backbone (ResNet-50, 127 px) + necks", lambda: model.neck_lp(model.feature_extractor(x_lp)), "rocm")
+    with torch.no_grad():
+        xf_lp = model.neck_lp(model.feature_extractor(x_lp))
+        out_lp = model.track_new_lp(x_moved, [0, 0])
+    add("MultiCircBAN head, packed", lambda: model.head_lp(model.zf_lp, xf_lp), "mixed")
+    s6 = [torch.randn(1, 256, 13, 13, device=dev).relu_() for _ in range(6)]
+    k6 = [torch.randn(1, 256, 13, 13, device=dev).relu_() for _ in range(6)]
+    o6 = [torch.empty(1, 256, 13, 13, device=dev) for _ in range(6)]
+    add("  of which: the 6 circular correlations 13x13 (one launch)", lambda: xcorr_depthwise_multi(s6, k6, circular=True, outs=o6), "hip")
+    add("log-polar decode, H_sim, crop / rotation records", lambda: dec.logpolar(out_lp["cls_lp"], out_lp["loc_lp"], sim.seq, sim.state), "hip")
+    from hdn_amd.similarity import state_fields
+    f = state_fields(row)
+    add("rotate back (bicubic full-frame warp)", lambda: FR.warp_affine_cubic(stab, f["rot_matrix"]), "hip")
+    rot = FR.warp_affine_cubic(stab, f["rot_matrix"])
+    add("homography crop 127 px (crop + resize + normalise)", lambda: FR.get_search_info(rot, None, None, None, model_sz=c.exemplar_size, params=f["params_homo"]), "hip")
+    search = FR.get_search_info(rot, None, None, None, model_sz=c.exemplar_size, params=f["params_homo"])
+    add("homography estimator (PreShareFeature x3, ResNet-34 trunk, DLT, warp, scores, refinement warp)",
+        lambda: homo_refine(trk.net, trk.init_homo_tmp, search, iterations=trk.iterations), "hip")
+    with torch.no_grad():
+        H_comp, score, _ = homo_refine(trk.net, trk.init_homo_tmp, search, iterations=trk.iterations)
+    sc = score.detach().reshape(-1).to(torch.float32).contiguous()
+    Hout = torch.empty_like(trk.H_total)
+
+    def accumulate():
+        _lib.check(lib.hdn_track_accumulate_f64(_lib.ptr(trk._Ht), _lib.ptr(sim.state), _lib.ptr(H_comp), _lib.ptr(sc), _lib.ptr(trk._consts),
+                                                _lib.ptr(trk.init_points), trk.init_points.shape[1], _lib.ptr(Hout), _lib.ptr(trk._out), 1, st()), "acc")
+    add("un-scale / un-shift, gate, accumulate, project the corners", accumulate, "hip")
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(200):
+        trk._out.cpu()
+    rows.append(("host read of 4 corners + score (synchronising)", (time.perf_counter() - t0) / 200 * 1e3, "pcie"))
+    return rows
+
+
+def parity(frames, init, model_cpu_src, dev, model, n, iterations=1):
+    """Device loop vs the CPU restatement on frames 1..n-1: free-running, and with H_total re-synchronised before every frame."""
+    import production_standin as PS
+    from oracle.tracker_oracle import HomoTrackerOracle, SimilarityOracle
+    cpu = PS.ProductionStandInCPU(model_cpu_src)
+    net_cpu = copy.deepcopy(model_cpu_src.hm_net).cpu().eval()
+    sd = {k: v.clone() for k, v in net_cpu.ShareFeature.state_dict().items()}
+    ref = HomoTrackerOracle(sd, lambda f: net_cpu.fc(net_cpu.avgpool(net_cpu.backbone(f)).flatten(1)), iterations, similarity=SimilarityOracle(cpu))
+    free, forced = DeviceTrackerHomo(model, graph=True, iterations=iterations), DeviceTrackerHomo(model, graph=True, iterations=iterations)
+    for t in (ref, free, forced):
+        t.init(frames[0], init["bbox"], init["poly"], init["gt_points"], init["first_point"])
+    e_free, e_forced = [], []
+    for i in range(1, n):
+        forced.H_total.copy_(torch.from_numpy(np.asarray(ref.H_total, np.float64)).to(dev))
+        b = ref.track_new(i, frames[i])
+        e_free.append(success_4pts_error(free.track_new(i, frames[i])["points"], b["points"]))
+        e_forced.append(success_4pts_error(forced.track_new(i, frames[i])["points"], b["points"]))
+    q = lambda e: {"first": e[0], "median": float(np.median(e)), "max": max(e), "frames": len(e)}
+    return {"free_running": q(e_free), "h_total_resynchronised_each_frame": q(e_forced)}
+
+
+def run_production(n_frames=501, n_parity=0, nchw=False, components=True, dev=None, quiet=False):
+    dev = dev or torch.device("cuda:0")
+    log = (lambda *a: None) if quiet else (lambda *a: print(*a, file=sys.stderr, flush=True))
+    t0 = time.perf_counter()
+    frames, corners, init = make_sequence(n_frames=n_frames, frame_hw=(720, 1280), target_wh=(300, 200), **LONG_WALK)
+    log(f"[sequence] {n_frames} frames generated in {time.perf_counter() - t0:.1f} s")
+    torch.backends.cudnn.benchmark = True          # MIOpen find mode
+    t0 = time.perf_counter()
+    model, cpu_src = build_production_model(frames, init, dev, nchw=nchw, crops="oracle" if n_parity else "product")
+
+    def new_tracker(graph=False):
+        t = DeviceTrackerHomo(model, graph=graph)
+        t.init(frames[0], init["bbox"], init["poly"], init["gt_points"], init["first_point"])
+        return t
+    ms_graph, syncs, p99_graph, trk = stream_loop(new_tracker, frames, True, graph=True)
+    log(f"[sequence] model built, graph loop over {n_frames} frames: {ms_graph:.3f} ms per frame ({time.perf_counter() - t0:.1f} s incl. MIOpen find)")
+    ms_eager, _, p99_eager, _ = stream_loop(new_tracker, frames[:min(n_frames, 121)], True, graph=False)
+    res = {"sequence": f"{n_frames} frames 1280x720, 300x200 target, seed 20260928, LONG_WALK (tools/synth_sequence.py)",
+           "model": "tests/production_standin.py: ResNet-50 stride-8 dilated backbone x2 per frame (255 px, 127 px) + 1x1 necks + 256-channel MultiBAN / "
+                    "MultiCircBAN + ResNet-34 homography estimator; seeded weights; fp32; " + ("NCHW" if nchw else "channels-last") + ", MIOpen find mode",
+           "tracker": "hdn_amd.tracker.DeviceTrackerHomo(model) — the object install(tracker=True) registers; one hipGraph per frame, host reads 4 corners + score every frame",
+           "frames": n_frames, "ms_per_frame": ms_graph, "fps": 1e3 / ms_graph, "p99_ms": p99_graph, "host_syncs_per_frame": syncs,
+           "ms_per_frame_eager": ms_eager, "p99_ms_eager": p99_eager, "reference_host_syncs_per_frame": 6}
+    if components:
+        rows = component_table(trk, frames[1])
+        own = {"hip": 0.0, "rocm": 0.0, "mixed": 0.0, "pcie": 0.0}
+        corr = 0.0
+        for name, ms, owner in rows:
+            if name.startswith("  of which"):
+                corr += ms
+            else:
+                own[owner] += ms
+        total = sum(own.values())
+        res["components"] = [{"stage": n, "ms": round(ms, 4), "owner": o} for n, ms, o in rows]
+        res["component_sum_ms"] = total
+        res["share"] = {"hand_written_hip_stages": own["hip"] / total, "pytorch_rocm_backbone_and_necks": own["rocm"] / total,
+                        "packed_heads_mixed": own["mixed"] / total, "of_which_hip_correlations": corr / total, "pcie_copies": own["pcie"] / total}
+    if n_parity:
+        res["corner_error_device_vs_cpu_loop_px"] = parity(frames, init, cpu_src, dev, model, n_parity)
+    return res
+
+
+def format_table(res):
+    lines = [f"{res['frames']} frames, {res['ms_per_frame']:.3f} ms per frame as one hipGraph ({res['fps']:.0f} frames/s), {res['ms_per_frame_eager']:.3f} ms eager",
+             f"{'stage':<100s} {'ms':>8s}  owner"]
+    for r in res.get("components", []):
+        lines.append(f"{r['stage']:<100s} {r['ms']:8.4f}  {r['owner']}")
+    if "share" in res:
+        lines.append(f"{'sum of the stage graphs':<100s} {res['component_sum_ms']:8.4f}")
+        lines.append("share: " + ", ".join(f"{k} {v * 100:.1f} %" for k, v in res["share"].items()))
+    return "\n".join(lines)
+
+
+# --------------------------------------------------------------------------------------------------- the earlier modes
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--frames", type=int, default=200); ap.add_argument("--parity", type=int, default=12)
+    ap.add_argument("--frames", type=int, default=None); ap.add_argument("--parity", type=int, default=None)
     ap.add_argument("--iterations", type=int, default=1); ap.add_argument("--similarity", action="store_true")
+    ap.add_argument("--production-shape", action="store_true"); ap.add_argument("--nchw", action="store_true")
     args = ap.parse_args()
+    if args.production_shape:
+        res = run_production(args.frames or 501, 61 if args.parity is None else args.parity, nchw=args.nchw)
+        print(format_table(res), file=sys.stderr)
+        print(json.dumps(res))
+        return
+    args.frames, args.parity = args.frames or 200, 12 if args.parity is None else args.parity
+    from hdn_amd.graph import GraphedTrackProj
+    from oracle.tracker_oracle import HomoTrackerOracle, SimilarityOracle
     dev = torch.device("cuda:0")
     frames, corners, init = make_sequence(n_frames=args.frames, frame_hw=(720, 1280), target_wh=(300, 200))
     net = seeded_net(); net_cpu = copy.deepcopy(net)
     sd = {k: v.clone() for k, v in net_cpu.ShareFeature.state_dict().items()}
     sim_cpu = twin = None
     if args.similarity:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
         import standin_model as SM
         from hdn_amd.similarity import DeviceSimilarity
         net.fc.bias.data.mul_(0.1); net_cpu = copy.deepcopy(net)
@@ -68,24 +307,13 @@ def main():
     errs = [success_4pts_error(trk.track_new(t, frames[t])["points"], ref.track_new(t, frames[t])["points"])
             for t in range(1, min(args.parity, args.frames))]
 
-    def stream(sync, graph=False):
-        t = new_tracker(graph)
-        for i in range(1, 6): t.track_new(i, frames[i])            # warm-up (MIOpen find, clocks, graph capture)
-        t.H_total.copy_(torch.eye(3, dtype=torch.float64, device=dev)); torch.cuda.synchronize(); s0 = t.host_syncs
-        t0 = time.perf_counter(); per = []
-        for i in range(1, args.frames):
-            a = time.perf_counter(); t.track_new(i, frames[i], sync=sync); per.append(time.perf_counter() - a)
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / (args.frames - 1) * 1e3, (t.host_syncs - s0) / (args.frames - 1), np.percentile(per, 99) * 1e3
-
-    ms_sync, syncs, p99 = stream(True)
-    ms_async, _, _ = stream(False)
-    ms_graph, _, p99_graph = stream(True, graph=True)
+    ms_sync, syncs, p99, _ = stream_loop(new_tracker, frames, True)
+    ms_async, _, _, _ = stream_loop(new_tracker, frames, False)
+    ms_graph, _, p99_graph, _ = stream_loop(new_tracker, frames, True, graph=True)
 
     # the B=1 head alone (track_proj), eager vs hipGraph, synchronised EVERY frame as the tracker's score read does
     t = new_tracker()
     tmpl = t.init_homo_tmp
-    from hdn_amd import frame as FR
     searches = [FR.get_search_info(FR.upload(frames[i]), t.init_pos, t.init_s_z_sm, t.channel_average) for i in range(1, min(60, args.frames))]
     h4p = torch.tensor([[0, 0, 0, 127, 127, 127, 127, 0]], dtype=torch.float32, device=dev)
     pidx = torch.arange(127 * 127, dtype=torch.float32, device=dev).unsqueeze(0)

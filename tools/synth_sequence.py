@@ -28,7 +28,9 @@ def _bilinear(img, x, y):
     return (img[y0c, x0c] * (1 - fx) * (1 - fy) + img[y0c, x1c] * fx * (1 - fy) + img[y1c, x0c] * (1 - fx) * fy + img[y1c, x1c] * fx * fy)
 
 
-def make_sequence(n_frames=501, frame_hw=(720, 1280), target_wh=(300, 200), seed=20260928, step=0.6, damping=0.97):
+def make_sequence(n_frames=501, frame_hw=(720, 1280), target_wh=(300, 200), seed=20260928, step=0.6, damping=0.97, off_decay=0.995):
+    """step / damping / off_decay shape the corner random walk (defaults: the short test sequences; LONG_WALK below keeps a 501-frame
+    sequence — the POT frame count, hdn/core/config.py:285 — inside the frame: corner excursions of a few tens of pixels)."""
     g = np.random.default_rng(seed)
     H, W = frame_hw
     tw, th = target_wh
@@ -36,14 +38,14 @@ def make_sequence(n_frames=501, frame_hw=(720, 1280), target_wh=(300, 200), seed
     tex = _band_limited(g, th, tw, 0.08)
     x0, y0 = (W - tw) / 2.0, (H - th) / 2.0
     base = np.array([[x0, y0], [x0, y0 + th], [x0 + tw, y0 + th], [x0 + tw, y0]], np.float64)   # TL, BL, BR, TR (the head's order)
-    yy, xx = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    bg8 = np.clip(np.rint(bg), 0, 255).astype(np.uint8)
     off = np.zeros((4, 2))
     vel = np.zeros((4, 2))
     frames, corners = [], []
     for t in range(n_frames):
         if t > 0:
             vel = damping * vel + step * g.standard_normal((4, 2))
-            off = 0.995 * off + vel
+            off = off_decay * off + vel
         dst = base + off
         # homography target (tex coords) -> frame through the 4 corners, then inverse-map every frame pixel
         src = np.array([[0, 0], [0, th], [tw, th], [tw, 0]], np.float64)
@@ -53,17 +55,26 @@ def make_sequence(n_frames=501, frame_hw=(720, 1280), target_wh=(300, 200), seed
             b += [dx, dy]
         Hm = np.append(np.linalg.solve(np.array(A), np.array(b)), 1.0).reshape(3, 3)
         Hi = np.linalg.inv(Hm)
+        # (only the bounding box of the target's quad is inverse-mapped: every pixel outside it is background)
+        bx0, by0 = max(int(np.floor(dst[:, 0].min())) - 2, 0), max(int(np.floor(dst[:, 1].min())) - 2, 0)
+        bx1, by1 = min(int(np.ceil(dst[:, 0].max())) + 3, W), min(int(np.ceil(dst[:, 1].max())) + 3, H)
+        yy, xx = np.meshgrid(np.arange(by0, by1, dtype=np.float64), np.arange(bx0, bx1, dtype=np.float64), indexing="ij")
         den = Hi[2, 0] * xx + Hi[2, 1] * yy + Hi[2, 2]
         u, v = (Hi[0, 0] * xx + Hi[0, 1] * yy + Hi[0, 2]) / den, (Hi[1, 0] * xx + Hi[1, 1] * yy + Hi[1, 2]) / den
         inside = (u >= 0) & (u <= tw - 1) & (v >= 0) & (v <= th - 1)
-        fr = np.where(inside[..., None], _bilinear(tex, np.clip(u, 0, tw - 1), np.clip(v, 0, th - 1)), bg)
-        frames.append(np.clip(np.rint(fr), 0, 255).astype(np.uint8))
+        fr = np.where(inside[..., None], _bilinear(tex, np.clip(u, 0, tw - 1), np.clip(v, 0, th - 1)), bg[by0:by1, bx0:bx1])
+        full = bg8.copy()
+        full[by0:by1, bx0:bx1] = np.clip(np.rint(fr), 0, 255).astype(np.uint8)
+        frames.append(full)
         corners.append(dst.astype(np.float32))
     c0 = corners[0]
     cx, cy = c0[:, 0].mean(), c0[:, 1].mean()
     init = {"bbox": [float(c0[:, 0].min()), float(c0[:, 1].min()), float(tw), float(th)], "poly": [float(cx), float(cy), float(tw), float(th), 0.0],
             "gt_points": c0.reshape(-1).tolist(), "first_point": c0[0].tolist()}
     return frames, corners, init
+
+
+LONG_WALK = dict(step=0.35, damping=0.9, off_decay=0.97)
 
 
 def success_4pts_error(pred, gt):
