@@ -269,6 +269,9 @@ def main():
         step(True)
     fence()
     elapsed = time.perf_counter() - t0
+    if hasattr(comm, "check_status"):
+        comm.check_status()       # one-shot gather: a peer that did not deliver within 2 s leaves NaN rows and a sticky status: fail loudly
+    oneshot_used = type(comm).__name__ == "OneShotGather"   # (from_process_group hands back an RcclComm when a pair of ranks lacks peer access)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -347,7 +350,7 @@ def main():
             "workload": ("north-star correlation only" if args.only_north else
                          "BASELINE configs[1]: batch=64 synthetic 127/255 pairs per GPU, 256-ch features; HIP kernels only: "
                          "1x xcorr 31x31(x)61x61 + 6x xcorr 5x5(x)29x29 + 6x circular xcorr 13x13(x)13x13 + "
-                         "3x PreShareFeature 127x127 + fused DLT/warp + the 2 L1 scores (one launch)" + ((" + direct-write all-gather of [64,8] offsets (hdn_gather_offsets_oneshot)" if args.collective == "oneshot" else " + RCCL all-gather of [64,8] offsets") if world > 1 else "")),
+                         "3x PreShareFeature 127x127 + fused DLT/warp + the 2 L1 scores (one launch)" + ((" + direct-write all-gather of [64,8] offsets (hdn_gather_offsets_oneshot)" if oneshot_used else " + RCCL all-gather of [64,8] offsets") if world > 1 else "")),
             "pairs_per_gpu": PAIRS,
             "channels": C,
             "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective except the offsets all-gather",

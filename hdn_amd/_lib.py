@@ -49,6 +49,7 @@ SIGNATURES = {
     "hdn_track_accumulate_f64": (_i, [_c_float_p] * 6 + [_i] + [_c_float_p] * 2 + [_i, ctypes.c_void_p]),
     "hdn_trunk_stem_f32": (_i, [_c_float_p] * 4 + [_i] * 4 + [ctypes.c_void_p]),
     "hdn_bias_relu_f32": (_i, [_c_float_p] * 3 + [_i] * 4 + [ctypes.c_void_p]),
+    "hdn_avgpool_fc_f32": (_i, [_c_float_p] * 4 + [_i] * 5 + [ctypes.c_void_p]),
     "hdn_conv3x3_pack_info": (_i, [_i, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "hdn_conv3x3_workspace_bytes": (ctypes.c_longlong, [_i, _i, _i, _i]),
     "hdn_conv3x3s2_ds_f32": (_i, [_c_float_p] * 6 + [ctypes.c_longlong] + [_i] * 3 + [ctypes.c_void_p]),
@@ -64,6 +65,8 @@ SIGNATURES = {
     "hdn_gather_offsets_oneshot": (_i, [ctypes.c_void_p, _c_float_p, _c_float_p, _i, ctypes.c_void_p]),
     "hdn_gather_status": (_i, [ctypes.c_void_p]),
     "hdn_gather_destroy": (_i, [ctypes.c_void_p]),
+    "hdn_gather_peer_access": (_i, [_i, ctypes.c_char_p]),
+    "hdn_device_pci_bus_id": (_i, [_i, ctypes.c_char_p, _i]),
     "hdn_logpolar_sample_f32": (_i, [_c_float_p] * 7 + [_i] * 5 + [ctypes.c_void_p]),
 }
 
@@ -73,6 +76,7 @@ ERRORS = {
     -3: "HDN_E_LIMIT: size exceeds what the kernels support",
     -4: "HDN_E_ALIAS: output aliases an input",
     -5: "HDN_E_NORCCL: librccl.so.1 could not be loaded",
+    -6: "HDN_E_PEER: an earlier one-shot gather timed out waiting for a peer; the context is unusable",
 }
 
 _lock = threading.Lock()

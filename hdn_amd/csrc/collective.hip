@@ -73,6 +73,9 @@ inline int hip_status(hipError_t e) { return e == hipSuccess ? HDN_OK : -(1000 +
 // local slice into peer p's slots[parity][r], release-store e into peer p's flags[parity][r]; spin (acquire, system scope)
 // on the own flags[parity][p] until it holds e, copy the own slots[parity][p] to the output.  Two parities suffice: a rank
 // reaches call e + 2 only after every peer raised its flag for e + 1, which a peer does after its call e has left the stream.
+// That argument needs every wait to END WITH THE FLAG: a wait that gives up (2 s) breaks it, so a timeout is terminal — the
+// rows of the peer that did not show up are filled with NaN (never with whatever the slot held), a STICKY bit is set in the
+// pinned status word, and hdn_gather_offsets_oneshot refuses every later call on that context (HDN_E_PEER).
 constexpr int kGatherMaxWorld = 16;
 constexpr unsigned long long kGatherSpinLimit = 200000000ull;   // 2 s of the 100 MHz wall clock, then status |= 1 and give up
 
@@ -96,6 +99,8 @@ __global__ __launch_bounds__(HDN_BLOCK) void gather_oneshot_kernel(const float4*
                                                                    int world, int rank, int n16, unsigned long long slot_bytes,
                                                                    unsigned* status) {
   const int p = blockIdx.x, tid = threadIdx.x;
+  __shared__ int timed_out;
+  if (tid == 0) timed_out = 0;
   char* mine = peers.win[rank];
   unsigned long long* ctl = reinterpret_cast<unsigned long long*>(mine);
   const unsigned long long epoch = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;   // the same for every workgroup
@@ -115,6 +120,7 @@ __global__ __launch_bounds__(HDN_BLOCK) void gather_oneshot_kernel(const float4*
     while (__hip_atomic_load(g, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
       if (wall_clock64() - t0 > kGatherSpinLimit) {
         __hip_atomic_fetch_or(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        timed_out = 1;
         break;
       }
       __builtin_amdgcn_s_sleep(8);
@@ -122,8 +128,13 @@ __global__ __launch_bounds__(HDN_BLOCK) void gather_oneshot_kernel(const float4*
   }
   __syncthreads();
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
-  const float4* src = reinterpret_cast<const float4*>(mine + gather_slots_off(world) + (size_t(parity) * world + p) * slot_bytes);
-  for (int i = tid; i < n16; i += HDN_BLOCK) all[size_t(p) * n16 + i] = src[i];
+  if (timed_out) {   // the peer never delivered: its rows are NaN, not stale slot contents
+    const float qnan = __builtin_nanf("");
+    for (int i = tid; i < n16; i += HDN_BLOCK) all[size_t(p) * n16 + i] = float4{qnan, qnan, qnan, qnan};
+  } else {
+    const float4* src = reinterpret_cast<const float4*>(mine + gather_slots_off(world) + (size_t(parity) * world + p) * slot_bytes);
+    for (int i = tid; i < n16; i += HDN_BLOCK) all[size_t(p) * n16 + i] = src[i];
+  }
   // the last workgroup to finish publishes the epoch for the next call (stream order makes it visible to that launch)
   __syncthreads();
   if (tid == 0) {
@@ -248,6 +259,7 @@ int hdn_gather_offsets_oneshot(void* ctx, const float* local, float* all, int Bl
   if (!ctx || !local || !all) return HDN_E_NULL;
   hdn::GatherCtx* c = static_cast<hdn::GatherCtx*>(ctx);
   if (Bl <= 0 || !c->connected) return HDN_E_SHAPE;
+  if (__atomic_load_n(c->status, __ATOMIC_ACQUIRE) != 0) return HDN_E_PEER;   // an earlier call timed out: the epoch protocol is broken for good
   const size_t bytes = (size_t)Bl * 8 * sizeof(float);
   if (bytes > c->slot_bytes) return HDN_E_LIMIT;
   if (!hdn::aligned16(local) || !hdn::aligned16(all)) return HDN_E_SHAPE;
@@ -263,9 +275,38 @@ int hdn_gather_status(void* ctx) {
   return (int)__atomic_load_n(static_cast<hdn::GatherCtx*>(ctx)->status, __ATOMIC_ACQUIRE);
 }
 
+// 1 / 0: can `device` of this process read and write the memory of the device with PCI bus id `peer_pci_bus_id` (as
+// hdn_device_pci_bus_id printed it in the peer's process)?  The same device counts as accessible.  HDN_E_SHAPE: that device is not
+// visible to this process (HIP_VISIBLE_DEVICES isolation): unknown.
+int hdn_gather_peer_access(int device, const char* peer_pci_bus_id) {
+  if (!peer_pci_bus_id) return HDN_E_NULL;
+  int peer = -1;
+  if (hipDeviceGetByPCIBusId(&peer, peer_pci_bus_id) != hipSuccess || peer < 0) {
+    (void)hipGetLastError();
+    return HDN_E_SHAPE;
+  }
+  if (peer == device) return 1;
+  int can = 0;
+  const hipError_t e = hipDeviceCanAccessPeer(&can, device, peer);
+  if (e != hipSuccess) return hdn::hip_status(e);
+  return can ? 1 : 0;
+}
+
+int hdn_device_pci_bus_id(int device, char* out, int len) {
+  if (!out) return HDN_E_NULL;
+  if (len < 16) return HDN_E_SHAPE;
+  return hdn::hip_status(hipDeviceGetPCIBusId(out, len, device));
+}
+
+// Every rank must have stopped calling AND every launch that stores into this window must have completed: run a group barrier
+// after a device synchronisation on every rank first (hdn_amd.dist.OneShotGather.destroy does).  The own device is synchronised here.
 int hdn_gather_destroy(void* ctx) {
   if (!ctx) return HDN_E_NULL;
   hdn::GatherCtx* c = static_cast<hdn::GatherCtx*>(ctx);
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  if (cur != c->device) (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();          // no launch of this rank is still reading the window or storing into a peer's
   hipError_t e = hipSuccess;
   for (int p = 0; p < c->world; ++p)
     if (p != c->rank && c->peers.win[p]) {
@@ -275,6 +316,7 @@ int hdn_gather_destroy(void* ctx) {
   const hipError_t e3 = hipFree(c->window);
   if (e == hipSuccess) e = e3;
   (void)hipHostFree(c->status);
+  if (cur != c->device) (void)hipSetDevice(cur);
   delete c;
   return hdn::hip_status(e);
 }

@@ -91,11 +91,17 @@ class OneShotGather:
     OneShotGather.from_process_group(max_rows, device) exchanges the 64-byte window handles over an initialised
     torch.distributed group (any backend); OneShotGather(world, rank, max_rows, exchange=...) over anything else, where
     exchange(my_handle: bytes) -> list of every rank's handle in rank order.  Drop-in for RcclComm in all_gather_offsets /
-    sharded_offsets (`comm=`).  Needs every pair of ranks to have peer access (one xGMI node)."""
+    sharded_offsets (`comm=`).  Needs every pair of ranks to have peer access (one xGMI node): from_process_group checks
+    hipDeviceCanAccessPeer for every pair first and hands back an RcclComm (with a warning) when any pair cannot.
 
-    def __init__(self, world: int, rank: int, max_rows: int, exchange, device=None):
+    Failure handling: a call that waits 2 s for a peer in vain fills that peer's rows with NaN and poisons the object — status()
+    is non-zero from then on and every later all_gather raises (the two-slot protocol cannot survive a wait that gave up).  Read
+    check_status() at your next synchronisation point; all_gather does it for the previous call."""
+
+    def __init__(self, world: int, rank: int, max_rows: int, exchange, device=None, group=None):
         self.world, self.rank, self.max_rows = int(world), int(rank), int(max_rows)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self._group = group
         h = ctypes.c_void_p()
         lib = _lib.load()
         with _lib.device_guard(self.device):
@@ -113,18 +119,81 @@ class OneShotGather:
                 lib.hdn_gather_destroy(h)
                 raise
 
-    @classmethod
-    def from_process_group(cls, max_rows: int, device=None, group=None):
-        if dist.is_available() and dist.is_initialized():
-            world, rank = dist.get_world_size(group), dist.get_rank(group)
+    @staticmethod
+    def peers_reachable(device, group=None):
+        """(every pair of ranks can reach each other's device memory?, reason).  Each rank publishes (host name, PCI bus id of its
+        device); a peer on another host, a peer device this process cannot see (HIP_VISIBLE_DEVICES isolation: hipIpc would still
+        work, but nothing can be checked up front) or hipDeviceCanAccessPeer == 0 all count as unreachable.  Two ranks on ONE
+        device (the one-GPU test rig) are reachable.  Collective over `group`."""
+        import socket
 
-            def exchange(mine):
-                box = [None] * world
-                dist.all_gather_object(box, mine, group=group)
-                return box
-        else:
-            world, rank, exchange = 1, 0, (lambda mine: [mine])
-        return cls(world, rank, max_rows, exchange, device)
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        lib = _lib.load()
+        buf = ctypes.create_string_buffer(64)
+        _lib.check(lib.hdn_device_pci_bus_id(idx, buf, 64), "hdn_device_pci_bus_id")
+        me = (socket.gethostname(), buf.value.decode())
+        world = dist.get_world_size(group)
+        box = [None] * world
+        dist.all_gather_object(box, me, group=group)
+        ok, why = True, ""
+        for r, (host, pci) in enumerate(box):
+            if r == dist.get_rank(group):
+                continue
+            if host != me[0]:
+                ok, why = False, f"rank {r} runs on another host ({host})"
+                break
+            rc = lib.hdn_gather_peer_access(idx, pci.encode())
+            if rc != 1:
+                ok, why = False, (f"device {pci} of rank {r} is not visible to this process" if rc == -2 else
+                                  f"hipDeviceCanAccessPeer({me[1]} -> {pci}) = {rc}")
+                break
+        verdicts = [None] * world
+        dist.all_gather_object(verdicts, (ok, why), group=group)
+        bad = [f"rank {r}: {w}" for r, (o, w) in enumerate(verdicts) if not o]
+        return (not bad), "; ".join(bad)
+
+    @classmethod
+    def from_process_group(cls, max_rows: int, device=None, group=None, fallback: bool = True):
+        """Collective.  Returns a OneShotGather, or — when some pair of ranks has no peer access, or a rank fails to map a peer's
+        window — an RcclComm on the same group (fallback=True, with a warning; fallback=False raises)."""
+        if not (dist.is_available() and dist.is_initialized()):
+            return cls(1, 0, max_rows, (lambda mine: [mine]), device)
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+
+        def exchange(mine):
+            box = [None] * world
+            dist.all_gather_object(box, mine, group=group)
+            return box
+
+        def give_up(reason):
+            msg = f"hdn_amd: one-shot gather unavailable ({reason})"
+            if not fallback:
+                raise _lib.HdnHipError(msg)
+            import warnings
+            warnings.warn(msg + "; using RCCL (hdn_allgather_offsets) instead")
+            return RcclComm.from_process_group(device, group)
+
+        if world > 1:
+            ok, why = cls.peers_reachable(device, group)
+            if not ok:
+                return give_up(why)
+        obj, err = None, ""
+        try:
+            obj = cls(world, rank, max_rows, exchange, device, group)
+        except Exception as e:       # (e.g. hipIpcOpenMemHandle refused): every rank must learn of it before anyone launches
+            err = f"rank {rank}: {type(e).__name__}: {e}"
+        if world > 1:
+            box = [None] * world
+            dist.all_gather_object(box, err, group=group)
+            bad = [b for b in box if b]
+            if bad:
+                if obj is not None:
+                    obj.destroy()
+                return give_up("; ".join(bad))
+        elif err:
+            raise _lib.HdnHipError(err)
+        return obj
 
     def all_gather(self, local: torch.Tensor) -> torch.Tensor:
         """local [Bl, 8] on this object's device -> [world * Bl, 8]; asynchronous on torch's current stream."""
@@ -135,6 +204,7 @@ class OneShotGather:
             raise ValueError(f"expected [1..{self.max_rows}, 8] corner offsets, got {tuple(local.shape)}")
         if self._h is None:
             raise _lib.HdnHipError("gather window destroyed")
+        self.check_status()            # (of the calls before this one: a host read of pinned memory, no synchronisation)
         loc = local.detach().to(torch.float32).contiguous()
         out = torch.empty((self.world * loc.shape[0], 8), dtype=torch.float32, device=dev)
         with _lib.device_guard(dev):
@@ -143,12 +213,25 @@ class OneShotGather:
         return out
 
     def status(self) -> int:
-        """0, or non-zero once a call gave up waiting for a peer (read it after the stream has drained)."""
+        """0, or non-zero (sticky) once a call gave up waiting for a peer (read it after the stream has drained)."""
         return int(_lib.load().hdn_gather_status(self._h)) if self._h is not None else 0
 
+    def check_status(self):
+        """Raise if any call so far timed out: the rows of the missing peer in that call's result are NaN and this object must
+        not be used again."""
+        st = self.status()
+        if st:
+            raise _lib.HdnHipError(f"one-shot gather: a peer did not deliver within 2 s (status {st}); the affected rows are NaN and "
+                                   "this communicator is unusable — destroy it and rebuild, or fall back to RcclComm")
+
     def destroy(self):
+        """Collective when the object came from a process group: every rank drains its device, then all meet at a barrier, and only
+        then are the windows unmapped and freed (a peer's launch may still be storing into this rank's window before that)."""
         if self._h is not None:
             h, self._h = self._h, None
+            torch.cuda.synchronize(self.device)
+            if self._group is not None or (dist.is_available() and dist.is_initialized() and self.world > 1 and dist.get_world_size() == self.world):
+                dist.barrier(group=self._group)
             with _lib.device_guard(self.device):
                 _lib.check(_lib.load().hdn_gather_destroy(h), "hdn_gather_destroy")
 

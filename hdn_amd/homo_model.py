@@ -16,10 +16,32 @@ from .share_feature import PreShareFeature
 from .trunk import resnet34_homo
 
 
+def avgpool_fc(x, fc):
+    """fc(avgpool(x).flatten(1)) as one launch (hdn_avgpool_fc_f32); x [B,C,H,W] float32, NCHW-contiguous or channels-last."""
+    from . import _lib
+
+    dev = _lib.require_device(x, fc.weight)
+    B, C, H, W = x.shape
+    nhwc = 0 if x.is_contiguous() else 1
+    if nhwc and not x.is_contiguous(memory_format=torch.channels_last):
+        x, nhwc = x.contiguous(), 0
+    w = fc.weight.detach().contiguous()
+    out = torch.empty((B, w.shape[0]), dtype=torch.float32, device=dev)
+    with _lib.device_guard(dev):
+        rc = _lib.load().hdn_avgpool_fc_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(fc.bias.detach()) if fc.bias is not None else None, _lib.ptr(out),
+                                            B, C, H * W, w.shape[0], nhwc, _lib.stream_ptr(dev))
+    _lib.check(rc, "avgpool_fc")
+    return out
+
+
 def _regress(net, feats):
     fast = getattr(net, "_hdn_fast_trunk", None)
     if fast is not None and not net.training:
         x = fast(feats.contiguous(memory_format=torch.channels_last) if getattr(net, "_hdn_fast_nhwc", False) else feats)
+        # the tail of the optimised trunk: AdaptiveAvgPool2d(1) + Linear(512, 8) in one launch
+        if (x.is_cuda and x.dtype == torch.float32 and isinstance(net.avgpool, nn.AdaptiveAvgPool2d) and net.avgpool.output_size in (1, (1, 1))
+                and isinstance(net.fc, nn.Linear) and net.fc.out_features <= 16 and net.fc.weight.dtype == torch.float32):
+            return avgpool_fc(x.detach(), net.fc)
     else:
         x = net.backbone(feats)
     x = net.avgpool(x)

@@ -29,6 +29,7 @@ extern "C" {
 #define HDN_E_LIMIT (-3) /* size exceeds what the kernels support */
 #define HDN_E_ALIAS (-4) /* output aliases an input               */
 #define HDN_E_NORCCL (-5) /* librccl.so.1 could not be loaded (collective entry points only) */
+#define HDN_E_PEER (-6)   /* one-shot gather: an earlier call timed out waiting for a peer; the context is unusable */
 /* RCCL failures are returned as -(2000 + ncclResult_t). */
 
 /* ABI version of this header; hdn_abi_version() of the loaded library must match. */
@@ -300,6 +301,15 @@ int hdn_trunk_stem_f32(const float* x, const float* wT, const float* bias, float
 int hdn_bias_relu_f32(float* y, const float* bias, const float* residual, int B, int C, int HW, int nhwc, void* stream);
 
 /*
+ * The regressor's tail as one launch: out[b, o] = bias[o] + sum_c W[o, c] * mean_p x[b, c, p], i.e. AdaptiveAvgPool2d(1) ->
+ * flatten -> Linear(C, O) of homo_estimator/Deep_homography/Oneline_DLTv1/models/homo_model_builder.py:161-165 (x = fc(avgpool(
+ * backbone(...)))) and hdn/models/model_builder_e2e_unconstrained_v2.py:190-194.  x [B,C,HW] (nhwc = 0) or [B,HW,C] (nhwc = 1)
+ * fp32, W [O,C] row-major, bias [O] or NULL, O <= 16.  The mean is the fp32 sum in position order times 1 / HW (ATen's reduction
+ * may associate differently: last-bit differences).
+ */
+int hdn_avgpool_fc_f32(const float* x, const float* w, const float* bias, float* out, int B, int C, int HW, int O, int nhwc, void* stream);
+
+/*
  * Whole residual-block convolutions of that trunk on the matrix cores, channels-last fp32 in and out:
  *   hdn_conv3x3_bias_relu_f32:  out = relu(conv3x3/s1/p1(x, W) + bias[c] (+ residual)),  x / residual / out [B,S,S,C], C -> C channels,
  *       (S, C) = (32, 64), (16, 128), (8, 256), (4, 512): conv1 / conv2 + bn + relu (+ `out += residual`) of BasicBlock.forward;
@@ -363,8 +373,15 @@ int hdn_rccl_comm_destroy(void* comm);
  *   hdn_gather_connect  maps the peers' windows (handles[world][64]; the own entry is ignored); collective, once
  *   hdn_gather_offsets_oneshot  local[Bl,8] -> all[world*Bl,8], same contract as hdn_allgather_offsets (Bl equal on all ranks,
  *                       Bl*32 <= slot_bytes, 16-byte aligned pointers, no overlap); asynchronous on `stream`.  A peer that does
- *                       not show up within 2 s makes the kernel give up: hdn_gather_status() != 0 after the stream has drained.
- *   hdn_gather_destroy  unmaps and frees; the peers must have stopped calling.
+ *                       not show up within 2 s makes the kernel give up: that peer's rows of `all` are NaN, hdn_gather_status()
+ *                       is non-zero from then on (sticky; read it at the next synchronisation point) and every later call on
+ *                       the context returns HDN_E_PEER — the two-parity protocol cannot survive a wait that ended without its flag.
+ *   hdn_gather_status   0, or the sticky error bits (1 = a wait timed out); a host read of pinned memory, no synchronisation
+ *   hdn_gather_destroy  synchronises the own device, unmaps and frees.  The peers must have stopped calling and their launches
+ *                       must have completed (device synchronisation + a group barrier on every rank first).
+ *   hdn_gather_peer_access / hdn_device_pci_bus_id   before creating the windows: can `device` reach the device a peer reported
+ *                       by PCI bus id (1 / 0; HDN_E_SHAPE = not visible to this process)?  hdn_amd.dist.OneShotGather falls back
+ *                       to RCCL with a warning unless every pair of ranks answers 1.
  * Every rank must make the same sequence of calls.  Validated with two processes sharing one device (tests/test_gpu_dist.py);
  * across devices it needs peer access over xGMI (hipIpcMemLazyEnablePeerAccess) and has not been run.
  */
@@ -375,6 +392,8 @@ int hdn_gather_connect(void* ctx, const void* handles);
 int hdn_gather_offsets_oneshot(void* ctx, const float* local, float* all, int Bl, void* stream);
 int hdn_gather_status(void* ctx);
 int hdn_gather_destroy(void* ctx);
+int hdn_gather_peer_access(int device, const char* peer_pci_bus_id);
+int hdn_device_pci_bus_id(int device, char* out, int len);
 
 #ifdef __cplusplus
 }

@@ -268,3 +268,64 @@ def test_oneshot_gather_two_processes_one_device(dev):
     assert set(res) == {0, 1}, "\n".join(outs)
     for r in (0, 1):
         assert res[r] == {"eager": True, "graph": True, "ragged": True, "status": 0}, (res, outs[r][-2000:])
+
+
+_ONESHOT_TIMEOUT_WORKER = r"""
+import os, sys, json, math
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+from hdn_amd import _lib, dist as hdist
+ok, why = hdist.OneShotGather.peers_reachable(dev)
+g = hdist.OneShotGather.from_process_group(16, dev)
+res = {"reachable": ok, "kind": type(g).__name__}
+if rank == 0:                       # rank 1 never makes the call: rank 0's wait must give up after 2 s
+    x = torch.arange(16 * 8, dtype=torch.float32, device=dev).reshape(16, 8)
+    out = g.all_gather(x)
+    torch.cuda.synchronize()
+    o = out.cpu()
+    res["own_rows_intact"] = bool(torch.equal(o[:16], x.cpu()))
+    res["peer_rows_nan"] = bool(torch.isnan(o[16:]).all())
+    res["status"] = g.status()
+    try:
+        g.all_gather(x); res["second_call"] = "ran"
+    except _lib.HdnHipError:
+        res["second_call"] = "raised"
+    buf = torch.zeros(32, 8, device=dev)
+    res["c_abi_rc"] = int(_lib.load().hdn_gather_offsets_oneshot(g._h, _lib.ptr(x), _lib.ptr(buf), 16, _lib.stream_ptr(dev)))
+else:
+    res["status"] = g.status()
+dist.barrier()
+g.destroy()
+print("RESULT", rank, json.dumps(res), flush=True)
+dist.destroy_process_group()
+"""
+
+
+def test_oneshot_gather_timeout_poisons_the_communicator(dev):
+    """A peer that never shows up: the waiting rank's kernel gives up after 2 s, the peer's rows come back NaN (not stale slot
+    contents), the status bit is sticky, the next all_gather raises and the C entry point returns HDN_E_PEER."""
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", _ONESHOT_TIMEOUT_WORKER % {"root": ROOT}], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+            o += "\nTIMEOUT"
+        outs.append(o)
+    res = _results(outs)
+    assert set(res) == {0, 1}, "\n".join(outs)
+    assert res[0] == {"reachable": True, "kind": "OneShotGather", "own_rows_intact": True, "peer_rows_nan": True, "status": 1,
+                      "second_call": "raised", "c_abi_rc": -6}, (res, outs[0][-2000:])
+    assert res[1] == {"reachable": True, "kind": "OneShotGather", "status": 0}, (res, outs[1][-2000:])

@@ -1231,3 +1231,23 @@ def test_benchmarked_full_head_configuration_parity(dev):
     print(f"benchmarked full head: max|x - oracle| = {e1:.2e} / {e2:.2e} over 16 pairs, run-to-run max|dx| = {rr:.2e} over 64 pairs")
     assert e1 <= 1e-4 and e2 <= 1e-4, (e1, e2)
     assert rr <= 2e-5, rr
+
+
+@pytest.mark.parametrize("B,C,S,O,nhwc", [(64, 512, 4, 8, True), (1, 512, 4, 8, True), (3, 512, 4, 8, False), (5, 96, 3, 16, True), (2, 700, 1, 1, False)])
+def test_avgpool_fc_fused_tail(dev, B, C, S, O, nhwc):
+    """hdn_avgpool_fc_f32 = fc(avgpool(x).flatten(1)) (homo_model_builder.py:161-165) against PyTorch-CPU in float64 and float32."""
+    from hdn_amd.homo_model import avgpool_fc
+    g = torch.Generator().manual_seed(B * 1000 + C)
+    x = torch.randn(B, C, S, S, generator=g).relu_()
+    fc = torch.nn.Linear(C, O)
+    fc.weight.data = torch.randn(O, C, generator=g) * 0.05
+    fc.bias.data = torch.randn(O, generator=g)
+    ref64 = torch.nn.functional.linear(x.double().mean(dim=(2, 3)), fc.weight.double(), fc.bias.double())
+    ref32 = fc(torch.nn.functional.adaptive_avg_pool2d(x, 1).flatten(1))
+    xd = x.to(dev)
+    if nhwc:
+        xd = xd.contiguous(memory_format=torch.channels_last)
+    got = avgpool_fc(xd, fc.to(dev)).cpu().double()
+    assert got.shape == (B, O)
+    e_ref = float((ref32.double() - ref64).abs().max())
+    assert float((got - ref64).abs().max()) <= 4 * e_ref + 1e-6, (float((got - ref64).abs().max()), e_ref)

@@ -32,8 +32,20 @@ def test_library_exports_every_declared_symbol():
 
 def test_library_loads_and_reports_abi():
     lib = _lib.load()
-    assert lib.hdn_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.hdn_abi_version() == _lib.ABI_VERSION == 5
     assert lib.hdn_last_xcorr_variant() == b"none"
+
+
+def test_documented_binding_stub_asserts_the_current_abi_version():
+    """INTEGRATION.md's copy-paste ctypes stub checks hdn_abi_version(): the number it asserts must be the header's."""
+    import re
+    header = open(os.path.join(ROOT, "include", "hdn_hip.h")).read()
+    abi = int(re.search(r"#define\s+HDN_ABI_VERSION\s+(\d+)", header).group(1))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    stub = [int(v) for v in re.findall(r"hdn_abi_version\(\)\s*==\s*(\d+)", doc)]
+    assert stub and all(v == abi for v in stub), (stub, abi)
+    from hdn_amd import _lib
+    assert _lib.ABI_VERSION == abi
 
 
 def test_c_abi_argument_errors_need_no_gpu():
