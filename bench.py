@@ -86,8 +86,8 @@ def parse():
                          "the start of the step (then the roofline block times the 31x31 kernel in --roofline-steps separate "
                          "after-north steps)")
     ap.add_argument("--roofline-steps", type=int, default=30, help="untimed steps after the timed region in which the 31x31 launch is bracketed")
-    ap.add_argument("--north", choices=["fft", "fftr", "fft2w", "direct", "dense", "mfma"], default=None,
-                    help="kernel for the 31x31 (x) 61x61 correlation (default: the library's default, fft = the column-first FFT kernel; fftr = the row-first one); A/B runs")
+    ap.add_argument("--north", choices=["fft", "direct"], default=None,
+                    help="kernel for the 31x31 (x) 61x61 correlation (default: the library's default, fft = the column-first FFT kernel); A/B runs")
     ap.add_argument("--config", type=int, choices=[2, 5], default=2,
                     help="2 = BASELINE configs[1] (default, the headline); 5 = configs[4]: 303-px search window (6x xcorr 5x5 (x) 35x35 "
                          "-> 31x31) + the 2-iteration refinement loop, 64 pairs per GPU (256 over 4 GPUs); kernels only")
@@ -315,8 +315,7 @@ def main():
     # gfx950 x2 correction on the 16 B/lane stream) and committed under profiles/; bench.py cannot collect PMCs itself.
     X.xcorr_depthwise(d["north_x"], d["north_k"])
     north_variant = X.last_variant()
-    north_kernel = {"north_fft_61x61_31x31": "xcorr_north_fft2_kernel", "north_fft2w_61x61_31x31": "xcorr_north_fft3_kernel", "north_fftc_61x61_31x31": "xcorr_north_fft4_kernel",
-                    "north_61x61_31x31": "xcorr_north_kernel", "north_mfma_61x61_31x31": "xcorr_north_mfma_kernel"}[north_variant]
+    north_kernel = {"north_fftc_61x61_31x31": "xcorr_north_fft4_kernel", "north_61x61_31x31": "xcorr_north_kernel"}[north_variant]
     traffic, traffic_note = None, None
     for rnd in ("round4", "round3", "round2", "round1"):  # the newest committed PMC measurement of this kernel
         path = os.path.join(ROOT, "profiles", rnd + "_pmc_hbm_traffic.json")
@@ -535,11 +534,11 @@ def sequence_block(n_frames, dev):
     return res
 
 
-def breakdown(d, imgs2, tmpl, folded, X, SF, G, iters=50):
-    """Per-kernel timing outside the timed region (informational; algorithmic GB/s per kernel): each launch captured as a
+def breakdown(d, imgs2, tmpl, folded, X, SF, G, iters=10):
+    """Per-kernel timing outside the timed region (informational; algorithmic GB/s per kernel): ten launches captured as one
     hipGraph and replayed back to back between two events, so the host side of a call (output allocations, pointer tables of
     the multi-problem launches) is not in the figure."""
-    def timed(fn):
+    def timed(fn, inner=10):
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -548,7 +547,7 @@ def breakdown(d, imgs2, tmpl, folded, X, SF, G, iters=50):
         torch.cuda.current_stream().wait_stream(side)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            keep = fn()
+            keep = [fn() for _ in range(inner)]     # `inner` launches per graph: a replay's fixed ~10 us is not in the figure
         for _ in range(3):
             g.replay()
         torch.cuda.synchronize()
@@ -559,7 +558,7 @@ def breakdown(d, imgs2, tmpl, folded, X, SF, G, iters=50):
         e1.record()
         torch.cuda.synchronize()
         del keep
-        return e0.elapsed_time(e1) / iters
+        return e0.elapsed_time(e1) / (iters * inner)
 
     warped = G.dlt_warp(d["h4p"], d["off"], tmpl)[1]
     rows = {

@@ -7,7 +7,7 @@
 // HBM-bound (5 FLOP/B) and the 31x31 (x) 61x61 stress shape is fp32-FMA-bound (82 FLOP/B).
 //
 // Shape-specialised kernels (compile-time shapes): xcorr_prod29_kernel (5x5 (x) 29x29), xcorr_cfg5_kernel (5x5 (x) 35x35),
-// xcorr_north_kernel / xcorr_north_mfma_kernel (31x31 (x) 61x61 direct forms; the FFT forms are in xcorr_fft.hip),
+// xcorr_north_kernel (31x31 (x) 61x61 direct form; the FFT form is in xcorr_fft.hip),
 // xcorr_circ13f_kernel (circular 13x13).  Common structure:
 //   * a workgroup's planes are ONE contiguous HBM range for x, k and out, moved with 16-byte coalesced accesses;
 //   * taps are wave-uniform and are read through the scalar cache into SGPRs (FMA takes the SGPR operand);
@@ -472,7 +472,7 @@ __device__ __forceinline__ void north_plane(float2v (&accE)[8], float2v (&accO)[
   fma_row<SKIP_ZERO_TAPS>(accE, accO, A);  // u = 30
 }
 
-// MODE 1 (default): exact-zero taps are skipped; MODE 0: dense FMA stream (HDN_NORTH_TAPS=dense).  A skipped tap costs a
+// MODE 1 (the one instantiated): exact-zero taps are skipped; MODE 0: dense FMA stream (rounds 1-3, 326-352 us).  A skipped tap costs a
 // taken scalar branch, ~20 clocks against 32 for its 8 packed FMAs; a kept one ~4 extra: skipping wins above ~25 % zero
 // taps (post-ReLU kernels: ~50 %), loses 12 % on fully dense taps.  A per-plane choice between both streams inside one
 // kernel was measured slower than either (register spills + two unrolled streams): profiles/round1_north_zero_taps.txt.
@@ -532,228 +532,6 @@ __global__ __launch_bounds__(HDN_BLOCK, 2) void xcorr_north_kernel(XcorrPtrs P, 
       }
       if (s == 0) o[15] = accE[7].y + odd15;  // column 31 (s = 1) does not exist
     }
-  }
-}
-
-// ---------------------------------------------------------------------------------------
-// 31x31 (x) 61x61 on the matrix cores: split-bf16 MFMA, fp32-exact operand representation.
-//
-// Every fp32 value is split into three bf16 pieces x = xh + xm + xl (8+8+8 mantissa bits: exact), products of pieces
-// are exact in the MFMA, and the six piece-products down to 2^-16 relative size are accumulated in fp32
-// (hh | hm, mh, mm, hl, lh): the dropped terms are < 2^-24 relative, i.e. below fp32 rounding of the result.
-// The correlation becomes, per tap ROW u, a GEMM with a Toeplitz left factor (computing out^T):
-//   out[i][j] += sum_c  k[u][c-j] * x[i+u][c]        M = j (31->32), N = i (31->32), K = c (61->64)
-//   B[c][i] = x[i+u][c]  : 8 consecutive c of image row i+u = one aligned 16-byte read of a bf16 image in LDS
-//   A[j][c] = k[u][c-j]  : Toeplitz.  With the K index of an MFMA chosen as c = C_b - 32*(lane>>5) + t, lane l needs
-//                          s_u[C_b - l + t], t = 0..7 (s_u = row u of k): ONE LDS word per lane, then 7 DPP
-//                          wave-shifts (zero fill = the Toeplitz zeros) and 4 byte-permutes build the fragment.
-// Two waves share a plane (tap rows 0..15 / 16..30) and add their 32x32 accumulators through LDS, which also
-// transposes out^T back for a contiguous store.  Workgroups are persistent: the next plane's global loads are in
-// flight in registers while the current one is on the matrix pipe.
-// 744 MFMAs (32x32x16 bf16) per plane instead of 7,688 packed fp32 FMAs per lane.  Summation order differs from the
-// vector kernel; the error class is the same (exact products, fp32 accumulation).
-// ---------------------------------------------------------------------------------------
-#ifndef NMF_UNROLL_U
-#define NMF_UNROLL_U 1
-#endif
-namespace nmf {
-constexpr int HX = 61, WX = 61, HK = 31, WK = 31, HO = 31, WO = 31;
-constexpr int XPLANE = HX * WX, KPLANE = HK * WK, OPLANE = HO * WO;
-constexpr int NS = 3;                       // bf16 pieces per value
-constexpr int XS_RS = 72;                   // bf16 per image row (61 + zero pad to 64 + 8): 144 B, conflict-free b128
-constexpr int XS_ROWS = 62;                 // rows 0..60 plus a zero row (junk lane i = 31)
-constexpr int XS_PIECE = XS_ROWS * XS_RS;   // bf16 elements per piece image
-constexpr int KW_RS = 32;                   // words per tap row
-constexpr int KW_N = HK * KW_RS;
-constexpr int RED_RS = 33;                  // floats per row of the reduction / transpose tile
-constexpr int RED_N = 32 * RED_RS;
-constexpr int PLANE_BYTES = NS * XS_PIECE * 2 + 2 * KW_N * 4 + RED_N * 4;  // 26,784 + 7,936 + 4,224 = 38,944
-constexpr int PPB = 2;                      // plane slots per workgroup (2 waves each)
-constexpr size_t LDS_BYTES = size_t(PPB) * PLANE_BYTES;        // 77,888 B: two workgroups per CU
-constexpr int XQ = cdiv(XPLANE, 128), KQ = cdiv(KPLANE, 128);  // elements per thread of a wave pair
-static_assert(PLANE_BYTES % 16 == 0, "plane slots must stay 16-byte aligned");
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-// round-to-nearest-even fp32 -> bf16 (finite inputs), and back
-__device__ __forceinline__ unsigned bf16_rne(float f) {
-  unsigned u = __float_as_uint(f);
-  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
-__device__ __forceinline__ float bf16_f32(unsigned h) { return __uint_as_float(h << 16); }
-
-// x = p0 + p1 + p2 exactly (each residual is exactly representable in fp32)
-__device__ __forceinline__ void split3(float x, unsigned& p0, unsigned& p1, unsigned& p2) {
-  p0 = bf16_rne(x);
-  const float r1 = x - bf16_f32(p0);
-  p1 = bf16_rne(r1);
-  const float r2 = r1 - bf16_f32(p1);
-  p2 = bf16_rne(r2);
-}
-
-__device__ __forceinline__ unsigned wave_shr1(unsigned v) {
-  return __builtin_amdgcn_update_dpp(0u, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, true /* shifted-in lane reads 0 */);
-}
-
-__device__ __forceinline__ f32x16 mfma(const u32x4& a, const u32x4& b, const f32x16& c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-
-__device__ __forceinline__ void fetch(float (&xv)[XQ], float (&kv)[KQ], const float* __restrict__ xg,
-                                      const float* __restrict__ kg, int tp) {
-#pragma unroll
-  for (int q = 0; q < XQ; ++q) xv[q] = xg[min(tp + q * 128, XPLANE - 1)];
-#pragma unroll
-  for (int q = 0; q < KQ; ++q) kv[q] = kg[min(tp + q * 128, KPLANE - 1)];
-}
-}  // namespace nmf
-
-__global__ __launch_bounds__(HDN_BLOCK, 2) void xcorr_north_mfma_kernel(XcorrPtrs P, int planes) {
-  using namespace nmf;
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & (HDN_WAVE - 1);
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int pl = wave >> 1;            // plane slot of this wave pair
-  const int half = wave & 1;           // which half of the tap rows
-  const int tp = tid & 127;            // thread inside the wave pair
-  const int prob = blockIdx.y;
-  const float* __restrict__ x = P.x[prob];
-  const float* __restrict__ k = P.k[prob];
-  float* __restrict__ out = P.out[prob];
-  const int stride = gridDim.x * PPB;  // planes between two iterations of a wave pair
-  const int first = blockIdx.x * PPB + pl;
-  const int iters = cdiv(planes - blockIdx.x * PPB, stride);  // workgroup-uniform (>= 1)
-
-  unsigned char* slot = lds + pl * PLANE_BYTES;
-  unsigned short* xs = reinterpret_cast<unsigned short*>(slot);                  // [NS][XS_ROWS][XS_RS]
-  unsigned* kw = reinterpret_cast<unsigned*>(slot + NS * XS_PIECE * 2);         // [2][HK][KW_RS]
-  float* red = reinterpret_cast<float*>(slot + NS * XS_PIECE * 2 + 2 * KW_N * 4);  // [32][RED_RS]
-
-  // zero once: image columns 61..71 and row 61 are the GEMM's zero padding and are never written again
-  {
-    u32x4* z = reinterpret_cast<u32x4*>(lds);
-    constexpr int NZ = int(LDS_BYTES / 16);
-    for (int q = tid; q < NZ; q += HDN_BLOCK) z[q] = u32x4{0u, 0u, 0u, 0u};
-  }
-  float xv[XQ], kv[KQ];
-  if (first < planes) fetch(xv, kv, x + size_t(first) * XPLANE, k + size_t(first) * KPLANE, tp);
-  __syncthreads();
-
-#pragma unroll 1
-  for (int it = 0; it < iters; ++it) {
-    const int plane = first + it * stride;
-    const bool have = plane < planes;  // uniform per wave pair
-
-    // ---- split into bf16 pieces, store the images --------------------------------------------------------
-#ifdef NMF_SKIP_P1
-    if (have && it == 0) {
-#else
-    if (have) {
-#endif
-#pragma unroll
-      for (int q = 0; q < XQ; ++q) {
-        const int e = tp + q * 128;
-        if (e < XPLANE) {
-          const int r = e / WX, c = e - r * WX;
-          unsigned p0, p1, p2;
-          split3(xv[q], p0, p1, p2);
-          const int a = r * XS_RS + c;
-          xs[a] = (unsigned short)p0;
-          xs[XS_PIECE + a] = (unsigned short)p1;
-          xs[2 * XS_PIECE + a] = (unsigned short)p2;
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < KQ; ++q) {
-        const int e = tp + q * 128;
-        if (e < KPLANE) {
-          const int u = e / WK, n = e - u * WK;
-          unsigned p0, p1, p2;
-          split3(kv[q], p0, p1, p2);
-          kw[u * KW_RS + n] = p0 | (p1 << 16);
-          kw[KW_N + u * KW_RS + n] = p2;
-        }
-      }
-    }
-    // next plane's loads fly while this one is on the matrix pipe
-    if (plane + stride < planes) fetch(xv, kv, x + size_t(plane + stride) * XPLANE, k + size_t(plane + stride) * KPLANE, tp);
-    __syncthreads();
-
-    // ---- 31 tap rows x 4 K-blocks x 6 piece products -----------------------------------------------------
-    f32x16 acc0, acc1, acc2;
-#pragma unroll
-    for (int g = 0; g < 16; ++g) acc0[g] = acc1[g] = acc2[g] = 0.f;
-#ifndef NMF_SKIP_P2
-    if (have) {
-      const int h = lane >> 5, i = lane & 31;
-      const int u0 = half ? 16 : 0, u1 = half ? HK : 16;
-#pragma unroll NMF_UNROLL_U
-      for (int u = u0; u < u1; ++u) {
-        const unsigned* ku1 = kw + u * KW_RS;
-        const unsigned* ku2 = kw + KW_N + u * KW_RS;
-        const unsigned short* xrow = xs + (i + u) * XS_RS - 32 * h;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const int Cb = 32 + 8 * b;
-          // A: lane l holds s_u[Cb - l + t], t = 0..7, for the three pieces
-          // (unconditional reads at a clamped index, then masked: a predicated read would put the whole K-block
-          //  behind a branch and serialise LDS latency -> DPP chain -> MFMAs)
-          const int n = Cb - lane;
-          const unsigned keep = ((unsigned)n <= (unsigned)(WK - 1)) ? 0xffffffffu : 0u;
-          const int nc = min(max(n, 0), KW_RS - 1);
-          unsigned w1[8], w2[8];
-          w1[0] = ku1[nc] & keep;
-          w2[0] = ku2[nc] & keep;
-#pragma unroll
-          for (int t = 1; t < 8; ++t) {
-            w1[t] = wave_shr1(w1[t - 1]);
-            w2[t] = wave_shr1(w2[t - 1]);
-          }
-          u32x4 Ah, Am, Al;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            Ah[q] = __builtin_amdgcn_perm(w1[2 * q + 1], w1[2 * q], 0x05040100u);
-            Am[q] = __builtin_amdgcn_perm(w1[2 * q + 1], w1[2 * q], 0x07060302u);
-            Al[q] = __builtin_amdgcn_perm(w2[2 * q + 1], w2[2 * q], 0x05040100u);
-          }
-          // B: x[i + u][Cb - 32h + t], t = 0..7: one aligned 16-byte read per piece
-          const u32x4 Bh = *reinterpret_cast<const u32x4*>(xrow + Cb);
-          const u32x4 Bm = *reinterpret_cast<const u32x4*>(xrow + XS_PIECE + Cb);
-          const u32x4 Bl = *reinterpret_cast<const u32x4*>(xrow + 2 * XS_PIECE + Cb);
-          acc0 = mfma(Ah, Bh, acc0);
-          acc1 = mfma(Ah, Bm, acc1);
-          acc2 = mfma(Am, Bh, acc2);
-          acc1 = mfma(Am, Bm, acc1);
-          acc2 = mfma(Ah, Bl, acc2);
-          acc1 = mfma(Al, Bh, acc1);
-        }
-      }
-    }
-#endif
-
-    // ---- add the two halves (D = out^T: lane column = i, register row = j), store contiguously -----------
-    const int h = lane >> 5, i = lane & 31;
-    if (half == 1) {
-#pragma unroll
-      for (int g = 0; g < 16; ++g) red[i * RED_RS + (g & 3) + 8 * (g >> 2) + 4 * h] = acc0[g] + (acc1[g] + acc2[g]);
-    }
-    __syncthreads();
-    if (half == 0) {
-#pragma unroll
-      for (int g = 0; g < 16; ++g) red[i * RED_RS + (g & 3) + 8 * (g >> 2) + 4 * h] += acc0[g] + (acc1[g] + acc2[g]);
-      if (have) {
-        float* og = out + size_t(plane) * OPLANE;
-        for (int e = lane; e < OPLANE; e += HDN_WAVE) {
-          const int oi = e / WO, oj = e - oi * WO;
-          og[e] = red[oi * RED_RS + oj];
-        }
-      }
-    }
-    __syncthreads();  // the images and the tile are free for the next plane
   }
 }
 
@@ -1056,39 +834,29 @@ __global__ __launch_bounds__(HDN_BLOCK) void xcorr_generic_kernel(XcorrPtrs P, i
 static thread_local const char* g_last_variant = "none";
 
 // Variant of the 31x31 (x) 61x61 kernel: set by hdn_xcorr_north_variant(), initially from the environment
-// (HDN_NORTH = fft | direct | dense | mfma; legacy: HDN_NORTH_MFMA=1, HDN_NORTH_TAPS=dense, HDN_NORTH_FFT=0).
+// (HDN_NORTH = fft | direct).  Rounds 1-3 carried four more forms (row-first FFT, two-waves-per-SIMD FFT, dense direct sum,
+// split-bf16 matrix cores): all parity-green, none faster than these two, retired in round 4 (DESIGN.md section 6 keeps what
+// each one taught).
 static std::atomic<int> g_north_variant{-1};
 static int north_variant() {
   int v = g_north_variant.load(std::memory_order_relaxed);
   if (v >= 0) return v;
   v = HDN_NORTH_FFT_COL;
   const char* e = getenv("HDN_NORTH");
-  const char* m = getenv("HDN_NORTH_MFMA");
-  const char* t = getenv("HDN_NORTH_TAPS");
-  const char* f = getenv("HDN_NORTH_FFT");
-  if (e && e[0] == 'd' && e[1] == 'i') v = HDN_NORTH_DIRECT;
-  else if (e && e[0] == 'd') v = HDN_NORTH_DIRECT_DENSE;
-  else if (e && e[0] == 'm') v = HDN_NORTH_MFMA;
-  else if (e && e[0] == 'f' && e[1] == 'f' && e[2] == 't' && e[3] == '2') v = HDN_NORTH_FFT_2W;
-  else if (e && e[0] == 'f' && e[1] == 'f' && e[2] == 't' && e[3] == 'r') v = HDN_NORTH_FFT;   // "fftr": row-first
-  else if (e && e[0] == 'f') v = HDN_NORTH_FFT_COL;
-  else if (m && m[0] == '1') v = HDN_NORTH_MFMA;
-  else if (t && t[0] == 'd') v = HDN_NORTH_DIRECT_DENSE;
-  else if (f && f[0] == '0') v = HDN_NORTH_DIRECT;
+  if (e && e[0] == 'd') v = HDN_NORTH_DIRECT;
   g_north_variant.store(v, std::memory_order_relaxed);
   return v;
 }
 
-static int launch_north(const XcorrPtrs& P, int n, int planes, hipStream_t stream, int mode) {
-  // mode 1: zero taps skipped (default), 0: dense: see xcorr_north_kernel
-  void (*kern)(XcorrPtrs, int) = mode == 0 ? &xcorr_north_kernel<0> : &xcorr_north_kernel<1>;
-  static PerDeviceOnce attr[2];  // dynamic LDS above 64 KiB needs the opt-in once per kernel and device
+static int launch_north(const XcorrPtrs& P, int n, int planes, hipStream_t stream) {
+  void (*kern)(XcorrPtrs, int) = &xcorr_north_kernel<1>;   // exact-zero taps skipped
+  static PerDeviceOnce attr;  // dynamic LDS above 64 KiB needs the opt-in once per kernel and device
   const int dev_ = PerDeviceOnce::device();
-  if (!attr[mode].done(dev_)) {
+  if (!attr.done(dev_)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)north::LDS_BYTES);
     if (e != hipSuccess) return -(1000 + (int)e);
-    attr[mode].set(dev_);
+    attr.set(dev_);
   }
   // persistent: 2 workgroups per CU x 256 CUs (fewer if there are fewer planes); n problems share the grid.
   // HDN_NORTH_BLOCKS caps the grid (e.g. 256 = one workgroup per CU, leaving LDS for kernels on other streams).
@@ -1101,37 +869,9 @@ static int launch_north(const XcorrPtrs& P, int n, int planes, hipStream_t strea
 
 // xcorr_fft.hip
 int launch_north_fft(const float* x, const float* k, float* out, int planes, int max_blocks, hipStream_t stream, int pair0);
-int launch_north_fft2(const float* x, const float* k, float* out, int planes, int max_blocks, hipStream_t stream);
-int launch_north_fft3(const float* x, const float* k, float* out, int planes, int max_blocks, hipStream_t stream);
 int launch_north_fft4(const float* x, const float* k, float* out, int planes, int max_blocks, hipStream_t stream);
 
-static int launch_north_fft_all(const XcorrPtrs& P, int n, int planes, hipStream_t stream, bool two_waves = false) {
-  // persistent: 4 one-wave workgroups per CU x 256 CUs (LDS-limited); n problems run back to back
-  static const int cap = [] { const char* e = getenv("HDN_NORTH_BLOCKS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
-  for (int i = 0; i < n; ++i) {
-    const int rc = (two_waves && planes % 4 == 0) ? launch_north_fft3(P.x[i], P.k[i], P.out[i], planes, 2 * cap, stream)
-                                                  : launch_north_fft2(P.x[i], P.k[i], P.out[i], planes, cap, stream);
-    if (rc) return rc;
-  }
-  g_last_variant = (two_waves && planes % 4 == 0) ? "north_fft2w_61x61_31x31" : "north_fft_61x61_31x31";
-  return HDN_OK;
-}
 
-static int launch_north_mfma(const XcorrPtrs& P, int n, int planes, hipStream_t stream) {
-  static PerDeviceOnce attr;
-  const int dev_ = PerDeviceOnce::device();
-  if (!attr.done(dev_)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xcorr_north_mfma_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)nmf::LDS_BYTES);
-    if (e != hipSuccess) return -(1000 + (int)e);
-    attr.set(dev_);
-  }
-  // persistent: 2 workgroups per CU x 256 CUs (fewer if there are fewer planes); n problems share the grid
-  const int per_problem = max(1, min(cdiv(planes, nmf::PPB), 512 / n));
-  hipLaunchKernelGGL(xcorr_north_mfma_kernel, dim3(per_problem, n), dim3(HDN_BLOCK), nmf::LDS_BYTES, stream, P, planes);
-  g_last_variant = "north_mfma_61x61_31x31";
-  return launch_status();
-}
 
 static int launch_prod29(const XcorrPtrs& P, int n, int planes, hipStream_t stream) {
   hipLaunchKernelGGL(xcorr_prod29_kernel, dim3(cdiv(planes, prod29::PPB), n), dim3(HDN_BLOCK), 0, stream, P, planes);
@@ -1167,9 +907,8 @@ static int xcorr_dispatch(const XcorrPtrs& P, int n, int circular, int B, int C,
       return launch_status();
     }
     if (Hx == 61 && Wx == 61 && Hk == 31 && Wk == 31) {
-      // Default: the FFT kernel (xcorr_fft.hip, ~125 us at B=64).  It needs 16-byte aligned x / k and 8-byte aligned
-      // out; otherwise, or on request (hdn_xcorr_north_variant / environment), one of the direct kernels runs:
-      // packed-FMA with zero-tap skipping (~255 us on post-ReLU data), the same without skipping, or split-bf16 MFMA.
+      // Default: the column-first FFT kernel (xcorr_fft.hip, ~92 us at B = 64, any pointer alignment); on request
+      // (hdn_xcorr_north_variant / HDN_NORTH=direct) the packed-FMA direct sum with zero-tap skipping (~250 us on post-ReLU data).
       const int v = north_variant();
       if (v == HDN_NORTH_FFT_COL) {  // column-first FFT kernel: no alignment requirement
         static const int cap = [] { const char* e = getenv("HDN_NORTH_BLOCKS"); int c = e ? atoi(e) : 0; return c > 0 ? c : 1024; }();
@@ -1180,14 +919,7 @@ static int xcorr_dispatch(const XcorrPtrs& P, int n, int circular, int B, int C,
         g_last_variant = "north_fftc_61x61_31x31";
         return HDN_OK;
       }
-      if (v == HDN_NORTH_FFT || v == HDN_NORTH_FFT_2W) {
-        bool ok = true;
-        for (int i = 0; i < n; ++i)
-          ok = ok && aligned16(P.x[i]) && aligned16(P.k[i]) && (reinterpret_cast<uintptr_t>(P.out[i]) & 7u) == 0;
-        if (ok) return launch_north_fft_all(P, n, planes, stream, v == HDN_NORTH_FFT_2W);
-      }
-      if (v == HDN_NORTH_MFMA) return launch_north_mfma(P, n, planes, stream);
-      return launch_north(P, n, planes, stream, v == HDN_NORTH_DIRECT_DENSE ? 0 : 1);
+      return launch_north(P, n, planes, stream);
     }
   } else {
     if (Hx == 13 && Wx == 13 && Hk == 13 && Wk == 13) return launch_circ13(P, n, planes, stream);
@@ -1221,7 +953,7 @@ const char* hdn_last_xcorr_variant(void) { return hdn::g_last_variant; }
 int hdn_xcorr_north_variant(int v) {
   const int prev = hdn::north_variant();
   if (v >= 0) {
-    if (v > HDN_NORTH_FFT_COL) return HDN_E_LIMIT;
+    if (v != HDN_NORTH_FFT_COL && v != HDN_NORTH_DIRECT) return HDN_E_LIMIT;
     hdn::g_north_variant.store(v, std::memory_order_relaxed);
   }
   return prev;

@@ -357,23 +357,6 @@ extern "C" int hdn_debug_read_kimg(float* host_dst) { return (int)hipMemcpyFromS
 #define NFFT_DBG_DUMP_KIMG()
 #endif
 
-// Experiment switch of the two-waves-per-SIMD kernel (round 3, profiles/round3_north_experiments.txt): issue priority by phase.
-// NF3_PRIO_MODE 1: high while a wave issues LDS / global traffic and waits for it, low in the arithmetic stretches (the
-// partner wave's memory instructions then never queue behind this wave's FFT); 2: the opposite.  0 (default): no s_setprio.
-#ifndef NF3_PRIO_MODE
-#define NF3_PRIO_MODE 0
-#endif
-#if NF3_PRIO_MODE == 1
-#define NF3_PRIO_MEM() __builtin_amdgcn_s_setprio(3)
-#define NF3_PRIO_ALU() __builtin_amdgcn_s_setprio(0)
-#elif NF3_PRIO_MODE == 2
-#define NF3_PRIO_MEM() __builtin_amdgcn_s_setprio(0)
-#define NF3_PRIO_ALU() __builtin_amdgcn_s_setprio(3)
-#else
-#define NF3_PRIO_MEM()
-#define NF3_PRIO_ALU()
-#endif
-
 static const nfft::cf* north_fft_table() {
   static const nfft::cf* tab[64] = {};  // per device
   const int d = PerDeviceOnce::device();
@@ -712,384 +695,6 @@ NF_DEV void add2(float& a, float& c, float b, float d) {
 // (tools/experiments/ubench_clock.hip: 2048 one-wave workgroups at "2 per SIMD" live between 2.19 and 2.98 ms).
 constexpr int NF2_TW_OFF = 31744;    // nfft::LDS_BYTES rounded up to 256 B: the worker's image ends here
 constexpr int NF2_WAVE_LDS = 32768;  // image + the per-lane twiddle table of the kernel row pass
-template <int WPG>
-__global__ __launch_bounds__(64 * WPG) void xcorr_north_fft2_kernel(const float* __restrict__ x, const float* __restrict__ k,
-                                                                    float* __restrict__ out, int npairs, int nmain, int planes,
-                                                                    int clamp_from, int tail_worker,
-                                                                    const nfft::cf* __restrict__ tab) {
-  using namespace nf2;
-  extern __shared__ __align__(16) float smem_wg[];
-  const int wave = WPG == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: an SGPR
-  float* const smem = smem_wg + wave * (NF2_WAVE_LDS / 4);
-  const int worker = (int)blockIdx.x * WPG + wave;
-  const int lane = threadIdx.x & 63;
-  if (worker >= nmain) {
-    if (worker == tail_worker) north_fft_v1_body(smem, x, k, out, planes, npairs, 0, 1, tab, lane);
-    return;  // (a surplus wave of the last workgroup)
-  }
-  const uint32_t sb = lds_addr(smem);
-
-  const int fc = lane & 31;
-  const float sgn = lane < 32 ? 1.f : -1.f;
-  const cf sg = {sgn, sgn};
-  // LDS byte addresses that do not depend on the pair
-  const uint32_t a_stash = sb + lane * 16;                     // linear 16-byte chunks
-  // lanes past the last row redo that row and rewrite it with identical values: no exec branches around the writes
-  const uint32_t a_row = sb + (lane < HX ? lane : HX - 1) * (RS * 8);    // search spectrum row
-  // kernel row pass: lanes 0..30 transform the rows' EVEN half-bins, lanes 32..62 the same rows' ODD half-bins (two
-  // pruned 32-point FFTs that differ only in the input twiddle e^{-i*pi*(1 + 2*hl)*j/64}, which is therefore per lane:
-  // a 2 x 32 table behind the wave's image, read through LDS broadcasts); lanes 31 / 63 redo row 30
-  const int hl = lane >> 5, krow = (lane & 31) < HK ? (lane & 31) : HK - 1;
-  const uint32_t a_rowk = sb + krow * (RS * 8) + hl * 8;       // kernel spectrum row, bins of this lane's parity
-  const uint32_t a_tw = sb + NF2_TW_OFF + hl * 256;
-  // inverse row pass, the same way: lanes 0..30 invert the EVEN bins of a row, lanes 32..62 its ODD bins (two 32-point
-  // inverse FFTs), z[j] = E[j] + w64^j O[j] is formed across the two halves of the wave (v_permlane32_swap); the un-shift
-  // e^{+i*pi*j/64} / 16384 (times w64^j on the odd half) is per lane again
-  const int orow = (lane & 31) < HO ? (lane & 31) : HO - 1;
-  const uint32_t a_ro = sb + orow * (RS * 8) + hl * 8;          // entries 2g + hl
-  const uint32_t a_ro2 = sb + orow * (RS * 8) + (1 - hl) * 8;   // entries 63 - 2g - hl = (62 - 2g) + (1 - hl)
-  const uint32_t a_tw2 = sb + NF2_TW_OFF + 512 + hl * 256;
-  const uint32_t a_ow = sb + orow * (HO * 4) + hl * 64, a_owB = a_ow + OPL * 4;   // outputs j (lanes < 32) / j + 16
-  const uint32_t a_o15 = hl ? sb + 8192 + lane * 8 : a_ow, a_o15B = hl ? sb + 8192 + 1024 + lane * 8 : a_owB;  // j = 31 does not exist
-  if (lane < 32) {
-    cf* const tw = reinterpret_cast<cf*>(smem + NF2_TW_OFF / 4);
-    tw[lane] = tab[NFFT_TAB_TAU + lane];
-    tw[32 + lane] = tab[NFFT_TAB_TAU3 + lane];
-    tw[64 + lane] = tab[NFFT_TAB_POST + lane];
-    tw[96 + lane] = tab[NFFT_TAB_POST3 + lane];
-  }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  const uint32_t a_col = sb + lane * 8;                        // spectrum column `lane` / linear 8-byte words
-  const uint32_t a_colp = sb + fc * 8, a_colq = sb + (63 - fc) * 8;
-  const uint32_t a_rowo = sb + (lane < HO ? lane : HO - 1) * (RS * 8);
-  const uint32_t a_out = sb + (lane < HO ? lane : HO - 1) * (HO * 4);
-  const uint32_t voff = lane * 16;
-
-  f4v Rx[XQ], Rk[KQ];  // the next pair's global data: AGPRs
-
-  // Pairs >= clamp_from have a load window that leaves the tensor; the launcher only sends them here when the tensor
-  // ends on a 16-byte boundary, so redirecting the chunks beyond the end to the last chunk inside is all it takes
-  // (what they deliver is never read).
-  const long long xlast = ((long long)planes * XPL - 4) * 4, klast = ((long long)planes * KPL - 4) * 4;  // byte offsets
-  auto fetch_x = [&](int p) NF2_LAMBDA {
-    const long long first = ((long long)p * (2 * XPL)) & ~3LL;
-    if (p < clamp_from) {
-      sfor<0, XQ>([&](auto Qi) NF2_LAMBDA {
-        constexpr int q = decltype(Qi)::value;
-        gload128_to_agpr<(q & 3) * 1024>(Rx[q], voff, reinterpret_cast<const char*>(x + first) + (q >> 2) * 4096);
-      });
-    } else {
-      const uint32_t lim = (uint32_t)(xlast - first * 4);
-      sfor<0, XQ>([&](auto Qi) NF2_LAMBDA {
-        constexpr int q = decltype(Qi)::value;
-        gload128_to_agpr<0>(Rx[q], min(voff + q * 1024, lim), reinterpret_cast<const char*>(x + first));
-      });
-    }
-  };
-  auto fetch_k = [&](int p) NF2_LAMBDA {
-    const long long first = ((long long)p * (2 * KPL)) & ~3LL;
-    if (p < clamp_from) {
-      sfor<0, KQ>([&](auto Qi) NF2_LAMBDA {
-        constexpr int q = decltype(Qi)::value;
-        gload128_to_agpr<(q & 3) * 1024>(Rk[q], voff, reinterpret_cast<const char*>(k + first) + (q >> 2) * 4096);
-      });
-    } else {
-      const uint32_t lim = (uint32_t)(klast - first * 4);
-      sfor<0, KQ>([&](auto Qi) NF2_LAMBDA {
-        constexpr int q = decltype(Qi)::value;
-        gload128_to_agpr<0>(Rk[q], min(voff + q * 1024, lim), reinterpret_cast<const char*>(k + first));
-      });
-    }
-  };
-
-  int p = worker;
-  if (p >= npairs) return;
-  NFFT_DBG_BEGIN(worker)
-  fetch_x(p);
-  fetch_k(p);
-  wait_vm0();
-
-  NFFT_DBG_ITER_DECL()
-  for (; p < npairs; p += nmain) {
-    const int offx = (int)(((long long)p * (2 * XPL)) & 3), offk = (int)(((long long)p * (2 * KPL)) & 3);
-    const int pn = min(p + nmain, npairs - 1);  // (the last iteration re-fetches its own pair: harmless)
-
-    NFFT_DBG_MARK(0)
-    // ---- search pair: AGPRs -> LDS; refill the AGPRs with the next pair.  (The loads were waited for before the
-    //      previous pair's stores were issued, see the end of the loop: nobody ever waits for a store.)
-    sfor<0, XQ>([&](auto Qi) NF2_LAMBDA { constexpr int q = decltype(Qi)::value; lw128_from_agpr<q * 1024>(a_stash, Rx[q]); });
-    fetch_x(pn);
-
-    NFFT_DBG_MARK(1)
-    // ---- row pass: lane = row; half-bin twiddle e^{-i*pi*j/64}, FFT, real/imaginary split, store
-    {
-      const uint32_t aA = sb + (offx + (lane < HX ? lane : HX - 1) * HX) * 4, aB = aA + XPL * 4;
-      cf ra[31], rb[31];
-      sfor<0, 31>([&](auto Mi) NF2_LAMBDA {
-        constexpr int m = decltype(Mi)::value;
-        ra[m] = lr2x32<2 * m, 2 * m + 1>(aA);
-        rb[m] = lr2x32<2 * m, 2 * m + 1>(aB);
-      });
-      wait_lgkm<0>();
-      NFFT_DBG_MARK(2)
-      cf v[64];
-      sfor<0, 31>([&](auto Mi) NF2_LAMBDA {
-        constexpr int j = 2 * decltype(Mi)::value;
-        cf lo, hi;
-        const cf A = ra[j / 2], B = rb[j / 2];
-        twiddle_in2<-j, -(j + 1), (j + 1 < HX)>(A, B, lo, hi);
-        v[bitrev(j, 6)] = lo;
-        if constexpr (j + 1 < HX) v[bitrev(j + 1, 6)] = hi;
-      });
-      fft<6, -1, HX, 64>(v);
-      NFFT_DBG_MARK(3)
-      {
-        cf sa[32], sb2[32];  // C(f) + conj C(63-f),  C(f) - conj C(63-f); each write trails its split by one element
-        sfor<0, 33>([&](auto F) NF2_LAMBDA {
-          constexpr int f = decltype(F)::value;
-          if constexpr (f < 32) {
-            const cf cp = v[f], cq = v[63 - f];
-            cf a, b;
-            asm volatile("v_pk_add_f32 %0, %2, %3 neg_hi:[0,1]\n\tv_pk_add_f32 %1, %2, %3 neg_lo:[0,1]"
-                         : "=&v"(a), "=&v"(b) : "v"(cp), "v"(cq));
-            sa[f] = a;
-            sb2[f] = b;
-          }
-          if constexpr (f > 0) lw2x64<f - 1, 32 + f - 1>(a_row, sa[f - 1], sb2[f - 1]);
-        });
-      }
-    }
-
-    NFFT_DBG_MARK(4)
-    // ---- column pass: lane = (plane, half-bin column); straight into X
-    cf X[64];
-    sfor<0, HX>([&](auto R) NF2_LAMBDA { constexpr int r = decltype(R)::value; X[bitrev(r, 6)] = lr64<r * RS * 8>(a_col); });
-    wait_lgkm<0>();
-    NFFT_DBG_MARK(5)
-    // kernel pair: AGPRs -> LDS (beyond spectrum rows 0..30) and its row-pass inputs: in flight under the column FFT
-    sfor<0, KQ>([&](auto Qi) NF2_LAMBDA { constexpr int q = decltype(Qi)::value; lw128_from_agpr<KSTAGE * 4 + q * 1024>(a_stash, Rk[q]); });
-    fetch_k(pn);
-    const uint32_t akA = sb + (KSTAGE + offk + krow * HK) * 4, akB = akA + KPL * 4;
-    cf ka[16], kb[16];
-    sfor<0, 16>([&](auto Mi) NF2_LAMBDA {
-      constexpr int m = decltype(Mi)::value;
-      ka[m] = lr2x32<2 * m, 2 * m + 1>(akA);
-      kb[m] = lr2x32<2 * m, 2 * m + 1>(akB);
-    });
-    fft<6, -1, HX, 64>(X);
-    NFFT_DBG_MARK(6)
-
-    // ---- kernel row pass, pruned: even bins = FFT32(c * e^{-i*pi*j/64}) on lanes 0..30, odd bins =
-    //      FFT32(c * e^{-3i*pi*j/64}) on lanes 32..62, in ONE pass; raw spectra to LDS (the real/imaginary split needs an
-    //      even and an odd bin: the column lanes do it)
-    {
-      wait_lgkm<0>();
-      cf v[32];
-      constexpr int TCH = 4;  // twiddles arrive in chunks of 4 (two ds_read2_b64), one chunk ahead of their use
-      cf tq[2][TCH];
-      auto tw_issue = [&](auto Ci) NF2_LAMBDA {
-        constexpr int c = decltype(Ci)::value;
-        lr2x64<TCH * c, TCH * c + 1>(a_tw, tq[c & 1][0], tq[c & 1][1]);
-        // entry 31 has no consumer: loading it would leave an in-flight write to a register the compiler considers dead
-        // (and hands to the next packed op) - these loads are invisible to its liveness / wait-count tracking
-        if constexpr (TCH * c + 3 < HK) lr2x64<TCH * c + 2, TCH * c + 3>(a_tw, tq[c & 1][2], tq[c & 1][3]);
-        else tq[c & 1][2] = lr64<(TCH * c + 2) * 8>(a_tw);
-      };
-      tw_issue(std::integral_constant<int, 0>{});
-      sfor<0, 8>([&](auto Ci) NF2_LAMBDA {
-        constexpr int c = decltype(Ci)::value;
-        if constexpr (c + 1 < 8) {
-          tw_issue(std::integral_constant<int, c + 1>{});
-          wait_lgkm<2>();
-        } else {
-          wait_lgkm<0>();
-        }
-        sfor<0, 2>([&](auto Ui) NF2_LAMBDA {
-          constexpr int m = 2 * c + decltype(Ui)::value, j = 2 * m;
-          cf lo, hi;
-          const cf A = ka[m], B = kb[m], T0 = tq[c & 1][j % TCH], T1 = tq[c & 1][j % TCH + 1];
-          // (a + i b) * conj(t), t = (cos, sin):  m = a * (c, -s);  r = b * (s, c) + m   (samples j: lo halves, j + 1: hi halves)
-          if constexpr (j + 1 < HK)
-            asm volatile("v_pk_mul_f32 %0, %2, %4 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
-                         "v_pk_mul_f32 %1, %2, %5 op_sel:[1,0] op_sel_hi:[1,1] neg_hi:[0,1]\n\t"
-                         "v_pk_fma_f32 %0, %3, %4, %0 op_sel:[0,1,0] op_sel_hi:[0,0,1]\n\t"
-                         "v_pk_fma_f32 %1, %3, %5, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1]"
-                         : "=&v"(lo), "=&v"(hi) : "v"(A), "v"(B), "v"(T0), "v"(T1));
-          else
-            asm volatile("v_pk_mul_f32 %0, %1, %3 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
-                         "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[0,1,0] op_sel_hi:[0,0,1]"
-                         : "=&v"(lo) : "v"(A), "v"(B), "v"(T0));
-          v[bitrev(j, 5)] = lo;
-          if constexpr (j + 1 < HK) v[bitrev(j + 1, 5)] = hi;
-        });
-      });
-      fft<5, -1, HK, 32>(v);
-      sfor<0, 16>([&](auto Gi) NF2_LAMBDA {
-        constexpr int g = 2 * decltype(Gi)::value;
-        lw2x64<2 * g, 2 * g + 2>(a_rowk, v[g], v[g + 1]);  // bins 2g + hl, 2(g + 1) + hl
-      });
-      NFFT_DBG_DUMP_KIMG()
-    }
-
-    NFFT_DBG_MARK(7)
-    // ---- kernel column pass (pruned halves; split by a per-lane sign while reading) and product X * conj(K)
-    sfor<0, 2>([&](auto Hf) NF2_LAMBDA {
-      constexpr int half = decltype(Hf)::value;
-      cf K[32];
-      constexpr int CH = 5, NCH = (HK + CH - 1) / CH;  // rows in chunks of 5, two chunks in flight
-      cf pp[2][CH], qq[2][CH];
-      auto issue = [&](auto Ci) NF2_LAMBDA {
-        constexpr int c = decltype(Ci)::value;
-        sfor<0, CH>([&](auto Ri) NF2_LAMBDA {
-          constexpr int r = c * CH + decltype(Ri)::value;
-          if constexpr (r < HK) {
-            pp[c & 1][r - c * CH] = lr64<r * RS * 8>(a_colp);
-            qq[c & 1][r - c * CH] = lr64<r * RS * 8>(a_colq);
-          }
-        });
-      };
-      issue(std::integral_constant<int, 0>{});
-      sfor<0, NCH>([&](auto Ci) NF2_LAMBDA {
-        constexpr int c = decltype(Ci)::value;
-        constexpr int next_rows = (c + 1 < NCH) ? ((c + 2) * CH <= HK ? CH : HK - (c + 1) * CH) : 0;
-        if constexpr (c + 1 < NCH) issue(std::integral_constant<int, c + 1>{});
-        wait_lgkm<2 * next_rows>();
-        cf sp[CH];
-        sfor<0, CH>([&](auto Ri) NF2_LAMBDA {
-          constexpr int r = c * CH + decltype(Ri)::value;
-          if constexpr (r < HK) {
-            cf s2;
-            const cf pv = pp[c & 1][r - c * CH], qv = qq[c & 1][r - c * CH], sgl = sg;
-            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 neg_hi:[1,0,0]" : "=v"(s2) : "v"(qv), "v"(sgl), "v"(pv));  // p +- conj q
-            sp[r - c * CH] = s2;
-          }
-        });
-        sfor<0, CH>([&](auto Ri) NF2_LAMBDA {  // odd bins: times w64^r, after all splits of the chunk (no dependent neighbours)
-          constexpr int r = c * CH + decltype(Ri)::value;
-          if constexpr (r < HK) {
-            if constexpr (half == 1 && r > 0) K[bitrev(r, 5)] = cmul_tw<-2 * r, false>(sp[r - c * CH]);
-            else K[bitrev(r, 5)] = sp[r - c * CH];
-          }
-        });
-      });
-      fft<5, -1, HK, 32>(K);
-      sfor<0, 16>([&](auto Gi) NF2_LAMBDA {
-        constexpr int g0 = 2 * decltype(Gi)::value, g1 = g0 + 1;
-        cf m0, m1;
-        cf x0 = X[2 * g0 + half], x1 = X[2 * g1 + half];
-        const cf k0 = K[g0], k1 = K[g1];
-        asm volatile("v_pk_mul_f32 %0, %2, %4 op_sel_hi:[1,0]\n\tv_pk_mul_f32 %1, %3, %5 op_sel_hi:[1,0]\n\t"
-                     "v_pk_fma_f32 %2, %2, %4, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]\n\t"
-                     "v_pk_fma_f32 %3, %3, %5, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
-                     : "=&v"(m0), "=&v"(m1), "+v"(x0), "+v"(x1) : "v"(k0), "v"(k1));
-        X[2 * g0 + half] = x0;
-        X[2 * g1 + half] = x1;
-      });
-    });
-
-    NFFT_DBG_MARK(8)
-    // ---- inverse column pass (rows 0..30 needed), to LDS
-    {
-      cf V[64];
-      sfor<0, 64>([&](auto F) NF2_LAMBDA { constexpr int f = decltype(F)::value; V[bitrev(f, 6)] = X[f]; });
-      fft<6, +1, 64, HO>(V);
-      sfor<0, HO>([&](auto R) NF2_LAMBDA { constexpr int r = decltype(R)::value; lw64<r * RS * 8>(a_col, V[r]); });
-    }
-
-    NFFT_DBG_MARK(9)
-    // ---- inverse row pass: lane = (output row, parity of the bins it inverts); Hermitian re-packing of the pair,
-    //      32-point inverse FFT, un-shift, cross-half sum
-    {
-      cf pa[32], pb[32];  // (ya, yb) of bin 2g + hl (g < 16) or of its mirror 63 - 2g - hl (g >= 16)
-      sfor<0, 16>([&](auto G) NF2_LAMBDA { constexpr int g = decltype(G)::value; lr2x64<2 * g, 32 + 2 * g>(a_ro, pa[g], pb[g]); });
-      sfor<16, 32>([&](auto G) NF2_LAMBDA { constexpr int g = decltype(G)::value; lr2x64<62 - 2 * g, 94 - 2 * g>(a_ro2, pa[g], pb[g]); });
-      constexpr int TCH = 4;
-      cf tq[2][TCH];
-      auto tw_issue = [&](auto Ci) NF2_LAMBDA {
-        constexpr int c = decltype(Ci)::value;
-        lr2x64<TCH * c, TCH * c + 1>(a_tw2, tq[c & 1][0], tq[c & 1][1]);
-        lr2x64<TCH * c + 2, TCH * c + 3>(a_tw2, tq[c & 1][2], tq[c & 1][3]);  // (entry 31 is consumed: see o[31] below)
-      };
-      tw_issue(std::integral_constant<int, 0>{});
-      wait_lgkm<2>();
-      NFFT_DBG_MARK(10)
-      cf v[32];
-      sfor<0, 32>([&](auto G) NF2_LAMBDA {
-        constexpr int g = decltype(G)::value;
-        cf c0;
-        const cf ya = pa[g], yb = pb[g];
-        if constexpr (g < 16) asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(c0) : "v"(ya), "v"(yb));  // ya + i yb
-        else asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]" : "=v"(c0) : "v"(ya), "v"(yb));          // conj ya + i conj yb
-        v[bitrev(g, 5)] = c0;
-      });
-      fft<5, +1, 32, 32>(v);
-      // un-shift: o[j] = v[j] * t[j], t per lane (e^{i*pi*j/64} or e^{3i*pi*j/64}, both / 16384);  m = v * (c, c);  r = (v.y, v.x) * (-s, s) + m
-      float ox[32], oy[32];
-      sfor<0, 8>([&](auto Ci) NF2_LAMBDA {
-        constexpr int c = decltype(Ci)::value;
-        if constexpr (c + 1 < 8) {
-          tw_issue(std::integral_constant<int, c + 1>{});
-          wait_lgkm<2>();
-        } else {
-          wait_lgkm<0>();
-        }
-        sfor<0, 2>([&](auto Ui) NF2_LAMBDA {
-          constexpr int j0 = TCH * c + 2 * decltype(Ui)::value, j1 = j0 + 1;
-          cf m0, m1, r0, r1;
-          const cf V0 = v[j0], V1 = v[j1], T0 = tq[c & 1][j0 % TCH], T1 = tq[c & 1][j1 % TCH];
-          asm volatile("v_pk_mul_f32 %0, %4, %6 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
-                       "v_pk_mul_f32 %1, %5, %7 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
-                       "v_pk_fma_f32 %2, %4, %6, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]\n\t"
-                       "v_pk_fma_f32 %3, %5, %7, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]"
-                       : "=&v"(m0), "=&v"(m1), "=&v"(r0), "=&v"(r1) : "v"(V0), "v"(V1), "v"(T0), "v"(T1));
-          ox[j0] = r0.x; oy[j0] = r0.y;
-          ox[j1] = r1.x; oy[j1] = r1.y;
-        });
-      });
-      // cross-half sum: after the swaps register k holds the even-bin parts of outputs k (lanes < 32) and k + 16 (lanes
-      // >= 32), register k + 16 the odd-bin parts of the same two; j = 31 is a by-product that is never stored.
-      // (v_permlane32_swap needs 2 wait states after a VALU write of its operands: the swaps start with the oldest.)
-      sfor<0, 16>([&](auto Ki) NF2_LAMBDA {
-        constexpr int kk = decltype(Ki)::value;
-        half_swap2(ox[kk], ox[kk + 16], oy[kk], oy[kk + 16]);
-      });
-      sfor<0, 16>([&](auto Ki) NF2_LAMBDA {
-        constexpr int kk = decltype(Ki)::value;
-        add2(ox[kk], oy[kk], ox[kk + 16], oy[kk + 16]);
-      });
-      sfor<0, 7>([&](auto Ki) NF2_LAMBDA {
-        constexpr int kk = 2 * decltype(Ki)::value;
-        lw2x32<kk, kk + 1>(a_ow, ox[kk], ox[kk + 1]);
-        lw2x32<kk, kk + 1>(a_owB, oy[kk], oy[kk + 1]);
-      });
-      lw32<14 * 4>(a_ow, ox[14]);
-      lw32<14 * 4>(a_owB, oy[14]);
-      lw32<15 * 4>(a_o15, ox[15]);
-      lw32<15 * 4>(a_o15B, oy[15]);
-    }
-
-    NFFT_DBG_MARK(11)
-    // ---- results: one contiguous 8-byte-aligned range per pair (both planes exist for every pair given to this kernel)
-    {
-      cf* o2 = reinterpret_cast<cf*>(out + (long long)p * (2 * OPL));
-      cf w[16];
-      sfor<0, 16>([&](auto Qi) NF2_LAMBDA { constexpr int q = decltype(Qi)::value; w[q] = lr64<q * 512>(a_col); });
-      wait_lgkm<0>();
-      NFFT_DBG_MARK(12)
-      wait_vm0();  // the next pair's loads (issued most of an iteration ago) have landed; the stores below stay in flight
-      sfor<0, 16>([&](auto Qi) NF2_LAMBDA {
-        constexpr int q = decltype(Qi)::value;
-        cf wq = w[q];
-        asm volatile("" : "+v"(wq));  // consumed only after the wait
-        if (lane + 64 * q < OPL) o2[lane + 64 * q] = wq;
-      });
-      NFFT_DBG_MARK(13)
-      NFFT_DBG_ITER()
-    }
-  }
-  NFFT_DBG_END()
-}
-
 // =======================================================================================
 // v4: v2 on the TRANSPOSED problem ("column first"): see the comment at its loads.  Same passes, same arithmetic per plane
 // pair up to the transposition (the summation order inside a plane differs from v2's: row and column transforms swap).
@@ -1115,7 +720,7 @@ __global__ __launch_bounds__(64 * WPG) void xcorr_north_fft4_kernel(const float*
     if (worker == tail_worker) north_fft_v1_body(smem, x, k, out, planes, npairs, 0, 1, tab, lane);
     return;  // (a surplus wave of the last workgroup)
   }
-#ifdef NF4_EXP_SOLO   // measurement only: NF4_EXP_SOLO of a workgroup's 4 waves work, the others leave (their pairs are skipped)
+#if defined(HDN_ABLATION) && defined(NF4_EXP_SOLO)   // measurement build only   // measurement only: NF4_EXP_SOLO of a workgroup's 4 waves work, the others leave (their pairs are skipped)
   if (wave >= NF4_EXP_SOLO) return;
 #endif
   const uint32_t sb = lds_addr(smem);
@@ -1473,448 +1078,6 @@ __global__ __launch_bounds__(64 * WPG) void xcorr_north_fft4_kernel(const float*
     NFFT_DBG_ITER()
   }
   NFFT_DBG_END()
-}
-
-
-// =======================================================================================
-// v3: the same transform with HALF the LDS image, so that two waves fit a SIMD (one wave alone cannot issue a packed op
-// every 4 clocks and exposes every LDS turn-around: profiles/round1_ubench_issue_rate.txt).  The pair of planes is
-// still packed into one complex signal for the ROW passes, but the column passes run one PLANE at a time: 64 lanes =
-// 32 half-bin columns x the two halves of a column's 64 bins (DIF split: lane (c, h) transforms
-// (a_r + s_h a_{r+32}) * tw_h(r), tw_0 = 1, tw_1 = w64^r, with a 32-point FFT and ends with bins 2g + h).  The LDS image
-// is 61 x 32 complex (16 KB), a lane holds 32 bins per plane (64 registers), nothing is prefetched in registers (the
-// second wave of the SIMD hides the loads), the whole kernel stays under 256 registers.  The inverse column pass is the
-// mirror image (DIT: each lane inverts its 32 bins; the ROW lanes combine E'[r] + w64^r O'[r] while they read).
-// Requires planes % 4 == 0 (aligned tensor ends); everything else goes to v2.
-// =======================================================================================
-namespace nf3 {
-using namespace nf2;
-typedef float f3v __attribute__((ext_vector_type(3)));
-constexpr int RSX = 33, RSK = 65;            // row strides (complex): x spectrum of ONE plane; raw kernel spectrum / inverse rows
-constexpr int T_BYTES = 16128;               // >= 61*33*8, 31*65*8, 15*1024 (one staged plane)
-constexpr int LDS_BYTES = T_BYTES;
-constexpr int NF3_WAVE_LDS = (T_BYTES + 255) / 256 * 256;  // one worker's image inside a multi-wave workgroup
-constexpr int PQ = 15;                       // 16-byte chunks per lane of one staged x plane
-
-template <int OFF>
-NF_DEV void gload128(f4v& v, uint32_t voff, const void* sbase) {
-  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(v) : "v"(voff), "s"(sbase), "n"(OFF));
-}
-template <int OFF>
-NF_DEV void gload96(f3v& v, uint32_t voff, const void* sbase) {
-  asm volatile("global_load_dwordx3 %0, %1, %2 offset:%3" : "=v"(v) : "v"(voff), "s"(sbase), "n"(OFF));
-}
-template <int OFF>
-NF_DEV void lw128(uint32_t a, const f4v& v) { asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(a), "v"(v), "n"(OFF)); }
-template <int CNT>
-NF_DEV void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT)); }
-
-// c * t, both per lane
-NF_DEV cf cmul_vv(cf c, cf t) {
-  cf m, r;
-  asm volatile("v_pk_mul_f32 %0, %2, %3 op_sel_hi:[1,0]\n\t"
-               "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
-               : "=&v"(m), "=&v"(r) : "v"(c), "v"(t));
-  return r;
-}
-// e + w * o, w per lane
-NF_DEV cf axpy_c(cf e, cf o, cf w) {
-  cf r;
-  asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]\n\t"
-               "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
-               : "=&v"(r) : "v"(o), "v"(w), "v"(e));
-  return r;
-}
-
-// t * (h ? w64^R : 1) without a per-lane table: t + hm * (t * (w64^R - 1)) with the lane mask hm = (h, h) and the
-// wave-uniform constant (w64^R - 1) from the twiddle table (one more packed op instead of one more LDS read).
-template <int R>
-NF_DEV cf dif_twiddle(cf t, cf hm) {
-  constexpr Tw w = tw(-2 * R);
-  const cf T = tconst<false, w.c>();
-  // d = t * w  (as cmul_tw), then r = t + hm * (d - t) = fma(hm, d, fma(-hm, t, t))
-  cf m, d, r;
-  asm volatile("v_pk_mul_f32 %0, %3, %4 op_sel:[0,%5] op_sel_hi:[1,%5] neg_lo:[0,%7] neg_hi:[0,%7]\n\t"
-               "v_pk_fma_f32 %1, %3, %4, %0 op_sel:[1,%6,0] op_sel_hi:[0,%6,1] neg_lo:[0,%9,0] neg_hi:[0,%8,0]\n\t"
-               "v_pk_fma_f32 %2, %10, %3, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-               "v_pk_fma_f32 %2, %10, %1, %2"
-               : "=&v"(m), "=&v"(d), "=&v"(r)
-               : "v"(t), "s"(T), "n"(w.hr), "n"(w.hi), "n"(w.nr), "n"(w.ni), "n"(1 - w.ni), "v"(hm));
-  return r;
-}
-
-// Forward column pass of one plane: reads T[r][c] (stride RSX) for r < NR, optional split p +- conj q (kernel: SPLIT = +1/-1
-// on the raw spectrum with stride RSK, q from the mirrored column), DIF fold, per-lane twiddle, 32-point FFT.
-// X[g] = bin 2g + h on exit.
-template <int NR, int SPLIT>
-NF_DEV void column_pass(cf (&X)[32], uint32_t a_p, uint32_t a_q, cf hm, cf sg) {
-  constexpr int STRIDE = (SPLIT == 0 ? RSX : RSK) * 8;
-  constexpr int CH = 8, NCH = 32 / CH;     // rows r and r + 32 (or p, q) in chunks of 8, two chunks in flight (<= 15 reads each)
-  cf lo[2][CH], hi[2][CH];
-  auto second = [](int r) constexpr -> bool { return SPLIT == 0 ? (r + 32 < NR) : (r < NR); };
-  auto issue = [&](auto Ci) NF2_LAMBDA {
-    constexpr int c = decltype(Ci)::value;
-    sfor<0, CH>([&](auto Ri) NF2_LAMBDA {
-      constexpr int r = c * CH + decltype(Ri)::value;
-      if constexpr (r < NR) lo[c & 1][r - c * CH] = lr64<r * STRIDE>(a_p);
-      if constexpr (SPLIT == 0) {
-        if constexpr (r + 32 < NR) hi[c & 1][r - c * CH] = lr64<(r + 32) * STRIDE>(a_p);
-      } else {
-        if constexpr (r < NR) hi[c & 1][r - c * CH] = lr64<r * STRIDE>(a_q);
-      }
-    });
-  };
-  auto reads_in = [second](int c) constexpr -> int {  // LDS reads issued for chunk c
-    int n = 0;
-    for (int i = 0; i < CH; ++i) {
-      const int r = c * CH + i;
-      if (r < NR) ++n;
-      if (second(r)) ++n;
-    }
-    return n;
-  };
-  NF3_PRIO_MEM();
-  issue(std::integral_constant<int, 0>{});
-  sfor<0, NCH>([&](auto Ci) NF2_LAMBDA {
-    constexpr int c = decltype(Ci)::value;
-    constexpr int nxt = (c + 1 < NCH) ? reads_in(c + 1) : 0;
-    if constexpr (c + 1 < NCH) issue(std::integral_constant<int, c + 1>{});
-    wait_lgkm<(nxt < 15 ? nxt : 15)>();   // (16 reads in flight: the counter saturates at 15, one read early is harmless
-    if constexpr (nxt > 15) wait_lgkm<15>();  //  because the chunk being waited for is older)
-    sfor<0, CH>([&](auto Ri) NF2_LAMBDA {
-      constexpr int r = c * CH + decltype(Ri)::value;
-      if constexpr (r < NR) {
-        cf t = lo[c & 1][r - c * CH];
-        if constexpr (SPLIT == 0) {
-          if constexpr (r + 32 < NR) {
-            const cf b2 = hi[c & 1][r - c * CH], sgl = sg;
-            asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(t) : "v"(b2), "v"(sgl));  // a_r +- a_{r+32}
-          }
-        } else {
-          const cf q = hi[c & 1][r - c * CH];
-          if constexpr (SPLIT > 0) asm volatile("v_pk_add_f32 %0, %0, %1 neg_hi:[0,1]" : "+v"(t) : "v"(q));   // p + conj q
-          else asm volatile("v_pk_add_f32 %0, %0, %1 neg_lo:[0,1]" : "+v"(t) : "v"(q));                        // p - conj q
-        }
-        if constexpr (r > 0) t = dif_twiddle<r>(t, hm);
-        X[bitrev(r, 5)] = t;
-      } else {
-        X[bitrev(r, 5)] = cf{0.f, 0.f};  // (only r = 31 of the kernel; the pruned FFT does not read it)
-      }
-    });
-  });
-  NF3_PRIO_ALU();
-  fft<5, -1, (NR < 32 ? NR : 32), 32>(X);
-}
-
-}  // namespace nf3
-
-// WPG autonomous waves per workgroup, as for the v2 kernel: 8 = two per SIMD by construction.
-template <int WPG>
-__global__ __launch_bounds__(64 * WPG, WPG == 1 ? 2 : 1) void xcorr_north_fft3_kernel(const float* __restrict__ x,
-                                                                                      const float* __restrict__ k,
-                                                                                      float* __restrict__ out, int npairs, int planes,
-                                                                                      const nfft::cf* __restrict__ tab) {
-  using namespace nf3;
-  extern __shared__ __align__(16) float smem_wg[];
-  const int wave = WPG == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: an SGPR
-  float* const smem = smem_wg + wave * (NF3_WAVE_LDS / 4);
-  const int worker = (int)blockIdx.x * WPG + wave, nworkers = (int)gridDim.x * WPG;
-  const int lane = threadIdx.x & 63;
-  const uint32_t sb = lds_addr(smem);
-  const int c = lane & 31, h = lane >> 5;
-  const float sgn = h ? -1.f : 1.f;
-  const cf sg = {sgn, sgn};
-  const cf hm = {(float)h, (float)h};  // lane mask of the odd-bin half
-  const int rrow = lane < HO ? lane : HO - 1;
-  const cf wrow = tab[NFFT_TAB_TAU + 2 * rrow];  // w64^{-r} = e^{+2*pi*i*r/64}: the inverse column combine of row r
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-
-  const uint32_t a_stash = sb + lane * 16;
-  const uint32_t a_rowx = sb + lane * (RSX * 8);           // x spectrum row `lane`, one plane
-  const uint32_t a_rowk = sb + lane * (RSK * 8);           // raw kernel spectrum row / inverse row `lane`
-  const uint32_t a_colx = sb + c * 8;                      // x spectrum column c
-  const uint32_t a_kp = sb + c * 8, a_kq = sb + (63 - c) * 8;
-  const uint32_t a_lane = sb + lane * 8;                   // column `lane` of a 64-wide image / linear 8-byte words
-  const uint32_t a_rowo = sb + rrow * (RSK * 8);
-  const uint32_t a_out = sb + lane * (HO * 4);
-  const long long xlast = ((long long)planes * XPL - 4) * 4;
-
-  NFFT_DBG_BEGIN(worker)
-  for (int p = worker; p < npairs; p += nworkers) {
-    // ---- the two search planes: coalesced 16-byte chunks of each plane's aligned window (clamped at the tensor end)
-    NF3_PRIO_MEM();
-    f4v RA[PQ], RB[PQ];
-    const long long baseA = (long long)(2 * p) * XPL, baseB = baseA + XPL;
-    const long long firstA = baseA & ~3LL, firstB = baseB & ~3LL;
-    const int offA = (int)(baseA - firstA), offB = (int)(baseB - firstB);
-    {
-      const long long cap32 = 0xffffff00LL;  // (voff is 32-bit; a window that far from the end is never clamped)
-      const uint32_t limA = (uint32_t)min(xlast - firstA * 4, cap32), limB = (uint32_t)min(xlast - firstB * 4, cap32);
-      sfor<0, PQ>([&](auto Qi) NF2_LAMBDA {
-        constexpr int q = decltype(Qi)::value;
-        gload128<0>(RA[q], min((uint32_t)(lane * 16 + q * 1024), limA), x + firstA);
-      });
-      sfor<0, PQ>([&](auto Qi) NF2_LAMBDA {
-        constexpr int q = decltype(Qi)::value;
-        gload128<0>(RB[q], min((uint32_t)(lane * 16 + q * 1024), limB), x + firstB);
-      });
-    }
-    cf X[2][32];  // spectra of the two planes: [plane][g] = bin 2g + h of column c
-    {
-      // ---- row pass: lane = row of the PAIR (plane A real part, plane B imaginary part), as in v2
-      const int rr = lane < HX ? lane : HX - 1;
-      cf ra[31], rb[31];
-      wait_vm<PQ>();  // plane A has landed (loads return in order)
-      sfor<0, PQ>([&](auto Qi) NF2_LAMBDA { constexpr int q = decltype(Qi)::value; lw128<q * 1024>(a_stash, RA[q]); });
-      {
-        const uint32_t aA = sb + (offA + rr * HX) * 4;
-        sfor<0, 31>([&](auto Mi) NF2_LAMBDA { constexpr int m = decltype(Mi)::value; ra[m] = lr2x32<2 * m, 2 * m + 1>(aA); });
-      }
-      wait_vm<0>();
-      sfor<0, PQ>([&](auto Qi) NF2_LAMBDA { constexpr int q = decltype(Qi)::value; lw128<q * 1024>(a_stash, RB[q]); });
-      {
-        const uint32_t aB = sb + (offB + rr * HX) * 4;
-        sfor<0, 31>([&](auto Mi) NF2_LAMBDA { constexpr int m = decltype(Mi)::value; rb[m] = lr2x32<2 * m, 2 * m + 1>(aB); });
-      }
-      wait_lgkm<0>();
-      NF3_PRIO_ALU();
-      cf v[64];
-      sfor<0, 31>([&](auto Mi) NF2_LAMBDA {
-        constexpr int j = 2 * decltype(Mi)::value;
-        cf lo, hi;
-        const cf A = ra[j / 2], B = rb[j / 2];
-        twiddle_in2<-j, -(j + 1), (j + 1 < HX)>(A, B, lo, hi);
-        v[bitrev(j, 6)] = lo;
-        if constexpr (j + 1 < HX) v[bitrev(j + 1, 6)] = hi;
-      });
-      fft<6, -1, HX, 64>(v);
-      NF3_PRIO_MEM();
-      cf sbp[32];  // plane B's half waits in registers while plane A's goes through the column pass
-      sfor<0, 16>([&](auto F) NF2_LAMBDA {
-        constexpr int f = 2 * decltype(F)::value;
-        cf sa0, sa1, sb0, sb1;
-        const cf p0 = v[f], q0 = v[63 - f], p1 = v[f + 1], q1 = v[62 - f];
-        asm volatile("v_pk_add_f32 %0, %4, %5 neg_hi:[0,1]\n\tv_pk_add_f32 %1, %6, %7 neg_hi:[0,1]\n\t"
-                     "v_pk_add_f32 %2, %4, %5 neg_lo:[0,1]\n\tv_pk_add_f32 %3, %6, %7 neg_lo:[0,1]"
-                     : "=&v"(sa0), "=&v"(sa1), "=&v"(sb0), "=&v"(sb1) : "v"(p0), "v"(q0), "v"(p1), "v"(q1));
-        sbp[f] = sb0;
-        sbp[f + 1] = sb1;
-        if (lane < HX) lw2x64<f, f + 1>(a_rowx, sa0, sa1);
-      });
-      column_pass<HX, 0>(X[0], a_colx, 0, hm, sg);
-      NF3_PRIO_MEM();
-      if (lane < HX) {
-        sfor<0, 16>([&](auto F) NF2_LAMBDA { constexpr int f = 2 * decltype(F)::value; lw2x64<f, f + 1>(a_rowx, sbp[f], sbp[f + 1]); });
-      }
-    }
-    column_pass<HX, 0>(X[1], a_colx, 0, hm, sg);
-
-    // ---- kernel row pass: lane = row of the pair, rows straight from global memory (31 floats, dword aligned),
-    //      pruned halves (even / odd bins), raw spectrum to LDS
-    {
-      const int rk = lane < HK ? lane : HK - 1;
-      const float* kpair = k + (long long)(2 * p) * KPL;
-      const uint32_t vA = rk * (HK * 4), vB = vA + KPL * 4;
-      sfor<0, 2>([&](auto Hf) NF2_LAMBDA {
-        constexpr int half = decltype(Hf)::value;
-        constexpr int mul = half ? 3 : 1;
-        cf v[32];
-        f4v a0, a1, a2, a3, b0, b1, b2, b3;
-        NF3_PRIO_MEM();
-        gload128<0>(a0, vA, kpair); gload128<16>(a1, vA, kpair); gload128<32>(a2, vA, kpair); gload128<48>(a3, vA, kpair);
-        gload128<0>(b0, vB, kpair); gload128<16>(b1, vB, kpair); gload128<32>(b2, vB, kpair); gload128<48>(b3, vB, kpair);
-        f4v a4, a5, a6, b4, b5, b6;
-        f3v a7, b7;
-        gload128<64>(a4, vA, kpair); gload128<80>(a5, vA, kpair); gload128<96>(a6, vA, kpair); gload96<112>(a7, vA, kpair);
-        gload128<64>(b4, vB, kpair); gload128<80>(b5, vB, kpair); gload128<96>(b6, vB, kpair); gload96<112>(b7, vB, kpair);
-        wait_vm<8>();
-        NF3_PRIO_ALU();
-        auto tw4 = [&](auto J, const f4v& fa, const f4v& fb) NF2_LAMBDA {
-          constexpr int j = decltype(J)::value;
-          cf l0, h0, l1, h1;
-          twiddle_in2<-mul * j, -mul * (j + 1), true>(cf{fa.x, fa.y}, cf{fb.x, fb.y}, l0, h0);
-          twiddle_in2<-mul * (j + 2), -mul * (j + 3), true>(cf{fa.z, fa.w}, cf{fb.z, fb.w}, l1, h1);
-          v[bitrev(j, 5)] = l0; v[bitrev(j + 1, 5)] = h0; v[bitrev(j + 2, 5)] = l1; v[bitrev(j + 3, 5)] = h1;
-        };
-        tw4(std::integral_constant<int, 0>{}, a0, b0);
-        tw4(std::integral_constant<int, 4>{}, a1, b1);
-        tw4(std::integral_constant<int, 8>{}, a2, b2);
-        tw4(std::integral_constant<int, 12>{}, a3, b3);
-        wait_vm<0>();
-        tw4(std::integral_constant<int, 16>{}, a4, b4);
-        tw4(std::integral_constant<int, 20>{}, a5, b5);
-        tw4(std::integral_constant<int, 24>{}, a6, b6);
-        {
-          cf l0, h0, l1, h1;
-          twiddle_in2<-mul * 28, -mul * 29, true>(cf{a7.x, a7.y}, cf{b7.x, b7.y}, l0, h0);
-          twiddle_in2<-mul * 30, -mul * 31, false>(cf{a7.z, a7.z}, cf{b7.z, b7.z}, l1, h1);
-          v[bitrev(28, 5)] = l0; v[bitrev(29, 5)] = h0; v[bitrev(30, 5)] = l1;
-        }
-        fft<5, -1, HK, 32>(v);
-        NF3_PRIO_MEM();
-        if (lane < HK) {
-          sfor<0, 16>([&](auto Gi) NF2_LAMBDA {
-            constexpr int g = 2 * decltype(Gi)::value;
-            lw2x64<2 * g + half, 2 * g + 2 + half>(a_rowk, v[g], v[g + 1]);
-          });
-        }
-      });
-    }
-
-    // ---- kernel column passes (split while reading) and products, one plane at a time from the same raw spectrum
-    {
-      cf K[32];
-      column_pass<HK, +1>(K, a_kp, a_kq, hm, sg);
-      sfor<0, 16>([&](auto Gi) NF2_LAMBDA {
-        constexpr int g0 = 2 * decltype(Gi)::value, g1 = g0 + 1;
-        cf m0, m1;
-        cf x0 = X[0][g0], x1 = X[0][g1];
-        const cf k0 = K[g0], k1 = K[g1];
-        asm volatile("v_pk_mul_f32 %0, %2, %4 op_sel_hi:[1,0]\n\tv_pk_mul_f32 %1, %3, %5 op_sel_hi:[1,0]\n\t"
-                     "v_pk_fma_f32 %2, %2, %4, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]\n\t"
-                     "v_pk_fma_f32 %3, %3, %5, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
-                     : "=&v"(m0), "=&v"(m1), "+v"(x0), "+v"(x1) : "v"(k0), "v"(k1));
-        X[0][g0] = x0; X[0][g1] = x1;
-      });
-      column_pass<HK, -1>(K, a_kp, a_kq, hm, sg);
-      sfor<0, 16>([&](auto Gi) NF2_LAMBDA {
-        constexpr int g0 = 2 * decltype(Gi)::value, g1 = g0 + 1;
-        cf m0, m1;
-        cf x0 = X[1][g0], x1 = X[1][g1];
-        const cf k0 = K[g0], k1 = K[g1];
-        asm volatile("v_pk_mul_f32 %0, %2, %4 op_sel_hi:[1,0]\n\tv_pk_mul_f32 %1, %3, %5 op_sel_hi:[1,0]\n\t"
-                     "v_pk_fma_f32 %2, %2, %4, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]\n\t"
-                     "v_pk_fma_f32 %3, %3, %5, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
-                     : "=&v"(m0), "=&v"(m1), "+v"(x0), "+v"(x1) : "v"(k0), "v"(k1));
-        X[1][g0] = x0; X[1][g1] = x1;
-      });
-    }
-
-    // ---- inverse column passes: each lane inverts its 32 bins (DIT halves E', O'); the row lanes combine while reading
-    cf Y[2][32];
-    sfor<0, 2>([&](auto Pl) NF2_LAMBDA {
-      constexpr int pl = decltype(Pl)::value;
-      {
-        cf V[32];
-        sfor<0, 32>([&](auto G) NF2_LAMBDA { constexpr int g = decltype(G)::value; V[bitrev(g, 5)] = X[pl][g]; });
-        NF3_PRIO_ALU();
-        fft<5, +1, 32, HO>(V);
-        NF3_PRIO_MEM();
-        sfor<0, HO>([&](auto R) NF2_LAMBDA { constexpr int r = decltype(R)::value; lw64<r * RSK * 8>(a_lane, V[r]); });
-      }
-      // row lane r: Y(r, c) = E'[r][c] + w64^{-r} O'[r][c], columns in chunks of 8
-      sfor<0, 4>([&](auto Cc) NF2_LAMBDA {
-        constexpr int c0 = 8 * decltype(Cc)::value;
-        cf e[8], o[8];
-        sfor<0, 8>([&](auto I) NF2_LAMBDA { constexpr int i = decltype(I)::value; lr2x64<c0 + i, 32 + c0 + i>(a_rowo, e[i], o[i]); });
-        wait_lgkm<0>();
-        sfor<0, 8>([&](auto I) NF2_LAMBDA { constexpr int i = decltype(I)::value; Y[pl][c0 + i] = axpy_c(e[i], o[i], wrow); });
-      });
-    });
-
-    // ---- inverse row pass (as v2): Hermitian re-packing of the pair, FFT, un-shift e^{+i*pi*j/64} / 16384
-    {
-      cf v[64];
-      sfor<0, 32>([&](auto F) NF2_LAMBDA {
-        constexpr int f = decltype(F)::value;
-        cf c0, c1;
-        const cf ya = Y[0][f], yb = Y[1][f];
-        asm volatile("v_pk_add_f32 %0, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
-                     "v_pk_add_f32 %1, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]"
-                     : "=&v"(c0), "=&v"(c1) : "v"(ya), "v"(yb));
-        v[bitrev(f, 6)] = c0;
-        v[bitrev(63 - f, 6)] = c1;
-      });
-      NF3_PRIO_ALU();
-      fft<6, +1, 64, HO>(v);
-      NF3_PRIO_MEM();
-      if (lane < HO) {
-        sfor<0, 16>([&](auto Ji) NF2_LAMBDA {
-          constexpr int j = 2 * decltype(Ji)::value;
-          const cf o0 = cmul_tw<j, true>(v[j]);
-          if constexpr (j + 1 < HO) {
-            const cf o1 = cmul_tw<j + 1, true>(v[j + 1]);
-            lw2x32<j, j + 1>(a_out, o0.x, o1.x);
-            lw2x32<j, j + 1>(a_out + OPL * 4, o0.y, o1.y);
-          } else {
-            lw32<j * 4>(a_out, o0.x);
-            lw32<(OPL + j) * 4>(a_out, o0.y);
-          }
-        });
-      }
-    }
-    {
-      cf* o2 = reinterpret_cast<cf*>(out + (long long)p * (2 * OPL));
-      cf w[16];
-      sfor<0, 16>([&](auto Qi) NF2_LAMBDA { constexpr int q = decltype(Qi)::value; w[q] = lr64<q * 512>(a_lane); });
-      wait_lgkm<0>();
-      sfor<0, 16>([&](auto Qi) NF2_LAMBDA {
-        constexpr int q = decltype(Qi)::value;
-        cf wq = w[q];
-        asm volatile("" : "+v"(wq));
-        if (lane + 64 * q < OPL) o2[lane + 64 * q] = wq;
-      });
-    }
-  }
-  NFFT_DBG_END()
-}
-
-int launch_north_fft3(const float* x, const float* k, float* out, int planes, int max_blocks, hipStream_t stream) {
-  const nfft::cf* tab = north_fft_table();
-  if (!tab) return -(1000 + (int)hipErrorInvalidSymbol);
-  const int npairs = planes / 2;
-  const int workers = npairs < max_blocks ? npairs : max_blocks;
-  static PerDeviceOnce attr;
-  const int dev_ = PerDeviceOnce::device();
-  if (!attr.done(dev_)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xcorr_north_fft3_kernel<8>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 8 * nf3::NF3_WAVE_LDS);
-    if (e != hipSuccess) return -(1000 + (int)e);
-    attr.set(dev_);
-  }
-  hipLaunchKernelGGL(xcorr_north_fft3_kernel<8>, dim3((workers + 7) / 8), dim3(512), 8 * nf3::NF3_WAVE_LDS, stream, x, k, out,
-                     npairs, planes, tab);
-  hipError_t e = hipGetLastError();
-  return e == hipSuccess ? HDN_OK : -(1000 + (int)e);
-}
-
-// Pairs whose load windows stay inside the tensors and whose two planes exist: those go to the v2 kernel.
-static int north_fft_full_pairs(int planes) {
-  const long long xtotal = (long long)planes * nfft::XPL, ktotal = (long long)planes * nfft::KPL;
-  int n = planes / 2;
-  while (n > 0) {
-    const long long xf = ((long long)(n - 1) * 2 * nfft::XPL) & ~3LL, kf = ((long long)(n - 1) * 2 * nfft::KPL) & ~3LL;
-    if (xf + nfft::XQ * 256 <= xtotal && kf + nfft::KQ * 256 <= ktotal) break;
-    --n;
-  }
-  return n;
-}
-
-int launch_north_fft2(const float* x, const float* k, float* out, int planes, int max_blocks, hipStream_t stream) {
-  const int npairs = (planes + 1) / 2, nfull = north_fft_full_pairs(planes);
-  const nfft::cf* tab = north_fft_table();
-  if (!tab) return -(1000 + (int)hipErrorInvalidSymbol);
-  // planes % 4 == 0: both tensors end on a 16-byte boundary and every plane has a partner: the fast kernel takes every
-  // pair (the last windows are clamped).  Otherwise the pairs from `nfull` on go to one extra, guarded workgroup.
-  const bool all = (planes % 4 == 0) && planes >= 4;
-  const int nfast = all ? npairs : nfull;
-  if (nfast == 0) return launch_north_fft(x, k, out, planes, max_blocks, stream, 0);
-  const int nmain = nfast < max_blocks ? nfast : max_blocks;
-  const int tail_worker = nfast < npairs ? nmain : -1;
-  const int workers = nmain + (tail_worker >= 0 ? 1 : 0);
-  static PerDeviceOnce attr;  // 4 x 31 KB of dynamic LDS needs the opt-in once per device
-  const int dev_ = PerDeviceOnce::device();
-  if (!attr.done(dev_)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xcorr_north_fft2_kernel<4>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 4 * NF2_WAVE_LDS);
-    if (e != hipSuccess) return -(1000 + (int)e);
-    attr.set(dev_);
-  }
-  const int grid = (workers + 3) / 4;
-  hipLaunchKernelGGL(xcorr_north_fft2_kernel<4>, dim3(grid), dim3(256), 4 * NF2_WAVE_LDS, stream, x, k, out, nfast, nmain,
-                     planes, all ? nfull : 0x7fffffff, tail_worker, tab);
-  hipError_t e = hipGetLastError();
-  return e == hipSuccess ? HDN_OK : -(1000 + (int)e);
 }
 
 

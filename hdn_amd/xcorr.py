@@ -140,7 +140,7 @@ def last_variant() -> str:
     return _lib.load().hdn_last_xcorr_variant().decode()
 
 
-NORTH_VARIANTS = {"fftr": 0, "fft": 5, "fftc": 5, "direct": 1, "dense": 2, "mfma": 3, "fft2w": 4}  # HDN_NORTH_* in include/hdn_hip.h
+NORTH_VARIANTS = {"fft": 5, "fftc": 5, "direct": 1}  # HDN_NORTH_* in include/hdn_hip.h
 
 
 class north_variant:

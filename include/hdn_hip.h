@@ -42,23 +42,20 @@ const char* hdn_last_xcorr_variant(void);
 
 /*
  * Kernel used for the 31x31 (x) 61x61 shape (BASELINE north-star shape).  v >= 0 selects it for the whole process,
- * v < 0 only queries; returns the previous value (or HDN_E_LIMIT).  HDN_NORTH_FFT / _2W need 16-byte aligned x / k and
- * 8-byte aligned out and otherwise fall back to HDN_NORTH_DIRECT; HDN_NORTH_FFT_COL (the default) takes any pointers.  All variants meet the same parity bar; they
- * differ in rounding: the direct kernels accumulate each output in one fixed fp32 chain (planes independent), the
- * FFT kernel has a smaller error against float64 but transforms planes in pairs, so a plane's rounding depends on
- * its neighbour's magnitude, and a NaN / Inf anywhere in a plane reaches every output of that plane and of its partner
- * (the direct kernels keep it to the windows that contain it, as the reference does).  For tests, benchmarks and A/B runs.
- * Error class of HDN_NORTH_FFT (measured, post-ReLU N(0,1) data, outputs of O(300)): rms 2.0e-5, max 1.8e-4 ABSOLUTE against
+ * v < 0 only queries; returns the previous value (or HDN_E_LIMIT for a value that is not one of the two below).  Both take any
+ * pointer alignment and meet the same parity bar; they differ in rounding: the direct kernel accumulates each output in one fixed
+ * fp32 chain (planes independent), the FFT kernel has a smaller error against float64 but transforms planes in pairs, so a plane's
+ * rounding depends on its neighbour's magnitude, and a NaN / Inf anywhere in a plane reaches every output of that plane and of its
+ * partner (the direct kernel keeps it to the windows that contain it, as the reference does).  For tests, benchmarks and A/B runs.
+ * Error class of the FFT kernel (measured, post-ReLU N(0,1) data, outputs of O(300)): rms 2.0e-5, max 1.8e-4 ABSOLUTE against
  * float64 — i.e. it does NOT meet 1e-4 abs on the correlation outputs themselves (neither does the reference's own fp32 sum:
  * 1.8e-4); the bound it is held to is |hip - ref| <= 1e-4 + 2e-6 * sum|x*k| and an error against float64 of at most twice the
  * reference's.  The 1e-4 abs of BASELINE's north_star is on the predicted corner offsets, which no correlation feeds.
+ * (Values 0, 2, 3, 4 named four more forms in ABI <= 4 — row-first FFT, dense direct sum, split-bf16 matrix cores, two-waves-per-SIMD
+ * FFT — retired in round 4: none was faster.)
  */
-#define HDN_NORTH_FFT 0          /* 64x64 fp32 FFT per pair of planes, rows first through a 30 KB LDS stash (round 1's default) */
-#define HDN_NORTH_DIRECT 1       /* packed-FMA direct sum, zero taps skipped            */
-#define HDN_NORTH_DIRECT_DENSE 2 /* packed-FMA direct sum, every tap                    */
-#define HDN_NORTH_MFMA 3         /* split-bf16 matrix-core direct sum                   */
-#define HDN_NORTH_FFT_2W 4       /* FFT, 16 KB LDS image, two waves per SIMD (planes % 4 == 0, else as HDN_NORTH_FFT) */
-#define HDN_NORTH_FFT_COL 5      /* (default) the same FFT on the transposed problem: planes go HBM -> registers row by row (no LDS stash, any alignment) */
+#define HDN_NORTH_DIRECT 1       /* packed-FMA direct sum, exact-zero taps skipped */
+#define HDN_NORTH_FFT_COL 5      /* (default) 64x64 fp32 FFT per pair of planes on the transposed problem: planes go HBM -> registers row by row */
 int hdn_xcorr_north_variant(int v);
 
 /*

@@ -1,5 +1,5 @@
-"""--preload hook of tests/test_host_logic.py::test_unchanged_launcher_runs_the_reference_test_script: makes the reference's
-tools/test.py importable in the build container (no cv2 / yacs / GPU there), lets it construct ModelBuilder() and call
+"""--preload hooks of tests/test_host_logic.py::test_unchanged_launcher_runs_the_reference_{test,demo}_script: make the reference's
+tools/test.py / tools/demo.py importable in the build container (no cv2 / yacs / GPU there), lets it construct ModelBuilder() and call
 build_tracker(model) (tools/test.py:65-72), and stops it at the next statement (the dataset, which does not exist here),
 reporting what the model and the tracker were built from.  Not part of the product."""
 import os
@@ -52,3 +52,22 @@ def prepare():
             raise SystemExit(0)
 
     ds.DatasetFactory = _Factory
+
+
+def prepare_demo():
+    """tools/demo.py (:95-106): cfg.merge_from_file, ModelBuilder(), load_pretrain(...).cuda().eval(), build_tracker(model), then its first
+    OpenCV GUI call (cv2.namedWindow, :117) — where this hook reports what was built and stops (no display, no video, no cv2 here)."""
+    prepare()
+    import types
+    cv2 = sys.modules["cv2"]
+    cv2.WND_PROP_FULLSCREEN = 0
+
+    def named_window(*a, **k):
+        import hdn_amd.tracker as T
+        loc = sys._getframe(1).f_locals                       # main()'s locals of tools/demo.py
+        trk, model = loc.get("tracker"), loc.get("model")
+        print("DEMO_REACHED_GUI", type(trk) is T.DeviceTrackerHomo, type(trk.similarity).__name__, trk.net is model.hm_net,
+              trk.model is model, flush=True)
+        raise SystemExit(0)
+
+    cv2.namedWindow = named_window

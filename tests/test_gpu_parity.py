@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden_rng, load_golden, relu_normal
+from conftest import ROOT, golden_rng, load_golden, relu_normal
 from oracle import hdn_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -56,7 +56,7 @@ def check_xcorr(got, x, k, ref, circular, name):
 def test_xcorr_depthwise_golden(dev):
     g = load_golden("xcorr_depthwise")
     seen = set()
-    for variant in ("fft", "fftr", "direct", "dense"):  # only the 31x31 (x) 61x61 fixtures depend on it
+    for variant in ("fft", "direct"):  # only the 31x31 (x) 61x61 fixtures depend on it
         with X.north_variant(variant):
             for n in cases(g):
                 x, k = g[n + "__x"], g[n + "__k"]
@@ -67,7 +67,7 @@ def test_xcorr_depthwise_golden(dev):
                 check_xcorr(y, x, k, g[n + "__y"], False, n + "/" + variant)
     assert X.current_north_variant() == "fft"
     # the fixtures exercise the specialised kernels (both families for the north-star shape) and the generic one
-    assert {"prod_29x29_5x5", "cfg5_35x35_5x5", "north_61x61_31x31", "north_fft_61x61_31x31", "north_fftc_61x61_31x31", "generic_lds"} <= seen, seen
+    assert {"prod_29x29_5x5", "cfg5_35x35_5x5", "north_61x61_31x31", "north_fftc_61x61_31x31", "generic_lds"} <= seen, seen
 
 
 def test_xcorr_depthwise_sampled_full_channel(dev):
@@ -105,11 +105,11 @@ def test_xcorr_ragged_plane_counts_vs_oracle(dev, shape):
     check_xcorr(y, x, k, O.xcorr_depthwise(T(x), T(k)).numpy(), False, str(shape))
 
 
-NORTH_NAME = {"fft": "north_fftc_61x61_31x31", "fftr": "north_fft_61x61_31x31", "direct": "north_61x61_31x31"}
+NORTH_NAME = {"fft": "north_fftc_61x61_31x31", "direct": "north_61x61_31x31"}
 
 
 @pytest.mark.parametrize("planes", [(1, 1), (1, 2), (1, 3), (1, 4), (3, 5), (2, 8), (1, 33), (5, 205), (8, 256)])
-@pytest.mark.parametrize("variant", ["fft", "fftr", "direct"])
+@pytest.mark.parametrize("variant", ["fft", "direct"])
 def test_xcorr_north_plane_counts(dev, planes, variant):
     """31x31 (x) 61x61 for odd / even / tiny plane counts (the FFT kernel works on PAIRS of planes, its last pair(s)
     take a guarded path in an extra workgroup) up to several persistent passes; signed and post-ReLU data."""
@@ -127,26 +127,12 @@ def test_xcorr_north_plane_counts(dev, planes, variant):
         check_xcorr(y, x, k, O.xcorr_depthwise(T(x), T(k)).numpy(), False, f"{planes} {variant} signed={signed}")
 
 
-@pytest.mark.parametrize("planes", [(1, 4), (2, 8), (3, 12), (5, 204), (1, 6)])
-def test_xcorr_north_two_wave_fft_variant(dev, planes):
-    """HDN_NORTH=fft2w: the 16 KB-LDS layout (column passes one plane at a time on lane pairs), two waves per SIMD.
-    Plane counts that are not multiples of 4 fall back to the default FFT kernel."""
-    B, C = planes
-    r = np.random.default_rng(31 * B + C)
-    x, k = relu_normal(r, (B, C, 61, 61)), relu_normal(r, (B, C, 31, 31))
-    with X.north_variant("fft2w"):
-        y = hdn_amd.xcorr_depthwise(T(x).to(dev), T(k).to(dev))
-        assert X.last_variant() == ("north_fft2w_61x61_31x31" if (B * C) % 4 == 0 else "north_fft_61x61_31x31")
-        assert torch.equal(y, hdn_amd.xcorr_depthwise(T(x).to(dev), T(k).to(dev)))
-    check_xcorr(y, x, k, O.xcorr_depthwise(T(x), T(k)).numpy(), False, f"{planes} fft2w")
-
-
 def test_xcorr_north_multi_problem_launch(dev):
     """Several 31x31 (x) 61x61 problems through the multi entry point (the FFT kernel runs them back to back)."""
     r = np.random.default_rng(404)
     xs = [T(relu_normal(r, (2, 9, 61, 61))).to(dev) for _ in range(3)]
     ks = [T(relu_normal(r, (2, 9, 31, 31))).to(dev) for _ in range(3)]
-    for variant in ("fft", "fftr", "direct"):
+    for variant in ("fft", "direct"):
         with X.north_variant(variant):
             outs = hdn_amd.xcorr_depthwise_multi(xs, ks)
             for x, k, o in zip(xs, ks, outs):
@@ -165,7 +151,7 @@ def test_xcorr_north_fft_pair_crosstalk_is_rounding_only(dev):
     truth = O.xcorr_depthwise_f64(x, k)
     mag = O.xcorr_depthwise_f64(np.abs(x), np.abs(k))
     pair_mag = np.maximum(mag[:, 0::2], mag[:, 1::2]).repeat(2, axis=1)  # per pair of planes
-    for variant in ("fft", "fftr"):
+    for variant in ("fft",):
         with X.north_variant(variant):
             y = hdn_amd.xcorr_depthwise(T(x).to(dev), T(k).to(dev)).cpu().numpy()
         assert np.all(np.abs(y - truth) <= 1e-4 + 2e-6 * pair_mag.max(axis=(2, 3), keepdims=True))
@@ -368,7 +354,7 @@ def test_xcorr_full_size_config5(dev):
         assert torch.equal(y2, y)
 
 
-@pytest.mark.parametrize("variant", ["fft", "fftr", "direct"])
+@pytest.mark.parametrize("variant", ["fft", "direct"])
 def test_xcorr_full_size_north_star(dev, variant):
     with X.north_variant(variant):
         _full_size_properties(dev, hdn_amd.xcorr_depthwise, O.xcorr_depthwise, (64, 256, 61, 61), (64, 256, 31, 31), False,
@@ -376,32 +362,24 @@ def test_xcorr_full_size_north_star(dev, variant):
         assert X.last_variant() == NORTH_NAME[variant]
 
 
-def test_xcorr_north_matrix_core_variant(dev):
-    """HDN_NORTH_MFMA=1 selects the split-bf16 MFMA kernel for the 31x31 (x) 61x61 shape (three bf16 pieces per
-    value, six piece products, fp32 accumulate); same parity bar.  The switch is read once per process, so the variant
-    runs in a child process."""
+def test_xcorr_north_variant_switch_rejects_retired_values(dev):
+    """hdn_xcorr_north_variant takes the two kernels that are left (ABI 5); the retired ids of ABI <= 4 come back as HDN_E_LIMIT, and
+    HDN_NORTH=direct in the environment selects the direct kernel for a whole process."""
     import os
     import subprocess
     import sys
-    code = r'''
-import sys, numpy as np, torch
-sys.path.insert(0, "%s"); sys.path.insert(0, "%s/tests")
-import hdn_amd
-from hdn_amd import xcorr as X
-from oracle import hdn_oracle as O
-from test_gpu_parity import check_xcorr
-r = np.random.default_rng(31)
-for B, C in ((1, 4), (3, 5), (2, 64), (5, 205)):  # 1025 planes: more than one persistent pass + a tail
-    x = np.maximum(r.standard_normal((B, C, 61, 61), dtype=np.float32), 0)
-    k = np.maximum(r.standard_normal((B, C, 31, 31), dtype=np.float32), 0)
-    y = hdn_amd.xcorr_depthwise(torch.from_numpy(x).cuda(), torch.from_numpy(k).cuda())
-    assert X.last_variant() == "north_mfma_61x61_31x31", X.last_variant()
-    check_xcorr(y, x, k, O.xcorr_depthwise(torch.from_numpy(x), torch.from_numpy(k)).numpy(), False, "mfma")
-print("VALU_OK")
-''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    env = dict(os.environ, HDN_NORTH_MFMA="1")
-    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
-    assert "VALU_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
+    from hdn_amd import _lib
+    lib = _lib.load()
+    prev = lib.hdn_xcorr_north_variant(-1)
+    for v in (0, 2, 3, 4, 6):
+        assert lib.hdn_xcorr_north_variant(v) == -3
+    assert lib.hdn_xcorr_north_variant(-1) == prev
+    with pytest.raises(ValueError):
+        X.north_variant("mfma")
+    code = ("import sys; sys.path.insert(0, %r); import torch, hdn_amd; from hdn_amd import xcorr as X; "
+            "y = hdn_amd.xcorr_depthwise(torch.rand(1, 4, 61, 61).cuda(), torch.rand(1, 4, 31, 31).cuda()); print(X.last_variant())") % ROOT
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, HDN_NORTH="direct"))
+    assert res.stdout.strip().endswith("north_61x61_31x31"), res.stdout[-500:] + res.stderr[-1500:]
 
 
 def test_xcorr_full_size_circular(dev):

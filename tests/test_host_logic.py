@@ -400,6 +400,28 @@ def test_unchanged_launcher_runs_the_reference_test_script():
     assert r.returncode == 0
 
 
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference tree only exists in the build container")
+def test_unchanged_launcher_runs_the_reference_demo_script():
+    """python -m hdn_amd.run /root/reference/tools/demo.py ...: the reference's demo (tools/demo.py:95-106,168,172), byte for byte,
+    up to its first OpenCV GUI call: the model it constructs carries the rebound modules and build_tracker(model) hands it the
+    device-resident tracker (whose init / track_new it calls at :168 / :172 with the signatures hdn_amd.tracker keeps)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "tests")]))
+    r = subprocess.run([sys.executable, "-m", "hdn_amd.run", "--no-build", "--preload", "launcher_preload:prepare_demo",
+                        "/root/reference/tools/demo.py", "--snapshot", "/nonexistent/model.pth", "--video", "/nonexistent/clip.mp4",
+                        "--config", "/root/reference/experiments/tracker_homo_config/proj_e2e_GOT_unconstrained_v2.yaml"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd="/tmp")
+    assert "LAUNCHER_REACHED_LOAD_PRETRAIN True True True True" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "DEMO_REACHED_GUI True DeviceSimilarity True True" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.returncode == 0
+    # the calls demo.py makes on the tracker exist with its argument lists (:168 init(frame, bbox, rect, points, first_point), :172 track_new(idx, frame))
+    import inspect
+    from hdn_amd.tracker import DeviceTrackerHomo
+    assert list(inspect.signature(DeviceTrackerHomo.init).parameters)[1:6] == ["img", "bbox", "poly", "gt_points", "first_point"]
+    assert list(inspect.signature(DeviceTrackerHomo.track_new).parameters)[1:3] == ["fr_idx", "img"]
+
+
 def test_launcher_argument_errors():
     from hdn_amd import run
     for argv in ([], ["--bogus", "x.py"], ["/nonexistent/script.py"], ["--reference-root"]):

@@ -41,7 +41,7 @@ def check(got, x, k, circular, tag):
 
 
 shapes = [(61, 31, False), (29, 5, False), (35, 5, False), (13, 13, True), (None, None, False), (None, None, True)]
-variants = ["fft", "fftr", "fft2w", "direct", "dense"]
+variants = ["fft", "direct"]
 only_fft = os.environ.get("FUZZ_FFT") == "1"  # aligned 31x31 (x) 61x61 problems on the two FFT kernels only
 if only_fft:
     shapes, variants = shapes[:1], variants[:3]

@@ -44,8 +44,9 @@ def seeded_net(fc_bias_scale=1.0):
 
 
 # --------------------------------------------------------------------------------------------------- timing helpers
-def graph_ms(fn, reps=200, warm=3):
-    """fn() captured as ONE hipGraph (static inputs), replayed `reps` times back to back: mean ms per replay."""
+def graph_ms(fn, reps=20, warm=3, inner=10):
+    """fn() captured `inner` times back to back in ONE hipGraph (static inputs), replayed `reps` times: mean ms per fn().  (A
+    replay has a fixed cost of ~10 us on this stack whatever the graph holds: one fn() per graph would put it into every row.)"""
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -54,8 +55,8 @@ def graph_ms(fn, reps=200, warm=3):
     torch.cuda.current_stream().wait_stream(side)
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
-        keep = fn()
-    for _ in range(5):
+        keep = [fn() for _ in range(inner)]
+    for _ in range(3):
         g.replay()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); a.record()
@@ -63,7 +64,7 @@ def graph_ms(fn, reps=200, warm=3):
         g.replay()
     b.record(); torch.cuda.synchronize()
     del keep
-    return a.elapsed_time(b) / reps
+    return a.elapsed_time(b) / (reps * inner)
 
 
 def stream_loop(new_tracker, frames, sync, graph=False, warm=6):
@@ -109,9 +110,9 @@ def build_production_model(frames, init, dev, nchw=False, instance_size=255, cro
     return twin, cpu_twin_src
 
 
-def component_table(trk, frame_u8, reps=200):
+def component_table(trk, frame_u8, reps=20):
     """Every stage of DeviceTrackerHomo's frame body as its own hipGraph on static inputs (the outputs of the stages before it,
-    computed once), replayed `reps` times: (name, ms, owner) rows.  owner: 'hip' = hand-written kernels of this repo only,
+    computed once; 10 executions per graph, see graph_ms), replayed `reps` times: (name, ms, owner) rows.  owner: 'hip' = hand-written kernels of this repo only,
     'rocm' = PyTorch-ROCm / MIOpen / hipBLASLt only, 'mixed' = the packed heads (library convolutions + matrix products around the
     HIP correlation launch; the correlation launch is timed again on its own in the row below each head)."""
     from hdn_amd.refine import homo_refine
