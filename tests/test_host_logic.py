@@ -430,7 +430,7 @@ def test_launcher_argument_errors():
         assert e.value.code == 2
 
 
-@pytest.mark.parametrize("name", ["round1_bench_line.json", "round2_bench_line.json", "round3_bench_line.json"])
+@pytest.mark.parametrize("name", ["round1_bench_line.json", "round2_bench_line.json", "round3_bench_line.json", "round4_bench_line.json"])
 def test_committed_bench_line_follows_the_contract(name):
     """profiles/roundN_bench_line.json is one output line of bench.py: the driver's fields, the roofline block of the
     dominant kernel and the CPU baseline must all be there and be self-consistent."""
@@ -442,7 +442,14 @@ def test_committed_bench_line_follows_the_contract(name):
         assert fh["unit"] == "frames/s" and abs(fh["value"] - 64 * fh["n_gpus"] / (fh["ms_per_step"] * 1e-3)) <= 1e-6 * fh["value"]
         assert d["cpu_baseline"]["cores"] >= 1 and "1 thread pinned" in d["cpu_baseline"]["sample"]
         assert "xcorr_north_fft4_kernel" in d["roofline"]["kernel"]
-    if name.startswith("round3"):
+    if name.startswith("round4"):
+        sq = d["sequence"]      # BASELINE configs[3]: the end-to-end tracker loop with a production-shaped model
+        assert sq["frames"] == 501 and sq["unit"] == "frames/s" and abs(sq["value"] - 1e3 / sq["ms_per_frame"]) <= 1e-6 * sq["value"]
+        assert sq["host_syncs_per_frame"] == 1.0 and "DeviceTrackerHomo" in sq["tracker"] and "ResNet-50" in sq["model"]
+        assert abs(sum(v for k, v in sq["share"].items() if k != "of_which_hip_correlations") - 1.0) <= 1e-6
+        assert abs(sum(r["ms"] for r in sq["components"] if not r["stage"].startswith("  of which")) - sq["component_sum_ms"]) <= 1e-3   # (rows are rounded to 1e-4 ms)
+        assert d["roofline"]["traffic"] is not None and "round4_pmc_hbm_traffic" in d["roofline"]["traffic_source"] or "round3_pmc_hbm_traffic" in d["roofline"]["traffic_source"]
+    if name.startswith(("round3", "round4")):
         r3 = d["roofline"]
         assert r3["min_launch_ms"] <= r3["median_launch_ms"] and "in-step" in r3["timing"] and r3["timed_region_launch_ms"]["schedule"] == "after-north"
         assert abs(r3["timed_region_launch_ms"]["mean"] - r3["avg_launch_ms"]) <= 1e-9      # default schedule: the brackets ARE the timed region's

@@ -212,7 +212,34 @@ def parity(frames, init, model_cpu_src, dev, model, n, iterations=1):
     return {"free_running": q(e_free), "h_total_resynchronised_each_frame": q(e_forced)}
 
 
-def run_production(n_frames=501, n_parity=0, nchw=False, components=True, dev=None, quiet=False):
+def kernel_profile(trk, frames, n=20):
+    """torch.profiler over `n` frames of the hipGraph loop: device time per kernel name, split into the hand-written hdn::
+    kernels of this repo and everything else (MIOpen / CK / hipBLASLt / ATen), per frame."""
+    from torch.profiler import ProfilerActivity, profile
+    for i in range(1, 4):
+        trk.track_new(i, frames[i])
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        for i in range(4, 4 + n):
+            trk.track_new(i, frames[i])
+        torch.cuda.synchronize()
+    agg = {}
+    for e in prof.events():
+        if e.device_type == torch.autograd.DeviceType.CUDA:
+            t = e.device_time if hasattr(e, "device_time") else e.cuda_time
+            a = agg.setdefault(e.name, [0.0, 0])
+            a[0] += t; a[1] += 1
+    own = sum(t for k, (t, c) in agg.items() if "hdn::" in k)
+    cp = sum(t for k, (t, c) in agg.items() if "memcpy" in k.lower() or "copyBuffer" in k)
+    tot = sum(t for t, c in agg.values())
+    top = sorted(agg.items(), key=lambda kv: -kv[1][0])[:25]
+    return {"frames": n, "device_ms_per_frame": tot / n / 1e3, "hdn_kernels_ms_per_frame": own / n / 1e3, "copies_ms_per_frame": cp / n / 1e3,
+            "library_kernels_ms_per_frame": (tot - own - cp) / n / 1e3, "hdn_kernel_launches_per_frame": sum(c for k, (t, c) in agg.items() if "hdn::" in k) / n,
+            "launches_per_frame": sum(c for t, c in agg.values()) / n,
+            "top": [{"kernel": k[:120], "us_per_frame": round(t / n, 2), "calls_per_frame": round(c / n, 2)} for k, (t, c) in top]}
+
+
+def run_production(n_frames=501, n_parity=0, nchw=False, components=True, dev=None, quiet=False, kprofile=False):
     dev = dev or torch.device("cuda:0")
     log = (lambda *a: None) if quiet else (lambda *a: print(*a, file=sys.stderr, flush=True))
     t0 = time.perf_counter()
@@ -249,6 +276,8 @@ def run_production(n_frames=501, n_parity=0, nchw=False, components=True, dev=No
         res["component_sum_ms"] = total
         res["share"] = {"hand_written_hip_stages": own["hip"] / total, "pytorch_rocm_backbone_and_necks": own["rocm"] / total,
                         "packed_heads_mixed": own["mixed"] / total, "of_which_hip_correlations": corr / total, "pcie_copies": own["pcie"] / total}
+    if kprofile:
+        res["kernel_profile"] = kernel_profile(trk, frames)
     if n_parity:
         res["corner_error_device_vs_cpu_loop_px"] = parity(frames, init, cpu_src, dev, model, n_parity)
     return res
@@ -262,6 +291,15 @@ def format_table(res):
     if "share" in res:
         lines.append(f"{'sum of the stage graphs':<100s} {res['component_sum_ms']:8.4f}")
         lines.append("share: " + ", ".join(f"{k} {v * 100:.1f} %" for k, v in res["share"].items()))
+    if "kernel_profile" in res:
+        k = res["kernel_profile"]
+        lines.append(f"torch.profiler over {k['frames']} graph frames: device time {k['device_ms_per_frame']:.3f} ms per frame in {k['launches_per_frame']:.0f} launches = "
+                     f"hdn:: kernels {k['hdn_kernels_ms_per_frame']:.3f} ms ({k['hdn_kernel_launches_per_frame']:.0f} launches) + library kernels "
+                     f"{k['library_kernels_ms_per_frame']:.3f} ms + copies {k['copies_ms_per_frame']:.3f} ms")
+        for r in k["top"]:
+            lines.append(f"  {r['kernel']:<120s} {r['us_per_frame']:9.2f} us  x{r['calls_per_frame']}")
+    if "corner_error_device_vs_cpu_loop_px" in res:
+        lines.append("corner error vs the CPU loop (px): " + json.dumps(res["corner_error_device_vs_cpu_loop_px"]))
     return "\n".join(lines)
 
 
@@ -271,9 +309,11 @@ def main():
     ap.add_argument("--frames", type=int, default=None); ap.add_argument("--parity", type=int, default=None)
     ap.add_argument("--iterations", type=int, default=1); ap.add_argument("--similarity", action="store_true")
     ap.add_argument("--production-shape", action="store_true"); ap.add_argument("--nchw", action="store_true")
+    ap.add_argument("--no-components", action="store_true", help="skip the per-stage table (profiling runs)")
+    ap.add_argument("--kernel-profile", action="store_true", help="torch.profiler over 20 graph frames: device time per kernel, hdn:: vs library")
     args = ap.parse_args()
     if args.production_shape:
-        res = run_production(args.frames or 501, 61 if args.parity is None else args.parity, nchw=args.nchw)
+        res = run_production(args.frames or 501, 61 if args.parity is None else args.parity, nchw=args.nchw, components=not args.no_components, kprofile=args.kernel_profile)
         print(format_table(res), file=sys.stderr)
         print(json.dumps(res))
         return
