@@ -1,6 +1,8 @@
-python bench.py > gpurun_out/bench_final_r3.json 2> gpurun_out/bench_final_r3.err
+# The round's committed measurements in one gpurun call (run from the repo root on the GPU box):
+#   bench line, rocprofv3 kernel stats + the two HBM PMC passes of the same command, the configs[4] line, full-head kernel stats
 bash tools/profile_round.sh > gpurun_out/profile_round.log 2>&1
-cd /tmp && export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_round
-rocprofv3 --kernel-trace --stats -d $O/stats_par --output-format csv -- python $R/bench.py --no-cpu-baseline --head-stream parallel > $O/stats_par.log 2>&1
-cd $R; bash tools/prof_full_head.sh > gpurun_out/prof_full_head.log 2>&1
-tail -c 400 gpurun_out/bench_final_r3.json
+python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
+python bench.py --config 5 --no-cpu-baseline > gpurun_out/bench_cfg5.json 2>/dev/null
+bash tools/prof_full_head.sh > gpurun_out/prof_full_head.log 2>&1
+find gpurun_out/prof_round gpurun_out/prof_full -name "*kernel_trace.csv" -delete     # (the traces exceed what gpurun copies back)
+tail -c 400 gpurun_out/bench_final.json
