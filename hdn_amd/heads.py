@@ -139,7 +139,7 @@ class _PackedHead:
         product with the weights [cw_0 W_0 | cw_1 W_1 | ...] per branch.
     Keyed on the version counters of every tensor it was built from (as _TemplateCache is)."""
 
-    __slots__ = ("key", "ws", "bs", "w1", "b1", "wf", "bf", "oc", "ol", "hidden")
+    __slots__ = ("key", "ws", "bs", "w1", "b1", "wf", "bf", "oc", "ol", "hidden", "w1p")
 
 
 def _head_key(self, boxes):
@@ -189,6 +189,33 @@ def _fold_bn(conv, bn):
     return conv.weight * s.reshape(-1, 1, 1, 1), bn.bias - bn.running_mean * s
 
 
+def _pack_w1(w1):
+    """[G, H, H] fp32 (row = output channel) -> the layout hdn_head_tail_f32 streams (include/hdn_hip.h): two fp16 pieces
+    (v = p0 + 2^-11 p1), MFMA A-fragment order [G][H / 32][H / 16][piece][lane = 32 * k half + row][8] as int16 bit patterns."""
+    G, H, _ = w1.shape
+    w = w1.detach().to(torch.float32)
+    p0 = w.to(torch.float16)
+    p1 = ((w - p0.float()) * 2048.0).to(torch.float16)
+    t = torch.stack([p0, p1]).view(2, G, H // 32, 32, H // 16, 2, 8)        # [piece, g, m tile, row, k step, k half, j]
+    return t.permute(1, 2, 4, 0, 5, 3, 6).contiguous().view(torch.int16)   # [g, m tile, k step, piece, k half, row, j]
+
+
+def head_tail(feats, pk, n):
+    """feats [2n, H, Ho, Wo] -> out [2, om, Ho * Wo] through hdn_head_tail_f32 (pk: a _PackedHead with w1p)."""
+    from . import _lib
+
+    dev = _lib.require_device(feats)
+    G, H = feats.shape[0], feats.shape[1]
+    P = feats.shape[2] * feats.shape[3]
+    om = pk.wf.shape[1]
+    out = torch.empty((2, om, P), dtype=torch.float32, device=dev)
+    with _lib.device_guard(dev):
+        rc = _lib.load().hdn_head_tail_f32(_lib.ptr(feats), _lib.ptr(pk.w1p), _lib.ptr(pk.b1), _lib.ptr(pk.wf), _lib.ptr(pk.bf), _lib.ptr(out),
+                                           n, H, P, om, _lib.stream_ptr(dev))
+    _lib.check(rc, "head_tail")
+    return out
+
+
 def _pack_head(self, boxes):
     n = len(boxes)
     pk = _PackedHead()
@@ -219,6 +246,10 @@ def _pack_head(self, boxes):
         pk.wf[1, :pk.ol, i * hidden:(i + 1) * hidden] = lw[i] * box.loc.head[3].weight.reshape(pk.ol, hidden)
         pk.bf[0, :pk.oc, 0] += cw[i] * box.cls.head[3].bias
         pk.bf[1, :pk.ol, 0] += lw[i] * box.loc.head[3].bias
+    # the whole tail as one launch (hdn_head_tail_f32) where its shapes allow; the two batched matrix products otherwise
+    lds = n * (hidden * 128 + 4 * hidden + 4 * om * hidden) + (hidden // 32) * 8 * 32 * 4       # what the kernel stages per workgroup (head_tail.hip)
+    fits = pk.w1.is_cuda and hidden in (128, 256) and om <= 8 and n <= 4 and lds <= 160 * 1024 and float(pk.w1.abs().max()) < 65504.0
+    pk.w1p = _pack_w1(pk.w1) if fits else None
     return pk
 
 
@@ -233,7 +264,13 @@ def _packed_forward(self, boxes, kern, x_fs, circular):
     h = pk.hidden
     s_cls, s_loc = [], []
     for l in range(n):
-        y = F.conv2d(x_fs[l], pk.ws[l])                  # [1, 2 hidden, Ho, Wo]: both branches of the level
+        # NCHW in, NCHW out: the correlation kernels read contiguous (b, c) planes.  A channels-last search feature (a channels-last
+        # backbone / neck) is converted ONCE here; left as it is, the convolution's channels-last output cost 11 layout copies per
+        # forward further down (54 of 201 us per head at 256 channels, tools/experiments/exp_head_profile.py).
+        xl = x_fs[l] if x_fs[l].is_contiguous() else x_fs[l].contiguous()
+        y = F.conv2d(xl, pk.ws[l])                       # [1, 2 hidden, Ho, Wo]: both branches of the level
+        if not y.is_contiguous():
+            y = y.contiguous()
         bias_relu_(y, pk.bs[l])
         s_cls.append(y[:, :h])
         s_loc.append(y[:, h:])
@@ -241,8 +278,11 @@ def _packed_forward(self, boxes, kern, x_fs, circular):
     shape = out_shape(s_cls[0].shape, k_cls[0].shape, circular)
     feats = torch.empty((2 * n, h, shape[2], shape[3]), dtype=torch.float32, device=y.device)
     xcorr_depthwise_multi(s_cls + s_loc, list(k_cls) + list(k_loc), circular=circular, outs=[feats[i:i + 1] for i in range(2 * n)])
-    hid = torch.baddbmm(pk.b1, pk.w1, feats.view(2 * n, h, -1)).relu_()
-    out = torch.baddbmm(pk.bf, pk.wf, hid.view(2, n * h, -1))
+    if pk.w1p is not None and not getattr(self, "_hdn_no_head_tail", False):
+        out = head_tail(feats, pk, n)
+    else:
+        hid = torch.baddbmm(pk.b1, pk.w1, feats.view(2 * n, h, -1)).relu_()
+        out = torch.baddbmm(pk.bf, pk.wf, hid.view(2, n * h, -1))
     return (out[0, :pk.oc].reshape(1, pk.oc, shape[2], shape[3]), out[1, :pk.ol].reshape(1, pk.ol, shape[2], shape[3]))
 
 
@@ -269,7 +309,7 @@ def fused_forward(self, z_fs, x_fs, circular=None):
     with torch.no_grad():
         cache = getattr(self, "_hdn_template_cache", None)
         if cache is None or not cache.matches(z_fs, branches, False):
-            kern = [br.conv_kernel(z) for box, z in zip(boxes, z_fs) for br in (box.cls, box.loc)]
+            kern = [br.conv_kernel(z).contiguous() for box, z in zip(boxes, z_fs) for br in (box.cls, box.loc)]   # (NCHW once, not per frame)
             cache = _TemplateCache(z_fs, branches, False, kern)
             object.__setattr__(self, "_hdn_template_cache", cache)
         kern = cache.kern

@@ -307,6 +307,23 @@ int hdn_bias_relu_f32(float* y, const float* bias, const float* residual, int B,
 int hdn_avgpool_fc_f32(const float* x, const float* w, const float* bias, float* out, int B, int C, int HW, int O, int nhwc, void* stream);
 
 /*
+ * Everything of a MultiBAN / MultiCircBAN forward behind the correlations, at the tracker's B = 1, as one launch:
+ *   hid[g] = relu(W1[g] . feats[g] + b1[g])             g = branch * n_levels + level; the first 1x1 convolution + BatchNorm (folded by the host) +
+ *                                                       ReLU of DepthwiseXCorr.head, hdn/models/head/ban.py:60-66
+ *   out[br] = bf[br] + sum_l Wf[br][:, l H : (l + 1) H] . hid[br * n_levels + l]
+ *                                                       the second 1x1 convolution, loc_scale and the (softmax-)weighted sum over the levels,
+ *                                                       MultiBAN.forward ban.py:113-127 / MultiCircBAN.forward ban_lp.py:77-92 (linear: folded into Wf, bf)
+ * feats [2 n_levels, hidden, pixels] (the stacked correlation outputs, cls groups first), b1 [2 n_levels, hidden], wf [2, n_out, n_levels * hidden],
+ * bf [2, n_out], out [2, n_out, pixels], all fp32 contiguous; hidden = 128 or 256, n_out <= 8, n_levels <= 4 (and the staged operands must fit the LDS: HDN_E_LIMIT otherwise).  w1_packed: W1 [2 n_levels, hidden, hidden]
+ * as two fp16 pieces (v = p0 + 2^-11 p1, as for hdn_conv3x3_bias_relu_f32) in MFMA fragment order
+ * [group][hidden / 32 row tiles][hidden / 16 k steps][2 pieces][64 lanes][8] with lane = 32 * (k half) + row: hdn_amd.heads._pack_w1; 16-byte aligned.
+ * The first product runs on the matrix cores with the error of an fp32 product, the second in fp32 FMAs; the sum over the levels is a fixed-order
+ * register accumulation (deterministic).
+ */
+int hdn_head_tail_f32(const float* feats, const void* w1_packed, const float* b1, const float* wf, const float* bf, float* out, int n_levels, int hidden,
+                      int pixels, int n_out, void* stream);
+
+/*
  * Whole residual-block convolutions of that trunk on the matrix cores, channels-last fp32 in and out:
  *   hdn_conv3x3_bias_relu_f32:  out = relu(conv3x3/s1/p1(x, W) + bias[c] (+ residual)),  x / residual / out [B,S,S,C], C -> C channels,
  *       (S, C) = (32, 64), (16, 128), (8, 256), (4, 512): conv1 / conv2 + bn + relu (+ `out += residual`) of BasicBlock.forward;

@@ -1229,3 +1229,36 @@ def test_avgpool_fc_fused_tail(dev, B, C, S, O, nhwc):
     assert got.shape == (B, O)
     e_ref = float((ref32.double() - ref64).abs().max())
     assert float((got - ref64).abs().max()) <= 4 * e_ref + 1e-6, (float((got - ref64).abs().max()), e_ref)
+
+
+@pytest.mark.parametrize("H,P,n,oc,ol", [(256, 625, 3, 2, 2), (256, 169, 3, 2, 4), (256, 961, 3, 2, 2), (128, 7, 2, 1, 8), (256, 33, 1, 2, 4)])
+def test_head_tail_one_launch_vs_float64(dev, H, P, n, oc, ol):
+    """hdn_head_tail_f32 (the first 1x1 convolution + folded BatchNorm + ReLU of the 2n (level, branch) heads on the matrix cores, then
+    the second 1x1 convolution / loc_scale / weighted level sum as one folded product; ban.py:60-66,113-127) against the same two
+    products in float64, held to PyTorch's own fp32 error on them."""
+    from hdn_amd import heads as HD
+    g = torch.Generator().manual_seed(H + P)
+    Ho = P                          # (any [Ho, Wo] with Ho * Wo = P: the kernel sees pixels)
+    feats = torch.randn(2 * n, H, Ho, 1, generator=g).relu_() * 3.0
+    pk = HD._PackedHead()
+    pk.w1 = (torch.randn(2 * n, H, H, generator=g) * 0.06).to(dev)
+    pk.b1 = torch.randn(2 * n, H, 1, generator=g).to(dev)
+    om = max(oc, ol)
+    pk.wf = (torch.randn(2, om, n * H, generator=g) * 0.05).to(dev)
+    pk.wf[0, oc:] = 0
+    pk.wf[1, ol:] = 0
+    pk.bf = torch.randn(2, om, 1, generator=g).to(dev)
+    pk.w1p = HD._pack_w1(pk.w1)
+    assert pk.w1p.dtype == torch.int16 and pk.w1p.numel() == 2 * (2 * n) * H * H
+    got = HD.head_tail(feats.to(dev), pk, n).cpu().double()
+    f64 = lambda t: t.detach().cpu().double()
+    hid = (torch.baddbmm(f64(pk.b1), f64(pk.w1), f64(feats).view(2 * n, H, -1))).relu()
+    ref = torch.baddbmm(f64(pk.bf), f64(pk.wf), hid.view(2, n * H, -1))
+    hid32 = torch.baddbmm(pk.b1.cpu(), pk.w1.cpu(), feats.view(2 * n, H, -1)).relu()
+    ref32 = torch.baddbmm(pk.bf.cpu(), pk.wf.cpu(), hid32.view(2, n * H, -1)).double()
+    assert got.shape == ref.shape == (2, om, P)
+    e_ref = float((ref32 - ref).abs().max())
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 4 * e_ref + 1e-6 * scale, (float((got - ref).abs().max()), e_ref, scale)
+    # deterministic
+    assert torch.equal(HD.head_tail(feats.to(dev), pk, n).cpu().double(), got)
