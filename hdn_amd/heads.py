@@ -139,7 +139,7 @@ class _PackedHead:
         product with the weights [cw_0 W_0 | cw_1 W_1 | ...] per branch.
     Keyed on the version counters of every tensor it was built from (as _TemplateCache is)."""
 
-    __slots__ = ("key", "ws", "bs", "w1", "b1", "wf", "bf", "oc", "ol", "hidden", "w1p")
+    __slots__ = ("key", "ws", "bs", "w1", "b1", "wf", "bf", "oc", "ol", "hidden", "w1p", "wsp", "bsp")
 
 
 def _head_key(self, boxes):
@@ -200,6 +200,43 @@ def _pack_w1(w1):
     return t.permute(1, 2, 4, 0, 5, 3, 6).contiguous().view(torch.int16)   # [g, m tile, k step, piece, k half, row, j]
 
 
+def _pack_conv_search(ws):
+    """n folded conv_search weights [CO, 256, 3, 3] fp32 -> the layout hdn_head_conv3x3_f32 streams (include/hdn_hip.h): two fp16 pieces,
+    [n][CO / 32][4 chunks][4 k slices][9 taps][piece][lane = 32 * k half + output channel][8] as int16 bit patterns."""
+    w = torch.stack([t.detach().to(torch.float32) for t in ws])                # [n, CO, CI, 3, 3]
+    n, CO, CI = w.shape[0], w.shape[1], w.shape[2]
+    p0 = w.to(torch.float16)
+    p1 = ((w - p0.float()) * 2048.0).to(torch.float16)
+    t = torch.stack([p0, p1]).reshape(2, n, CO // 32, 32, CI // 64, 4, 2, 8, 9)    # [piece, n, cb, m, chunk, k slice, k half, j, tap]
+    return t.permute(1, 2, 4, 5, 8, 0, 6, 3, 7).contiguous().view(torch.int16)   # [n, cb, chunk, k slice, tap, piece, k half, m, j]
+
+
+def head_conv_search(x_fs, pk):
+    """The n levels' conv_search (both branches) + bias + ReLU in one launch -> [n, 2 hidden, Ho, Wo] contiguous (hdn_head_conv3x3_f32)."""
+    import ctypes
+
+    from . import _lib
+
+    x0 = x_fs[0]
+    dev = _lib.require_device(*x_fs)
+    n, (_, C, Hi, Wi) = len(x_fs), x0.shape
+    nhwc = 0 if x0.is_contiguous() else 1
+    xs = []
+    for x in x_fs:
+        x = x.detach()
+        if not (x.is_contiguous() if nhwc == 0 else x.is_contiguous(memory_format=torch.channels_last)):
+            x = x.contiguous() if nhwc == 0 else x.contiguous(memory_format=torch.channels_last)
+        xs.append(x)
+    CO = pk.bsp.shape[1]
+    out = torch.empty((n, CO, Hi - 2, Wi - 2), dtype=torch.float32, device=dev)
+    arr = ctypes.c_void_p * n
+    with _lib.device_guard(dev):
+        rc = _lib.load().hdn_head_conv3x3_f32(arr(*[t.data_ptr() for t in xs]), _lib.ptr(pk.wsp), _lib.ptr(pk.bsp),
+                                              arr(*[out[i].data_ptr() for i in range(n)]), n, CO, Hi, Wi, nhwc, _lib.stream_ptr(dev))
+    _lib.check(rc, "head_conv_search")
+    return out
+
+
 def head_tail(feats, pk, n):
     """feats [2n, H, Ho, Wo] -> out [2, om, Ho * Wo] through hdn_head_tail_f32 (pk: a _PackedHead with w1p)."""
     from . import _lib
@@ -250,6 +287,12 @@ def _pack_head(self, boxes):
     lds = n * (hidden * 128 + 4 * hidden + 4 * om * hidden) + (hidden // 32) * 8 * 32 * 4       # what the kernel stages per workgroup (head_tail.hip)
     fits = pk.w1.is_cuda and hidden in (128, 256) and om <= 8 and n <= 4 and lds <= 160 * 1024 and float(pk.w1.abs().max()) < 65504.0
     pk.w1p = _pack_w1(pk.w1) if fits else None
+    # conv_search of all levels as one launch on the matrix cores (hdn_head_conv3x3_f32): 3x3 / stride 1 / no padding, 256 input channels
+    w0 = pk.ws[0]
+    fits_conv = (w0.is_cuda and n <= 4 and tuple(w0.shape[1:]) == (256, 3, 3) and w0.shape[0] % 32 == 0 and all(w.shape == w0.shape for w in pk.ws)
+                 and max(float(w.abs().max()) for w in pk.ws) < 65504.0)
+    pk.wsp = _pack_conv_search(pk.ws) if fits_conv else None
+    pk.bsp = torch.stack(pk.bs).contiguous() if fits_conv else None
     return pk
 
 
@@ -263,7 +306,15 @@ def _packed_forward(self, boxes, kern, x_fs, circular):
         object.__setattr__(self, "_hdn_packed_head", pk)
     h = pk.hidden
     s_cls, s_loc = [], []
-    for l in range(n):
+    Hi, Wi = x_fs[0].shape[2], x_fs[0].shape[3]
+    rows = min((63 + Wi - 3) // (Wi - 2) + 3, Hi) if Wi > 2 else 0          # patch rows of 64 consecutive output pixels (head_conv.hip)
+    use_conv = (pk.wsp is not None and x_fs[0].shape[1] == 256 and Hi >= 3 and Wi >= 3 and rows * Wi <= 224
+                and not getattr(self, "_hdn_no_head_conv", False))
+    if use_conv:
+        y = head_conv_search(x_fs, pk)
+        s_cls = [y[l:l + 1, :h] for l in range(n)]
+        s_loc = [y[l:l + 1, h:] for l in range(n)]
+    for l in range(0 if not use_conv else n, n):
         # NCHW in, NCHW out: the correlation kernels read contiguous (b, c) planes.  A channels-last search feature (a channels-last
         # backbone / neck) is converted ONCE here; left as it is, the convolution's channels-last output cost 11 layout copies per
         # forward further down (54 of 201 us per head at 256 channels, tools/experiments/exp_head_profile.py).

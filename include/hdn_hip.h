@@ -324,6 +324,20 @@ int hdn_head_tail_f32(const float* feats, const void* w1_packed, const float* b1
                       int pixels, int n_out, void* stream);
 
 /*
+ * conv_search of the correlation heads at B = 1: n (<= 4) same-shaped problems in one launch, each
+ *   out[i] [CO, Hi - 2, Wi - 2] = relu(conv3x3 / stride 1 / no padding (x[i] [256, Hi, Wi], W[i]) + bias[i])
+ * = DepthwiseXCorr.conv_search (Conv2d 3x3 no bias + BatchNorm, folded by the host, + ReLU; hdn/models/head/ban.py:55-59,75) for the levels of a
+ * MultiBAN / MultiCircBAN, the cls and loc branches of a level concatenated along CO (they share their input).  x[i]: fp32, 256 channels, NCHW
+ * (nhwc = 0) or channels-last (nhwc = 1) strides; out[i]: contiguous NCHW planes (what hdn_xcorr_depthwise_multi_f32 reads); bias [n, CO]; CO a
+ * multiple of 32.  w_packed: the folded weights as two fp16 pieces (v = p0 + 2^-11 p1, as for hdn_conv3x3_bias_relu_f32) in MFMA fragment order
+ * [problem][CO / 32][4 chunks of 64 input channels][4 k slices of 16][9 taps][2 pieces][64 lanes][8], lane = 32 * (k half) + output channel,
+ * hdn_amd.heads._pack_conv_search; 16-byte aligned.  The patch of 64 consecutive output pixels (their rows + 2, full width) must fit 224 pixels
+ * (HDN_E_LIMIT otherwise: widths up to ~60).  Error class of an fp32 convolution; deterministic.
+ */
+int hdn_head_conv3x3_f32(const float* const* xs, const void* w_packed, const float* bias, float* const* outs, int n, int CO, int Hi, int Wi, int nhwc,
+                         void* stream);
+
+/*
  * Whole residual-block convolutions of that trunk on the matrix cores, channels-last fp32 in and out:
  *   hdn_conv3x3_bias_relu_f32:  out = relu(conv3x3/s1/p1(x, W) + bias[c] (+ residual)),  x / residual / out [B,S,S,C], C -> C channels,
  *       (S, C) = (32, 64), (16, 128), (8, 256), (4, 512): conv1 / conv2 + bn + relu (+ `out += residual`) of BasicBlock.forward;

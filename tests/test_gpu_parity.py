@@ -1262,3 +1262,28 @@ def test_head_tail_one_launch_vs_float64(dev, H, P, n, oc, ol):
     assert float((got - ref).abs().max()) <= 4 * e_ref + 1e-6 * scale, (float((got - ref).abs().max()), e_ref, scale)
     # deterministic
     assert torch.equal(HD.head_tail(feats.to(dev), pk, n).cpu().double(), got)
+
+
+@pytest.mark.parametrize("Hi,Wi,n,CO,nhwc", [(31, 31, 3, 512, False), (31, 31, 3, 512, True), (15, 15, 3, 512, True), (37, 37, 3, 512, False),
+                                              (9, 14, 1, 64, True), (3, 3, 2, 32, False), (33, 20, 4, 96, False)])
+def test_head_conv_search_one_launch_vs_float64(dev, Hi, Wi, n, CO, nhwc):
+    """hdn_head_conv3x3_f32 (conv_search of the heads at B = 1: 3x3 / no padding, 256 input channels, folded bias + ReLU, NCHW planes out,
+    n levels per launch; ban.py:55-59,75) against float64, held to PyTorch's own fp32 error on the same convolution."""
+    from hdn_amd import heads as HD
+    g = torch.Generator().manual_seed(Hi * 100 + Wi + CO)
+    xs = [torch.randn(1, 256, Hi, Wi, generator=g).relu_() * 2.0 for _ in range(n)]
+    ws = [torch.randn(CO, 256, 3, 3, generator=g) * 0.03 for _ in range(n)]
+    bs = [torch.randn(CO, generator=g) for _ in range(n)]
+    pk = HD._PackedHead()
+    pk.wsp = HD._pack_conv_search([w.to(dev) for w in ws])
+    pk.bsp = torch.stack(bs).to(dev)
+    xd = [x.to(dev).contiguous(memory_format=torch.channels_last) if nhwc else x.to(dev) for x in xs]
+    got = HD.head_conv_search(xd, pk).cpu().double()
+    assert got.shape == (n, CO, Hi - 2, Wi - 2)
+    for i in range(n):
+        ref = torch.nn.functional.conv2d(xs[i].double(), ws[i].double(), bs[i].double()).relu()[0]
+        ref32 = torch.nn.functional.conv2d(xs[i], ws[i], bs[i]).relu()[0].double()
+        e_ref, scale = float((ref32 - ref).abs().max()), float(ref.abs().max())
+        err = float((got[i] - ref).abs().max())
+        assert err <= 4 * e_ref + 1e-6 * scale, (i, err, e_ref, scale)
+    assert torch.equal(HD.head_conv_search(xd, pk).cpu().double(), got)          # deterministic

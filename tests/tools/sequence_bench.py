@@ -113,8 +113,9 @@ def build_production_model(frames, init, dev, nchw=False, instance_size=255, cro
 def component_table(trk, frame_u8, reps=20):
     """Every stage of DeviceTrackerHomo's frame body as its own hipGraph on static inputs (the outputs of the stages before it,
     computed once; 10 executions per graph, see graph_ms), replayed `reps` times: (name, ms, owner) rows.  owner: 'hip' = hand-written kernels of this repo only,
-    'rocm' = PyTorch-ROCm / MIOpen / hipBLASLt only, 'mixed' = the packed heads (library convolutions + matrix products around the
-    HIP correlation launch; the correlation launch is timed again on its own in the row below each head)."""
+    'rocm' = PyTorch-ROCm / MIOpen / hipBLASLt only, 'mixed' = a packed head whose convolutions / matrix products fell back to the
+    libraries (since round 4 the 256-channel heads are all HIP: conv_search, correlations and tail are three launches; the correlation
+    launch is timed again on its own in the row below each head)."""
     from hdn_amd.refine import homo_refine
     from hdn_amd.xcorr import xcorr_depthwise_multi
     sim, model, c, dev = trk.similarity, trk.model, trk.cfg, trk.dev
@@ -145,7 +146,10 @@ def component_table(trk, frame_u8, reps=20):
     with torch.no_grad():
         xf = model.neck(model.feature_extractor(x_crop))
         out = model.track_new(x_crop)
-    add("MultiBAN head, packed (2 x 3 levels)", lambda: model.head(model.zf, xf), "mixed")
+    def head_owner(head):   # all-HIP when the packed head runs its convolutions and its tail on the HIP kernels (hdn_head_conv3x3_f32, hdn_head_tail_f32)
+        pk = getattr(head, "_hdn_packed_head", None)
+        return "hip" if pk is not None and pk.wsp is not None and pk.w1p is not None else "mixed"
+    add("MultiBAN head, packed (2 x 3 levels)", lambda: model.head(model.zf, xf), head_owner(model.head))
     s6 = [torch.randn(1, 256, 29, 29, device=dev).relu_() for _ in range(6)]
     k6 = [torch.randn(1, 256, 5, 5, device=dev).relu_() for _ in range(6)]
     o6 = [torch.empty(1, 256, 25, 25, device=dev) for _ in range(6)]
@@ -161,7 +165,7 @@ def component_table(trk, frame_u8, reps=20):
     with torch.no_grad():
         xf_lp = model.neck_lp(model.feature_extractor(x_lp))
         out_lp = model.track_new_lp(x_moved, [0, 0])
-    add("MultiCircBAN head, packed", lambda: model.head_lp(model.zf_lp, xf_lp), "mixed")
+    add("MultiCircBAN head, packed", lambda: model.head_lp(model.zf_lp, xf_lp), head_owner(model.head_lp))
     s6 = [torch.randn(1, 256, 13, 13, device=dev).relu_() for _ in range(6)]
     k6 = [torch.randn(1, 256, 13, 13, device=dev).relu_() for _ in range(6)]
     o6 = [torch.empty(1, 256, 13, 13, device=dev) for _ in range(6)]
