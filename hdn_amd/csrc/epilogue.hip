@@ -79,7 +79,17 @@ __global__ __launch_bounds__(HDN_BLOCK) void avgpool_fc_kernel(const float* __re
   for (int o = 0; o < AF_MAX_OUT; ++o) acc[o] = 0.f;
   for (int c = tid; c < C; c += HDN_BLOCK) {
     float s = 0.f;
-    for (int p = 0; p < HW; ++p) s += NHWC ? xb[(size_t)p * C + c] : xb[(size_t)c * HW + p];
+    for (int pb = 0; pb < HW; pb += 16) {     // 16 positions in flight at a time (one round trip for the trunk's 4 x 4 map), added in position order
+      float v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int p = min(pb + j, HW - 1);
+        v[j] = NHWC ? xb[(size_t)p * C + c] : xb[(size_t)c * HW + p];
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (pb + j < HW) s += v[j];
+    }
     const float m = s * inv;
 #pragma unroll
     for (int o = 0; o < AF_MAX_OUT; ++o)
