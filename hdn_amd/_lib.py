@@ -56,6 +56,9 @@ SIGNATURES = {
     "hdn_conv3x3_workspace_bytes": (ctypes.c_longlong, [_i, _i, _i, _i]),
     "hdn_conv3x3s2_ds_f32": (_i, [_c_float_p] * 6 + [ctypes.c_longlong] + [_i] * 3 + [ctypes.c_void_p]),
     "hdn_conv3x3_bias_relu_f32": (_i, [_c_float_p] * 6 + [ctypes.c_longlong] + [_i] * 3 + [ctypes.c_void_p]),
+    "hdn_conv3x3_chain_slices": (_i, [_i, _i, _i, _i]),
+    "hdn_conv3x3_chain_f32": (_i, [_c_float_p, _i, _c_float_p, _c_float_p, _i, _c_float_p, ctypes.c_void_p, _c_float_p, _c_float_p] + [_i] * 4 + [ctypes.c_void_p]),
+    "hdn_conv3x3_finish_f32": (_i, [_c_float_p, _i, _c_float_p, _c_float_p, _i, _c_float_p] + [_i] * 3 + [ctypes.c_void_p]),
     "hdn_allgather_offsets": (_i, [_c_float_p] * 2 + [_i, ctypes.c_void_p, ctypes.c_void_p]),
     "hdn_rccl_available": (_i, []),
     "hdn_rccl_unique_id": (_i, [ctypes.c_void_p]),

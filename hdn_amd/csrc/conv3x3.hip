@@ -123,6 +123,44 @@ __device__ __forceinline__ int mrow_to_pixel(int i) {
   }
 }
 
+// A convolution input that was never written out as an activation (B = 1: every launch is a dependent step of ~5 us, and the
+// launch that only adds the K slices up was half of them): the raw K-slice sums [zx][B][SI][SI][CI] of the convolution that
+// produced it, finished while it is staged: relu(sum of the slices in slice order + bias (+ residual)), the arithmetic of
+// conv3x3_reduce_kernel.  The residual is an activation (zr = 1) or, behind a downsample branch, raw slices again.  `xout`: the
+// finished activation is also written out (the NEXT block's residual) — every element by exactly one workgroup (output-channel
+// block 0; the tile's own rows; the K slice's channels).
+struct LazyIn {
+  const float* bias;
+  const float* res;
+  float* xout;
+  int zx, zr;
+};
+
+// s (+)= the N slices p[j * MX] (8 floats each), all N loads in flight at once, added in slice order
+template <int N>
+__device__ __forceinline__ void add_slices(const float* p, size_t MX, bool init, f4& s0, f4& s1) {
+  f4 a[N][2];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const f4* q = reinterpret_cast<const f4*>(p + (size_t)j * MX);
+    a[j][0] = q[0];
+    a[j][1] = q[1];
+  }
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    if (init && j == 0) s0 = a[0][0], s1 = a[0][1];
+    else s0 = s0 + a[j][0], s1 = s1 + a[j][1];
+  }
+}
+__device__ __forceinline__ void sum_slices(const float* p, size_t MX, int z, f4& s0, f4& s1) {
+  int j = 0;
+  for (; j + 16 <= z; j += 16) add_slices<16>(p + (size_t)j * MX, MX, j == 0, s0, s1);
+  if (z & 8) { add_slices<8>(p + (size_t)j * MX, MX, j == 0, s0, s1); j += 8; }
+  if (z & 4) { add_slices<4>(p + (size_t)j * MX, MX, j == 0, s0, s1); j += 4; }
+  if (z & 2) { add_slices<2>(p + (size_t)j * MX, MX, j == 0, s0, s1); j += 2; }
+  if (z & 1) add_slices<1>(p + (size_t)j * MX, MX, j == 0, s0, s1);
+}
+
 // MODE 0: out = relu(conv + bias); 1: out = relu(conv + bias + res); 2: the K slice blockIdx.z of `cps` chunks, raw sums to
 // out[blockIdx.z][M][CO] (the workspace; conv3x3_reduce_kernel finishes).  Cf::DS: out2 = the downsample branch (raw sums, no
 // bias / ReLU; mode 2: out2[blockIdx.z][M][CO]).
@@ -130,10 +168,12 @@ __device__ __forceinline__ int mrow_to_pixel(int i) {
 // global memory, split to fp16 pieces and fill the LDS images (producers).  A consumer never waits for a global load or for the operands
 // of an LDS store; the two roles meet at the one barrier per stage, and the producers run TWO stages ahead, so that a consumer can
 // read the first fragments of stage s + 1 while it still issues the MFMAs of stage s.
-template <class Cf, int MODE>
+// LAZY: x is a LazyIn's slices (mode 2 only: the chained form of the small-batch trunk, launch_chain).
+template <class Cf, int MODE, bool LAZY = false>
 __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __restrict__ x, const u32x4* __restrict__ wp, const float* __restrict__ bias,
                                                             const float* __restrict__ res, float* __restrict__ out, float* __restrict__ out2, int B,
-                                                            int cps) {
+                                                            int cps, LazyIn lz) {
+  static_assert(!LAZY || MODE == 2, "a lazy input feeds the K-sliced form");
   constexpr bool RES = MODE == 1, PARTIAL = MODE == 2, DS = Cf::DS;
   constexpr int S = Cf::S, SI = Cf::SI, CI = Cf::CI, C = Cf::CO, MT = Cf::MT, NT = Cf::NT, BM = Cf::BM, BN = Cf::BN, KS = Cf::KS, ST = Cf::STRIDE;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -235,6 +275,48 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __r
     }
   };
 
+  // LAZY: the finished input of this launch's (at most two) chunks goes straight into the two A images, by all 512 threads, before
+  // the roles split: one round trip of zx (+ zr) slice loads per item.
+  if constexpr (LAZY) {
+    if (produce) {   // the first two weight stages travel meanwhile
+      load_w(0, std::integral_constant<int, 0>{});
+      load_w(1, std::integral_constant<int, 1>{});
+    }
+    const size_t MX = (size_t)B * SI * SI * CI;
+    for (int it = threadIdx.x; it < nchunk * Cf::AITEMS; it += 2 * HDN_BLOCK) {
+      const int chunk = it / Cf::AITEMS, item = it % Cf::AITEMS;
+      const int px = item / (2 * KS), sub = item % (2 * KS);
+      const int img = px / Cf::IPITCH, ry = (px % Cf::IPITCH) / Cf::PW, rx = px % Cf::IPITCH % Cf::PW;
+      const int b = b0 + img, y = ST * y0 + ry - 1, xx = rx - 1;
+      const bool ok = img < Cf::IMGS && b < B && ry < Cf::PH && y >= 0 && y < SI && xx >= 0 && xx < SI;
+      f4 s0 = f4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
+      if (ok) {
+        const int ch = (chunk0 + chunk) * (16 * KS) + sub * 8;
+        const size_t off = (((size_t)b * SI + y) * SI + xx) * CI + ch;
+        const f4 b0v = *reinterpret_cast<const f4*>(lz.bias + ch), b1v = *reinterpret_cast<const f4*>(lz.bias + ch + 4);
+        f4 r0 = s0, r1 = s0;
+        if (lz.res) sum_slices(lz.res + off, MX, lz.zr, r0, r1);
+        sum_slices(x + off, MX, lz.zx, s0, s1);
+        s0 = s0 + b0v; s1 = s1 + b1v;
+        if (lz.res) { s0 = s0 + r0; s1 = s1 + r1; }
+        s0.x = fmaxf(s0.x, 0.f); s0.y = fmaxf(s0.y, 0.f); s0.z = fmaxf(s0.z, 0.f); s0.w = fmaxf(s0.w, 0.f);
+        s1.x = fmaxf(s1.x, 0.f); s1.y = fmaxf(s1.y, 0.f); s1.z = fmaxf(s1.z, 0.f); s1.w = fmaxf(s1.w, 0.f);
+        if (lz.xout && nb == 0 && ry >= 1 && ry <= Cf::PH - (ST == 1 ? 2 : 1)) {   // the tile's own input rows (not the halo)
+          *reinterpret_cast<f4*>(lz.xout + off) = s0;
+          *reinterpret_cast<f4*>(lz.xout + off + 4) = s1;
+        }
+      }
+      unsigned q0[4], q1[4];
+      split2x2(s0.x, s0.y, q0[0], q1[0]);
+      split2x2(s0.z, s0.w, q0[1], q1[1]);
+      split2x2(s1.x, s1.y, q0[2], q1[2]);
+      split2x2(s1.z, s1.w, q0[3], q1[3]);
+      unsigned char* dst = sA + chunk * Cf::A_BYTES + sub * Cf::KG_BYTES + px * 16;
+      *reinterpret_cast<u32x4*>(dst) = u32x4{q0[0], q0[1], q0[2], q0[3]};
+      *reinterpret_cast<u32x4*>(dst + Cf::PIECE_BYTES) = u32x4{q1[0], q1[1], q1[2], q1[3]};
+    }
+  }
+
   struct Frags {
     u32x4 a[MT][Cf::NP], b[NT][Cf::NP];
   };
@@ -287,13 +369,15 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __r
   // The two roles run separate loops with the same barrier sequence (so that neither role's registers are live in the other's code).
   // J = position of a stage in the six-stage period, `base` = the period's first chunk.
   if (produce) {
-    load_a(0);
-    load_w(0, P0{});
-    load_w(1, P1{});
-    store_a(0);
+    if (!LAZY) {
+      load_a(0);
+      load_w(0, P0{});
+      load_w(1, P1{});
+      store_a(0);
+    }
     store_w(P0{}, 0);
     store_w(P1{}, 1);
-    if (nchunk > 1) load_a(1);
+    if (!LAZY && nchunk > 1) load_a(1);
     if (2 < nstage) load_w(2, P0{});
     if (3 < nstage) load_w(3, P1{});
     __syncthreads();
@@ -302,7 +386,7 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __r
       const int chunk = base + J / 3, stage = chunk * 3 + ky;
       if (stage + 2 < nstage) store_w(std::integral_constant<int, J & 1>{}, (J + 2) % 3);   // W(stage + 2): that slot was read last in stage - 1
       if (stage + 4 < nstage) load_w(stage + 4, std::integral_constant<int, J & 1>{});
-      if (ky == 1 && chunk + 1 < nchunk) {
+      if (!LAZY && ky == 1 && chunk + 1 < nchunk) {         // (LAZY: both images were filled before the loop)
         store_a(1 - ab);                                   // A(chunk + 1): that image was read last in chunk - 1
         if (chunk + 2 < nchunk) load_a(chunk + 2);
       }
@@ -444,13 +528,16 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __r
 // sum (the downsample branch).
 template <bool RES, bool ACT>
 __global__ __launch_bounds__(HDN_BLOCK) void conv3x3_reduce_kernel(const f4* __restrict__ ws, const f4* __restrict__ bias, const f4* __restrict__ res,
-                                                                   f4* __restrict__ out, unsigned n4, unsigned c4n, int slices) {
+                                                                   f4* __restrict__ out, unsigned n4, unsigned c4n, int slices, int res_slices) {
   for (unsigned i = blockIdx.x * HDN_BLOCK + threadIdx.x; i < n4; i += gridDim.x * HDN_BLOCK) {
     // up to 16 slices in flight at once (at B = 1 the launch is a handful of workgroups and nothing but load latency: one round
     // trip instead of one per four slices); the additions stay in slice order, so the sum is the same for any grouping
     f4 v = f4{0.f, 0.f, 0.f, 0.f}, bv = v, rv = v;
     if (ACT) bv = bias[i % c4n];     // (asked for together with the slices, not after them)
-    if (ACT && RES) rv = res[i];
+    if (ACT && RES) {
+      rv = res[i];
+      for (int j = 1; j < res_slices; ++j) rv = rv + res[(size_t)j * n4 + i];   // (a downsample branch's raw slices, in slice order)
+    }
     for (int z0 = 0; z0 < slices; z0 += 16) {
       f4 a[16];
 #pragma unroll
@@ -481,6 +568,13 @@ static int k_slices(int B) {
   return z;
 }
 
+// ... of the chained form: at least NCHUNK / 2, so that a launch's input is at most the two A images (conv3x3_kernel, LAZY)
+template <class Cf>
+static int k_slices_chain(int B) {
+  const int z = k_slices<Cf>(B), zmin = Cf::NCHUNK > 2 ? Cf::NCHUNK / 2 : 1;
+  return z > zmin ? z : zmin;
+}
+
 template <class Cf>
 static size_t workspace_bytes(int B) {
   const int z = k_slices<Cf>(B);
@@ -509,18 +603,49 @@ static int launch(const float* x, const void* wp, const float* bias, const float
   const dim3 grid((unsigned)((M + Cf::BM - 1) / Cf::BM), Cf::NB, z), blk(2 * HDN_BLOCK);
   const u32x4* w4 = (const u32x4*)wp;
   if (z == 1) {
-    if (res) hipLaunchKernelGGL((conv3x3_kernel<Cf, 1>), grid, blk, Cf::LDS_BYTES, stream, x, w4, bias, res, out, out2, B, Cf::NCHUNK);
-    else hipLaunchKernelGGL((conv3x3_kernel<Cf, 0>), grid, blk, Cf::LDS_BYTES, stream, x, w4, bias, res, out, out2, B, Cf::NCHUNK);
+    if (res) hipLaunchKernelGGL((conv3x3_kernel<Cf, 1>), grid, blk, Cf::LDS_BYTES, stream, x, w4, bias, res, out, out2, B, Cf::NCHUNK, LazyIn{});
+    else hipLaunchKernelGGL((conv3x3_kernel<Cf, 0>), grid, blk, Cf::LDS_BYTES, stream, x, w4, bias, res, out, out2, B, Cf::NCHUNK, LazyIn{});
     return launch_status();
   }
   float* ws2 = ws + (size_t)z * M * Cf::CO;
-  hipLaunchKernelGGL((conv3x3_kernel<Cf, 2>), grid, blk, Cf::LDS_BYTES, stream, x, w4, bias, res, ws, ws2, B, Cf::NCHUNK / z);
+  hipLaunchKernelGGL((conv3x3_kernel<Cf, 2>), grid, blk, Cf::LDS_BYTES, stream, x, w4, bias, res, ws, ws2, B, Cf::NCHUNK / z, LazyIn{});
   const unsigned n4 = (unsigned)(M * Cf::CO / 4);
   const int blocks = (int)((n4 + HDN_BLOCK - 1) / HDN_BLOCK < 1024 ? (n4 + HDN_BLOCK - 1) / HDN_BLOCK : 1024);
   const f4* b4 = (const f4*)bias;
-  if (res) hipLaunchKernelGGL((conv3x3_reduce_kernel<true, true>), dim3(blocks), dim3(HDN_BLOCK), 0, stream, (const f4*)ws, b4, (const f4*)res, (f4*)out, n4, Cf::CO / 4, z);
-  else hipLaunchKernelGGL((conv3x3_reduce_kernel<false, true>), dim3(blocks), dim3(HDN_BLOCK), 0, stream, (const f4*)ws, b4, (const f4*)res, (f4*)out, n4, Cf::CO / 4, z);
-  if (Cf::DS) hipLaunchKernelGGL((conv3x3_reduce_kernel<false, false>), dim3(blocks), dim3(HDN_BLOCK), 0, stream, (const f4*)ws2, b4, (const f4*)nullptr, (f4*)out2, n4, Cf::CO / 4, z);
+  if (res) hipLaunchKernelGGL((conv3x3_reduce_kernel<true, true>), dim3(blocks), dim3(HDN_BLOCK), 0, stream, (const f4*)ws, b4, (const f4*)res, (f4*)out, n4, Cf::CO / 4, z, 1);
+  else hipLaunchKernelGGL((conv3x3_reduce_kernel<false, true>), dim3(blocks), dim3(HDN_BLOCK), 0, stream, (const f4*)ws, b4, (const f4*)res, (f4*)out, n4, Cf::CO / 4, z, 1);
+  if (Cf::DS) hipLaunchKernelGGL((conv3x3_reduce_kernel<false, false>), dim3(blocks), dim3(HDN_BLOCK), 0, stream, (const f4*)ws2, b4, (const f4*)nullptr, (f4*)out2, n4, Cf::CO / 4, z, 1);
+  return launch_status();
+}
+
+// The chained form (small batches): raw K-slice sums out ([z][M][CO], z = k_slices; the downsample branch to out2), whatever z is,
+// from an activation (lz.zx == 0) or from the previous convolution's slices (LazyIn).  Nothing is reduced here: the next
+// convolution of the chain does that while it stages, the last one's slices go through finish().
+template <class Cf>
+static int launch_chain(const float* x, const LazyIn& lz, const void* wp, float* out, float* out2, int B, hipStream_t stream) {
+  const long long M = (long long)B * Cf::S * Cf::S;
+  const int z = k_slices_chain<Cf>(B);
+  static PerDeviceOnce attr;
+  const int dev_ = PerDeviceOnce::device();
+  if (!attr.done(dev_)) {
+    for (const void* fn : {reinterpret_cast<const void*>(&conv3x3_kernel<Cf, 2, false>), reinterpret_cast<const void*>(&conv3x3_kernel<Cf, 2, true>)}) {
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS_BYTES);
+      if (e != hipSuccess) return -(1000 + (int)e);
+    }
+    attr.set(dev_);
+  }
+  const dim3 grid((unsigned)((M + Cf::BM - 1) / Cf::BM), Cf::NB, z), blk(2 * HDN_BLOCK);
+  const u32x4* w4 = (const u32x4*)wp;
+  if (lz.zx > 0) hipLaunchKernelGGL((conv3x3_kernel<Cf, 2, true>), grid, blk, Cf::LDS_BYTES, stream, x, w4, nullptr, nullptr, out, out2, B, Cf::NCHUNK / z, lz);
+  else hipLaunchKernelGGL((conv3x3_kernel<Cf, 2, false>), grid, blk, Cf::LDS_BYTES, stream, x, w4, nullptr, nullptr, out, out2, B, Cf::NCHUNK / z, LazyIn{});
+  return launch_status();
+}
+
+static int finish(const float* slices, int z, const float* bias, const float* res, int res_slices, float* out, long long n, int C, hipStream_t stream) {
+  const unsigned n4 = (unsigned)(n / 4);
+  const int blocks = (int)((n4 + HDN_BLOCK - 1) / HDN_BLOCK < 1024 ? (n4 + HDN_BLOCK - 1) / HDN_BLOCK : 1024);
+  if (res) hipLaunchKernelGGL((conv3x3_reduce_kernel<true, true>), dim3(blocks), dim3(HDN_BLOCK), 0, stream, (const f4*)slices, (const f4*)bias, (const f4*)res, (f4*)out, n4, C / 4, z, res_slices);
+  else hipLaunchKernelGGL((conv3x3_reduce_kernel<false, true>), dim3(blocks), dim3(HDN_BLOCK), 0, stream, (const f4*)slices, (const f4*)bias, (const f4*)res, (f4*)out, n4, C / 4, z, 1);
   return launch_status();
 }
 
@@ -609,4 +734,41 @@ extern "C" int hdn_conv3x3s2_ds_f32(const float* x, const void* wpacked, const f
   return cv_dispatch(S, CI, 2, B, [&](auto cfg) {
     return hdn::cv::launch<decltype(cfg)>(x, wpacked, bias, nullptr, out, out_ds, workspace, workspace_bytes > 0 ? (size_t)workspace_bytes : 0, B, s);
   });
+}
+
+// ---- the chained form of the trunk at small batches (hdn_amd.trunk.LazyAct): convolutions hand each other raw K-slice sums
+extern "C" int hdn_conv3x3_chain_slices(int B, int S, int CI, int stride) {
+  if (B <= 0) return HDN_E_SHAPE;
+  return cv_dispatch(S, CI, stride, B, [&](auto cfg) { return hdn::cv::k_slices_chain<decltype(cfg)>(B); });
+}
+
+extern "C" int hdn_conv3x3_chain_f32(const float* x, int x_slices, const float* x_bias, const float* x_res, int res_slices, float* x_out, const void* wpacked,
+                                     float* out_slices, float* out_ds_slices, int B, int S, int CI, int stride, void* stream) {
+  if (B <= 0 || S <= 0 || CI <= 0 || x_slices < 0 || res_slices < 0 || (stride != 1 && stride != 2)) return HDN_E_SHAPE;
+  if (!x || !wpacked || !out_slices || (stride == 2 && !out_ds_slices)) return HDN_E_NULL;
+  if (x_slices > 0 && !x_bias) return HDN_E_NULL;
+  if (x_slices == 0 && (x_res || x_out)) return HDN_E_SHAPE;          // an activation needs no finishing
+  if ((x_res != nullptr) != (res_slices > 0)) return HDN_E_SHAPE;
+  if (out_slices == x || out_slices == x_res || out_slices == x_out || (x_out && (x_out == x || x_out == x_res))) return HDN_E_ALIAS;
+  const long long n_in = (long long)B * S * S * stride * stride * CI;
+  if (n_in > 0x7fffffffLL) return HDN_E_LIMIT;
+  for (const void* p : {(const void*)x, wpacked, (const void*)out_slices, (const void*)x_bias, (const void*)x_res, (const void*)x_out, (const void*)out_ds_slices})
+    if (p && !hdn::aligned16(p)) return HDN_E_LIMIT;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const hdn::cv::LazyIn lz{x_bias, x_res, x_out, x_slices, res_slices};
+  return cv_dispatch(S, CI, stride, B, [&](auto cfg) {
+    return hdn::cv::launch_chain<decltype(cfg)>(x, lz, wpacked, out_slices, out_ds_slices, B, s);
+  });
+}
+
+extern "C" int hdn_conv3x3_finish_f32(const float* slices, int n_slices, const float* bias, const float* res, int res_slices, float* out, int B, int S, int C,
+                                      void* stream) {
+  if (B <= 0 || S <= 0 || C <= 0 || C % 4 || n_slices <= 0 || res_slices < 0) return HDN_E_SHAPE;
+  if (!slices || !bias || !out) return HDN_E_NULL;
+  if ((res != nullptr) != (res_slices > 0)) return HDN_E_SHAPE;
+  if (out == slices) return HDN_E_ALIAS;
+  const long long n = (long long)B * S * S * C;
+  if (n > 0x7fffffffLL) return HDN_E_LIMIT;
+  if (!hdn::aligned16(slices) || !hdn::aligned16(bias) || !hdn::aligned16(out) || (res && !hdn::aligned16(res))) return HDN_E_LIMIT;
+  return hdn::cv::finish(slices, n_slices, bias, res, res_slices, out, n, C, static_cast<hipStream_t>(stream));
 }

@@ -69,6 +69,39 @@ __device__ __forceinline__ void fma8(float2v (&acc)[NPAIR], float2v xv, f16v w) 
           "s"(STEM_PAIR(w, 5)), "s"(STEM_PAIR(w, 6)), "s"(STEM_PAIR(w, 7)));
 }
 
+// ... the small-batch form: a tap's 16 weights as four uniform ds_read_b128 (every lane reads the same address: a broadcast) into
+// VGPR pairs.  LDS reads retire in order and a read costs ~100 clk, so one tap ahead is enough; the scalar loads above are a cache
+// miss per tap on a cold CU (~0.25 us each, 98 in a row: the tracker's B = 1 call was 25 us of exactly that).
+struct W16v {
+  f4e q[4];
+};
+template <int OFF>
+__device__ __forceinline__ void lds_w16(W16v& w, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8"
+               : "=&v"(w.q[0]), "=&v"(w.q[1]), "=&v"(w.q[2]), "=&v"(w.q[3])
+               : "v"(addr), "n"(OFF), "n"(OFF + 16), "n"(OFF + 32), "n"(OFF + 48));
+}
+__device__ __forceinline__ void lds_wait(W16v& w) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w.q[0]), "+v"(w.q[1]), "+v"(w.q[2]), "+v"(w.q[3])); }
+template <int HALF>
+__device__ __forceinline__ void fma8v(float2v (&acc)[NPAIR], float2v xv, const W16v& w) {
+#define STEM_VP(k) __builtin_shufflevector(w.q[(k) >> 1], w.q[(k) >> 1], 2 * ((k) & 1), 2 * ((k) & 1) + 1)
+  if constexpr (HALF == 0)
+    asm volatile("v_pk_fma_f32 %0, %8, %9, %0 op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 %1, %8, %10, %1 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %2, %8, %11, %2 op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 %3, %8, %12, %3 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %4, %8, %13, %4 op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 %5, %8, %14, %5 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %6, %8, %15, %6 op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 %7, %8, %16, %7 op_sel_hi:[0,1,1]"
+        : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
+        : "v"(xv), "v"(STEM_VP(0)), "v"(STEM_VP(1)), "v"(STEM_VP(2)), "v"(STEM_VP(3)), "v"(STEM_VP(4)), "v"(STEM_VP(5)), "v"(STEM_VP(6)), "v"(STEM_VP(7)));
+  else
+    asm volatile("v_pk_fma_f32 %0, %8, %9, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\tv_pk_fma_f32 %1, %8, %10, %1 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %2, %8, %11, %2 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\tv_pk_fma_f32 %3, %8, %12, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %4, %8, %13, %4 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\tv_pk_fma_f32 %5, %8, %14, %5 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %6, %8, %15, %6 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\tv_pk_fma_f32 %7, %8, %16, %7 op_sel:[1,0,0] op_sel_hi:[1,1,1]"
+        : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
+        : "v"(xv), "v"(STEM_VP(0)), "v"(STEM_VP(1)), "v"(STEM_VP(2)), "v"(STEM_VP(3)), "v"(STEM_VP(4)), "v"(STEM_VP(5)), "v"(STEM_VP(6)), "v"(STEM_VP(7)));
+#undef STEM_VP
+}
+
 template <int I = 0, class F>
 __device__ __forceinline__ void sfor7(F&& f) {
   if constexpr (I < KS) {
@@ -163,8 +196,56 @@ __global__ __launch_bounds__(HDN_BLOCK, 2) void trunk_stem_kernel(const float* _
     bool rk[2 * KS][NR];
 #pragma unroll
     for (int t = 0; t < 2 * KS; ++t) load_rows(t, raw[t], rk[t]);
+    // this wave's 98 x 16 weights -> its LDS table [tap][16] (one round trip, beside the rows')
+    constexpr int WTAB = 2 * KS * KS * CB;                       // floats
+    __shared__ __attribute__((aligned(16))) float sw[HDN_BLOCK / 64][WTAB];
+    float* const tab = sw[threadIdx.x >> 6];
+    {
+      constexpr int N4 = WTAB / 4, WIT = cdiv(N4, 64);
+      f4e wv[WIT];
 #pragma unroll
-    for (int t = 0; t < 2 * KS; ++t) do_step(t, raw[t], rk[t]);
+      for (int q = 0; q < WIT; ++q) {
+        const int i4 = min(lane + q * 64, N4 - 1), tap = i4 >> 2, k4 = i4 & 3;
+        wv[q] = *reinterpret_cast<const f4e*>(wT + size_t(tap) * CO + cb * CB + k4 * 4);
+      }
+#pragma unroll
+      for (int q = 0; q < WIT; ++q)
+        if (lane + q * 64 < N4) reinterpret_cast<f4e*>(tab)[lane + q * 64] = wv[q];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the table is written (a wave reads only its own table: no barrier)
+    const uint32_t tab_addr = lds_addr(tab);
+    auto do_step_lds = [&](int t, const float2v (&rw)[NR], const bool (&rkk)[NR]) {
+      const uint32_t wa = tab_addr + t * (KS * CB * 4);
+      W16v w;
+      lds_w16<0>(w, wa);
+      float2v xv[NR][4];
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        const float2v v = rw[i];
+        const float2v own = float2v{ok0 && rkk[i] ? (sh ? v.y : v.x) : 0.f, ok1 && rkk[i] ? v.y : 0.f};
+        xv[i][1] = float2v{from_prev_lane(own.x), from_prev_lane(own.y)};
+        xv[i][0] = float2v{0.f, from_prev_lane(xv[i][1].y)};
+        xv[i][2] = own;
+        xv[i][3] = float2v{from_next_lane(own.x), from_next_lane(own.y)};
+      }
+      lds_wait(w);
+      sfor7([&](auto KX) {
+        constexpr int kx = decltype(KX)::value;
+        W16v wn;
+        if constexpr (kx + 1 < KS) lds_w16<(kx + 1) * CB * 4>(wn, wa);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+          if constexpr ((kx + 1) & 1) fma8v<1>(acc[i], xv[i][(kx + 1) >> 1], w);
+          else fma8v<0>(acc[i], xv[i][(kx + 1) >> 1], w);
+        }
+        if constexpr (kx + 1 < KS) {
+          lds_wait(wn);
+          w = wn;
+        }
+      });
+    };
+#pragma unroll
+    for (int t = 0; t < 2 * KS; ++t) do_step_lds(t, raw[t], rk[t]);
   } else {
     // large batches: enough waves per SIMD to hide the rows' round trip; asking for step t + 1's rows a step ahead costs registers
     // and measured 48 -> 53 us at B = 64

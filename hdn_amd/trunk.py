@@ -61,7 +61,8 @@ class HomoResNet(nn.Module):
 
     def forward(self, x):
         x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
-        return self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        return x.finish() if isinstance(x, LazyAct) else x       # (the chained small-batch form of the folded trunk: FusedBasicBlock)
 
 
 def resnet34_homo():
@@ -249,6 +250,82 @@ def conv3x3s2_ds(x, wpacked, bias):
     return out, out_ds
 
 
+# Batches up to this run the blocks CHAINED (hdn_conv3x3_chain_f32): at the tracker's B = 1 every launch is a dependent step of ~5 us
+# and the launches that only add the K slices up were half of the trunk's 70
+CHAIN_MAX_BATCH = 16
+
+
+class LazyAct:
+    """An activation of the chained trunk that was never written out: relu(sum of `slices` [z,B,S,S,C] + bias[c] (+ res)), finished by
+    the convolution that reads it (or by finish()).  res: None, a channels-last activation [B,C,S,S], or raw slices [zr,B,S,S,C]
+    (the downsample branch)."""
+
+    __slots__ = ("slices", "bias", "res")
+
+    def __init__(self, slices, bias, res=None):
+        self.slices, self.bias, self.res = slices, bias, res
+
+    @property
+    def shape(self):
+        z, B, S, _, C = self.slices.shape
+        return (B, C, S, S)
+
+    def res_args(self):
+        from . import _lib
+
+        if self.res is None:
+            return None, 0
+        return _lib.ptr(self.res), (self.res.shape[0] if self.res.dim() == 5 else 1)
+
+    def finish(self):
+        """The activation itself, channels-last [B,C,S,S] (hdn_conv3x3_finish_f32)."""
+        import torch
+
+        from . import _lib
+
+        z, B, S, _, C = self.slices.shape
+        dev = self.slices.device
+        out = torch.empty((B, C, S, S), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+        rp, rz = self.res_args()
+        with _lib.device_guard(dev):
+            rc = _lib.load().hdn_conv3x3_finish_f32(_lib.ptr(self.slices), z, _lib.ptr(self.bias), rp, rz, _lib.ptr(out), B, S, C, _lib.stream_ptr(dev))
+        _lib.check(rc, "conv3x3_finish")
+        return out
+
+
+def chain_conv(x, wpacked, stride=1, want_x=False):
+    """One convolution of the chained trunk (hdn_conv3x3_chain_f32): x a channels-last activation [B,CI,SI,SI] or a LazyAct; returns
+    (slices [z,B,S,S,CO], downsample slices or None (stride 2), the finished input as an activation or None (want_x, LazyAct input))."""
+    import torch
+
+    from . import _lib
+
+    lazy = isinstance(x, LazyAct)
+    B, CI, SI, SI2 = x.shape
+    src = x.slices if lazy else x
+    dev = _lib.require_device(src)
+    if SI != SI2 or SI % stride or (not lazy and not x.is_contiguous(memory_format=torch.channels_last)):
+        raise ValueError("chain_conv: square channels-last input")
+    S, CO = SI // stride, CI * stride
+    T = 4 if stride == 2 else 3
+    if wpacked.dtype != torch.int16 or wpacked.device != dev or wpacked.numel() != SPLIT_PIECES * 3 * T * CI * CO:
+        raise ValueError("chain_conv: weights must come from pack_conv3x3 / pack_conv3x3s2_ds for this channel count")
+    lib = _lib.load()
+    z = lib.hdn_conv3x3_chain_slices(B, S, CI, stride)
+    if z < 0:
+        _lib.check(int(z), "conv3x3_chain")
+    out = torch.empty((z, B, S, S, CO), dtype=torch.float32, device=dev)
+    out_ds = torch.empty_like(out) if stride == 2 else None
+    x_out = torch.empty((B, CI, SI, SI), dtype=torch.float32, device=dev, memory_format=torch.channels_last) if (lazy and want_x) else None
+    rp, rz = x.res_args() if lazy else (None, 0)
+    with _lib.device_guard(dev):
+        rc = lib.hdn_conv3x3_chain_f32(_lib.ptr(src), src.shape[0] if lazy else 0, _lib.ptr(x.bias) if lazy else None, rp, rz,
+                                       _lib.ptr(x_out) if x_out is not None else None, _lib.ptr(wpacked), _lib.ptr(out),
+                                       _lib.ptr(out_ds) if out_ds is not None else None, B, S, CI, stride, _lib.stream_ptr(dev))
+    _lib.check(rc, "conv3x3_chain")
+    return out, out_ds, x_out
+
+
 class FusedBasicBlock(nn.Module):
     """BasicBlock.forward (backbone/resnet.py:78-94) of the BN-folded trunk with its elementwise tail fused.  Stride-1 3x3
     convolutions of MATRIX_CORE_CHANNELS run, bias / residual / ReLU included, as ONE launch of the split-fp16 matrix-core kernel
@@ -293,6 +370,11 @@ class FusedBasicBlock(nn.Module):
         def shape_ok(t):   # the kernel's shapes: square, side tied to the channel count (127-px crops), channels-last
             return t.is_contiguous(memory_format=torch.channels_last) and t.shape[2] == t.shape[3] == _MC_SIDE.get(t.shape[1], -1)
 
+        chained = self._chained(x)
+        if chained is not None:
+            return chained
+        if isinstance(x, LazyAct):
+            x = x.finish()
         if (self.p1s2 is not None and x.is_contiguous(memory_format=torch.channels_last)
                 and x.shape[2] == x.shape[3] == 2 * _MC_SIDE.get(2 * x.shape[1], -1)):
             y, idt = conv3x3s2_ds(x, self.p1s2, self.b1)       # stride-2 convolution + the downsample branch from one staged input
@@ -305,6 +387,32 @@ class FusedBasicBlock(nn.Module):
         if self.p2 is not None and shape_ok(y) and idt.is_contiguous(memory_format=torch.channels_last):
             return conv3x3_bias_relu(y, self.p2, self.b2, idt)
         return bias_relu_(F.conv2d(y, self.w2, None, 1, 1), self.b2, idt)
+
+
+def _chained(self, x):
+    """The block as two chained launches (None: not this input).  A LazyAct in: the previous block's output, finished while conv1
+    stages it (and written out once, as this block's residual); a LazyAct out."""
+    import torch
+
+    lazy = isinstance(x, LazyAct)
+    if self.p2 is None or getattr(self, "_hdn_no_chain", False) or FusedBasicBlock.chain_disabled:
+        return None
+    B, C, S, S2 = x.shape
+    if not lazy and not (x.is_cuda and x.dtype == torch.float32 and B <= CHAIN_MAX_BATCH and x.is_contiguous(memory_format=torch.channels_last)):
+        return None
+    if self.p1s2 is not None and S == S2 == 2 * _MC_SIDE.get(2 * C, -1):
+        s1, sd, _ = chain_conv(x, self.p1s2, 2)
+        s2, _, _ = chain_conv(LazyAct(s1, self.b1), self.p2)
+        return LazyAct(s2, self.b2, sd)
+    if self.p1 is not None and self.wd is None and S == S2 == _MC_SIDE.get(C, -1):
+        s1, _, idt = chain_conv(x, self.p1, 1, want_x=True)
+        s2, _, _ = chain_conv(LazyAct(s1, self.b1), self.p2)
+        return LazyAct(s2, self.b2, idt if lazy else x)
+    return None
+
+
+FusedBasicBlock._chained = _chained
+FusedBasicBlock.chain_disabled = False     # A/B switch (tests, tools/experiments)
 
 
 def fold_for_inference(net: HomoResNet, channels_last: bool = True, fused_stem: bool = False, fused_epilogue: bool = False,

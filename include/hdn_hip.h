@@ -369,6 +369,29 @@ int hdn_conv3x3s2_ds_f32(const float* x, const void* wpacked, const float* bias,
                          long long workspace_bytes, int B, int S, int CI, void* stream);
 
 /*
+ * The same convolutions chained (ABI 5, the tracker's B = 1, where every launch is a dependent step of ~5 us and the launches that only
+ * add K slices up were half of the trunk's): a convolution writes its raw K-slice sums and the NEXT convolution finishes them while it
+ * stages its input, so a BasicBlock is two launches instead of four.
+ *   hdn_conv3x3_chain_slices(B, S, CI, stride): z >= 1, the number of slices hdn_conv3x3_chain_f32 writes for this problem.
+ *   hdn_conv3x3_chain_f32: out_slices[z][B,S,S,CO] = the K slices of conv3x3/stride/p1(X, W) without bias (stride 2: CO = 2 CI and
+ *     out_ds_slices[z][B,S,S,CO] = the slices of the 1x1 / stride-2 downsample branch), where the input X [B, S stride, S stride, CI] is
+ *       x_slices == 0: the activation x itself (x_bias / x_res / x_out NULL), or
+ *       x_slices  > 0: relu(sum of x[0 .. x_slices) in slice order + x_bias[c] (+ the residual)), x = the slices a previous call wrote;
+ *                      x_res: the residual as res_slices >= 1 arrays like X, added up in slice order (1: an activation; more: the
+ *                      out_ds_slices of the block's first convolution), NULL with res_slices == 0 for none;
+ *                      x_out (optional): X is also written here, once (the next block's residual).
+ *     The arithmetic and its order are those of hdn_conv3x3_bias_relu_f32's reduction launch: the chain is bit-identical to the
+ *     unchained calls.
+ *   hdn_conv3x3_finish_f32: out[B,S,S,C] = relu(sum of slices[0 .. n_slices) + bias[c] (+ residual as above)): the end of a chain.
+ * Same shapes, packing and value range as above; pointers 16-byte aligned; out_slices / x_out must not alias an input.
+ */
+int hdn_conv3x3_chain_slices(int B, int S, int CI, int stride);
+int hdn_conv3x3_chain_f32(const float* x, int x_slices, const float* x_bias, const float* x_res, int res_slices, float* x_out, const void* wpacked,
+                          float* out_slices, float* out_ds_slices, int B, int S, int CI, int stride, void* stream);
+int hdn_conv3x3_finish_f32(const float* slices, int n_slices, const float* bias, const float* res, int res_slices, float* out, int B, int S, int C,
+                           void* stream);
+
+/*
  * Multi-GPU: template/search pairs are independent, so ranks own disjoint contiguous blocks of pairs
  * and the path's ONLY exchange is one all-gather of the predicted corner offsets, on RCCL over xGMI.
  *   local[Bl,8] (this rank's offsets) -> all[world*Bl,8] on every rank, in rank order; Bl must be equal on all

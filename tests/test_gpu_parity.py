@@ -1147,6 +1147,131 @@ def test_conv3x3s2_ds_matrix_core_vs_float64(dev, CI, S, B):
             assert e <= 4 * e_ref + 1e-5 * scale, (e, e_ref, scale)
 
 
+@pytest.mark.parametrize("C,S", [(64, 32), (128, 16), (256, 8), (512, 4)])
+@pytest.mark.parametrize("B", [1, 2, 3, 9, 16])
+def test_conv3x3_chain_vs_unchained_and_float64(dev, C, S, B):
+    """hdn_conv3x3_chain_f32 / hdn_conv3x3_finish_f32: two BasicBlocks as four chained launches (each convolution finishes the
+    previous one's raw K slices while it stages them; the second block's residual is the activation the first launch of that block
+    wrote out on the way) against the same blocks through hdn_conv3x3_bias_relu_f32 — bit-identical whenever both forms split K the same
+    way (they do at small B) — and against float64."""
+    import ctypes
+    import torch.nn.functional as F
+    from hdn_amd import _lib
+    from hdn_amd.trunk import pack_conv3x3, conv3x3_bias_relu, chain_conv, LazyAct
+    g = torch.Generator().manual_seed(7 * C + B)
+    cl = torch.channels_last
+    ws = [torch.randn(C, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5 for _ in range(4)]
+    bs = [torch.randn(C, generator=g) * 0.1 for _ in range(4)]
+    x = torch.randn(B, C, S, S, generator=g).clamp_min_(0)
+    wp, bd = [pack_conv3x3(w).to(dev) for w in ws], [b.to(dev) for b in bs]
+    xd = x.to(dev).contiguous(memory_format=cl)
+    # unchained
+    y1 = conv3x3_bias_relu(conv3x3_bias_relu(xd, wp[0], bd[0]), wp[1], bd[1], xd)
+    y2 = conv3x3_bias_relu(conv3x3_bias_relu(y1, wp[2], bd[2]), wp[3], bd[3], y1)
+    # chained
+    s1, none, xo = chain_conv(xd, wp[0], 1, want_x=True)
+    assert none is None and xo is None
+    s2, _, _ = chain_conv(LazyAct(s1, bd[0]), wp[1])
+    l1 = LazyAct(s2, bd[1], xd)
+    s3, _, y1c = chain_conv(l1, wp[2], 1, want_x=True)
+    s4, _, _ = chain_conv(LazyAct(s3, bd[2]), wp[3])
+    y2c = LazyAct(s4, bd[3], y1c).finish()
+    lib = _lib.load()
+    same_split = lib.hdn_conv3x3_chain_slices(B, S, C, 1) * B * S * S * C * 4 == max(lib.hdn_conv3x3_workspace_bytes(B, S, C, 1), B * S * S * C * 4)
+    assert y1c.shape == y1.shape and y1c.is_contiguous(memory_format=cl) and y2c.is_contiguous(memory_format=cl)
+    assert torch.equal(y1c, l1.finish())                   # the activation written on the way == the finishing launch
+    if same_split:
+        assert torch.equal(y1c, y1) and torch.equal(y2c, y2)
+    assert torch.equal(y2c, LazyAct(chain_conv(LazyAct(s3, bd[2]), wp[3])[0], bd[3], y1c).finish())   # deterministic
+    xt = x.double()
+    t1 = torch.relu(F.conv2d(torch.relu(F.conv2d(xt, ws[0].double(), bs[0].double(), padding=1)), ws[1].double(), bs[1].double(), padding=1) + xt)
+    t2 = torch.relu(F.conv2d(torch.relu(F.conv2d(t1, ws[2].double(), bs[2].double(), padding=1)), ws[3].double(), bs[3].double(), padding=1) + t1)
+    for got, truth in ((y1c, t1), (y2c, t2), (y2, t2)):
+        assert float((got.cpu().double() - truth).abs().max()) <= 2e-5 * float(truth.abs().max())
+    one = ctypes.c_void_p(64)
+    assert lib.hdn_conv3x3_chain_f32(one, 0, None, None, 0, None, one, None, None, 1, S, C, 1, None) == -1          # no output
+    assert lib.hdn_conv3x3_chain_f32(one, 2, None, None, 0, None, one, ctypes.c_void_p(128), None, 1, S, C, 1, None) == -1   # slices without their bias
+    assert lib.hdn_conv3x3_chain_f32(one, 0, None, one, 1, None, one, ctypes.c_void_p(128), None, 1, S, C, 1, None) == -2    # an activation with a residual
+    assert lib.hdn_conv3x3_chain_f32(one, 0, None, None, 0, None, one, one, None, 1, S, C, 1, None) == -4                   # in place
+    assert lib.hdn_conv3x3_finish_f32(one, 0, one, None, 0, ctypes.c_void_p(128), 1, S, C, None) == -2
+
+
+@pytest.mark.parametrize("CI,S", [(64, 16), (128, 8), (256, 4)])
+@pytest.mark.parametrize("B", [1, 3])
+def test_conv3x3_chain_downsample_block(dev, CI, S, B):
+    """The first block of layer2..4 chained: stride-2 convolution + downsample branch from a LazyAct input, the second convolution
+    from the first one's slices, the block's output with the downsample SLICES as its residual — against the unchained launches
+    (bit-identical at these batch sizes) and float64."""
+    import torch.nn.functional as F
+    from hdn_amd.trunk import pack_conv3x3, pack_conv3x3s2_ds, conv3x3s2_ds, conv3x3_bias_relu, chain_conv, LazyAct
+    g = torch.Generator().manual_seed(11 * CI + B)
+    cl = torch.channels_last
+    CO = 2 * CI
+    w0 = torch.randn(CI, CI, 3, 3, generator=g) * (2.0 / (9 * CI)) ** 0.5
+    w1 = torch.randn(CO, CI, 3, 3, generator=g) * (2.0 / (9 * CI)) ** 0.5
+    wd = torch.randn(CO, CI, 1, 1, generator=g) * (1.0 / CI) ** 0.5
+    w2 = torch.randn(CO, CO, 3, 3, generator=g) * (2.0 / (9 * CO)) ** 0.5
+    b0, b1, b2 = (torch.randn(c, generator=g) * 0.1 for c in (CI, CO, CO))
+    x = torch.randn(B, CI, 2 * S, 2 * S, generator=g).clamp_min_(0)
+    r = torch.randn(B, CI, 2 * S, 2 * S, generator=g)
+    xd, rd = x.to(dev).contiguous(memory_format=cl), r.to(dev).contiguous(memory_format=cl)
+    p0, p1, p2 = pack_conv3x3(w0).to(dev), pack_conv3x3s2_ds(w1, wd).to(dev), pack_conv3x3(w2).to(dev)
+    b0d, b1d, b2d = b0.to(dev), b1.to(dev), b2.to(dev)
+    # unchained: a = relu(conv(x, w0) + b0 + r); (y, idt) = s2 block; out = relu(conv(y, w2) + b2 + idt)
+    a = conv3x3_bias_relu(xd, p0, b0d, rd)
+    y, idt = conv3x3s2_ds(a, p1, b1d)
+    out = conv3x3_bias_relu(y, p2, b2d, idt)
+    # chained
+    s0, _, _ = chain_conv(xd, p0)
+    s1, sd, _ = chain_conv(LazyAct(s0, b0d, rd), p1, 2)
+    s2, _, _ = chain_conv(LazyAct(s1, b1d), p2)
+    outc = LazyAct(s2, b2d, sd).finish()
+    assert sd.dim() == 5 and sd.shape == s1.shape and outc.shape == out.shape
+    assert torch.equal(outc, out)
+    # ... and into the next block: the downsample slices as the residual of a LAZY input
+    w3 = torch.randn(CO, CO, 3, 3, generator=g) * (2.0 / (9 * CO)) ** 0.5
+    p3 = pack_conv3x3(w3).to(dev)
+    s3, _, xo = chain_conv(LazyAct(s2, b2d, sd), p3, 1, want_x=True)
+    assert torch.equal(xo, out)
+    assert torch.equal(LazyAct(s3, b1d).finish(), conv3x3_bias_relu(out, p3, b1d))
+    at = torch.relu(F.conv2d(x.double(), w0.double(), b0.double(), padding=1) + r.double())
+    yt = torch.relu(F.conv2d(at, w1.double(), b1.double(), stride=2, padding=1))
+    tt = torch.relu(F.conv2d(yt, w2.double(), b2.double(), padding=1) + F.conv2d(at, wd.double(), None, stride=2))
+    assert float((outc.cpu().double() - tt).abs().max()) <= 2e-5 * float(tt.abs().max())
+
+
+def test_chained_trunk_equals_unchained(dev):
+    """The folded trunk at B = 1 and 2 in its chained form (37 launches instead of 70) against the same trunk with the switch off:
+    bit-identical (same K split, same order of additions), eagerly and as a captured hipGraph."""
+    from hdn_amd.trunk import fold_for_inference, resnet34_homo, FusedBasicBlock
+    torch.manual_seed(5)
+    net = resnet34_homo().to(dev).eval()
+    fast = fold_for_inference(net, channels_last=True, fused_stem=True, fused_epilogue=True)
+    for B in (1, 2):
+        x = torch.randn(B, 2, 127, 127, device=dev).contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            y = fast(x)
+            FusedBasicBlock.chain_disabled = True
+            try:
+                y0 = fast(x)
+            finally:
+                FusedBasicBlock.chain_disabled = False
+            assert y.shape == (B, 512, 4, 4) and torch.equal(y, y0)
+            ref = net(x)
+            assert float((y - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                fast(x)
+            torch.cuda.current_stream().wait_stream(side)
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                yg = fast(x)
+            gr.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(yg, y)
+
+
 def test_fused_epilogue_trunk_vs_unfused(dev):
     """The BN-folded trunk with FusedBasicBlock (bias-free MIOpen convolutions + hdn_bias_relu_f32) against the same folded
     trunk on PyTorch's own bias / add / relu kernels, NCHW and NHWC: the only arithmetic difference is (b2 + b_downsample)
