@@ -66,20 +66,25 @@ static void launch_vec(float* y, const float* res, const float* bias, unsigned n
 // workgroup per sample; a thread owns channels tid, tid + 256, ...: the mean over the HW positions (summed in position order, then
 // times 1 / HW), its O partial products, then a workgroup reduction per output (wave shuffles, one LDS word per wave and output).
 // Replaces at::mean + a hipBLASLt GEMM (5 + 7 us at B = 64, two latency-bound launches at the tracker's B = 1).
-constexpr int AF_MAX_OUT = 16;
+constexpr int AF_MAX_OUT = 16, AF_THREADS = 512;
 template <bool NHWC>
-__global__ __launch_bounds__(HDN_BLOCK) void avgpool_fc_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                               float* __restrict__ out, int C, int HW, int O) {
-  __shared__ float part[HDN_BLOCK / HDN_WAVE][AF_MAX_OUT];
+__global__ __launch_bounds__(AF_THREADS) void avgpool_fc_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                                float* __restrict__ out, int C, int HW, int O) {
+  __shared__ float part[AF_THREADS / HDN_WAVE][AF_MAX_OUT];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & (HDN_WAVE - 1), wave = tid >> 6;
   const float* xb = x + (size_t)b * C * HW;
   const float inv = 1.0f / (float)HW;
   float acc[AF_MAX_OUT];
 #pragma unroll
   for (int o = 0; o < AF_MAX_OUT; ++o) acc[o] = 0.f;
-  for (int c = tid; c < C; c += HDN_BLOCK) {
+  // 512 threads: the trunk's 512 channels are ONE pass, and a pass is one round trip (the channel's weights are asked for together with its
+  // 16 positions; at B = 1 the launch is a single workgroup and nothing but load latency: it was four round trips, 10 us)
+  for (int c = tid; c < C; c += AF_THREADS) {
+    float wv[AF_MAX_OUT];
+#pragma unroll
+    for (int o = 0; o < AF_MAX_OUT; ++o) wv[o] = w[(size_t)min(o, O - 1) * C + c];
     float s = 0.f;
-    for (int pb = 0; pb < HW; pb += 16) {     // 16 positions in flight at a time (one round trip for the trunk's 4 x 4 map), added in position order
+    for (int pb = 0; pb < HW; pb += 16) {     // 16 positions in flight at a time, added in position order
       float v[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(HDN_BLOCK) void avgpool_fc_kernel(const float* __re
     const float m = s * inv;
 #pragma unroll
     for (int o = 0; o < AF_MAX_OUT; ++o)
-      if (o < O) acc[o] = __builtin_fmaf(m, w[(size_t)o * C + c], acc[o]);
+      if (o < O) acc[o] = __builtin_fmaf(m, wv[o], acc[o]);
   }
 #pragma unroll
   for (int o = 0; o < AF_MAX_OUT; ++o) {
@@ -106,7 +111,7 @@ __global__ __launch_bounds__(HDN_BLOCK) void avgpool_fc_kernel(const float* __re
   if (tid < O) {
     float v = bias ? bias[tid] : 0.f;
 #pragma unroll
-    for (int k = 0; k < HDN_BLOCK / HDN_WAVE; ++k) v += part[k][tid];
+    for (int k = 0; k < AF_THREADS / HDN_WAVE; ++k) v += part[k][tid];
     out[(size_t)b * O + tid] = v;
   }
 }
@@ -119,8 +124,8 @@ extern "C" int hdn_avgpool_fc_f32(const float* x, const float* w, const float* b
   if (O > hdn::AF_MAX_OUT || (long long)B * C * HW > 0x7fffffffLL) return HDN_E_LIMIT;
   if ((const void*)out == (const void*)x) return HDN_E_ALIAS;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (nhwc) hipLaunchKernelGGL((hdn::avgpool_fc_kernel<true>), dim3(B), dim3(HDN_BLOCK), 0, s, x, w, bias, out, C, HW, O);
-  else hipLaunchKernelGGL((hdn::avgpool_fc_kernel<false>), dim3(B), dim3(HDN_BLOCK), 0, s, x, w, bias, out, C, HW, O);
+  if (nhwc) hipLaunchKernelGGL((hdn::avgpool_fc_kernel<true>), dim3(B), dim3(hdn::AF_THREADS), 0, s, x, w, bias, out, C, HW, O);
+  else hipLaunchKernelGGL((hdn::avgpool_fc_kernel<false>), dim3(B), dim3(hdn::AF_THREADS), 0, s, x, w, bias, out, C, HW, O);
   return hdn::launch_status();
 }
 

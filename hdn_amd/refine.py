@@ -53,12 +53,13 @@ def _constants(dev, B, H, W):
     return _CONST[key]
 
 
-def homo_refine(net, template: torch.Tensor, search: torch.Tensor, iterations: int = 2, cache_template: bool = True):
+def homo_refine(net, template: torch.Tensor, search: torch.Tensor, iterations: int = 2, cache_template: bool = True, patch_1: torch.Tensor = None):
     """template / search: [B,1,127,127] normalised gray crops on the device (get_template_info / get_search_info output).
 
     Returns (H_comp [B,3,3] float64 = product of the normalised inverse homographies, as the tracker composes it,
     similarity_norm, similarity_norm_simi of the LAST iteration — the values the tracker's `> 2.5` gate sees).
-    ShareFeature(template) is computed once (it is constant: SURVEY §3d)."""
+    ShareFeature(template) is computed once (it is constant: SURVEY §3d) — or not at all when the caller hands it in as `patch_1`
+    (the tracker keeps it for the whole sequence: the template crop is cut once, in init)."""
     if iterations < 1:
         raise ValueError("iterations must be >= 1")
     B, _, H, W = template.shape
@@ -66,7 +67,12 @@ def homo_refine(net, template: torch.Tensor, search: torch.Tensor, iterations: i
     h4p, pidx, eye = _constants(dev, B, H, W)
     H_comp = eye.clone()
     cur = search
-    p1 = net.ShareFeature(template) if cache_template else None
+    if patch_1 is not None:
+        if patch_1.shape != template.shape or patch_1.device != template.device:
+            raise ValueError(f"patch_1 must be ShareFeature(template): {tuple(template.shape)} on {template.device}, got {tuple(patch_1.shape)}")
+        p1 = patch_1
+    else:
+        p1 = net.ShareFeature(template) if cache_template else None
     score = score_simi = None
     for _ in range(iterations):
         if p1 is not None:

@@ -73,6 +73,8 @@ class HomoTracker:
         self.z_crop_points_sm = FR.crop_points(self.center_pos, self.init_s_z_sm, H, W)
         # get_template_info(get_subwindow_for_homo(...)[:, 0:3]) : the normalised gray template, constant for the sequence
         self.init_homo_tmp = FR.get_search_info(frame, self.center_pos, self.init_s_z_sm, self.channel_average, model_sz=c.exemplar_size)
+        with torch.no_grad():   # ShareFeature(template): constant for the sequence, so not part of the per-frame work
+            self.init_patch_1 = self.net.ShareFeature(self.init_homo_tmp).detach()
         if self.similarity is not None:
             self.similarity.init(frame, self.init_pos, self.init_s_z, self.init_s_z_sm, self.channel_average)   # model.template(z_crop), :99-107
         self.init_points = torch.tensor(np.asarray(gt_points, np.float64).reshape(1, -1, 2), dtype=torch.float64, device=self.dev).contiguous()
@@ -116,7 +118,7 @@ class HomoTracker:
         # :224-239  cut the homography crop, normalise
         search = FR.get_search_info(rot_img, None, None, None, model_sz=self.cfg.exemplar_size, params=params)
         # :242-250  refinement loop around track_proj
-        H_comp, homo_score, _ = homo_refine(self.net, self.init_homo_tmp, search, iterations=self.iterations)
+        H_comp, homo_score, _ = homo_refine(self.net, self.init_homo_tmp, search, iterations=self.iterations, patch_1=self.init_patch_1)
         # :251-272  un-scale, un-shift, gate, accumulate, project the initial corners
         score = homo_score.detach().reshape(-1).to(torch.float32).contiguous()
         with _lib.device_guard(self.dev):
