@@ -12,3 +12,4 @@ from .heads import MultiBAN, MultiCircBAN  # noqa: F401
 from .refine import homo_refine, refine_warp  # noqa: F401
 
 __version__ = "0.1.0"
+from .backbone import optimize_similarity_model, restore_similarity_model  # noqa: F401

@@ -209,9 +209,10 @@ class DeviceTrackerHomo(HomoTracker):
     """Drop-in for hdnTrackerHomo (hdn_tracker_proj_e2e.py:22-285) behind build_tracker(model)
     (hdn/tracker/tracker_builder.py:18-19): same constructor argument, same init / track_new signatures and result keys.
     `model` is the reference's ModelBuilder (hm_net = the homography estimator, template / track_new / track_new_lp = the
-    similarity branch).  HDN_TRACKER_GRAPH=1 replays each frame as one hipGraph."""
+    similarity branch).  HDN_TRACKER_GRAPH=1 replays each frame as one hipGraph.  The model's backbone and necks are switched to their
+    BatchNorm-folded, epilogue-fused form (hdn_amd.backbone; fold_backbone=False or HDN_FOLD_BACKBONE=0: left as they are)."""
 
-    def __init__(self, model, graph: bool = None, iterations: int = 1, cfg: TrackerConfig = None):
+    def __init__(self, model, graph: bool = None, iterations: int = 1, cfg: TrackerConfig = None, fold_backbone: bool = None):
         cls_out = 2
         if cfg is None:
             cfg = TrackerConfig()
@@ -229,4 +230,7 @@ class DeviceTrackerHomo(HomoTracker):
             graph = os.environ.get("HDN_TRACKER_GRAPH", "0") not in ("", "0")
         model.eval()
         self.model = model
+        # backbone + necks stay PyTorch-ROCm's convolutions; their BatchNorm / ReLU / add launches (a third of the B = 1 frame) are folded away
+        from . import backbone as BB
+        self.folded = BB.optimize_similarity_model(model) if (BB.enabled() if fold_backbone is None else fold_backbone) else []
         super().__init__(model.hm_net, iterations=iterations, similarity=DeviceSimilarity(model, cfg), graph=graph, cfg=cfg)

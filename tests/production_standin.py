@@ -36,25 +36,31 @@ import torch.nn.functional as F
 
 
 # ------------------------------------------------------------------------------------------------------------- backbone
+# Attribute names follow the reference's modules (Bottleneck: conv1 / bn1 / conv2 / bn2 / conv3 / bn3 / relu / downsample,
+# resnet_atrous.py:60-108; ResNet: conv1 / bn1 / relu / maxpool / layer1..4 / used_layers, :111-199; AdjustLayer.downsample and
+# AdjustAllLayer.downsample2..4, neck.py:11-51), so that whatever hdn_amd does to the reference's networks by structure
+# (hdn_amd.backbone: BatchNorm folding, fused epilogues) happens to this stand-in too.
 class _Unit(nn.Module):
     """1x1 reduce -> 3x3 (stride / dilation) -> 1x1 expand, BatchNorm after each, residual add, ReLU."""
 
     def __init__(self, cin, mid, stride=1, dil=1, pad=1, skip=None):
         super().__init__()
         cout = 4 * mid
-        self.reduce = nn.Conv2d(cin, mid, 1, bias=False)
-        self.n0 = nn.BatchNorm2d(mid)
-        self.spatial = nn.Conv2d(mid, mid, 3, stride=stride, padding=pad, dilation=dil, bias=False)
-        self.n1 = nn.BatchNorm2d(mid)
-        self.expand = nn.Conv2d(mid, cout, 1, bias=False)
-        self.n2 = nn.BatchNorm2d(cout)
-        self.skip = skip
+        self.conv1 = nn.Conv2d(cin, mid, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(mid)
+        self.conv2 = nn.Conv2d(mid, mid, 3, stride=stride, padding=pad, dilation=dil, bias=False)
+        self.bn2 = nn.BatchNorm2d(mid)
+        self.conv3 = nn.Conv2d(mid, cout, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(cout)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = skip
+        self.stride = stride
 
     def forward(self, x):
-        y = F.relu(self.n0(self.reduce(x)))
-        y = F.relu(self.n1(self.spatial(y)))
-        y = self.n2(self.expand(y))
-        return F.relu(y + (x if self.skip is None else self.skip(x)))
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.relu(self.bn2(self.conv2(y)))
+        y = self.bn3(self.conv3(y))
+        return self.relu(y + (x if self.downsample is None else self.downsample(x)))
 
 
 def _skip(cin, cout, k, stride=1, dil=1, pad=0):
@@ -74,30 +80,45 @@ class AtrousResNet50(nn.Module):
 
     def __init__(self):
         super().__init__()
-        self.stem = nn.Sequential(nn.Conv2d(3, 64, 7, stride=2, padding=0, bias=False), nn.BatchNorm2d(64), nn.ReLU(inplace=True),
-                                  nn.MaxPool2d(3, stride=2, padding=1))
-        self.s1 = _stage(64, 64, 3, (1, 1, 1, 1, 1, 0), (1, 1))             # 1x1 skip
-        self.s2 = _stage(256, 128, 4, (2, 1, 0, 3, 1, 0), (1, 1))           # stride 2 without padding, 3x3 skip
-        self.s3 = _stage(512, 256, 6, (1, 1, 1, 3, 1, 1), (2, 2))           # dilation 2 (first unit: 1), 3x3 skip
-        self.s4 = _stage(1024, 512, 3, (1, 2, 2, 3, 2, 2), (4, 4))          # dilation 4 (first unit: 2), dilated 3x3 skip
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=0, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
+        self.layer1 = _stage(64, 64, 3, (1, 1, 1, 1, 1, 0), (1, 1))             # 1x1 skip
+        self.layer2 = _stage(256, 128, 4, (2, 1, 0, 3, 1, 0), (1, 1))           # stride 2 without padding, 3x3 skip
+        self.layer3 = _stage(512, 256, 6, (1, 1, 1, 3, 1, 1), (2, 2))           # dilation 2 (first unit: 1), 3x3 skip
+        self.layer4 = _stage(1024, 512, 3, (1, 2, 2, 3, 2, 2), (4, 4))          # dilation 4 (first unit: 2), dilated 3x3 skip
+        self.used_layers = [2, 3, 4]
 
     def forward(self, x):
-        p2 = self.s2(self.s1(self.stem(x)))
-        p3 = self.s3(p2)
-        return [p2, p3, self.s4(p3)]
+        x_ = self.relu(self.bn1(self.conv1(x)))
+        p1 = self.layer1(self.maxpool(x_))
+        p2 = self.layer2(p1)
+        p3 = self.layer3(p2)
+        out = [x_, p1, p2, p3, self.layer4(p3)]
+        return [out[i] for i in self.used_layers]
+
+
+class _Adjust(nn.Module):
+    def __init__(self, cin, cout, cut):
+        super().__init__()
+        self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, bias=False), nn.BatchNorm2d(cout))
+        self.cut = cut
+
+    def forward(self, x):
+        x = self.downsample(x)
+        return x[:, :, 4:11, 4:11] if self.cut and x.size(3) < 20 else x
 
 
 class Necks(nn.Module):
     def __init__(self, cut):
         super().__init__()
-        self.cut = cut
-        self.adjust = nn.ModuleList([nn.Sequential(nn.Conv2d(c, 256, 1, bias=False), nn.BatchNorm2d(256)) for c in (512, 1024, 2048)])
+        self.num = 3
+        for i, c in enumerate((512, 1024, 2048)):
+            self.add_module("downsample" + str(i + 2), _Adjust(c, 256, cut))
 
     def forward(self, feats):
-        out = [a(f) for a, f in zip(self.adjust, feats)]
-        if self.cut:
-            out = [o[:, :, 4:11, 4:11] if o.shape[3] < 20 else o for o in out]
-        return out
+        return [getattr(self, "downsample" + str(i + 2))(f) for i, f in enumerate(feats)]
 
 
 def _prior(n, cy, cx, width, amp=6.0):
@@ -116,7 +137,7 @@ def _seed(module, seed):
             if m.bias is not None:
                 m.bias.data.zero_()
         elif isinstance(m, _Unit):
-            m.n2.weight.data.fill_(0.25)
+            m.bn3.weight.data.fill_(0.25)
 
 
 class ProductionStandIn(nn.Module):

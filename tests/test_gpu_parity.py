@@ -10,6 +10,8 @@ Tolerances (fp32 path, BASELINE.json north_star: 1e-4 abs on the predicted corne
     solution for general quadrilaterals (tests/test_oracle_golden.py::test_dlt_solve), so those compare to
     the float64 solution at 1e-5 and to the reference at 5e-4.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1412,3 +1414,47 @@ def test_head_conv_search_one_launch_vs_float64(dev, Hi, Wi, n, CO, nhwc):
         err = float((got[i] - ref).abs().max())
         assert err <= 4 * e_ref + 1e-6 * scale, (i, err, e_ref, scale)
     assert torch.equal(HD.head_conv_search(xd, pk).cpu().double(), got)          # deterministic
+
+
+# --------------------------------------------------------------------------- similarity backbone + necks: BatchNorm folded, epilogues fused
+@pytest.mark.parametrize("nhwc", [False, True])
+def test_backbone_folding_on_the_device(dev, nhwc):
+    """hdn_amd.backbone.optimize_similarity_model on the production-shaped stand-in (the reference's module layout: tests/production_standin.py):
+    backbone (ResNet-50, stride 8, dilated) and both necks through MIOpen convolutions + hdn_bias_relu_f32 passes against the same modules'
+    own forward (BatchNorm / ReLU / add launches), 127- and 255-px crops; the switch is reversible and leaves state_dict alone."""
+    import types
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import production_standin as PS
+    from hdn_amd import backbone as BB
+    torch.manual_seed(2)
+    model = types.SimpleNamespace(backbone=PS.AtrousResNet50(), neck=PS.Necks(True), neck_lp=PS.Necks(False))
+    for i, part in enumerate((model.backbone, model.neck, model.neck_lp)):
+        PS._seed(part, 40 + i)
+        for m in part.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.uniform_(-0.1, 0.1); m.running_var.uniform_(0.8, 1.3); m.bias.data.uniform_(-0.1, 0.1)
+        part.to(dev).eval()
+        if nhwc:
+            part.to(memory_format=torch.channels_last)
+    keys = list(model.backbone.state_dict().keys())
+    xs = [torch.randn(1, 3, s, s, device=dev) * 60 + 110 for s in (127, 255)]
+    if nhwc:
+        xs = [x.contiguous(memory_format=torch.channels_last) for x in xs]
+    with torch.no_grad():
+        ref = [(f, model.neck(f), model.neck_lp(f)) for f in (model.backbone(x) for x in xs)]
+        assert BB.optimize_similarity_model(model, strict=True) == ["backbone", "neck", "neck_lp"]
+        assert list(model.backbone.state_dict().keys()) == keys and type(model.backbone).__name__ == "AtrousResNet50"
+        for x, (rf, rn, rl) in zip(xs, ref):
+            f = model.backbone(x)
+            for got, want in list(zip(f, rf)) + list(zip(model.neck(f), rn)) + list(zip(model.neck_lp(f), rl)):
+                assert got.shape == want.shape
+                assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max()), (float((got - want).abs().max()), float(want.abs().max()))
+        model.backbone.train()
+        assert not BB._use_fused(model.backbone, xs[0])          # training mode: the class's own forward (BatchNorm statistics are live)
+        model.backbone.eval()
+        BB.restore_similarity_model(model)
+        again = model.backbone(xs[0])
+        assert "_hdn_fused" not in vars(model.backbone) and type(model.backbone) is PS.AtrousResNet50
+        # (two runs of MIOpen's convolutions are not bit-identical: a tolerance, not torch.equal)
+        assert all(float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) for a, b in zip(again, ref[0][0]))

@@ -382,6 +382,84 @@ print("INSTALL_OK")
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference tree only exists in the build container")
+def test_backbone_folding_against_the_real_reference_modules():
+    """hdn_amd.backbone on the reference's OWN ResNet-50 (resnet_atrous.py, used_layers [2, 3, 4]) and AdjustAllLayer necks, BatchNorm
+    statistics randomised: the folded / fused copies reproduce the modules' eval-mode outputs (CPU arithmetic of the same formulas),
+    build_tracker(model) switches all three modules, state_dict keys are unchanged, training mode and restore_similarity_model give
+    the original forward back."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, torch
+sys.path.insert(0, "%s"); sys.path.insert(0, "%s/tests/golden")
+import make_golden as mg
+mg.install_stubs(); sys.path.insert(0, "/root/reference")
+from hdn.core.config import cfg
+cfg.merge_from_file("/root/reference/experiments/tracker_homo_config/proj_e2e_GOT_unconstrained_v2.yaml")
+import hdn_amd, hdn_amd.install as hi, hdn_amd.backbone as BB
+hi.install(strict=True, tracker=True)
+from hdn.models.model_builder_e2e_unconstrained_v2 import ModelBuilder
+torch.manual_seed(3)
+m = ModelBuilder().eval()
+for part in (m.backbone, m.neck, m.neck_lp):
+    for mod in part.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.uniform_(-0.2, 0.2); mod.running_var.uniform_(0.6, 1.6); mod.weight.data.uniform_(0.4, 0.9); mod.bias.data.uniform_(-0.2, 0.2)
+keys = list(m.state_dict().keys())
+x = torch.randn(1, 3, 127, 127)
+with torch.no_grad():
+    ref_f = m.backbone(x)
+    ref_n, ref_l = m.neck(ref_f), m.neck_lp(ref_f)
+    fused = BB.FusedAtrousResNet(m.backbone).eval()
+    got_f = fused(x)
+    got_n, got_l = BB.fold_sequentials(m.neck).eval()(ref_f), BB.fold_sequentials(m.neck_lp).eval()(ref_f)
+assert [tuple(t.shape) for t in got_f] == [(1, 512, 15, 15), (1, 1024, 15, 15), (1, 2048, 15, 15)]
+for a, b in list(zip(got_f, ref_f)) + list(zip(got_n, ref_n)) + list(zip(got_l, ref_l)):
+    assert a.shape == b.shape and float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-6, float((a - b).abs().max())
+assert [tuple(t.shape) for t in got_n] == [(1, 256, 7, 7)] * 3 and [tuple(t.shape) for t in got_l] == [(1, 256, 15, 15)] * 3
+from hdn.tracker.tracker_builder import build_tracker
+trk = build_tracker(m)
+assert trk.folded == ["backbone", "neck", "neck_lp"], trk.folded
+assert list(m.state_dict().keys()) == keys and type(m.backbone).__name__ == "ResNet"
+with torch.no_grad():
+    again = m.backbone(x)                      # CPU tensors: the class's own forward
+assert all(torch.equal(a, b) for a, b in zip(again, ref_f))
+BB.restore_similarity_model(m)
+assert "_hdn_fused" not in vars(m.backbone) and type(m.backbone).__module__ == "hdn.models.backbone.resnet_atrous"
+print("FOLD_OK")
+''' % (ROOT, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert "FOLD_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_fold_conv_bn_arithmetic():
+    """fold_conv_bn: eval-mode BatchNorm(conv(x)) == conv'(x) with the folded weights and shift (strided / dilated, with and without the
+    convolution's own bias, affine-free BatchNorm), and the argument errors."""
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from hdn_amd.backbone import fold_conv_bn, FusedBottleneck
+    torch.manual_seed(0)
+    for bias, affine, kw in ((False, True, dict(stride=2, padding=0)), (True, True, dict(padding=2, dilation=2)), (False, False, dict(padding=1))):
+        conv, bn = nn.Conv2d(5, 7, 3, bias=bias, **kw), nn.BatchNorm2d(7, affine=affine).eval()
+        bn.running_mean.uniform_(-1, 1); bn.running_var.uniform_(0.5, 2)
+        if affine:
+            bn.weight.data.uniform_(0.5, 1.5); bn.bias.data.uniform_(-1, 1)
+        x = torch.randn(2, 5, 17, 17)
+        w, b = fold_conv_bn(conv, bn)
+        with torch.no_grad():
+            ref = bn(conv(x))
+            got = F.conv2d(x, w, b, conv.stride, conv.padding, conv.dilation)
+        assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    with pytest.raises(ValueError):
+        fold_conv_bn(nn.Conv2d(4, 4, 3, groups=2), nn.BatchNorm2d(4))
+    with pytest.raises(ValueError):
+        fold_conv_bn(nn.Conv2d(4, 4, 3), nn.BatchNorm2d(4, track_running_stats=False))
+    with pytest.raises(ValueError):
+        FusedBottleneck(nn.Conv2d(4, 4, 3))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference tree only exists in the build container")
 def test_unchanged_launcher_runs_the_reference_test_script():
     """python -m hdn_amd.run /root/reference/tools/test.py ...: the reference's own benchmark script, byte for byte, with the
     hot path rebound before it starts; driven through ModelBuilder() and build_tracker(model) up to the dataset (the snapshot,
