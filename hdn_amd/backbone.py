@@ -62,7 +62,10 @@ def _epilogue(y, bias, residual=None):
 
 
 class _FoldedConv(nn.Module):
-    """A convolution with a BatchNorm folded in; `bias` is applied by the caller's epilogue (or by forward(), for the necks)."""
+    """A convolution with a BatchNorm folded in.  raw(x): without the shift (the caller's epilogue adds it); act(x): relu(conv + shift);
+    forward(x): conv + shift (the necks).  (The 1x1 convolutions as hipBLASLt GEMMs with the shift and the ReLU in the GEMM's epilogue
+    were measured and dropped: 2-13 us faster per shape in isolation, but under the frame's hipGraph the library picked 60-120-us
+    kernels for some of them: profiles/round4_experiments.txt item 9.)"""
 
     def __init__(self, conv, bn):
         super().__init__()
@@ -73,6 +76,9 @@ class _FoldedConv(nn.Module):
 
     def raw(self, x):
         return F.conv2d(x, self.weight, None, self.stride, self.padding, self.dilation)
+
+    def act(self, x):
+        return _epilogue(self.raw(x), self.bias)
 
     def forward(self, x):
         return F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation)
@@ -107,8 +113,7 @@ class FusedBottleneck(nn.Module):
             self.register_buffer("b3", self.c3.bias + self.cd.bias)      # (b3 + b_downsample) once: differs from the unfused sum by rounding
 
     def forward(self, x):
-        y = _epilogue(self.c1.raw(x), self.c1.bias)
-        y = _epilogue(self.c2.raw(y), self.c2.bias)
+        y = self.c2.act(self.c1.act(x))
         idt = x if self.cd is None else self.cd.raw(x)
         return _epilogue(self.c3.raw(y), self.b3, idt)
 
@@ -136,7 +141,7 @@ class FusedAtrousResNet(nn.Module):
         self.used_layers = list(net.used_layers)
 
     def forward(self, x):
-        x_ = _epilogue(self.c1.raw(x), self.c1.bias)
+        x_ = self.c1.act(x)
         p1 = self.layers[0](self.maxpool(x_))
         p2 = self.layers[1](p1)
         p3 = self.layers[2](p2)
