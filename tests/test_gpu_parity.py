@@ -987,6 +987,13 @@ def test_homo_refine_two_iterations_config5(dev):
     Hp, sp, ssp = hdn_amd.homo_refine(netd, t8, s8, iterations=2, cache_template=True)
     Hd, sd_, ssd = hdn_amd.homo_refine(netd, t8, s8, iterations=2, cache_template=False)
     assert float((Hp - Hd).abs().max()) <= 2e-4 and abs(float(sp) - float(sd_)) <= 1e-5 and abs(float(ssp) - float(ssd)) <= 1e-6
+    # ... and with ShareFeature(template) handed in (what the tracker keeps for the whole sequence): the same launches minus one
+    with torch.no_grad():
+        p1 = netd.ShareFeature(t8)
+    Hq, sq, ssq = hdn_amd.homo_refine(netd, t8, s8, iterations=2, patch_1=p1)
+    assert float((Hq - Hp).abs().max()) <= 1e-6 and abs(float(sq) - float(sp)) <= 1e-6 and abs(float(ssq) - float(ssp)) <= 1e-7
+    with pytest.raises(ValueError):
+        hdn_amd.homo_refine(netd, t8, s8, iterations=1, patch_1=p1[:4])
     from hdn_amd.homo_model import track_proj_pair
     with pytest.raises(ValueError):
         track_proj_pair(netd, t8, s8[:, :, :100], None, None)
