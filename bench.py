@@ -201,7 +201,10 @@ def main():
         if world > 1 and collective:
             hdist.all_gather_offsets(st["x"], PAIRS * world, comm=comm)
 
-    head_stream = torch.cuda.Stream(device=dev)
+    # HDN_BENCH_HEAD_PRIORITY (A/B switch, tools/experiments/ab_priority.sh): queue priority of the head stream relative to the
+    # correlation stream (torch: lower number = higher priority)
+    _prio = os.environ.get("HDN_BENCH_HEAD_PRIORITY")
+    head_stream = torch.cuda.Stream(device=dev) if _prio is None else torch.cuda.Stream(device=dev, priority=int(_prio))
 
     def step(record, collective=True, mode=None, sink=None):
         if args.workload == "full":

@@ -384,6 +384,9 @@ __global__ __launch_bounds__(HDN_BLOCK) void share_feature_rows_kernel(const flo
                                                                        float* __restrict__ out, int H, int W, int rows_per_strip,
                                                                        int strips_per_img, int total_strips) {
   using namespace sfv;
+#if defined(HDN_ABLATION) && defined(SF_EXP_PRIO)   // measurement build only: tools/build_variant.sh -DHDN_ABLATION -DSF_EXP_PRIO=3
+  __builtin_amdgcn_s_setprio(SF_EXP_PRIO);
+#endif
   const int lane = threadIdx.x & 63;
   const int strip = __builtin_amdgcn_readfirstlane(blockIdx.x * (HDN_BLOCK / 64) + (threadIdx.x >> 6));
   if (strip >= total_strips) return;
