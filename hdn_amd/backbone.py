@@ -17,7 +17,9 @@ launches, 1.1 ms of the 3.4 ms frame (profiles/round4_sequence.txt), none of the
 
 The modules keep their classes' names and parameters (state_dict unchanged): the object gets a subclass whose forward() uses the
 folded copy for CUDA float32 inputs in eval mode and the original forward() for anything else (training, CPU tensors).  The
-folded copy does not track later weight changes — call optimize_similarity_model again after loading another snapshot.
+folded copy does not track later weight changes — call optimize_similarity_model again after loading another snapshot; a switched
+module deep-copies and moves like any other, but pickling the MODULE object (torch.save(model), not state_dict) needs
+restore_similarity_model first, because the subclass exists only in this process.
 hdn_amd.tracker.DeviceTrackerHomo applies it to the model it is given (HDN_FOLD_BACKBONE=0 keeps the modules as they are).
 """
 from __future__ import annotations

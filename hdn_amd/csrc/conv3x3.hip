@@ -625,6 +625,7 @@ template <class Cf>
 static int launch_chain(const float* x, const LazyIn& lz, const void* wp, float* out, float* out2, int B, hipStream_t stream) {
   const long long M = (long long)B * Cf::S * Cf::S;
   const int z = k_slices_chain<Cf>(B);
+  if (lz.zx > 0 && Cf::NCHUNK / z > 2) return HDN_E_LIMIT;   // (cannot happen: k_slices_chain; the LAZY staging fills two A images)
   static PerDeviceOnce attr;
   const int dev_ = PerDeviceOnce::device();
   if (!attr.done(dev_)) {

@@ -263,6 +263,8 @@ class LazyAct:
     __slots__ = ("slices", "bias", "res")
 
     def __init__(self, slices, bias, res=None):
+        if slices.dim() != 5 or slices.shape[2] != slices.shape[3] or not slices.is_contiguous() or bias.numel() != slices.shape[4]:
+            raise ValueError(f"LazyAct: slices [z,B,S,S,C] contiguous with a bias of C elements, got {tuple(slices.shape)}, {tuple(bias.shape)}")
         self.slices, self.bias, self.res = slices, bias, res
 
     @property
@@ -271,11 +273,22 @@ class LazyAct:
         return (B, C, S, S)
 
     def res_args(self):
+        """(pointer, slice count) of the residual for the C ABI: a channels-last activation counts as one slice."""
+        import torch
+
         from . import _lib
 
-        if self.res is None:
+        r = self.res
+        if r is None:
             return None, 0
-        return _lib.ptr(self.res), (self.res.shape[0] if self.res.dim() == 5 else 1)
+        z, B, S, _, C = self.slices.shape
+        if r.dim() == 5:
+            ok = tuple(r.shape[1:]) == (B, S, S, C) and r.is_contiguous()
+        else:
+            ok = tuple(r.shape) == (B, C, S, S) and r.is_contiguous(memory_format=torch.channels_last)
+        if not ok or r.dtype != torch.float32 or r.device != self.slices.device:
+            raise ValueError(f"LazyAct residual must be a channels-last [B,C,S,S] activation or [z,B,S,S,C] slices matching {tuple(self.slices.shape)}")
+        return _lib.ptr(r), (r.shape[0] if r.dim() == 5 else 1)
 
     def finish(self):
         """The activation itself, channels-last [B,C,S,S] (hdn_conv3x3_finish_f32)."""
