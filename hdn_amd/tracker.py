@@ -209,7 +209,9 @@ class DeviceTrackerHomo(HomoTracker):
     """Drop-in for hdnTrackerHomo (hdn_tracker_proj_e2e.py:22-285) behind build_tracker(model)
     (hdn/tracker/tracker_builder.py:18-19): same constructor argument, same init / track_new signatures and result keys.
     `model` is the reference's ModelBuilder (hm_net = the homography estimator, template / track_new / track_new_lp = the
-    similarity branch).  HDN_TRACKER_GRAPH=1 replays each frame as one hipGraph.  The model's backbone and necks are switched to their
+    similarity branch).  Each frame is replayed as ONE hipGraph, captured at a sequence's first frame (2.9 against 5.3 ms per frame with the
+    production-shaped model: at B = 1 the loop is launch-bound; a body that cannot be captured falls back to eager launches with a warning;
+    graph=False or HDN_TRACKER_GRAPH=0: eager).  The model's backbone and necks are switched to their
     BatchNorm-folded, epilogue-fused form (hdn_amd.backbone; fold_backbone=False or HDN_FOLD_BACKBONE=0: left as they are)."""
 
     def __init__(self, model, graph: bool = None, iterations: int = 1, cfg: TrackerConfig = None, fold_backbone: bool = None):
@@ -227,7 +229,7 @@ class DeviceTrackerHomo(HomoTracker):
             raise NotImplementedError("hdn_amd's device decode implements cfg.BAN.KWARGS.cls_out_channels == 2 (softmax); run the "
                                       "reference's host tracker for the 1-channel sigmoid head (python -m hdn_amd.run --host-tracker ...)")
         if graph is None:
-            graph = os.environ.get("HDN_TRACKER_GRAPH", "0") not in ("", "0")
+            graph = os.environ.get("HDN_TRACKER_GRAPH", "1") not in ("", "0")
         model.eval()
         self.model = model
         # backbone + necks stay PyTorch-ROCm's convolutions; their BatchNorm / ReLU / add launches (a third of the B = 1 frame) are folded away

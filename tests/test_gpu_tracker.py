@@ -361,7 +361,7 @@ def _production_pair(dev, frames, init, instance_size=255, iterations=1, fc_bias
 def test_device_tracker_homo_runs_production_shaped_model(dev, monkeypatch):
     """The exact object install(tracker=True) registers — DeviceTrackerHomo(model), constructed as build_tracker(model) constructs
     it (hdn/tracker/tracker_builder.py:18-19) — around a model with the production shapes and the reference's ModelBuilder
-    interface (template / track_new / track_new_lp / hm_net / logpolar_instance): eager, and with HDN_TRACKER_GRAPH=1 as ONE
+    interface (template / track_new / track_new_lp / hm_net / logpolar_instance): with HDN_TRACKER_GRAPH=0 eagerly, and by default as ONE
     hipGraph per frame, against the CPU restatement of the loop on every frame.  prod29 / circ13 kernels at 256 channels, packed
     heads, device decode and crops all run inside the loop."""
     from synth_sequence import make_sequence, success_4pts_error
@@ -369,10 +369,12 @@ def test_device_tracker_homo_runs_production_shaped_model(dev, monkeypatch):
     from hdn_amd import xcorr as X
     frames, corners, init = make_sequence(n_frames=13, frame_hw=(720, 1280), target_wh=(300, 200), seed=20260928)
     ref, model = _production_pair(dev, frames, init)
+    monkeypatch.setenv("HDN_TRACKER_GRAPH", "0")
     eager = DeviceTrackerHomo(model)
-    monkeypatch.setenv("HDN_TRACKER_GRAPH", "1")
-    graphed = DeviceTrackerHomo(model)
+    monkeypatch.delenv("HDN_TRACKER_GRAPH")
+    graphed = DeviceTrackerHomo(model)                   # the default: one hipGraph per frame
     assert eager.use_graph is False and graphed.use_graph is True and eager.cfg.score_size == 25
+    assert graphed.folded == ["backbone", "neck", "neck_lp"]
     ref.init(frames[0], init["bbox"], init["poly"], init["gt_points"], init["first_point"])
     for t in (eager, graphed):
         t.init(frames[0], init["bbox"], init["poly"], init["gt_points"], init["first_point"])
