@@ -232,6 +232,11 @@ class DeviceTrackerHomo(HomoTracker):
             graph = os.environ.get("HDN_TRACKER_GRAPH", "1") not in ("", "0")
         model.eval()
         self.model = model
+        # The backbone's convolutions are PyTorch-ROCm's, and their shapes are fixed for a whole sequence: let MIOpen search for its kernels once
+        # (find mode; the search runs in the first frames / the capture warm-up).  Measured with the production-shaped model: 2.9 against 4.5 ms
+        # per frame (profiles/round4_experiments.txt item 11).  The reference's inference scripts leave torch's default (off); HDN_MIOPEN_FIND=0 does too.
+        if os.environ.get("HDN_MIOPEN_FIND", "1") not in ("", "0") and next(model.parameters()).is_cuda:
+            torch.backends.cudnn.benchmark = True
         # backbone + necks stay PyTorch-ROCm's convolutions; their BatchNorm / ReLU / add launches (a third of the B = 1 frame) are folded away
         from . import backbone as BB
         self.folded = BB.optimize_similarity_model(model) if (BB.enabled() if fold_backbone is None else fold_backbone) else []

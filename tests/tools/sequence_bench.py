@@ -249,7 +249,7 @@ def run_production(n_frames=501, n_parity=0, nchw=False, components=True, dev=No
     t0 = time.perf_counter()
     frames, corners, init = make_sequence(n_frames=n_frames, frame_hw=(720, 1280), target_wh=(300, 200), **LONG_WALK)
     log(f"[sequence] {n_frames} frames generated in {time.perf_counter() - t0:.1f} s")
-    torch.backends.cudnn.benchmark = True          # MIOpen find mode
+    torch.backends.cudnn.benchmark = os.environ.get("HDN_SEQ_FIND", "1") != "0"     # MIOpen find mode (A/B switch: HDN_SEQ_FIND=0)
     t0 = time.perf_counter()
     model, cpu_src = build_production_model(frames, init, dev, nchw=nchw, crops="oracle" if n_parity else "product")
 
