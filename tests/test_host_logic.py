@@ -447,6 +447,47 @@ print("FOLD_OK")
     assert "FOLD_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference tree only exists in the build container")
+def test_production_standin_is_the_reference_architecture():
+    """tests/production_standin.py (what the GPU box measures configs[3] with) against the reference's own modules: the stand-in's backbone and
+    necks take the reference's state_dict STRICTLY (same parameter names and shapes: resnet_atrous.py:113-199, neck.py:11-51) and then
+    compute the same features, at both crop sizes — the production-shaped measurement runs the reference's architecture, not a look-alike."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, torch
+sys.path.insert(0, "%s"); sys.path.insert(0, "%s/tests"); sys.path.insert(0, "%s/tests/golden")
+import make_golden as mg
+mg.install_stubs(); sys.path.insert(0, "/root/reference")
+from hdn.core.config import cfg
+cfg.merge_from_file("/root/reference/experiments/tracker_homo_config/proj_e2e_GOT_unconstrained_v2.yaml")
+from hdn.models.model_builder_e2e_unconstrained_v2 import ModelBuilder
+import production_standin as PS
+torch.manual_seed(11)
+m = ModelBuilder().eval()
+for part in (m.backbone, m.neck, m.neck_lp):
+    for mod in part.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.uniform_(-0.2, 0.2); mod.running_var.uniform_(0.6, 1.6); mod.weight.data.uniform_(0.4, 0.9); mod.bias.data.uniform_(-0.2, 0.2)
+bb, nk, nl = PS.AtrousResNet50().eval(), PS.Necks(True).eval(), PS.Necks(False).eval()
+assert list(bb.state_dict().keys()) == list(m.backbone.state_dict().keys())
+bb.load_state_dict(m.backbone.state_dict(), strict=True)
+nk.load_state_dict(m.neck.state_dict(), strict=True); nl.load_state_dict(m.neck_lp.state_dict(), strict=True)
+assert sum(p.numel() for p in bb.parameters()) == sum(p.numel() for p in m.backbone.parameters())
+for side, fs, cut in ((127, 15, 7), (255, 31, 31)):
+    x = torch.randn(1, 3, side, side)
+    with torch.no_grad():
+        rf, sf = m.backbone(x), bb(x)
+        assert [tuple(t.shape) for t in sf] == [(1, c, fs, fs) for c in (512, 1024, 2048)]
+        pairs = list(zip(sf, rf)) + list(zip(nk(sf), m.neck(rf))) + list(zip(nl(sf), m.neck_lp(rf)))
+    assert all(a.shape == b.shape and torch.equal(a, b) for a, b in pairs)
+    assert tuple(nk(sf)[0].shape) == (1, 256, cut, cut)
+print("STANDIN_OK")
+''' % (ROOT, ROOT, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert "STANDIN_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 def test_fold_conv_bn_arithmetic():
     """fold_conv_bn: eval-mode BatchNorm(conv(x)) == conv'(x) with the folded weights and shift (strided / dilated, with and without the
     convolution's own bias, affine-free BatchNorm), and the argument errors."""
