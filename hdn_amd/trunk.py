@@ -401,31 +401,28 @@ class FusedBasicBlock(nn.Module):
             return conv3x3_bias_relu(y, self.p2, self.b2, idt)
         return bias_relu_(F.conv2d(y, self.w2, None, 1, 1), self.b2, idt)
 
+    chain_disabled = False     # A/B switch for every block at once (tests, tools/experiments)
 
-def _chained(self, x):
-    """The block as two chained launches (None: not this input).  A LazyAct in: the previous block's output, finished while conv1
-    stages it (and written out once, as this block's residual); a LazyAct out."""
-    import torch
+    def _chained(self, x):
+        """The block as two chained launches (None: not this input).  A LazyAct in: the previous block's output, finished while conv1
+        stages it (and written out once, as this block's residual); a LazyAct out."""
+        import torch
 
-    lazy = isinstance(x, LazyAct)
-    if self.p2 is None or getattr(self, "_hdn_no_chain", False) or FusedBasicBlock.chain_disabled:
+        lazy = isinstance(x, LazyAct)
+        if self.p2 is None or getattr(self, "_hdn_no_chain", False) or FusedBasicBlock.chain_disabled:
+            return None
+        B, C, S, S2 = x.shape
+        if not lazy and not (x.is_cuda and x.dtype == torch.float32 and B <= CHAIN_MAX_BATCH and x.is_contiguous(memory_format=torch.channels_last)):
+            return None
+        if self.p1s2 is not None and S == S2 == 2 * _MC_SIDE.get(2 * C, -1):
+            s1, sd, _ = chain_conv(x, self.p1s2, 2)
+            s2, _, _ = chain_conv(LazyAct(s1, self.b1), self.p2)
+            return LazyAct(s2, self.b2, sd)
+        if self.p1 is not None and self.wd is None and S == S2 == _MC_SIDE.get(C, -1):
+            s1, _, idt = chain_conv(x, self.p1, 1, want_x=True)
+            s2, _, _ = chain_conv(LazyAct(s1, self.b1), self.p2)
+            return LazyAct(s2, self.b2, idt if lazy else x)
         return None
-    B, C, S, S2 = x.shape
-    if not lazy and not (x.is_cuda and x.dtype == torch.float32 and B <= CHAIN_MAX_BATCH and x.is_contiguous(memory_format=torch.channels_last)):
-        return None
-    if self.p1s2 is not None and S == S2 == 2 * _MC_SIDE.get(2 * C, -1):
-        s1, sd, _ = chain_conv(x, self.p1s2, 2)
-        s2, _, _ = chain_conv(LazyAct(s1, self.b1), self.p2)
-        return LazyAct(s2, self.b2, sd)
-    if self.p1 is not None and self.wd is None and S == S2 == _MC_SIDE.get(C, -1):
-        s1, _, idt = chain_conv(x, self.p1, 1, want_x=True)
-        s2, _, _ = chain_conv(LazyAct(s1, self.b1), self.p2)
-        return LazyAct(s2, self.b2, idt if lazy else x)
-    return None
-
-
-FusedBasicBlock._chained = _chained
-FusedBasicBlock.chain_disabled = False     # A/B switch (tests, tools/experiments)
 
 
 def fold_for_inference(net: HomoResNet, channels_last: bool = True, fused_stem: bool = False, fused_epilogue: bool = False,
