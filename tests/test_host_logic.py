@@ -488,6 +488,82 @@ print("STANDIN_OK")
     assert "STANDIN_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
+def test_backbone_switch_keeps_the_module_intact():
+    """optimize_similarity_model on a small model of the reference's layout (CPU): class name, parameters and state_dict untouched, CPU / training
+    inputs still take the class's own forward, the folded copy reproduces it (torch-op epilogue), deep copies carry their own folded copy,
+    restore_similarity_model undoes everything, a second call replaces the first, an unrecognised backbone is left alone (strict: raises)."""
+    import copy
+    import types
+    import torch
+    import torch.nn as nn
+    from hdn_amd import backbone as BB
+
+    class Block(nn.Module):
+        def __init__(self, c, down):
+            super().__init__()
+            self.conv1, self.bn1 = nn.Conv2d(c, 4, 1, bias=False), nn.BatchNorm2d(4)
+            self.conv2, self.bn2 = nn.Conv2d(4, 4, 3, padding=2, dilation=2, bias=False), nn.BatchNorm2d(4)
+            self.conv3, self.bn3 = nn.Conv2d(4, 16, 1, bias=False), nn.BatchNorm2d(16)
+            self.relu = nn.ReLU(inplace=True)
+            self.downsample = nn.Sequential(nn.Conv2d(c, 16, 3, padding=1, bias=False), nn.BatchNorm2d(16)) if down else None
+
+        def forward(self, x):
+            y = self.relu(self.bn1(self.conv1(x)))
+            y = self.relu(self.bn2(self.conv2(y)))
+            y = self.bn3(self.conv3(y))
+            return self.relu(y + (x if self.downsample is None else self.downsample(x)))
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv1, self.bn1, self.relu, self.maxpool = nn.Conv2d(3, 8, 7, 2, 0, bias=False), nn.BatchNorm2d(8), nn.ReLU(inplace=True), nn.MaxPool2d(3, 2, 1)
+            self.layer1 = nn.Sequential(Block(8, True), Block(16, False))
+            self.layer2 = nn.Sequential(Block(16, True))
+            self.layer3 = lambda x: x            # (an unused stage, as resnet_atrous.py:134-141 writes it)
+            self.used_layers = [0, 1, 2]
+
+        def forward(self, x):
+            x_ = self.relu(self.bn1(self.conv1(x)))
+            p1 = self.layer1(self.maxpool(x_))
+            return [x_, p1, self.layer2(p1)]
+
+    class Neck(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.downsample = nn.Sequential(nn.Conv2d(16, 5, 1, bias=False), nn.BatchNorm2d(5))
+
+        def forward(self, f):
+            return self.downsample(f[2])[:, :, 1:4, 1:4]
+
+    torch.manual_seed(1)
+    model = types.SimpleNamespace(backbone=Net().eval(), neck=Neck().eval(), neck_lp=nn.Identity())
+    for m in list(model.backbone.modules()) + list(model.neck.modules()):
+        if isinstance(m, nn.BatchNorm2d):
+            m.running_mean.uniform_(-0.5, 0.5); m.running_var.uniform_(0.5, 2); m.weight.data.uniform_(0.5, 1.5); m.bias.data.uniform_(-0.5, 0.5)
+    keys = list(model.backbone.state_dict().keys())
+    x = torch.randn(2, 3, 41, 41)
+    with torch.no_grad():
+        ref = model.backbone(x)
+        ref_n = model.neck(ref)
+        assert BB.optimize_similarity_model(model) == ["backbone", "neck"]          # (neck_lp: nothing to fold)
+        with pytest.raises(ValueError):
+            BB.optimize_similarity_model(model, strict=True)                         # strict: the Identity neck is reported
+        bb = model.backbone
+        assert type(bb).__name__ == "Net" and isinstance(bb, Net) and list(bb.state_dict().keys()) == keys
+        assert all(torch.equal(a, b) for a, b in zip(bb(x), ref))                    # CPU input: the class's own forward
+        fused = vars(bb)["_hdn_fused"]
+        for a, b in list(zip(fused(x), ref)) + [(vars(model.neck)["_hdn_fused"](ref), ref_n)]:
+            assert a.shape == b.shape and float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+        twin = copy.deepcopy(bb)
+        assert vars(twin)["_hdn_fused"] is not fused and list(twin.state_dict().keys()) == keys and all(torch.equal(a, b) for a, b in zip(twin(x), ref))
+        assert BB.optimize_similarity_model(model) == ["backbone", "neck"] and vars(bb)["_hdn_fused"] is not fused      # again: replaced, not stacked
+        assert type(bb).__mro__[1] is Net
+        BB.restore_similarity_model(model)
+        assert type(bb) is Net and "_hdn_fused" not in vars(bb) and type(model.neck) is Neck
+        plain = types.SimpleNamespace(backbone=nn.Sequential(nn.Conv2d(3, 4, 3)), neck=None, neck_lp=None)
+        assert BB.optimize_similarity_model(plain) == [] and type(plain.backbone) is nn.Sequential
+
+
 def test_fold_conv_bn_arithmetic():
     """fold_conv_bn: eval-mode BatchNorm(conv(x)) == conv'(x) with the folded weights and shift (strided / dilated, with and without the
     convolution's own bias, affine-free BatchNorm), and the argument errors."""
