@@ -1280,6 +1280,19 @@ def test_chained_trunk_equals_unchained(dev):
             gr.replay()
             torch.cuda.synchronize()
             assert torch.equal(yg, y)
+    # larger chained batches (the two forms may split K differently there: a tolerance), and the first unchained one
+    from hdn_amd import trunk as T
+    for B in (5, T.CHAIN_MAX_BATCH, T.CHAIN_MAX_BATCH + 1):
+        x = torch.randn(B, 2, 127, 127, device=dev).contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            y = fast(x)
+            FusedBasicBlock.chain_disabled = True
+            try:
+                y0 = fast(x)
+            finally:
+                FusedBasicBlock.chain_disabled = False
+            assert float((y - y0).abs().max()) <= 2e-5 * float(y0.abs().max())
+            assert float((y - net(x)).abs().max()) <= 1e-4 * float(y0.abs().max())
 
 
 def test_fused_epilogue_trunk_vs_unfused(dev):
