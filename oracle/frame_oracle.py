@@ -10,6 +10,9 @@ only — identity, integer shifts, borders, monotonicity):
     resize_linear_u8          cv2.resize(INTER_LINEAR), called by get_subwindow when original_sz != model_sz
     warp_perspective_u8       cv2.warpPerspective(INTER_LINEAR, BORDER_REPLICATE) of the full frame, hdn_tracker_proj_e2e.py:154
     warp_affine_cubic_u8      cv2.warpAffine(flags=2 = INTER_CUBIC, BORDER_REPLICATE), hdn/utils/transform.py:98-99
+    warp_affine_linear_f32    cv2.warpAffine(float32 image, default flags = INTER_LINEAR, BORDER_CONSTANT 0), hdn/utils/transform.py:237
+                              (get_mask_window; ModelBuilder.track_proj ignores the mask it is handed, so nothing downstream reads it)
+    log_polar_maps / remap_linear_u8 / get_polar_img   cv2.logPolar, hdn/models/logpolar.py:11-29
 """
 from __future__ import annotations
 
@@ -261,6 +264,40 @@ def warp_affine_cubic_u8(img: np.ndarray, M2x3: np.ndarray) -> np.ndarray:
             xx = np.clip(sx + k2, 0, Ww - 1)
             acc += s[yy, xx] * tab[:, :, k1, k2][..., None]
     return np.clip((acc + (1 << 14)) >> 15, 0, 255).astype(np.uint8)
+
+
+def warp_affine_linear_f32(img: np.ndarray, M2x3: np.ndarray, dw: int, dh: int) -> np.ndarray:
+    """cv2.warpAffine(img, M, (dw, dh)) for a float32 HxW image with the default flags (INTER_LINEAR, BORDER_CONSTANT, value 0):
+    the same 1/1024-px coordinate walk as warp_affine_cubic_u8, 2 x 2 taps weighted by BilinearTab_f (float32 products
+    (1 - fy)(1 - fx), ... for 1/32-px fractions), taps outside the image contribute 0, summed left to right in float32."""
+    img = np.asarray(img, np.float32)
+    Hh, Ww = img.shape
+    M = np.asarray(M2x3, np.float64).reshape(2, 3).copy()
+    D = M[0, 0] * M[1, 1] - M[0, 1] * M[1, 0]
+    D = 1.0 / D if D != 0 else 0.0
+    A11, A22 = M[1, 1] * D, M[0, 0] * D
+    M[0, 0], M[0, 1], M[1, 0], M[1, 1] = A11, M[0, 1] * (-D), M[1, 0] * (-D), A22
+    b1 = -M[0, 0] * M[0, 2] - M[0, 1] * M[1, 2]
+    b2 = -M[1, 0] * M[0, 2] - M[1, 1] * M[1, 2]
+    M[0, 2], M[1, 2] = b1, b2
+    x = np.arange(dw, dtype=np.float64)
+    y = np.arange(dh, dtype=np.float64)
+    adelta, bdelta = _cv_round(M[0, 0] * x * 1024), _cv_round(M[1, 0] * x * 1024)
+    X0 = _cv_round((M[0, 1] * y + M[0, 2]) * 1024) + 16
+    Y0 = _cv_round((M[1, 1] * y + M[1, 2]) * 1024) + 16
+    X = (X0[:, None] + adelta[None, :]) >> 5
+    Y = (Y0[:, None] + bdelta[None, :]) >> 5
+    sx, sy = np.clip(X >> 5, -32768, 32767), np.clip(Y >> 5, -32768, 32767)
+    one = np.float32(1.0)
+    fx = (X & 31).astype(np.float32) * np.float32(1.0 / 32.0)
+    fy = (Y & 31).astype(np.float32) * np.float32(1.0 / 32.0)
+    w = [(one - fy) * (one - fx), (one - fy) * fx, fy * (one - fx), fy * fx]
+    acc = np.zeros((dh, dw), np.float32)
+    for (dy, dx), wk in zip(((0, 0), (0, 1), (1, 0), (1, 1)), w):
+        yy, xx = sy + dy, sx + dx
+        ok = (yy >= 0) & (yy < Hh) & (xx >= 0) & (xx < Ww)
+        acc = acc + np.where(ok, img[np.clip(yy, 0, Hh - 1), np.clip(xx, 0, Ww - 1)], np.float32(0.0)) * wk
+    return acc
 
 
 def rot_matrix_2x3(cx, cy, rot):

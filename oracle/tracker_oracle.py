@@ -102,7 +102,7 @@ def decode_logpolar(cls_lp, loc_lp, points_lp, stop, cur_sz, init_s_z):
     scale_delta = sim_lp[0] * np.float64(cur_sz) / np.float64(init_s_z)
     rot_delta = sim_lp[2]
     return {"score_lp": score_lp, "pred_center_lp": pred, "best_idx_lp": best, "sim_lp": np.asarray(sim_lp, np.float64),
-            "scale_delta": float(scale_delta), "rot_delta": float(rot_delta)}
+            "scale_delta": float(scale_delta), "rot_delta": float(rot_delta), "rot_delta_raw": rot_delta}
 
 
 class SimilarityOracle:
@@ -133,7 +133,8 @@ class SimilarityOracle:
         lp = decode_logpolar(out["cls_lp"], out["loc_lp"], self.points_lp, tr["stop"], init_s_z, init_s_z)
         H_sim = rot_scale_around_center_shift_tran(cx, cy, lp["rot_delta"], lp["scale_delta"], tr["center"][0], tr["center"][1])
         return {"dcx": tr["center"][0], "dcy": tr["center"][1], "cx": cx, "cy": cy, "scale_delta": lp["scale_delta"],
-                "rot_delta": lp["rot_delta"], "best_score": float(tr["best_score"]), "H_sim": H_sim}
+                "rot_delta": lp["rot_delta"], "best_score": float(tr["best_score"]), "H_sim": H_sim,
+                "s_x": s_x, "x_crop": x_crop, "x_crop_moved": x_moved, "translation": tr, "logpolar": lp}
 
 
 def track_prepare(H_total):
@@ -143,7 +144,20 @@ def track_prepare(H_total):
     return H_total, np.linalg.inv(H_total)
 
 
-def track_accumulate(H_total, H_sim, H_hm_comp, score, z_crop_points_sm, init_points, score_gate=2.5):
+def perspective_transform(points, H):
+    """cv2.perspectiveTransform (hdn_tracker_proj_e2e.py:272) restated — OpenCV's perspectiveTransform_<float> with the matrix
+    converted to double: per point x*m0 + y*m1 + m2 etc. in double, multiplied by 1 / w (0 when |w| is below eps), stored as
+    float32.  PARITY UNPINNED like every OpenCV piece (no cv2 in the reference tree or the image).  points float32 [N,2]."""
+    H = np.asarray(H, np.float64).reshape(3, 3)
+    q = np.asarray(points, np.float32).reshape(-1, 2).astype(np.float64)
+    w = q[:, 0] * H[2, 0] + q[:, 1] * H[2, 1] + H[2, 2]
+    ok = np.abs(w) > np.finfo(np.float64).eps
+    w = np.where(ok, 1.0 / np.where(ok, w, 1.0), 0.0)
+    pts = np.stack([(q[:, 0] * H[0, 0] + q[:, 1] * H[0, 1] + H[0, 2]) * w, (q[:, 0] * H[1, 0] + q[:, 1] * H[1, 1] + H[1, 2]) * w], 1)
+    return pts.astype(np.float32)
+
+
+def track_accumulate(H_total, H_sim, H_hm_comp, score, z_crop_points_sm, init_points, score_gate=2.5, return_homo=False):
     """hdn_tracker_proj_e2e.py:251-272: un-scale / un-shift the residual, gate it, accumulate, project the initial corners
     (cv2.perspectiveTransform restated: double arithmetic on the float32 points, multiplied by 1 / w)."""
     cw = z_crop_points_sm[2] - z_crop_points_sm[0] + 1
@@ -152,23 +166,59 @@ def track_accumulate(H_total, H_sim, H_hm_comp, score, z_crop_points_sm, init_po
     H_hm_comp = np.linalg.inv(S) @ H_hm_comp @ S
     Sh = np.array([[1, 0, -z_crop_points_sm[0]], [0, 1, -z_crop_points_sm[1]], [0, 0, 1]]).astype(np.float32)
     H_homo = np.linalg.inv(Sh) @ H_hm_comp @ Sh
-    H = H_total @ H_sim if float(score) > score_gate else H_total @ H_sim @ H_homo
+    H = H_total @ H_sim if float(np.asarray(score).reshape(-1)[0]) > score_gate else H_total @ H_sim @ H_homo
     H = (1.0 / H.item(8)) * H
-    q = np.asarray(init_points, np.float32).reshape(-1, 2).astype(np.float64)
-    w = q[:, 0] * H[2, 0] + q[:, 1] * H[2, 1] + H[2, 2]
-    ok = np.abs(w) > np.finfo(np.float64).eps
-    w = np.where(ok, 1.0 / np.where(ok, w, 1.0), 0.0)
-    pts = np.stack([(q[:, 0] * H[0, 0] + q[:, 1] * H[0, 1] + H[0, 2]) * w, (q[:, 0] * H[1, 0] + q[:, 1] * H[1, 1] + H[1, 2]) * w], 1)
-    return H, pts.astype(np.float32)
+    if return_homo:
+        return H, perspective_transform(init_points, H), H_homo
+    return H, perspective_transform(init_points, H)
+
+
+def refine_loop(track_proj, init_homo_tmp, homo_search_img, iterations=1):
+    """hdn_tracker_proj_e2e.py:241-250 as the reference executes it: per iteration ModelBuilder.track_proj on the (template, search)
+    pair (float32 tensors made from the float64 crops, homo_estimate :42-57), H_hm = inv(H_mat) in float32 (np.linalg.inv of a float32
+    array), normalised by its last element, the float64 search crop warped by cv2.warpPerspective(inv(H_hm)) for the next iteration,
+    H_hm_comp (float64) @= H_hm.  `track_proj(template [1,1,127,127] float32, search [1,1,127,127] float32) -> (H_mat [1,3,3], score, simi)`.
+    -> (H_hm_comp float64 [3,3], score of the last iteration, list of per-iteration (H_mat, H_hm))."""
+    H_hm_comp = np.identity(3)
+    tmpl = torch.Tensor(np.asarray(init_homo_tmp)).float().unsqueeze(0)
+    cur = np.asarray(homo_search_img)
+    steps, score = [], None
+    for _ in range(iterations):
+        with torch.no_grad():
+            H_mat, score, _ = track_proj(tmpl, torch.Tensor(cur).float().unsqueeze(0))
+        score = np.asarray(score.detach().cpu().numpy() if isinstance(score, torch.Tensor) else score)
+        H_hm = H_mat.detach().cpu().squeeze(0).numpy()
+        H_hm = np.linalg.inv(H_hm)
+        H_hm = (1.0 / H_hm.item(8)) * H_hm
+        cur = np.expand_dims(O.warp_perspective_replicate(cur[0], np.linalg.inv(H_hm).astype(np.float64)), 0)
+        H_hm_comp = H_hm_comp @ H_hm
+        steps.append((H_mat.detach().cpu().numpy().copy(), H_hm.copy()))
+    return H_hm_comp, score, steps
 
 
 class HomoTrackerOracle:
-    def __init__(self, sf_sd: dict, regress, iterations: int = 1, score_gate: float = 2.5, similarity: SimilarityOracle = None):
+    """hdnTrackerHomo (hdn_tracker_proj_e2e.py:22-285) on the CPU.  The homography estimate is either `track_proj` — a callable with
+    ModelBuilder.track_proj's role, see refine_loop — or, when that is None, the oracle's own track_proj (oracle/hdn_oracle.py) around
+    PreShareFeature weights `sf_sd` and a trunk `regress`.  After init / every track_new `self.trace` holds the intermediates the
+    reference's method has as local variables (crops, stabilised frame, H_sim, H_hm, ...): tests/test_oracle_golden.py holds them to
+    tests/golden/tracker_loop.npz, the values the reference's own init / track_new produced when they were executed."""
+
+    def __init__(self, sf_sd: dict, regress, iterations: int = 1, score_gate: float = 2.5, similarity: SimilarityOracle = None, track_proj=None):
         self.sf_sd, self.regress, self.iterations, self.score_gate = sf_sd, regress, iterations, score_gate
         self.similarity = similarity
+        self.trace = {}
+        if track_proj is None:
+            h4p = torch.tensor([[0, 0, 0, 127, 127, 127, 127, 0]], dtype=torch.float32)
+
+            def track_proj(tmpl, srch):
+                imgs = torch.cat([tmpl, srch], dim=1)
+                Hm, score, simi, _ = O.track_proj({"org_imgs": imgs, "input_tensors": imgs, "h4p": h4p}, self.sf_sd, self.regress)
+                return Hm, score, simi
+        self._track_proj = track_proj
 
     def init(self, img, bbox, poly, gt_points, first_point=None):
         self.init_pos = np.array([poly[0], poly[1]], np.float64)
+        self.center_pos = self.init_pos.copy()
         self.size = np.array([poly[2], poly[3]], np.float64)
         w_z = self.size[0] + CONTEXT_AMOUNT * np.sum(self.size)
         h_z = self.size[1] + CONTEXT_AMOUNT * np.sum(self.size)
@@ -177,32 +227,38 @@ class HomoTrackerOracle:
         self.channel_average = np.mean(img, axis=(0, 1))
         crop, self.z_crop_points_sm = F.get_subwindow_for_homo(img, self.init_pos, 127, self.init_s_z_sm, self.channel_average)
         self.init_homo_tmp = F.search_info(crop[0])                      # float64 [1,127,127]
-        if self.similarity is not None:   # :99-107  z_crop with the log-polar channels appended (islog=1), model.template(z_crop)
-            z = F.get_subwindow(img, self.init_pos, 127, self.init_s_z, self.channel_average)
-            z_u8 = z[0].transpose(1, 2, 0).astype(np.uint8)
-            z_log = F.get_polar_img(z_u8).transpose(2, 0, 1)[None].astype(np.float32)
-            self.z_crop = np.concatenate([z, z_log], axis=1)
+        sm_log = F.get_polar_img(crop[0].transpose(1, 2, 0).astype(np.uint8)).transpose(2, 0, 1)[None].astype(np.float32)
+        self.trace = {"z_crop_sm": np.concatenate([crop, sm_log], axis=1)}     # :103-107 asks for islog=1 here too; only [:, 0:3] is used (:119)
+        # :99-107  z_crop with the log-polar channels appended (islog=1), model.template(z_crop)
+        z, self.z_crop_points = F.get_subwindow_for_homo(img, self.init_pos, 127, self.init_s_z, self.channel_average)
+        z_u8 = z[0].transpose(1, 2, 0).astype(np.uint8)
+        z_log = F.get_polar_img(z_u8).transpose(2, 0, 1)[None].astype(np.float32)
+        self.z_crop = np.concatenate([z, z_log], axis=1)
+        if self.similarity is not None:
             with torch.no_grad():
                 self.similarity.model.template(torch.from_numpy(self.z_crop))
         self.init_points = np.asarray(gt_points, np.float32).reshape(-1, 2)
         self.H_total = np.eye(3, dtype=np.float32)
+        self.scale, self.rot = 1, poly[4] if len(poly) > 4 else 0.0
 
     def track_new(self, fr_idx, img):
         self.H_total, H_inv = track_prepare(self.H_total)
         img = F.warp_perspective_u8(img, H_inv)
         cx, cy = self.init_pos
-        H_sim, scale_delta, best_score, sim = np.eye(3), 1.0, 0.0, None
+        H_sim, scale_delta, rot_delta, best_score, sim = np.eye(3), 1.0, 0.0, 0.0, None
         rot_img = img   # rot_delta = 0: img_rot_around_center is the bicubic identity
         if self.similarity is not None:
             sim = self.similarity(img, self.init_pos, self.init_s_z, self.channel_average)
-            cx, cy, H_sim, scale_delta, best_score = sim["cx"], sim["cy"], sim["H_sim"], sim["scale_delta"], sim["best_score"]
-            rot_img = F.warp_affine_cubic_u8(img, F.rot_matrix_2x3(cx, cy, -sim["rot_delta"]))   # :223
-        crop, _ = F.get_subwindow_for_homo(rot_img, np.array([cx, cy]), 127, self.init_s_z_sm * scale_delta, self.channel_average)
+            cx, cy, H_sim, scale_delta, rot_delta, best_score = sim["cx"], sim["cy"], sim["H_sim"], sim["scale_delta"], sim["rot_delta"], sim["best_score"]
+            self.center_pos = np.array([cx, cy])
+            self.rot += sim["logpolar"]["rot_delta_raw"]   # (:215; np.float32 unless gated: the sum is float32 from the first un-gated frame on)
+            self.scale *= scale_delta
+            rot_img = F.warp_affine_cubic_u8(img, F.rot_matrix_2x3(cx, cy, -rot_delta))   # :223
+        crop, crop_points = F.get_subwindow_for_homo(rot_img, np.array([cx, cy]), 127, self.init_s_z_sm * scale_delta, self.channel_average)
         search = F.search_info(crop[0])
-        tmpl = torch.from_numpy(self.init_homo_tmp).float().unsqueeze(0)
-        srch = torch.from_numpy(search).float().unsqueeze(0)
-        with torch.no_grad():
-            H_comp, score, _, _ = O.homo_refine(tmpl, srch, self.sf_sd, self.regress, self.iterations)
-        H, pts = track_accumulate(self.H_total, H_sim, H_comp[0], score, self.z_crop_points_sm, self.init_points, self.score_gate)
+        H_comp, score, steps = refine_loop(self._track_proj, self.init_homo_tmp, search, self.iterations)
+        H, pts, H_homo = track_accumulate(self.H_total, H_sim, H_comp, score, self.z_crop_points_sm, self.init_points, self.score_gate, return_homo=True)
         self.H_total = H
-        return {"points": pts, "polygon": pts, "score": float(score), "best_score": best_score, "similarity": sim}
+        self.trace = {"H_homo": H_homo, "img": img, "rot_img": rot_img, "x_crop_homo": crop, "crop_points": crop_points, "search": search, "H_hm": steps[-1][1],
+                      "H_mat": steps[-1][0], "H_hm_comp": H_comp, "homo_score": score, "H_sim": H_sim, "scale_delta": scale_delta, "rot_delta": rot_delta}
+        return {"points": pts, "polygon": pts, "score": float(np.asarray(score).reshape(-1)[0]), "best_score": best_score, "similarity": sim}

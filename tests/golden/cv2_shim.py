@@ -1,0 +1,102 @@
+"""TEST INFRASTRUCTURE (build container only): a module that stands in for `cv2` so that the REFERENCE's own
+hdnTrackerHomo.init / track_new (hdn/tracker/hdn_tracker_proj_e2e.py:60-120,141-285) can be executed verbatim by
+tests/golden/make_golden.py, which installs it as sys.modules['cv2'] before importing /root/reference.
+
+OpenCV is a third-party dependency that neither the reference tree nor this image holds.  The tracker
+reaches exactly six OpenCV entry points; each is served here by the oracle's restatement of OpenCV 4.x's published algorithm
+(oracle/frame_oracle.py, oracle/hdn_oracle.py).  These six are the ONLY part of the tracker loop that stays parity-unpinned:
+everything the reference's Python does around them (crop arithmetic, padding, decode, gates, the 3x3 bookkeeping, dtype
+promotion) is the reference's own code running on its own interpreter path.
+
+    cv2.resize(u8 HxWxC, (w, h))                                         base_tracker.py:118,195          -> frame_oracle.resize_linear_u8
+    cv2.warpPerspective(u8 HxWxC | float HxW, M, dsize, REPLICATE)       hdn_tracker_proj_e2e.py:154,248   -> frame_oracle.warp_perspective_u8 /
+                                                                                                            hdn_oracle.warp_perspective_replicate
+    cv2.warpAffine(u8 HxWxC, M, dsize, flags=2, REPLICATE)               hdn/utils/transform.py:98-99      -> frame_oracle.warp_affine_cubic_u8
+    cv2.warpAffine(f32 HxW, M, dsize)   (linear, constant border)        hdn/utils/transform.py:237        -> frame_oracle.warp_affine_linear_f32
+                                                                         (get_mask_window: its result is handed to track_proj, which ignores it,
+                                                                          model_builder_e2e_unconstrained_v2.py:161,186-188)
+    cv2.logPolar(u8 HxWxC, center, M, WARP_FILL_OUTLIERS + INTER_LINEAR) hdn/models/logpolar.py:22         -> frame_oracle.log_polar_maps + remap_linear_u8
+    cv2.perspectiveTransform(f32 [1,N,2], H)                             hdn_tracker_proj_e2e.py:272       -> tracker_oracle.perspective_transform
+
+Anything else raises: a call this file does not list would be a seventh unpinned primitive and has to be looked at.
+Every call is appended to `CALLS` (name, argument summary) so that the generator can assert which primitives a frame used.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from oracle import frame_oracle as _F
+from oracle import hdn_oracle as _O
+from oracle import tracker_oracle as _T
+
+# OpenCV 4.x constant values (imgproc.hpp / core/base.hpp)
+INTER_NEAREST, INTER_LINEAR, INTER_CUBIC, INTER_AREA, INTER_LANCZOS4 = 0, 1, 2, 3, 4
+WARP_FILL_OUTLIERS, WARP_INVERSE_MAP = 8, 16
+WARP_POLAR_LINEAR, WARP_POLAR_LOG = 0, 256
+BORDER_CONSTANT, BORDER_REPLICATE, BORDER_REFLECT, BORDER_WRAP, BORDER_REFLECT_101 = 0, 1, 2, 3, 4
+COLOR_BGR2GRAY, RANSAC = 6, 8
+__version__ = "0.0-oracle-shim"
+
+CALLS = []
+
+
+def _log(name, **kw):
+    CALLS.append((name, kw))
+
+
+def resize(src, dsize, dst=None, fx=0, fy=0, interpolation=INTER_LINEAR):
+    src = np.asarray(src)
+    if src.dtype != np.uint8 or src.ndim != 3 or interpolation != INTER_LINEAR:
+        raise NotImplementedError(f"cv2 shim: resize of {src.dtype} {src.shape} interpolation {interpolation}")
+    dw, dh = int(dsize[0]), int(dsize[1])
+    _log("resize", src=src.shape, dsize=(dw, dh))
+    return _F.resize_linear_u8(src, dw, dh)
+
+
+def warpPerspective(src, M, dsize, dst=None, flags=INTER_LINEAR, borderMode=BORDER_CONSTANT, borderValue=0):
+    src = np.asarray(src)
+    M = np.asarray(M, np.float64)      # OpenCV converts the matrix to CV_64F whatever it is handed
+    dw, dh = int(dsize[0]), int(dsize[1])
+    if flags != INTER_LINEAR or borderMode != BORDER_REPLICATE or (dh, dw) != src.shape[:2]:
+        raise NotImplementedError(f"cv2 shim: warpPerspective flags {flags} border {borderMode} dsize {dsize} of {src.shape}")
+    _log("warpPerspective", src=src.shape, dtype=str(src.dtype))
+    if src.dtype == np.uint8 and src.ndim == 3:
+        return _F.warp_perspective_u8(src, M)
+    if src.dtype in (np.float32, np.float64) and src.ndim == 2:
+        return _O.warp_perspective_replicate(src, M)
+    raise NotImplementedError(f"cv2 shim: warpPerspective of {src.dtype} {src.shape}")
+
+
+def warpAffine(src, M, dsize, dst=None, flags=INTER_LINEAR, borderMode=BORDER_CONSTANT, borderValue=0):
+    src = np.asarray(src)
+    M = np.asarray(M, np.float64).reshape(2, 3)
+    dw, dh = int(dsize[0]), int(dsize[1])
+    _log("warpAffine", src=src.shape, dtype=str(src.dtype), flags=flags, border=borderMode)
+    if src.dtype == np.uint8 and src.ndim == 3 and flags == INTER_CUBIC and borderMode == BORDER_REPLICATE and (dh, dw) == src.shape[:2]:
+        return _F.warp_affine_cubic_u8(src, M)
+    if src.dtype == np.float32 and src.ndim == 2 and flags == INTER_LINEAR and borderMode == BORDER_CONSTANT:
+        return _F.warp_affine_linear_f32(src, M, dw, dh)
+    raise NotImplementedError(f"cv2 shim: warpAffine of {src.dtype} {src.shape} flags {flags} border {borderMode} dsize {dsize}")
+
+
+def logPolar(src, center, M, flags):
+    src = np.asarray(src)
+    if src.dtype != np.uint8 or src.ndim != 3 or flags != WARP_FILL_OUTLIERS + INTER_LINEAR:
+        raise NotImplementedError(f"cv2 shim: logPolar of {src.dtype} {src.shape} flags {flags}")
+    _log("logPolar", src=src.shape, center=tuple(float(c) for c in center), M=float(M))
+    h, w = src.shape[:2]
+    mx, my = _F.log_polar_maps(w, h, (float(center[0]), float(center[1])), float(M))
+    return _F.remap_linear_u8(src, mx, my)     # WARP_FILL_OUTLIERS: BORDER_CONSTANT, value 0
+
+
+def perspectiveTransform(src, m, dst=None):
+    src = np.asarray(src)
+    if src.dtype != np.float32 or src.ndim != 3 or src.shape[2] != 2:
+        raise NotImplementedError(f"cv2 shim: perspectiveTransform of {src.dtype} {src.shape}")
+    _log("perspectiveTransform", n=src.shape[1])
+    return _T.perspective_transform(src.reshape(-1, 2), np.asarray(m, np.float64)).reshape(src.shape)
+
+
+def __getattr__(name):
+    raise AttributeError(f"cv2 shim: cv2.{name} is not one of the six OpenCV entry points the tracker loop reaches "
+                         "(tests/golden/cv2_shim.py); add a restatement to oracle/ before using it")

@@ -6,11 +6,13 @@ in the build container only (the GPU box has no /root/reference) and writes
 small .npz fixtures = inputs + parameters + the reference's outputs.  Nothing
 from the reference's source travels: fixtures are data.
 
-Import recipe: the reference needs yacs / cv2 / imageio /
+Import recipe: the reference needs yacs / imageio /
 memory_profiler / colorama / matplotlib at import time and hard-codes .cuda();
 none of that is on the tensor path, so they are replaced by inert stubs and
 .cuda() is made a no-op so the reference's own torch-CPU arithmetic runs
-verbatim.
+verbatim.  cv2 is replaced by tests/golden/cv2_shim.py: the six OpenCV entry
+points the tracker loop reaches, served by the oracle's restatements, so that
+hdnTrackerHomo.init / track_new themselves execute (gen_tracker_loop).
 
     python tests/golden/make_golden.py [--reference /root/reference]
 """
@@ -83,8 +85,17 @@ def install_stubs():
 
     yacs = mod("yacs")
     yacs.config = mod("yacs.config", CfgNode=_CfgNode)
-    for name in ("cv2", "imageio", "colorama", "psutil_stub"):
+    for name in ("imageio", "colorama", "psutil_stub"):
         mod(name)
+    # cv2: the six OpenCV entry points the tracker loop reaches, served by the oracle's restatements (tests/golden/cv2_shim.py);
+    # every other attribute raises, so a generator cannot silently run on an unlisted OpenCV call
+    root = os.path.dirname(os.path.dirname(HERE))
+    for p in (root, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import cv2_shim
+
+    sys.modules["cv2"] = cv2_shim
     sys.modules["colorama"].Fore = types.SimpleNamespace(RED="", GREEN="", RESET="", YELLOW="", BLUE="")
     sys.modules["colorama"].Style = types.SimpleNamespace(RESET_ALL="")
     mod("memory_profiler", profile=lambda f: f)
@@ -506,15 +517,66 @@ def gen_frame(ref_bt, ref_gi):
     save("frame", **out)
 
 
+def _similarity_cases_through_track_new(ref_te, cfg, cases, with_s_x=False):
+    """Decode seeded head maps by EXECUTING the reference's hdnTrackerHomo.track_new (hdn_tracker_proj_e2e.py:141-285) around a model that
+    returns the case's maps: every value stored — score, pred_c, pscore, best_idx, the 0.05 / 0.25 gates, centre, score_lp,
+    pred_center_lp, sim_lp, scale_delta, rot_delta, H_sim — is one of track_new's own local variables, read when it returns
+    (_LocalsAtReturn); no statement of the method is re-typed here.  The tracker is initialised on a blank frame with the case's target
+    size / position (init :60-120 executed as well); track_proj returns the identity."""
+
+    class _MapsModel(torch.nn.Module):
+        def template(self, z):
+            pass
+
+        def track_new(self, x, delta=[0, 0]):
+            return {"cls": t(self.case[0]), "loc_c": t(self.case[1].copy())}      # (copies: the decode works in place)
+
+        def track_new_lp(self, x, delta=[0, 0]):
+            return {"cls_lp": t(self.case[2]), "loc_lp": t(self.case[3].copy())}
+
+        def track_proj(self, data, tmp_mask):
+            return torch.eye(3).unsqueeze(0), torch.tensor(0.0), torch.tensor(0.0)
+
+    cfg.CUDA = False
+    model = _MapsModel()
+    trk = ref_te.hdnTrackerHomo(model)
+    frame = np.full((480, 720, 3), 100, np.uint8)
+    out = {}
+    for n, cs in enumerate(cases):
+        size, pos = np.array(cs["size"]), np.array(cs["pos"])
+        cfg.TRACK.WINDOW_INFLUENCE = cs["wi"]
+        model.case = cs["m"]
+        corners = [pos[0] - size[0] / 2, pos[1] - size[1] / 2, pos[0] - size[0] / 2, pos[1] + size[1] / 2,
+                   pos[0] + size[0] / 2, pos[1] + size[1] / 2, pos[0] + size[0] / 2, pos[1] - size[1] / 2]
+        trk.init(frame, [corners[0], corners[1], size[0], size[1]], [pos[0], pos[1], size[0], size[1], 0.0], corners, corners[:2])
+        with torch.no_grad(), _LocalsAtReturn(ref_te.hdnTrackerHomo.track_new.__code__) as cap:
+            trk.track_new(1, frame)
+        L = cap.locals
+        cls, loc_c, cls_lp, loc_lp = cs["m"]
+        k = f"c{n}__"
+        out.update({k + "cls": cls, k + "loc_c": loc_c, k + "cls_lp": cls_lp, k + "loc_lp": loc_lp, k + "size": size,
+                    k + "center_pos": pos, k + "window_influence": np.array(cs["wi"]), k + "init_s_z": np.array(trk.init_s_z),
+                    k + "score": L["score"], k + "pred_c": L["pred_c"], k + "pscore": L["pscore"], k + "best_idx": np.array(L["best_idx"]),
+                    k + "stop": np.array(L["stop_update_flag"]), k + "center": np.array(L["center"], np.float64),
+                    k + "cxcy": np.array([L["cx"], L["cy"]], np.float64), k + "score_lp": L["score_lp"], k + "pred_center_lp": L["pred_center_lp"],
+                    k + "best_idx_lp": np.array(L["best_idx_lp"]), k + "sim_lp": np.array(L["sim_lp"], np.float64),
+                    k + "best_score": np.array(L["best_score"]), k + "scale_delta": np.array(L["scale_delta"], np.float64),
+                    k + "rot_delta": np.array(L["rot_delta"], np.float64), k + "H_sim": L["H_sim"]})
+        if with_s_x:
+            out[k + "s_x"] = np.array(L["s_x"])
+        assert np.array_equal(trk.center_pos, [L["cx"], L["cy"]])
+    return out
+
+
 def gen_similarity(ref_te, cfg):
     """The similarity half of hdnTrackerHomo.track_new (hdn/tracker/hdn_tracker_proj_e2e.py:164-214) from the two heads'
     output maps to H_sim.  Every numeric routine is the reference's own, called on a real hdnTrackerHomo instance (its
     constructor builds the Hanning window :26-29 and the anchor points): hdnTracker._convert_score
     (hdn_tracker.py:84-91), SiameseTracker._convert_c (base_tracker.py:54-59), hdnTracker._convert_logpolar_simi
-    (hdn_tracker.py:51-67), rot_scale_around_center_shift_tran (hdn/utils/transform.py:250-298).  The statements between
-    those calls (:172-185 window blend / argmax / 0.05 gate, :203-214 argmax / 0.25 gate / scale_delta / rot_delta) are
-    re-executed here in the reference's order on the reference's dtypes; they cannot be reached through track_new itself,
-    which needs cv2 for the crops in between.  cfg.TRACK.WINDOW_INFLUENCE is the production YAML's except where a case
+    (hdn_tracker.py:51-67), rot_scale_around_center_shift_tran (hdn/utils/transform.py:250-298) — and so are the statements
+    between them (:172-185 window blend / argmax / 0.05 gate, :203-214 argmax / 0.25 gate / scale_delta / rot_delta): since round 5
+    the values come out of the EXECUTED track_new (_similarity_cases_through_track_new; the cv2 calls between them run on
+    tests/golden/cv2_shim.py), not out of a re-typed copy of those statements.  cfg.TRACK.WINDOW_INFLUENCE is the production YAML's except where a case
     overrides it (with the shipped value the 0.05 gate cannot fire: the window alone contributes WINDOW_INFLUENCE at the
     centre)."""
     import hdn.utils.transform as ref_tf
@@ -564,58 +626,7 @@ def gen_similarity(ref_te, cfg):
 
     out = {"window": trk.window, "points": trk.points, "points_lp": trk.points_lp, "n_cases": np.array(len(cases)),
            "window_influence_production": np.array(wi_prod)}
-    for n, cs in enumerate(cases):
-        cls, loc_c, cls_lp, loc_lp = cs["m"]
-        size = np.array(cs["size"])
-        cfg.TRACK.WINDOW_INFLUENCE = cs["wi"]
-        # hdnTrackerHomo.init :85-94
-        w_z = size[0] + cfg.TRACK.CONTEXT_AMOUNT * np.sum(size)
-        h_z = size[1] + cfg.TRACK.CONTEXT_AMOUNT * np.sum(size)
-        init_s_z = np.floor(np.sqrt(w_z * h_z))
-        center_pos = np.array(cs["pos"])
-        # track_new :157-186
-        s_z = init_s_z
-        cur_sz = init_s_z
-        scale_z = cfg.TRACK.EXEMPLAR_SIZE / s_z
-        outputs = {"cls": t(cls), "loc_c": t(loc_c.copy())}
-        score = trk._convert_score(outputs["cls"])
-        pred_c = trk._convert_c(outputs["loc_c"], trk.points)
-        pscore = score
-        pscore = pscore * (1 - cfg.TRACK.WINDOW_INFLUENCE) + trk.window * cfg.TRACK.WINDOW_INFLUENCE
-        best_idx = np.argmax(pscore)
-        stop_update_flag = 0
-        if pscore[best_idx] < 0.05:
-            center = [0, 0]
-            stop_update_flag = 1
-        else:
-            center = pred_c[:, best_idx] / scale_z
-        cx = center[0] + center_pos[0]
-        cy = center[1] + center_pos[1]
-        delta_cx = center[0]
-        delta_cy = center[1]
-        # :196-214
-        outputs = {"cls_lp": t(cls_lp), "loc_lp": t(loc_lp.copy())}
-        score_lp = trk._convert_score(outputs["cls_lp"])
-        peak_idx = np.argmax(score_lp.copy())
-        pred_center_lp = trk._convert_logpolar_simi(outputs["loc_lp"], trk.points_lp, peak_idx, 1)
-        pscore_lp = score_lp
-        best_idx_lp = np.argmax(pscore_lp)
-        sim_lp = pred_center_lp[:, best_idx_lp]
-        if stop_update_flag or pscore_lp[best_idx_lp] < 0.25:
-            sim_lp = [1, 1, 0, 0]
-        best_score = score[best_idx]
-        scale_delta = sim_lp[0] * cur_sz / init_s_z
-        rot_delta = sim_lp[2]
-        H_sim = ref_tf.rot_scale_around_center_shift_tran(cx, cy, rot_delta, scale_delta, delta_cx, delta_cy)
-        k = f"c{n}__"
-        out.update({k + "cls": cls, k + "loc_c": loc_c, k + "cls_lp": cls_lp, k + "loc_lp": loc_lp, k + "size": size,
-                    k + "center_pos": center_pos, k + "window_influence": np.array(cs["wi"]), k + "init_s_z": np.array(init_s_z),
-                    k + "score": score, k + "pred_c": pred_c, k + "pscore": pscore, k + "best_idx": np.array(best_idx),
-                    k + "stop": np.array(stop_update_flag), k + "center": np.array(center, np.float64),
-                    k + "cxcy": np.array([cx, cy], np.float64), k + "score_lp": score_lp, k + "pred_center_lp": pred_center_lp,
-                    k + "best_idx_lp": np.array(best_idx_lp), k + "sim_lp": np.array(sim_lp, np.float64),
-                    k + "best_score": np.array(best_score), k + "scale_delta": np.array(scale_delta, np.float64),
-                    k + "rot_delta": np.array(rot_delta, np.float64), k + "H_sim": H_sim})
+    out.update(_similarity_cases_through_track_new(ref_te, cfg, cases))
     cfg.TRACK.WINDOW_INFLUENCE = wi_prod
     save("similarity", **out)
 
@@ -669,57 +680,7 @@ def gen_config5(ref_te, ref_ban, ref_bt, cfg):
 
         out = {"window": trk.window, "points": trk.points, "points_lp": trk.points_lp, "n_cases": np.array(len(cases)),
                "score_size": np.array(S), "window_influence_production": np.array(wi_prod)}
-        for n, cs in enumerate(cases):
-            cls, loc_c, cls_lp, loc_lp = cs["m"]
-            size = np.array(cs["size"])
-            cfg.TRACK.WINDOW_INFLUENCE = cs["wi"]
-            w_z = size[0] + cfg.TRACK.CONTEXT_AMOUNT * np.sum(size)
-            h_z = size[1] + cfg.TRACK.CONTEXT_AMOUNT * np.sum(size)
-            init_s_z = np.floor(np.sqrt(w_z * h_z))
-            center_pos = np.array(cs["pos"])
-            s_z = init_s_z
-            cur_sz = init_s_z
-            INS_EXAM_RATIO = np.round(cfg.TRACK.INSTANCE_SIZE / cfg.TRACK.EXEMPLAR_SIZE)      # :159 (= 2 at 303 as well)
-            scale_z = cfg.TRACK.EXEMPLAR_SIZE / s_z
-            s_x = np.floor(s_z * INS_EXAM_RATIO)
-            outputs = {"cls": t(cls), "loc_c": t(loc_c.copy())}
-            score = trk._convert_score(outputs["cls"])
-            pred_c = trk._convert_c(outputs["loc_c"], trk.points)
-            pscore = score
-            pscore = pscore * (1 - cfg.TRACK.WINDOW_INFLUENCE) + trk.window * cfg.TRACK.WINDOW_INFLUENCE
-            best_idx = np.argmax(pscore)
-            stop_update_flag = 0
-            if pscore[best_idx] < 0.05:
-                center = [0, 0]
-                stop_update_flag = 1
-            else:
-                center = pred_c[:, best_idx] / scale_z
-            cx = center[0] + center_pos[0]
-            cy = center[1] + center_pos[1]
-            delta_cx = center[0]
-            delta_cy = center[1]
-            outputs = {"cls_lp": t(cls_lp), "loc_lp": t(loc_lp.copy())}
-            score_lp = trk._convert_score(outputs["cls_lp"])
-            peak_idx = np.argmax(score_lp.copy())
-            pred_center_lp = trk._convert_logpolar_simi(outputs["loc_lp"], trk.points_lp, peak_idx, 1)
-            pscore_lp = score_lp
-            best_idx_lp = np.argmax(pscore_lp)
-            sim_lp = pred_center_lp[:, best_idx_lp]
-            if stop_update_flag or pscore_lp[best_idx_lp] < 0.25:
-                sim_lp = [1, 1, 0, 0]
-            best_score = score[best_idx]
-            scale_delta = sim_lp[0] * cur_sz / init_s_z
-            rot_delta = sim_lp[2]
-            H_sim = ref_tf.rot_scale_around_center_shift_tran(cx, cy, rot_delta, scale_delta, delta_cx, delta_cy)
-            k = f"c{n}__"
-            out.update({k + "cls": cls, k + "loc_c": loc_c, k + "cls_lp": cls_lp, k + "loc_lp": loc_lp, k + "size": size,
-                        k + "center_pos": center_pos, k + "window_influence": np.array(cs["wi"]), k + "init_s_z": np.array(init_s_z),
-                        k + "s_x": np.array(s_x), k + "score": score, k + "pred_c": pred_c, k + "pscore": pscore,
-                        k + "best_idx": np.array(best_idx), k + "stop": np.array(stop_update_flag), k + "center": np.array(center, np.float64),
-                        k + "cxcy": np.array([cx, cy], np.float64), k + "score_lp": score_lp, k + "pred_center_lp": pred_center_lp,
-                        k + "best_idx_lp": np.array(best_idx_lp), k + "sim_lp": np.array(sim_lp, np.float64),
-                        k + "best_score": np.array(best_score), k + "scale_delta": np.array(scale_delta, np.float64),
-                        k + "rot_delta": np.array(rot_delta, np.float64), k + "H_sim": H_sim})
+        out.update(_similarity_cases_through_track_new(ref_te, cfg, cases, with_s_x=True))
         cfg.TRACK.WINDOW_INFLUENCE = wi_prod
         save("similarity303", **out)
     finally:
@@ -756,6 +717,244 @@ def gen_config5(ref_te, ref_ban, ref_bt, cfg):
         out[f"crop{i}"] = a.numpy().astype(np.uint8)
         out[f"pts{i}"] = np.array(pts, np.float64)
     save("frame303", **out)
+
+
+# --------------------------------------------------------------------------- #
+# the tracker loop itself, executed
+# --------------------------------------------------------------------------- #
+class _LocalsAtReturn:
+    """sys.setprofile hook that copies the local variables of ONE function (identified by its code object) at the moment it
+    returns: how the generator reads track_new's intermediates (scale_delta, H_sim, H_hm, the crops ...) without touching or
+    re-typing a line of it."""
+
+    def __init__(self, code):
+        self.code, self.locals = code, None
+
+    def __call__(self, frame, event, arg):
+        if event == "return" and frame.f_code is self.code:
+            self.locals = dict(frame.f_locals)
+
+    def __enter__(self):
+        sys.setprofile(self)
+        return self
+
+    def __exit__(self, *a):
+        sys.setprofile(None)
+
+
+def _crc(a):
+    import zlib
+
+    return np.array(zlib.crc32(np.ascontiguousarray(a).tobytes()), np.int64)
+
+
+TRACKER_LOOP_SEQ = dict(n_frames=13, frame_hw=(360, 640), target_wh=(150, 100))   # tools/synth_sequence.make_sequence(seed=SEED, **this)
+TRACKER_LOOP_EVENTS = {"gate_frame": 5, "singular_frame": 9}
+
+
+def gen_tracker_loop(ref_te, ref_mb, cfg):
+    """hdnTrackerHomo.init / track_new (hdn/tracker/hdn_tracker_proj_e2e.py:60-120,141-285) EXECUTED, verbatim, around the reference's
+    real ModelBuilder (83.6 M parameters, production YAML) over a synthetic sequence (tools/synth_sequence.py) -> tracker_loop.npz.
+
+    What runs is the reference's own code: init's size arithmetic, get_subwindow / get_subwindow_for_homo (crop, padding),
+    getPolarImg, _convert_score / _convert_c / _convert_logpolar_simi, the window blend and both gates, img_rot_around_center,
+    get_search_info / get_template_info / merge_tmp_search, ModelBuilder.template / track_new / track_new_lp / track_proj, the
+    inverse / normalise / compose of the residual, the un-scale / un-shift block, the `> 2.5` gate, the H_total recurrence, the singular
+    reset.  The only stand-ins are the six OpenCV entry points (tests/golden/cv2_shim.py -> oracle restatements; parity-unpinned).
+
+    The model is seeded, not trained (no snapshot exists in the image), so it is prepared to behave like a tracker's model:
+      * hm_net: BatchNorm statistics / fc as gen_homo_model seeds them (corner offsets of a few pixels);
+      * similarity branch: BatchNorm running statistics calibrated on the first frame's crops (default statistics let a random
+        50-layer network's activations grow to 1e6); loc_scale 0.5 / 0.05; and a fixed Gaussian prior added to the class-1 logit maps by
+        a subclass of the reference's ModelBuilder (an untrained head has no peak; with the prior the argmax sits near the centre and
+        moves between neighbouring cells with the data).
+    Two events exercise the rarely taken branches: at frame `gate_frame` the homography score returned by track_proj is raised by 10
+    (the `homo_score > 2.5` branch, :261-262), before frame `singular_frame` the generator sets tracker.H_total to a singular matrix
+    (the reset, :150-153).
+
+    Stored per frame: the four head maps and track_proj's outputs (so that tests can replay the networks), the trunk output x, and what the
+    reference computed from them — read from track_new's own local variables when it returns (s_x, best_idx, centre, sim_lp, scale_delta,
+    rot_delta, H_sim, H_hm, crop_points, H_hm_comp) and from the tracker object (H_total, center_pos, scale, rot) — plus CRC-32 of the
+    stabilised frame, the rotated frame and the three crops (frame 1: the crops themselves).  A second, shorter run under
+    cfg.TRACK.INSTANCE_SIZE = 303 (BASELINE configs[4]: 31 x 31 score map; the model keeps its STN_Polar(255), the reference's own
+    log-polar branch cannot run at 303) is stored under the prefix `b__`."""
+    root = os.path.dirname(os.path.dirname(HERE))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import cv2_shim
+    from tools.synth_sequence import make_sequence
+
+    class _Conditioned(ref_mb.ModelBuilder):
+        """The reference's ModelBuilder with a fixed prior on the class-1 logit maps (see gen_tracker_loop) and a switch that raises
+        the homography score of one call."""
+
+        score_bias = 0.0
+
+        def track_new(self, x, delta=[0, 0]):
+            o = super().track_new(x)
+            o["cls"] = torch.cat([o["cls"][:, 0:1], o["cls"][:, 1:2] + self.cls_prior[o["cls"].shape[-1]]], dim=1)
+            return o
+
+        def track_new_lp(self, x, delta=[0, 0]):
+            o = super().track_new_lp(x, delta)
+            o["cls_lp"] = torch.cat([o["cls_lp"][:, 0:1], o["cls_lp"][:, 1:2] + self.cls_prior_lp], dim=1)
+            return o
+
+        def track_proj(self, data, tmp_mask):
+            H, s, ss = super().track_proj(data, tmp_mask)
+            return H, s + self.score_bias, ss
+
+    torch.manual_seed(SEED + 20)
+    mb = _Conditioned()
+    g = rng(1200)
+    for mod in mb.hm_net.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            seeded_bn_(mod, g)
+    # PreShareFeature ends in ONE channel behind a ReLU: a seeded BatchNorm can leave it dead (all zeros, both scores 0).  Re-draw its
+    # statistics until at least half of a noise image survives.
+    probe_img = t(rng(1201).standard_normal((1, 1, 127, 127), dtype=np.float32))
+    for attempt in range(32):
+        with torch.no_grad():
+            alive = float((mb.hm_net.ShareFeature.eval()(probe_img) > 0).float().mean())
+        if alive > 0.5:
+            break
+        gg = rng(1210 + attempt)
+        for mod in mb.hm_net.ShareFeature.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                seeded_bn_(mod, gg)
+    assert alive > 0.5
+    mb.hm_net.fc.weight.data = t((0.01 * g.standard_normal((8, 512))).astype(np.float32))
+    fc_bias = t((0.7 * g.standard_normal(8)).astype(np.float32))     # (centred on the first frame's pooled features below)
+    mb.head.loc_scale.data = torch.full((3,), 0.5)
+    mb.head_lp.loc_scale.data = torch.full((3,), 0.05)
+    mb.cls_prior = {}
+    for S, c in ((25, (12.25, 11.85)), (31, (15.25, 14.85))):
+        yy, xx = torch.meshgrid(torch.arange(float(S)), torch.arange(float(S)), indexing="ij")
+        mb.cls_prior[S] = 3.0 * torch.exp(-((yy - c[0]) ** 2 + (xx - c[1]) ** 2) / 8.0).reshape(1, 1, S, S)
+    yy, xx = torch.meshgrid(torch.arange(13.0), torch.arange(13.0), indexing="ij")
+    mb.cls_prior_lp = 4.0 * torch.exp(-((yy - 6.1) ** 2 + (xx - 5.95) ** 2) / 6.0).reshape(1, 1, 13, 13)
+
+    frames, corners, init = make_sequence(seed=SEED, **TRACKER_LOOP_SEQ)
+    cfg.CUDA = False
+    out = {"seq__n_frames": np.array(TRACKER_LOOP_SEQ["n_frames"]), "seq__frame_hw": np.array(TRACKER_LOOP_SEQ["frame_hw"]),
+           "seq__target_wh": np.array(TRACKER_LOOP_SEQ["target_wh"]), "seq__seed": np.array(SEED),
+           "seq__frames_crc": np.array([int(_crc(f)) for f in frames], np.int64),
+           "seq__gate_frame": np.array(TRACKER_LOOP_EVENTS["gate_frame"]), "seq__singular_frame": np.array(TRACKER_LOOP_EVENTS["singular_frame"]),
+           "seq__bbox": np.array(init["bbox"], np.float64), "seq__poly": np.array(init["poly"], np.float64),
+           "seq__gt_points": np.array(init["gt_points"], np.float64), "seq__first_point": np.array(init["first_point"], np.float64),
+           "window_influence": np.array(float(cfg.TRACK.WINDOW_INFLUENCE)), "context_amount": np.array(float(cfg.TRACK.CONTEXT_AMOUNT))}
+    for k, v in mb.hm_net.ShareFeature.state_dict().items():
+        out["sf__" + k.replace(".", "__")] = v.numpy().copy()
+
+    # BatchNorm statistics of the similarity branch: cumulative batch statistics over the first frame's template / search crops
+    probe = ref_te.hdnTrackerHomo(mb)
+    avg0 = np.mean(frames[0], axis=(0, 1))
+    pos0 = np.array(init["poly"][:2])
+    size0 = np.array(init["poly"][2:4])
+    s_z0 = np.floor(np.sqrt((size0[0] + 0.5 * size0.sum()) * (size0[1] + 0.5 * size0.sum())))
+    sim_bns = [m for n, m in mb.named_modules() if isinstance(m, torch.nn.BatchNorm2d) and not n.startswith("hm_net")]
+    for m in sim_bns:
+        m.reset_running_stats()
+        m.momentum = None
+    mb.train()
+    mb.hm_net.eval()
+    with torch.no_grad():
+        z = probe.get_subwindow(frames[0], pos0, 127, s_z0, avg0, islog=1)
+        x = probe.get_subwindow(frames[0], pos0, 255, 2 * s_z0, avg0)
+        ref_mb.ModelBuilder.template(mb, z)
+        ref_mb.ModelBuilder.track_new(mb, x)
+        ref_mb.ModelBuilder.track_new_lp(mb, x, [0, 0])
+    mb.eval()
+    # the regressor: x = fc_bias + W (f - f0), f0 = pooled trunk features of the (template, template) pair of frame 0 — corner offsets of
+    # about a pixel whose data-dependent part is a few tenths (the pooled features of a seeded trunk are O(100): W f alone is +-50 px)
+    with torch.no_grad():
+        zc, _ = probe.get_subwindow_for_homo(frames[0], pos0, 127, np.floor(np.sqrt(size0[0] * size0[1])), avg0)
+        tmp0, _ = ref_te.get_template_info(zc[:, 0:3])
+        pair = torch.Tensor(ref_te.merge_tmp_search(tmp0, tmp0)["input_tensors"]).float().unsqueeze(0)
+        p0 = mb.hm_net.ShareFeature(pair[:, :1])
+        f0 = mb.hm_net.avgpool(mb.hm_net.backbone(torch.cat((p0, p0), dim=1))).flatten(1)
+        mb.hm_net.fc.bias.data = fc_bias - (f0 @ mb.hm_net.fc.weight.data.t())[0]
+
+    rec = {}
+    fc_out = []
+    mb.hm_net.fc.register_forward_hook(lambda m, i, o: fc_out.append(o.detach().numpy().copy()))
+    for name in ("template", "track_new", "track_new_lp", "track_proj"):
+        def wrap(name=name, orig=getattr(mb, name)):
+            def f(*a, **k):
+                r = orig(*a, **k)
+                # copies: _convert_c / _convert_logpolar_simi decode IN PLACE (for a batch of one, permute(1, 2, 3, 0).contiguous() is
+                # a view and .numpy() shares its memory: base_tracker.py:54-59, hdn_tracker.py:51-67)
+                keep = {kk: vv.clone() for kk, vv in r.items()} if isinstance(r, dict) else r
+                rec[name] = (a, keep)
+                return r
+            return f
+        setattr(mb, name, wrap())
+
+    def run(prefix, instance_size, n_track, events):
+        old = cfg.TRACK.INSTANCE_SIZE
+        cfg.TRACK.INSTANCE_SIZE = instance_size
+        try:
+            trk = ref_te.hdnTrackerHomo(mb)
+            with torch.no_grad():
+                trk.init(frames[0], init["bbox"], init["poly"], init["gt_points"], init["first_point"])
+            P = prefix
+            out.update({P + "instance_size": np.array(instance_size), P + "score_size": np.array(trk.score_size), P + "n_track": np.array(n_track),
+                        P + "init__z_crop_crc": _crc(rec["template"][0][0].numpy().astype(np.uint8)), P + "init__z_crop_points": np.array(trk.z_crop_points, np.float64),
+                        P + "init__z_crop_sm_crc": _crc(trk.z_crop_sm.numpy().astype(np.uint8)),
+                        P + "init__z_crop_points_sm": np.array(trk.z_crop_points_sm, np.float64), P + "init__init_s_z": np.array(trk.init_s_z),
+                        P + "init__init_s_z_sm": np.array(trk.init_s_z_sm), P + "init__channel_average": np.array(trk.channel_average),
+                        P + "init__center_pos": np.array(trk.center_pos), P + "init__size": np.array(trk.size),
+                        P + "init__init_homo_tmp_crc": _crc(np.array(trk.init_homo_tmp)), P + "init__init_points": np.array(trk.init_points),
+                        P + "init__poly_shift_l": np.array(trk.poly_shift_l)})
+            assert np.array_equal(trk.z_crop.numpy(), rec["template"][0][0].numpy())
+            if P == "a__":   # (init does not depend on INSTANCE_SIZE: the second run stores the checksums only)
+                out.update({P + "init__z_crop": trk.z_crop.numpy().astype(np.uint8), P + "init__init_homo_tmp": np.array(trk.init_homo_tmp)})
+            for i in range(1, n_track + 1):
+                mb.score_bias = 10.0 if i == events.get("gate_frame") else 0.0
+                if i == events.get("singular_frame"):
+                    trk.H_total = np.array([[1, 0, 0], [0, 1, 0], [0, 0, 0]], np.float32)
+                del cv2_shim.CALLS[:]
+                del fc_out[:]
+                with torch.no_grad(), _LocalsAtReturn(ref_te.hdnTrackerHomo.track_new.__code__) as cap:
+                    res = trk.track_new(i, frames[i])
+                L = cap.locals
+                names = [c[0] for c in cv2_shim.CALLS]
+                assert names == ["warpPerspective", "resize", "resize", "warpAffine", "resize", "warpAffine", "warpPerspective",
+                                 "perspectiveTransform"], names
+                k = f"{P}f{i}__"
+                H_mat, score, simi = rec["track_proj"][1]
+                out.update({
+                    k + "cls": rec["track_new"][1]["cls"].numpy(), k + "loc_c": rec["track_new"][1]["loc_c"].numpy(),
+                    k + "cls_lp": rec["track_new_lp"][1]["cls_lp"].numpy(), k + "loc_lp": rec["track_new_lp"][1]["loc_lp"].numpy(),
+                    k + "x": fc_out[-1], k + "H_mat": H_mat.numpy(), k + "homo_score": np.array(L["homo_score"]), k + "simi_score": np.array(float(simi), np.float32),
+                    k + "s_x": np.array(L["s_x"]), k + "scale_z": np.array(L["scale_z"]), k + "best_idx": np.array(L["best_idx"]),
+                    k + "pscore_best": np.array(L["pscore"][L["best_idx"]]), k + "stop": np.array(L["stop_update_flag"]),
+                    k + "center": np.array([L["delta_cx"], L["delta_cy"]], np.float64), k + "cxcy": np.array([L["cx"], L["cy"]], np.float64),
+                    k + "best_idx_lp": np.array(L["best_idx_lp"]), k + "pscore_lp_best": np.array(L["pscore_lp"][L["best_idx_lp"]]),
+                    k + "sim_lp": np.array(L["sim_lp"], np.float64), k + "best_score": np.array(L["best_score"]),
+                    k + "scale_delta": np.array(L["scale_delta"], np.float64), k + "rot_delta": np.array(L["rot_delta"], np.float64),
+                    k + "H_sim": np.array(L["H_sim"]), k + "H_hm": np.array(L["H_hm"]), k + "crop_points": np.array(L["crop_points"], np.float64),
+                    k + "H_hm_comp": np.array(L["H_hm_comp"]), k + "H_total": np.array(trk.H_total), k + "center_pos": np.array(trk.center_pos),
+                    k + "scale": np.array(trk.scale, np.float64), k + "rot": np.array(trk.rot, np.float64),
+                    k + "points": np.array(res["points"]), k + "bbox": np.array(res["bbox"], np.float64),
+                    k + "img_crc": _crc(L["img"]), k + "rot_img_crc": _crc(L["rot_img_homo"]),
+                    k + "x_crop_crc": _crc(L["x_crop"].numpy().astype(np.uint8)), k + "x_crop_moved_crc": _crc(L["x_crop_moved"].numpy().astype(np.uint8)),
+                    k + "x_crop_homo_crc": _crc(L["x_crop_homo"].numpy().astype(np.uint8)),
+                    k + "search_crc": _crc(np.ascontiguousarray(rec["track_proj"][0][0]["input_tensors"][0, 1].numpy())),
+                })
+                assert all(np.array_equal(L[n].numpy(), L[n].numpy().astype(np.uint8)) for n in ("x_crop", "x_crop_moved", "x_crop_homo"))
+                if i == 1 and P == "a__":
+                    out.update({k + "x_crop": L["x_crop"].numpy().astype(np.uint8), k + "x_crop_moved": L["x_crop_moved"].numpy().astype(np.uint8),
+                                k + "x_crop_homo": L["x_crop_homo"].numpy().astype(np.uint8)})
+                err = np.sqrt(((res["points"].astype(np.float64) - corners[i]) ** 2).sum() / 4)
+                print(f"    {P}frame {i}: best_idx {int(L['best_idx'])} lp {int(L['best_idx_lp'])} centre ({L['delta_cx']:+.3f}, {L['delta_cy']:+.3f}) "
+                      f"scale {float(L['scale_delta']):.5f} rot {float(L['rot_delta']):+.5f} homo_score {float(L['homo_score']):.4f} vs ground truth {err:.2f} px")
+        finally:
+            cfg.TRACK.INSTANCE_SIZE = old
+
+    run("a__", 255, TRACKER_LOOP_SEQ["n_frames"] - 1, TRACKER_LOOP_EVENTS)
+    run("b__", 303, 5, {"gate_frame": 3})
+    save("tracker_loop", **out)
 
 
 def main():
@@ -811,6 +1010,10 @@ def main():
         import hdn.tracker.base_tracker as ref_bt
         import hdn.tracker.hdn_tracker_proj_e2e as ref_te
         gen_config5(ref_te, ref_ban, ref_bt, cfg)
+    if want("tracker_loop"):
+        import hdn.models.model_builder_e2e_unconstrained_v2 as ref_mb
+        import hdn.tracker.hdn_tracker_proj_e2e as ref_te
+        gen_tracker_loop(ref_te, ref_mb, cfg)
     print("torch", torch.__version__, "numpy", np.__version__)
 
 

@@ -342,3 +342,118 @@ def test_similarity_decode_oracle_vs_reference(fixture, S, n_expected):
         fired["stop"] += tr["stop"]
         fired["lp_gate"] += int(not tr["stop"] and lp["score_lp"][lp["best_idx_lp"]] < 0.25 and list(lp["sim_lp"]) == [1, 1, 0, 0])
     assert fired["stop"] == 1 and fired["lp_gate"] == 1   # both gate branches are in the fixture
+
+
+# --------------------------------------------------------------------------- the tracker loop, against the EXECUTED reference
+class ReplayModel:
+    """Plays back the network outputs tests/golden/tracker_loop.npz recorded while the reference's own hdnTrackerHomo.init / track_new
+    ran around its real ModelBuilder: template / track_new / track_new_lp / track_proj (model_builder_e2e_unconstrained_v2.py:87-217)
+    return what the reference's networks returned for that frame, and keep what they were handed (the crops) for the caller to check."""
+
+    def __init__(self, g, prefix, to=lambda a: torch.from_numpy(np.ascontiguousarray(a))):
+        self.g, self.p, self.to, self.frame, self.seen = g, prefix, to, 0, {}
+
+    def key(self, name):
+        return f"{self.p}f{self.frame}__{name}"
+
+    def template(self, z):
+        self.seen["z_crop"] = z
+
+    def track_new(self, x, delta=[0, 0]):
+        self.seen["x_crop"] = x
+        return {"cls": self.to(self.g[self.key("cls")]), "loc_c": self.to(self.g[self.key("loc_c")])}
+
+    def track_new_lp(self, x, delta=[0, 0]):
+        self.seen["x_crop_moved"] = x
+        return {"cls_lp": self.to(self.g[self.key("cls_lp")]), "loc_lp": self.to(self.g[self.key("loc_lp")])}
+
+    def track_proj(self, tmpl, srch):
+        self.seen["search"] = srch
+        return self.to(self.g[self.key("H_mat")]), self.to(self.g[self.key("homo_score")]), self.to(self.g[self.key("simi_score")])
+
+
+def crc(a):
+    import zlib
+    return zlib.crc32(np.ascontiguousarray(a).tobytes())
+
+
+def tracker_loop_sequence(g):
+    """The frames of tests/golden/tracker_loop.npz, regenerated from the seed (tools/synth_sequence.py) and checked against the
+    fixture's CRCs: a NumPy whose FFT / generator differs from the build container's is reported as such, not as a parity failure."""
+    from tools.synth_sequence import make_sequence
+    frames, corners, init = make_sequence(n_frames=int(g["seq__n_frames"]), frame_hw=tuple(int(v) for v in g["seq__frame_hw"]),
+                                          target_wh=tuple(int(v) for v in g["seq__target_wh"]), seed=int(g["seq__seed"]))
+    got = np.array([crc(f) for f in frames], np.int64)
+    if not np.array_equal(got, g["seq__frames_crc"]):
+        pytest.skip("tools/synth_sequence.make_sequence does not reproduce the fixture's frames on this NumPy build")
+    np.testing.assert_array_equal(np.array(init["poly"]), g["seq__poly"])
+    return frames, init
+
+
+@pytest.mark.parametrize("prefix", ["a__", "b__"])
+def test_tracker_loop_oracle_vs_executed_reference(prefix):
+    """oracle/tracker_oracle.py (HomoTrackerOracle + SimilarityOracle: what every sequence-level GPU test is compared with) against the
+    values the reference's OWN hdnTrackerHomo.init / track_new produced when make_golden.py:gen_tracker_loop executed them, verbatim,
+    around the real ModelBuilder (tests/golden/tracker_loop.npz; `a__`: INSTANCE_SIZE 255, 12 frames with a gated frame and a singular
+    reset; `b__`: 303, 5 frames).  The networks are replayed, everything else is recomputed: uint8 crops and frames must match bit for
+    bit (CRC-32), float64 quantities to 1e-9 (observed: exact), float32 ones exactly.  What stays unpinned after this test are the six
+    OpenCV entry points only (tests/golden/cv2_shim.py): both sides use the same restatements of them."""
+    from oracle import tracker_oracle as TO
+    g = load_golden("tracker_loop")
+    frames, init = tracker_loop_sequence(g)
+    P = prefix
+    model = ReplayModel(g, P)
+    sim = TO.SimilarityOracle(model, window_influence=float(g["window_influence"]), instance_size=int(g[P + "instance_size"]))
+    assert sim.score_size == int(g[P + "score_size"])
+    trk = TO.HomoTrackerOracle(None, None, iterations=1, similarity=sim, track_proj=model.track_proj)
+    trk.init(frames[0], g["seq__bbox"].tolist(), g["seq__poly"].tolist(), g["seq__gt_points"].tolist(), g["seq__first_point"].tolist())
+    # init (:60-120)
+    assert float(trk.init_s_z) == float(g[P + "init__init_s_z"]) and float(trk.init_s_z_sm) == float(g[P + "init__init_s_z_sm"])
+    np.testing.assert_array_equal(trk.channel_average, g[P + "init__channel_average"])
+    np.testing.assert_array_equal(np.array(trk.z_crop_points_sm, np.float64), g[P + "init__z_crop_points_sm"])
+    np.testing.assert_array_equal(np.array(trk.z_crop_points, np.float64), g[P + "init__z_crop_points"])
+    assert crc(model.seen["z_crop"].numpy().astype(np.uint8)) == int(g[P + "init__z_crop_crc"])
+    assert crc(trk.trace["z_crop_sm"].astype(np.uint8)) == int(g[P + "init__z_crop_sm_crc"])
+    assert crc(trk.init_homo_tmp) == int(g[P + "init__init_homo_tmp_crc"])
+    np.testing.assert_array_equal(trk.init_points.reshape(-1), g[P + "init__init_points"].reshape(-1))
+    if P == "a__":
+        np.testing.assert_array_equal(model.seen["z_crop"].numpy().astype(np.uint8), g["a__init__z_crop"])
+        np.testing.assert_array_equal(trk.init_homo_tmp, g["a__init__init_homo_tmp"])
+    worst, worst_at = 0.0, None
+    for i in range(1, int(g[P + "n_track"]) + 1):
+        k = f"{P}f{i}__"
+        model.frame = i
+        if P == "a__" and i == int(g["seq__singular_frame"]):
+            trk.H_total = np.array([[1, 0, 0], [0, 1, 0], [0, 0, 0]], np.float32)    # what the generator did to the reference's tracker
+        res = trk.track_new(i, frames[i])
+        tr, s = trk.trace, res["similarity"]
+        # uint8 images: stabilised frame (:154), both search crops (:162-166, :194-196), rotated frame (:223), homography crop (:224-227)
+        assert crc(tr["img"]) == int(g[k + "img_crc"]), f"frame {i}: stabilised frame"
+        assert crc(s["x_crop"].astype(np.uint8)) == int(g[k + "x_crop_crc"]), f"frame {i}: x_crop"
+        assert crc(s["x_crop_moved"].astype(np.uint8)) == int(g[k + "x_crop_moved_crc"]), f"frame {i}: x_crop_moved"
+        assert crc(tr["rot_img"]) == int(g[k + "rot_img_crc"]), f"frame {i}: rotated frame"
+        assert crc(tr["x_crop_homo"].astype(np.uint8)) == int(g[k + "x_crop_homo_crc"]), f"frame {i}: x_crop_homo"
+        assert crc(model.seen["search"][0, 0].numpy()) == int(g[k + "search_crc"]), f"frame {i}: normalised search crop"
+        if k + "x_crop" in g.files:
+            np.testing.assert_array_equal(s["x_crop"].astype(np.uint8), g[k + "x_crop"])
+            np.testing.assert_array_equal(tr["x_crop_homo"].astype(np.uint8), g[k + "x_crop_homo"])
+        # decode (:157-214)
+        assert float(s["s_x"]) == float(g[k + "s_x"])
+        assert s["translation"]["best_idx"] == int(g[k + "best_idx"]) and s["translation"]["stop"] == int(g[k + "stop"])
+        assert s["logpolar"]["best_idx_lp"] == int(g[k + "best_idx_lp"])
+        assert s["best_score"] == float(g[k + "best_score"])
+        for name, got, want in (("center", [s["dcx"], s["dcy"]], g[k + "center"]), ("cxcy", [s["cx"], s["cy"]], g[k + "cxcy"]),
+                                ("scale_delta", s["scale_delta"], g[k + "scale_delta"]), ("rot_delta", s["rot_delta"], g[k + "rot_delta"]),
+                                ("sim_lp", s["logpolar"]["sim_lp"], g[k + "sim_lp"]), ("H_sim", s["H_sim"], g[k + "H_sim"]),
+                                ("crop_points", np.array(tr["crop_points"], np.float64), g[k + "crop_points"]),
+                                ("H_hm", tr["H_hm"], g[k + "H_hm"]), ("H_hm_comp", tr["H_homo"], g[k + "H_hm_comp"]),
+                                ("H_total", trk.H_total, g[k + "H_total"]), ("center_pos", trk.center_pos, g[k + "center_pos"]),
+                                ("scale", trk.scale, g[k + "scale"]), ("rot", trk.rot, g[k + "rot"])):
+            d = float(np.max(np.abs(np.asarray(got, np.float64) - np.asarray(want, np.float64))))
+            rel = d / max(1.0, float(np.max(np.abs(want))))
+            if rel > worst:
+                worst, worst_at = rel, (i, name)
+            assert d <= 1e-9 * max(1.0, float(np.max(np.abs(want)))), f"frame {i}: {name} differs by {d}"
+        assert tr["H_hm"].dtype == g[k + "H_hm"].dtype == np.float32 and trk.H_total.dtype == g[k + "H_total"].dtype
+        np.testing.assert_array_equal(res["points"], g[k + "points"])
+    assert worst <= 1e-12, (worst, worst_at)    # observed: 0.0 (the same numpy operations in the same order)
