@@ -47,8 +47,10 @@ def test_sequence_stream_device_loop_vs_cpu_restatement(dev):
         errs.append(success_4pts_error(a["points"], b["points"]))
     # the chain is a recurrence (H_total feeds the next frame's warp, whose 1/32-px taps feed the head): differences of
     # ~1e-5 px per frame in the head's offsets may grow, but stay far below a pixel over the sequence
-    assert errs[0] <= 1e-3, errs
-    assert max(errs[:5]) <= 1e-2 and max(errs) <= 0.25, errs
+    print("homography-only loop, corner errors vs CPU loop (px):", " ".join(f"{e:.1e}" for e in errs))
+    # observed (round 5): 1.3e-5 on the first frame, <= 4.5e-5 over the first ten, 3.2e-4 on the 15th
+    assert errs[0] <= 2e-4, errs
+    assert max(errs[:5]) <= 5e-4 and max(errs) <= 5e-3, errs
     assert trk.host_syncs == 1 + (len(frames) - 1)   # the channel mean at init + one read of 4 corners per frame
     # without the host read nothing synchronises: the same frame again, asynchronously, gives device tensors
     out = trk.track_new(99, frames[-1], sync=False)
@@ -260,8 +262,8 @@ def test_sequence_stream_with_similarity_device_vs_cpu(dev):
         assert abs(float(a["best_score"]) - s["best_score"]) <= 1e-4
         errs.append(success_4pts_error(a["points"], b["points"]))
     assert moved == len(frames) - 1, "the stand-in's similarity estimate must be non-trivial in every component"
-    assert errs[0] <= 1e-3, errs                 # observed 2e-5 ... 1.4e-4 px over the 11 frames
-    assert max(errs) <= 0.05, errs
+    assert errs[0] <= 2e-4, errs                 # observed 1.9e-5 ... 1.4e-4 px over the 11 frames
+    assert max(errs) <= 2e-3, errs
     assert trk.host_syncs - syncs0 == len(frames) - 1          # ONE read (4 corners + best_score) per frame
     print("similarity sequence corner errors (px):", " ".join(f"{e:.2e}" for e in errs))
 
@@ -303,8 +305,8 @@ def test_long_sequence_720p_graph_loop_vs_cpu(dev):
         errs.append(success_4pts_error(a["points"], b["points"]))
     print("720p graph loop, corner error vs CPU loop (px): first %.2e  median %.2e  max %.2e" % (errs[0], float(np.median(errs)), max(errs)))
     assert trk._graph is not None and trk.host_syncs - syncs0 == len(frames) - 1
-    assert errs[0] <= 1e-3 and max(errs[:10]) <= 1e-2, errs[:10]
-    assert max(errs) <= 0.25, errs
+    assert errs[0] <= 2e-4 and max(errs[:10]) <= 5e-3, errs[:10]      # observed: first 1.5e-5, median 2.9e-3, max 6.0e-3 over 60 frames
+    assert max(errs) <= 0.05, errs
 
 
 def test_graph_capture_failure_falls_back_to_eager(dev):
@@ -395,8 +397,10 @@ def test_device_tracker_homo_runs_production_shaped_model(dev, monkeypatch):
     print("                                                               hipGraph", " ".join(f"{e:.1e}" for e in errs_g))
     assert graphed._graph is not None, "the production-shaped frame body was not captured"
     assert moved == len(frames) - 1, "the stand-in's similarity estimate must be non-trivial in every component"
-    assert errs_e[0] <= 2e-2 and errs_g[0] <= 2e-2, (errs_e, errs_g)
-    assert max(errs_e) <= 0.25 and max(errs_g) <= 0.25, (errs_e, errs_g)
+    # observed: first frame 8.4e-5, 1.1e-2 at most over 12 frames (a random 50-layer network amplifies per-frame differences; run to run
+    # the later frames move with MIOpen's kernel choice).  One decode cell off would be 16 px.
+    assert errs_e[0] <= 1e-3 and errs_g[0] <= 1e-3, (errs_e, errs_g)
+    assert max(errs_e) <= 0.1 and max(errs_g) <= 0.1, (errs_e, errs_g)
     f = eager.similarity_state()
     assert abs(float(f["center"][0]) - s["cx"]) <= 5e-2 and abs(float(f["center"][1]) - s["cy"]) <= 5e-2
     model.track_new(torch.zeros((1, 3, 255, 255), device=dev))
@@ -427,7 +431,7 @@ def test_config5_tracker_loop_303_two_iterations_vs_cpu(dev):
         assert abs(st[16] - s["scale_delta"]) <= 1e-3 and abs(st[17] - s["rot_delta"]) <= 1e-3, (t, st[16:18], s)
         errs.append(success_4pts_error(a["points"], b["points"]))
     print("config 5 tracker loop (303 px, 2 iterations), corner error vs CPU loop (px):", " ".join(f"{e:.1e}" for e in errs))
-    assert errs[0] <= 2e-2 and max(errs) <= 0.25, errs
+    assert errs[0] <= 5e-4 and max(errs) <= 3e-2, errs          # observed 3.7e-5 ... 2.6e-3
     out = model.track_new(torch.zeros((1, 3, 303, 303), device=dev))
     assert X.last_variant() == "cfg5_35x35_5x5" and tuple(out["cls"].shape) == (1, 2, 31, 31)
     # and as one hipGraph per frame
@@ -438,3 +442,117 @@ def test_config5_tracker_loop_303_two_iterations_vs_cpu(dev):
     for t in range(1, 5):
         assert success_4pts_error(g.track_new(t, frames[t])["points"], e.track_new(t, frames[t])["points"]) <= 2e-2
     assert g._graph is not None
+
+
+# ------------------------------------------------------------------------------------------ against the EXECUTED reference loop
+class _ReplayX(torch.nn.Module):
+    """Stands where hm_net.fc stands and returns the trunk output the reference's hm_net produced for the current frame."""
+
+    def __init__(self, replay, dev):
+        super().__init__()
+        self.replay, self.dev = replay, dev
+
+    def forward(self, feats):
+        r = self.replay
+        return torch.from_numpy(np.ascontiguousarray(r.g[r.key("x")])).to(self.dev)
+
+
+def _replay_device_model(g, P, dev):
+    """A model object with the reference's ModelBuilder interface whose networks are the recorded outputs of tracker_loop.npz: the
+    similarity branch returns the recorded head maps, hm_net = PreShareFeature with the fixture's weights (HIP) + the recorded trunk
+    output, so that DLT, warp, scores and everything around them run on the device."""
+    from tracker_loop_replay import ReplayModel
+    import hdn_amd
+
+    class Hm(torch.nn.Module):
+        def __init__(self, replay):
+            super().__init__()
+            self.ShareFeature = hdn_amd.PreShareFeature()
+            self.ShareFeature.load_state_dict({k[4:].replace("__", "."): torch.from_numpy(np.asarray(g[k])) for k in g.files if k.startswith("sf__")})
+            self.backbone, self.avgpool = torch.nn.Identity(), torch.nn.Identity()
+            self.fc = _ReplayX(replay, dev)
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.replay = ReplayModel(g, P, to=lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev))
+            self.hm_net = Hm(self.replay)
+            self.template, self.track_new, self.track_new_lp = self.replay.template, self.replay.track_new, self.replay.track_new_lp
+
+    return Model().to(dev).eval()
+
+
+@pytest.mark.parametrize("prefix", ["a__", "b__"])
+def test_device_tracker_vs_executed_reference(dev, prefix):
+    """DeviceTrackerHomo — the object install(tracker=True) registers — against tests/golden/tracker_loop.npz: what the reference's OWN
+    hdnTrackerHomo.init / track_new computed when they were executed, verbatim, around the real ModelBuilder
+    (make_golden.py:gen_tracker_loop; `a__` INSTANCE_SIZE 255 with a gated frame and a singular-H_total reset, `b__` 303).  The recorded
+    head maps and trunk outputs are replayed; crops, full-frame warps, decode, H_sim, DLT, the refinement step, un-scale / un-shift,
+    accumulation and corner projection run on the device.  Bounds are set from what is observed (in brackets)."""
+    from conftest import load_golden
+    from tracker_loop_replay import ReplayModel, crc, tracker_loop_sequence
+    from synth_sequence import success_4pts_error
+    from hdn_amd.tracker import DeviceTrackerHomo
+    from hdn_amd.similarity import TrackerConfig
+    g = load_golden("tracker_loop")
+    frames, init = tracker_loop_sequence(g)
+    P = prefix
+    model = _replay_device_model(g, P, dev)
+    cfg = TrackerConfig(instance_size=int(g[P + "instance_size"]), window_influence=float(g["window_influence"]))
+    trk = DeviceTrackerHomo(model, graph=False, cfg=cfg, fold_backbone=False)
+    trk.init(frames[0], g["seq__bbox"].tolist(), g["seq__poly"].tolist(), g["seq__gt_points"].tolist(), g["seq__first_point"].tolist())
+    rp = model.replay
+    # the CPU oracle's replay of the same fixture (held to it exactly by tests/test_oracle_golden.py) supplies every frame's crops in full
+    from oracle import tracker_oracle as TO
+    cpu_model = ReplayModel(g, P)
+    ref = TO.HomoTrackerOracle(None, None, similarity=TO.SimilarityOracle(cpu_model, window_influence=cfg.window_influence, instance_size=cfg.instance_size),
+                               track_proj=cpu_model.track_proj)
+    ref.init(frames[0], g["seq__bbox"].tolist(), g["seq__poly"].tolist(), g["seq__gt_points"].tolist(), g["seq__first_point"].tolist())
+    assert trk.init_s_z == float(g[P + "init__init_s_z"]) and trk.init_s_z_sm == float(g[P + "init__init_s_z_sm"])
+    np.testing.assert_allclose(trk.channel_average, g[P + "init__channel_average"], rtol=1e-13)
+    assert tuple(trk.z_crop_points_sm) == tuple(g[P + "init__z_crop_points_sm"])
+    assert crc(rp.seen["z_crop"].cpu().numpy().astype(np.uint8)) == int(g[P + "init__z_crop_crc"])          # template crop + its log-polar image
+    if P == "a__":
+        np.testing.assert_allclose(trk.init_homo_tmp.cpu().numpy()[0], g["a__init__init_homo_tmp"].astype(np.float32), atol=1e-6)
+    gate0 = float(trk._consts[36])
+    worst = {"points_px": 0.0, "H_total_rel": 0.0, "H_sim_rel": 0.0, "center": 0.0, "scale": 0.0, "rot": 0.0, "H_mat": 0.0, "score": 0.0, "crop_px": 0}
+    for i in range(1, int(g[P + "n_track"]) + 1):
+        k = f"{P}f{i}__"
+        rp.frame = i
+        gated = float(g[k + "homo_score"]) > 2.5
+        trk._consts[36] = -1.0 if gated else gate0      # (the generator raised that frame's score by 10; here the gate is lowered instead)
+        if P == "a__" and i == int(g["seq__singular_frame"]):
+            trk.H_total.copy_(torch.tensor([[1, 0, 0], [0, 1, 0], [0, 0, 0]], dtype=torch.float64))
+            ref.H_total = np.array([[1, 0, 0], [0, 1, 0], [0, 0, 0]], np.float32)
+        res = trk.track_new(i, frames[i])
+        st = trk.similarity_state()
+        cpu_model.frame = i
+        rres = ref.track_new(i, frames[i])
+        np.testing.assert_array_equal(rres["points"], g[k + "points"])                   # the CPU replay IS the fixture
+        assert crc(rres["similarity"]["x_crop"].astype(np.uint8)) == int(g[k + "x_crop_crc"])
+        # crops: uint8-valued; the first frame's are the executed reference's bit for bit; later ones are cut from a frame warped by the
+        # device's H_total (1e-7 from the reference's), whose 1/32-px coordinate rounding flips for a few pixels
+        for name in ("x_crop", "x_crop_moved"):
+            got = rp.seen[name].cpu().numpy()
+            assert np.array_equal(got, np.rint(got)) and got.min() >= 0 and got.max() <= 255
+            want = rres["similarity"][name]
+            nd, md = int((got != want).sum()), float(np.abs(got - want).max())
+            if i == 1:
+                assert crc(got.astype(np.uint8)) == int(g[k + name + "_crc"]), f"frame 1: {name} differs from the reference's crop"
+            worst["crop_px"], worst["crop_max"] = max(worst["crop_px"], nd), max(worst.get("crop_max", 0.0), md)
+        assert int(st["best_idx"]) == int(g[k + "best_idx"]) and int(st["stop"]) == int(g[k + "stop"]) and int(st["best_idx_lp"]) == int(g[k + "best_idx_lp"]), i
+        worst["center"] = max(worst["center"], float(np.abs(st["center"] - g[k + "cxcy"]).max()))
+        worst["scale"] = max(worst["scale"], abs(float(st["scale_delta"]) - float(g[k + "scale_delta"])))
+        worst["rot"] = max(worst["rot"], abs(float(st["rot_delta"]) - float(g[k + "rot_delta"])))
+        worst["H_sim_rel"] = max(worst["H_sim_rel"], float(np.abs(st["H_sim"] - g[k + "H_sim"]).max() / np.abs(g[k + "H_sim"]).max()))
+        worst["score"] = max(worst["score"], abs(float(trk.last_score) - (float(g[k + "homo_score"]) - (10.0 if gated else 0.0))))
+        Ht = trk.H_total.cpu().numpy()
+        worst["H_total_rel"] = max(worst["H_total_rel"], float(np.abs(Ht - g[k + "H_total"]).max() / np.abs(g[k + "H_total"]).max()))
+        e = success_4pts_error(res["points"], g[k + "points"])
+        worst["points_px"] = max(worst["points_px"], e)
+        assert e <= 2e-4, (i, e, worst)            # [4.6e-5 px over the 12 frames incl. the gated frame and the reset]
+        assert abs(float(res["best_score"]) - float(g[k + "best_score"])) <= 1e-6
+    print("device tracker vs executed reference", P, worst)
+    assert worst["crop_px"] <= 200 and worst["crop_max"] <= 3, worst      # of 195,075 / 275,427 values per crop [47 values by at most 2]
+    assert worst["center"] <= 1e-9 and worst["scale"] <= 1e-9 and worst["rot"] <= 1e-9 and worst["H_sim_rel"] <= 1e-12, worst   # [0, 0, 0, 2e-16]
+    assert worst["H_total_rel"] <= 2e-5 and worst["score"] <= 2e-5, worst      # [3.6e-6, 3.8e-6]
