@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libhdn_hip.so"
 LIB_PATH = os.environ.get("HDN_LIB_PATH", os.path.join(_HERE, LIB_NAME))  # override: A/B builds of the kernels
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _c_float_p = ctypes.c_void_p  # device pointers travel as integers
 _i = ctypes.c_int
@@ -56,6 +56,9 @@ SIGNATURES = {
     "hdn_conv3x3_workspace_bytes": (ctypes.c_longlong, [_i, _i, _i, _i]),
     "hdn_conv3x3s2_ds_f32": (_i, [_c_float_p] * 6 + [ctypes.c_longlong] + [_i] * 3 + [ctypes.c_void_p]),
     "hdn_conv3x3_bias_relu_f32": (_i, [_c_float_p] * 6 + [ctypes.c_longlong] + [_i] * 3 + [ctypes.c_void_p]),
+    "hdn_conv3x3_v2_pack_info": (_i, [_i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+    "hdn_conv3x3_v2_workspace_bytes": (ctypes.c_longlong, [_i, _i, _i]),
+    "hdn_conv3x3_v2_f32": (_i, [_c_float_p] * 6 + [ctypes.c_longlong] + [_i] * 3 + [ctypes.c_void_p]),
     "hdn_conv3x3_chain_slices": (_i, [_i, _i, _i, _i]),
     "hdn_conv3x3_chain_f32": (_i, [_c_float_p, _i, _c_float_p, _c_float_p, _i, _c_float_p, ctypes.c_void_p, _c_float_p, _c_float_p] + [_i] * 4 + [ctypes.c_void_p]),
     "hdn_conv3x3_finish_f32": (_i, [_c_float_p, _i, _c_float_p, _c_float_p, _i, _c_float_p] + [_i] * 3 + [ctypes.c_void_p]),

@@ -111,16 +111,21 @@ struct Cfg {
 // Row i (0..31) of an MFMA tile -> pixel of the tile's 32-pixel block, (image, y, x) order.  Stride-1 tiles with rows shorter than
 // 32 pixels hand the two 16-lane access groups of a fragment read pixel sets that are 16 distinct columns of the bank row:
 // group = which of the two, k = rank inside it; S = 16: group = row; S = 8: rows (0, 2) | (1, 3); S = 4: even | odd rows of two images.
-template <class Cf>
-__device__ __forceinline__ int mrow_to_pixel(int i) {
-  if constexpr (Cf::STRIDE != 1 || Cf::S >= 32) {
+template <int S>
+__host__ __device__ constexpr __forceinline__ int mrow_to_pixel_s1(int i) {   // stride-1 tiles of side S
+  if constexpr (S >= 32) {
     return i;
   } else {
     const int q = i >> 2, grp = (0x96 >> q) & 1, k = ((q >> 1) << 2) | (i & 3);
-    if constexpr (Cf::S == 16) return grp * 16 + k;
-    else if constexpr (Cf::S == 8) return (2 * (k >> 3) + grp) * 8 + (k & 7);
+    if constexpr (S == 16) return grp * 16 + k;
+    else if constexpr (S == 8) return (2 * (k >> 3) + grp) * 8 + (k & 7);
     else return (k >> 3) * 16 + (2 * ((k >> 2) & 1) + grp) * 4 + (k & 3);
   }
+}
+template <class Cf>
+__host__ __device__ constexpr __forceinline__ int mrow_to_pixel(int i) {
+  if constexpr (Cf::STRIDE != 1) return i;
+  else return mrow_to_pixel_s1<Cf::S>(i);
 }
 
 // A convolution input that was never written out as an activation (B = 1: every launch is a dependent step of ~5 us, and the
@@ -393,6 +398,9 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __r
       if (stage + 1 < nstage) __syncthreads();
     };
     int c2 = 0;
+#if defined(HDN_ABLATION) && defined(CV_EXP_NOLOOP)   // measurement build only: prologue + epilogue of a launch
+    c2 = nchunk;
+#endif
 #pragma unroll 1
     for (; c2 + 1 < nchunk; c2 += 2) static_for<6>([&](auto Jc) { stage_p(c2, Jc); });
     if (c2 < nchunk) static_for<3>([&](auto Jc) { stage_p(c2, Jc); });   // an odd chunk count: one more chunk, at position 0 of the period again
@@ -449,6 +457,9 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __r
       if (stage + 1 < nstage) __syncthreads();
     };
     int c2 = 0;
+#if defined(HDN_ABLATION) && defined(CV_EXP_NOLOOP)
+    c2 = nchunk;
+#endif
 #pragma unroll 1
     for (; c2 + 1 < nchunk; c2 += 2) static_for<6>([&](auto Jc) { stage_c(c2, Jc); });
     if (c2 < nchunk) static_for<3>([&](auto Jc) { stage_c(c2, Jc); });
@@ -458,17 +469,24 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __r
   // The tile goes through LDS once ([pixel][BN] fp32) so that the residual is read and the result written as 16 bytes per lane,
   // a pixel's BN channels (contiguous in NHWC) by BN / 4 consecutive lanes.
   __syncthreads();  // every wave is done with the A / W images
+#if defined(HDN_ABLATION) && defined(CV_EXP_NOEPI)   // measurement build only: no output staging, residual read or store (one float per workgroup keeps the loop alive)
+  if (threadIdx.x == 0) out[blockIdx.x] = acc[0][0][0] + accl[0][0][0];
+  return;
+#endif
   float* const sO = reinterpret_cast<float*>(smem);
+  // (the pixel of accumulator row r is a compile-time constant for each of the two half waves: one multiply-add per store instead of
+  //  the mapping's dozen integer operations - round 5)
   if (consume) {
+    float* const obase = sO + wm * MT * 32 * Cf::EPI_STRIDE + wn * NT * 32 + li;
+    static_for<MT>([&](auto MTc) {
+      static_for<16>([&](auto Rc) {
+        constexpr int mt = decltype(MTc)::value, r = decltype(Rc)::value, i0 = (r & 3) + 8 * (r >> 2);
+        constexpr int row0 = mt * 32 + mrow_to_pixel<Cf>(i0), row1 = mt * 32 + mrow_to_pixel<Cf>(i0 + 4);
+        float* const q = obase + (row0 + g * (row1 - row0)) * Cf::EPI_STRIDE;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (wm * MT + mt) * 32 + mrow_to_pixel<Cf>((r & 3) + 8 * (r >> 2) + 4 * g);
-          sO[row * Cf::EPI_STRIDE + (wn * NT + nt) * 32 + li] = acc[mt][nt][r] + accl[mt][nt][r] * LO_UNSCALE;
-        }
+        for (int nt = 0; nt < NT; ++nt) q[nt * 32] = acc[mt][nt][r] + accl[mt][nt][r] * LO_UNSCALE;
+      });
+    });
   }
   __syncthreads();
   constexpr int ETHREADS = 2 * HDN_BLOCK;   // every thread of the workgroup stores
@@ -502,15 +520,16 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __r
   if (DS) {   // the downsample branch: raw sums (its bias travels with the block's second convolution)
     __syncthreads();
     if (consume) {
+      float* const obase = sO + wm * MT * 32 * Cf::EPI_STRIDE + wn * NT * 32 + li;
+      static_for<MT>([&](auto MTc) {
+        static_for<16>([&](auto Rc) {
+          constexpr int mt = decltype(MTc)::value, r = decltype(Rc)::value, i0 = (r & 3) + 8 * (r >> 2);
+          constexpr int row0 = mt * 32 + mrow_to_pixel<Cf>(i0), row1 = mt * 32 + mrow_to_pixel<Cf>(i0 + 4);
+          float* const q = obase + (row0 + g * (row1 - row0)) * Cf::EPI_STRIDE;
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = (wm * MT + mt) * 32 + mrow_to_pixel<Cf>((r & 3) + 8 * (r >> 2) + 4 * g);
-            sO[row * Cf::EPI_STRIDE + (wn * NT + nt) * 32 + li] = accd[DS ? mt : 0][DS ? nt : 0][r] + accdl[DS ? mt : 0][DS ? nt : 0][r] * LO_UNSCALE;
-          }
+          for (int nt = 0; nt < NT; ++nt) q[nt * 32] = accd[DS ? mt : 0][DS ? nt : 0][r] + accdl[DS ? mt : 0][DS ? nt : 0][r] * LO_UNSCALE;
+        });
+      });
     }
     __syncthreads();
 #pragma unroll
@@ -650,6 +669,359 @@ static int finish(const float* slices, int z, const float* bias, const float* re
   return launch_status();
 }
 
+
+// =====================================================================================================================================
+// Round 5: the form for batches that fill the chip (B >= V2_MIN_BATCH, stride 1, C -> C).  What round 4's profile showed for the kernel
+// above (profiles/round5_conv3x3.txt): with ONE 32 x 32 MFMA tile per wave and step the LDS moves 8 KB of fragments + the producers'
+// weight stores per 6 MFMAs and is the bound (256-channel stage: loop 17.5 us against 6.6 us of matrix pipe), and all of a launch's
+// output leaves at its very end.  Here
+//   * every consumer wave owns a 64 x 64 output tile (2 x 2 MFMA tiles, 12 MFMAs per step): half the fragment bytes per MFMA;
+//   * the four consumers of a workgroup are WM tiles along the pixels x WK slices of K (k step ks of every 16 KS-channel chunk belongs
+//     to wave ks % WK), so that a workgroup's tile is 64 WM pixels x 64 channels and the launch still has ~256 workgroups at every stage;
+//     the WK partial tiles meet in LDS at the end;
+//   * the weights never touch the LDS: a wave's B fragments are its own (no other wave of the workgroup needs that k step, or the
+//     other one loads the same lines through the CU's L1), the host packs them in fragment order per (k slice, step), and they stream
+//     L2 -> registers two steps ahead (volatile asm loads on a scalar base, explicit vmcnt);
+//   * the LDS holds the activations only: image of 16 KS channels, [piece][k step][k half][pixel] x 16 B as above, double-buffered,
+//     staged (and split to fp16 pieces) by the four producer waves; ONE barrier per chunk, placed before the MFMAs of a chunk's last
+//     step, so that the next chunk's first fragments travel under them;
+//   * the producers also own the epilogue: they ask for the residual during the last chunk and, once the partial tiles are in LDS,
+//     add them in slice order + bias (+ residual), ReLU, 16-byte NHWC stores.
+template <int S_, int C_, int WM_, int WK_, int KS_>
+struct Cfg2 {
+  static constexpr int S = S_, C = C_, WM = WM_, WK = WK_, KS = KS_;
+  static_assert(WM * WK == 4 && KS % WK == 0, "four consumer waves: WM pixel tiles x WK k slices");
+  static constexpr int BM = 64 * WM, BN = 64, MT = 2, NT = 2, NP = 2;
+  static_assert(C % BN == 0 && C % (16 * KS) == 0, "channel blocking");
+  static_assert((BM % S == 0) && ((S * S) % BM == 0 || BM % (S * S) == 0), "a tile is whole rows of one image, or whole images");
+  static constexpr int IMGS = BM > S * S ? BM / (S * S) : 1;
+  static constexpr int R = BM / (S * IMGS);
+  static constexpr int PWV = S + 2, PH = R + 2;
+  static constexpr int PW = S == 8 ? 12 : PWV;                       // (bank mapping of the fragment reads: see Cfg)
+  static constexpr int IPITCH = PH * PW + (S == 4 ? 4 : 0);
+  static constexpr int LPV = IMGS * IPITCH;
+  static constexpr int LP = LPV + ((8 / (2 * KS) - LPV % 8) + 8) % 8;
+  static constexpr int KG_BYTES = LP * 16, KSTEP_BYTES = 2 * KG_BYTES, PIECE_BYTES = KS * KSTEP_BYTES, A_BYTES = NP * PIECE_BYTES;
+  static constexpr int NCHUNK = C / (16 * KS), NB = C / BN;
+  static constexpr int SPW = KS / WK, NS = 9 * SPW;                  // k steps / steps (tap, k step) of one wave per chunk
+  static_assert(NS % 3 == 0, "three B register sets rotate with the step");
+  static constexpr int PER = (NS % 2) ? 2 : 1;                       // chunks per unrolled period (two A register sets)
+  static constexpr int WSTEP = NT * NP * 64;                         // 16-byte words of one wave step: [n tile][piece][lane]
+  static constexpr int WCHUNK = WK * NS * WSTEP;                     // ... of one (channel block, chunk): [k slice][step]
+  static constexpr int EPI_STRIDE = BN + 4;
+  static constexpr int RED_BYTES = WK * BM * EPI_STRIDE * 4;
+  static constexpr int LDS_BYTES = 2 * A_BYTES > RED_BYTES ? 2 * A_BYTES : RED_BYTES;
+  static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit the LDS");
+  static constexpr int AITEMS = LP * 2 * KS, AITER = cdiv(AITEMS, HDN_BLOCK);
+  static constexpr int E4 = BM * (BN / 4), EITER = cdiv(E4, HDN_BLOCK);   // 16-byte output items per tile / per producer thread
+};
+
+#if defined(HDN_ABLATION) && defined(CV2_EXP_TIME)   // measurement build only: s_memtime stamps per workgroup (tools/experiments/exp_conv3x3_v2_phases.py)
+__device__ unsigned long long cv2_times[4096 * 8];
+#define CV2_STAMP(slot) do { if (lane == 0 && (wave == 0)) { const unsigned wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); if (wg < 4096) cv2_times[wg * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define CV2_STAMP(slot) do {} while (0)
+#endif
+
+// MODE 0: out = relu(conv + bias); 1: out = relu(conv + bias + res); 2: raw sums of the K slice blockIdx.z (`cps` chunks) to out[blockIdx.z][M][C]
+template <class Cf, int MODE>
+__global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_v2_kernel(const float* __restrict__ x, const u32x4* __restrict__ wp, const float* __restrict__ bias,
+                                                               const float* __restrict__ res, float* __restrict__ out, int B, int cps) {
+  constexpr bool RES = MODE == 1, PARTIAL = MODE == 2;
+  constexpr int S = Cf::S, C = Cf::C, BM = Cf::BM, BN = Cf::BN, KS = Cf::KS, WK = Cf::WK, NS = Cf::NS, SPW = Cf::SPW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x & (HDN_BLOCK - 1), lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool produce = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) != 0;
+  const int li = lane & 31, g = lane >> 5;
+  const long long m0 = (long long)blockIdx.x * BM;
+  const int nb = blockIdx.y;
+  const int b0 = (int)(m0 / (S * S)), y0 = (int)((m0 % (S * S)) / S);
+  const long long M = (long long)B * S * S;
+  const int chunk0 = PARTIAL ? (int)blockIdx.z * cps : 0, nchunk = PARTIAL ? cps : Cf::NCHUNK;
+  float* const red = reinterpret_cast<float*>(smem);
+
+  if (produce) {
+    // ------------------------------------------------------------------------------------------------ producers
+    f4 av[Cf::AITER][2];
+    auto load_a = [&](int chunk) {
+#pragma unroll
+      for (int q = 0; q < Cf::AITER; ++q) {
+        const int item = tid + q * HDN_BLOCK;
+        const int px = min(item / (2 * KS), Cf::LP - 1), sub = item % (2 * KS);
+        const int img = px / Cf::IPITCH, ry = (px % Cf::IPITCH) / Cf::PW, rx = px % Cf::IPITCH % Cf::PW;   // (pad pixels: zeros)
+        const int b = b0 + img, y = y0 + ry - 1, xx = rx - 1;
+        const bool ok = item < Cf::AITEMS && img < Cf::IMGS && b < B && ry < Cf::PH && y >= 0 && y < S && xx >= 0 && xx < S;
+        const f4* src = reinterpret_cast<const f4*>(x + (((size_t)b * S + y) * S + xx) * C + (chunk0 + chunk) * (16 * KS) + sub * 8);
+        av[q][0] = ok ? src[0] : f4{0.f, 0.f, 0.f, 0.f};
+        av[q][1] = ok ? src[1] : f4{0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    auto store_a = [&](int ab) {
+#pragma unroll
+      for (int q = 0; q < Cf::AITER; ++q) {
+        const int item = tid + q * HDN_BLOCK;
+        if (item < Cf::AITEMS) {
+          const int px = item / (2 * KS), sub = item % (2 * KS);
+          unsigned q0[4], q1[4];
+          split2x2(av[q][0].x, av[q][0].y, q0[0], q1[0]);
+          split2x2(av[q][0].z, av[q][0].w, q0[1], q1[1]);
+          split2x2(av[q][1].x, av[q][1].y, q0[2], q1[2]);
+          split2x2(av[q][1].z, av[q][1].w, q0[3], q1[3]);
+          unsigned char* dst = smem + ab * Cf::A_BYTES + sub * Cf::KG_BYTES + px * 16;
+          *reinterpret_cast<u32x4*>(dst) = u32x4{q0[0], q0[1], q0[2], q0[3]};
+          *reinterpret_cast<u32x4*>(dst + Cf::PIECE_BYTES) = u32x4{q1[0], q1[1], q1[2], q1[3]};
+        }
+      }
+    };
+    f4 rv[RES ? Cf::EITER : 1];
+    CV2_STAMP(0);
+    load_a(0);
+    store_a(0);
+    if (nchunk > 1) load_a(1);
+    CV2_STAMP(1);
+    __syncthreads();                                   // chunk 0 is staged
+#if defined(HDN_ABLATION) && defined(CV2_EXP_TWICE)   // measurement build only: the chunk loop twice (the difference to the shipping build = one loop)
+    for (int c = 0; c < nchunk; ++c) {
+      if (c + 1 < nchunk) { store_a((c + 1) & 1); if (c + 2 < nchunk) load_a(c + 2); }
+      __syncthreads();
+    }
+    load_a(0); store_a(0); if (nchunk > 1) load_a(1);
+#endif
+    for (int c = 0; c < nchunk; ++c) {
+      if (c + 1 < nchunk) {
+        store_a((c + 1) & 1);                          // that image was read last in chunk c - 1, one barrier ago
+        if (c + 2 < nchunk) load_a(c + 2);
+      }
+      if (RES && c + 1 == nchunk) {                    // the residual travels during the last chunk
+#pragma unroll
+        for (int q = 0; q < Cf::EITER; ++q) {
+          const int idx = tid + q * HDN_BLOCK, px = idx / (BN / 4), c4 = idx % (BN / 4);
+          const long long m = min(m0 + px, M - 1);
+          rv[q] = *reinterpret_cast<const f4*>(res + m * C + nb * BN + c4 * 4);
+        }
+      }
+      __syncthreads();                                 // chunk c + 1 is staged; the consumers have read the last fragment of chunk c
+    }
+    CV2_STAMP(2);
+    __syncthreads();                                   // the partial tiles are in LDS
+    CV2_STAMP(3);
+#if defined(HDN_ABLATION) && defined(CV2_EXP_NOEPI)
+    return;
+#endif
+    // ---- epilogue: sum of the WK partial tiles in slice order (+ bias (+ residual), ReLU), a pixel's 64 channels = 16 consecutive lanes
+#pragma unroll
+    for (int q = 0; q < Cf::EITER; ++q) {
+      const int idx = tid + q * HDN_BLOCK, px = idx / (BN / 4), c4 = idx % (BN / 4);
+      const long long m = m0 + px;
+      if (idx < Cf::E4 && m < M) {
+        f4 v = *reinterpret_cast<const f4*>(red + px * Cf::EPI_STRIDE + c4 * 4);
+#pragma unroll
+        for (int w = 1; w < WK; ++w) v = v + *reinterpret_cast<const f4*>(red + (w * BM + px) * Cf::EPI_STRIDE + c4 * 4);
+        if (PARTIAL) {
+          *reinterpret_cast<f4*>(out + ((long long)blockIdx.z * M + m) * C + nb * BN + c4 * 4) = v;
+        } else {
+          v = v + *reinterpret_cast<const f4*>(bias + nb * BN + c4 * 4);
+          if (RES) v = v + rv[q];
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+          *reinterpret_cast<f4*>(out + m * C + nb * BN + c4 * 4) = v;
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CV2_STAMP(4);
+    return;
+  }
+
+  // -------------------------------------------------------------------------------------------------- consumers
+  const int wm = wave / WK, wk = wave % WK;
+  uint32_t aoff[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int i = (wm * 2 + mt) * 32 + mrow_to_pixel_s1<S>(li);       // pixel inside the workgroup's tile
+    const int img = i / (Cf::R * S), yy = (i / S) % Cf::R, xx = i % S;
+    aoff[mt] = lds_addr(smem) + g * Cf::KG_BYTES + wk * Cf::KSTEP_BYTES + (img * Cf::IPITCH + yy * Cf::PW + xx) * 16;   // top-left tap, k step wk (+ WK j)
+  }
+  f32x16 acc[2][2], accl[2][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = accl[mt][nt][r] = 0.f;
+
+  // this wave's weight stream: [channel block][chunk][k slice][step][n tile][piece][lane] x 16 B
+  const u32x4* const wbase = wp + ((size_t)nb * Cf::NCHUNK + chunk0) * Cf::WCHUNK + (size_t)wk * NS * Cf::WSTEP;
+  const uint32_t voff = (uint32_t)lane * 16u;
+  u32x4 fb[3][2][2], fa[2][2][2];
+  const int last_chunk = nchunk - 1;
+  // B fragments of (chunk ch, step st); past the end: the last step again (keeps the count of outstanding loads static)
+  auto load_b = [&](u32x4 (&b)[2][2], int ch, int st) {
+#if defined(HDN_ABLATION) && (defined(CV2_EXP_NOBLOAD) || defined(CV2_EXP_PURE))   // measurement build only
+    if (ch + st > 1) { asm volatile("s_nop 0" ::: "memory"); return; }
+#endif
+    const bool past = ch > last_chunk;
+    const u32x4* sp = wbase + (size_t)(past ? last_chunk : ch) * Cf::WCHUNK + (size_t)(past ? NS - 1 : st) * Cf::WSTEP;
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b[0][0]) : "v"(voff), "s"(sp));
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(b[0][1]) : "v"(voff), "s"(sp));
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(b[1][0]) : "v"(voff), "s"(sp));
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=v"(b[1][1]) : "v"(voff), "s"(sp));
+  };
+  // A fragments of step ST (tap ST / SPW, the wave's k step wk + WK (ST % SPW)) of the image at `base` (+ IMG images, when the image
+  // parity is static): the whole step-dependent part of the address is the instruction's offset field (no address arithmetic, and
+  // nothing the compiler could hoist out of the chunk loop into dozens of live registers)
+  auto read_a = [&](u32x4 (&a)[2][2], const uint32_t (&base)[2], auto STc, auto IMGc) {
+    constexpr int ST = decltype(STc)::value, IMG = decltype(IMGc)::value, t = ST / SPW;
+    constexpr int OFF = ((t / 3) * Cf::PW + (t % 3)) * 16 + WK * (ST % SPW) * Cf::KSTEP_BYTES + IMG * Cf::A_BYTES;
+    static_assert(OFF + Cf::PIECE_BYTES < 65536, "ds_read offset field");
+#if defined(HDN_ABLATION) && defined(CV2_EXP_PURE)      // measurement build only: MFMAs and barriers, nothing else
+    if (ST > 0) return;
+#endif
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[mt][0]) : "v"(base[mt]), "n"(OFF));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[mt][1]) : "v"(base[mt]), "n"(OFF + Cf::PIECE_BYTES));
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  constexpr bool STATIC_IMG = Cf::PER == 2 && 2 * Cf::A_BYTES < 65536;   // two chunks per period: the image of a step is a constant of the offset field
+
+  load_b(fb[0], 0, 0);
+  load_b(fb[1], 0, 1);
+  __builtin_amdgcn_s_barrier();                        // chunk 0 is staged
+  CV2_STAMP(5);
+  read_a(fa[0], aoff, I0{}, I0{});
+#if defined(HDN_ABLATION) && defined(CV2_EXP_TWICE)
+  for (int rep = 0; rep < 2; ++rep)
+#endif
+  for (int c0 = 0; c0 < nchunk; c0 += Cf::PER) {
+    static_for<Cf::PER * NS>([&](auto Pc) {
+      constexpr int p = decltype(Pc)::value, cp = p / NS, st = p % NS;
+      constexpr int as = p % 2, bs = p % 3;
+      const int chunk = c0 + cp;
+      uint32_t cur[2] = {aoff[0], aoff[1]}, nxt[2] = {aoff[0], aoff[1]};     // this chunk's image, the next chunk's
+      if constexpr (!STATIC_IMG) {
+        const uint32_t o = (uint32_t)(chunk & 1) * Cf::A_BYTES;
+        cur[0] += o; cur[1] += o;
+        nxt[0] += o ^ (uint32_t)Cf::A_BYTES; nxt[1] += o ^ (uint32_t)Cf::A_BYTES;
+      }
+      using CurImg = std::integral_constant<int, STATIC_IMG ? (cp & 1) : 0>;
+      using NxtImg = std::integral_constant<int, STATIC_IMG ? ((cp + 1) & 1) : 0>;
+      {  // the B fragments two steps ahead
+        constexpr int q = st + 2;
+        load_b(fb[(p + 2) % 3], chunk + q / NS, q % NS);
+      }
+      if constexpr (st + 1 < NS) {
+        read_a(fa[as ^ 1], cur, std::integral_constant<int, (st + 1) % NS>{}, CurImg{});
+#if defined(HDN_ABLATION) && defined(CV2_EXP_PURE)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#elif defined(HDN_ABLATION) && defined(CV2_EXP_NOBLOAD)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(4)" ::: "memory");
+#else
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(4)" ::: "memory");
+#endif
+      } else {
+#if defined(HDN_ABLATION) && (defined(CV2_EXP_NOBLOAD) || defined(CV2_EXP_PURE))
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#else
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+#endif
+        // the chunk's last fragments are in registers: the producers may overwrite its image, and the next chunk's image is complete
+        __builtin_amdgcn_s_barrier();
+        if (chunk + 1 < nchunk) read_a(fa[as ^ 1], nxt, I0{}, NxtImg{});
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) asm volatile("" : "+v"(fa[as][mt][pc]));
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) asm volatile("" : "+v"(fb[bs][nt][pc]));
+      // 12 MFMAs, the three products of an output tile two MFMAs apart
+#if defined(HDN_ABLATION) && defined(CV2_EXP_NOMFMA)
+      return;
+#endif
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) accl[mt][nt] = mfma(fa[as][mt][1], fb[bs][nt][0], accl[mt][nt]);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma(fa[as][mt][0], fb[bs][nt][0], acc[mt][nt]);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) accl[mt][nt] = mfma(fa[as][mt][0], fb[bs][nt][1], accl[mt][nt]);
+    });
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the two surplus B loads at the tail)
+  CV2_STAMP(6);
+  // ---- this wave's partial tile -> LDS (over the images: every consumer has passed the last chunk's barrier after its last read).
+  // C/D layout of v_mfma_f32_32x32x16_f16: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+#if defined(HDN_ABLATION) && defined(CV2_EXP_NOEPI)
+  if (lane == 0) out[blockIdx.x * 4 + wave] = acc[0][0][0] + accl[0][0][0] + acc[1][1][5] + accl[1][0][3] + acc[0][1][2] + acc[1][0][7];
+  __syncthreads();
+  return;
+#endif
+  // The pixel of accumulator row r is a compile-time constant for each of the two half waves: one multiply-add per store, not the
+  // mapping's dozen integer operations.
+  float* const rbase = red + (wk * BM + wm * 64) * Cf::EPI_STRIDE + li;
+  static_for<2>([&](auto MTc) {
+    static_for<16>([&](auto Rc) {
+      constexpr int mt = decltype(MTc)::value, r = decltype(Rc)::value, i0 = (r & 3) + 8 * (r >> 2);
+      constexpr int row0 = mt * 32 + mrow_to_pixel_s1<S>(i0), row1 = mt * 32 + mrow_to_pixel_s1<S>(i0 + 4);
+      float* const q = rbase + (row0 + g * (row1 - row0)) * Cf::EPI_STRIDE;
+      q[0] = acc[mt][0][r] + accl[mt][0][r] * LO_UNSCALE;
+      q[32] = acc[mt][1][r] + accl[mt][1][r] * LO_UNSCALE;
+    });
+  });
+  CV2_STAMP(7);
+  __syncthreads();
+}
+
+template <class Cf>
+static int k_slices_v2(int B) {
+  const long long M = (long long)B * Cf::S * Cf::S;
+  const long long tiles = ((M + Cf::BM - 1) / Cf::BM) * Cf::NB;
+  static const int target = [] { const char* e = getenv("HDN_CV2_SLICE_TARGET"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 200; }();  // A/B switch
+  int z = 1;
+  while (tiles * z < target && (Cf::NCHUNK / (z * 2)) % Cf::PER == 0 && Cf::NCHUNK % (z * 2) == 0 && z * 2 <= Cf::NCHUNK) z *= 2;
+  return z;
+}
+
+template <class Cf>
+static int launch_v2(const float* x, const void* wp, const float* bias, const float* res, float* out, float* ws, size_t ws_bytes, int B, hipStream_t stream) {
+  static_assert(Cf::NCHUNK % Cf::PER == 0, "whole periods");
+  const long long M = (long long)B * Cf::S * Cf::S;
+  const int z = k_slices_v2<Cf>(B);
+  if (z > 1) {
+    if (!ws) return HDN_E_NULL;
+    if (ws_bytes < (size_t)z * M * Cf::C * sizeof(float) || !aligned16(ws)) return HDN_E_LIMIT;
+  }
+  static PerDeviceOnce attr;
+  const int dev_ = PerDeviceOnce::device();
+  if (!attr.done(dev_)) {
+    for (const void* fn : {reinterpret_cast<const void*>(&conv3x3_v2_kernel<Cf, 0>), reinterpret_cast<const void*>(&conv3x3_v2_kernel<Cf, 1>),
+                           reinterpret_cast<const void*>(&conv3x3_v2_kernel<Cf, 2>)}) {
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS_BYTES);
+      if (e != hipSuccess) return -(1000 + (int)e);
+    }
+    attr.set(dev_);
+  }
+  const dim3 grid((unsigned)((M + Cf::BM - 1) / Cf::BM), Cf::NB, z), blk(2 * HDN_BLOCK);
+  const u32x4* w4 = (const u32x4*)wp;
+  if (z == 1) {
+    if (res) hipLaunchKernelGGL((conv3x3_v2_kernel<Cf, 1>), grid, blk, Cf::LDS_BYTES, stream, x, w4, bias, res, out, B, Cf::NCHUNK);
+    else hipLaunchKernelGGL((conv3x3_v2_kernel<Cf, 0>), grid, blk, Cf::LDS_BYTES, stream, x, w4, bias, res, out, B, Cf::NCHUNK);
+    return launch_status();
+  }
+  hipLaunchKernelGGL((conv3x3_v2_kernel<Cf, 2>), grid, blk, Cf::LDS_BYTES, stream, x, w4, bias, res, ws, B, Cf::NCHUNK / z);
+  return finish(ws, z, bias, res, res ? 1 : 0, out, M * Cf::C, Cf::C, stream);
+}
+
 }  // namespace cv
 }  // namespace hdn
 
@@ -734,6 +1106,63 @@ extern "C" int hdn_conv3x3s2_ds_f32(const float* x, const void* wpacked, const f
   hipStream_t s = static_cast<hipStream_t>(stream);
   return cv_dispatch(S, CI, 2, B, [&](auto cfg) {
     return hdn::cv::launch<decltype(cfg)>(x, wpacked, bias, nullptr, out, out_ds, workspace, workspace_bytes > 0 ? (size_t)workspace_bytes : 0, B, s);
+  });
+}
+
+
+// ---- round 5: the large-batch form (conv3x3_v2_kernel).                  S    C  WM WK KS
+using CV2_L1 = hdn::cv::Cfg2<32, 64, 4, 1, 2>;    // 256 pixels (8 rows) x 64 channels per workgroup, chunks of 32 channels
+using CV2_L2 = hdn::cv::Cfg2<16, 128, 2, 2, 4>;   // 128 pixels (8 rows), two k slices, chunks of 64 channels
+using CV2_L3 = hdn::cv::Cfg2<8, 256, 1, 4, 4>;    // 64 pixels (one image), four k slices
+using CV2_L4 = hdn::cv::Cfg2<4, 512, 1, 4, 4>;    // 64 pixels (four images), four k slices; K split over two workgroups at B = 64
+
+template <class F>
+static int cv2_dispatch(int S, int C, F&& f) {
+  if (S == 32 && C == 64) return f(CV2_L1{});
+  if (S == 16 && C == 128) return f(CV2_L2{});
+  if (S == 8 && C == 256) return f(CV2_L3{});
+  if (S == 4 && C == 512) return f(CV2_L4{});
+  return HDN_E_LIMIT;
+}
+
+#if defined(HDN_ABLATION) && defined(CV2_EXP_TIME)
+extern "C" int hdn_cv2_debug_times(void* dst_device, int clear) {   // measurement build only
+  void* sym = nullptr;
+  if (hipGetSymbolAddress(&sym, HIP_SYMBOL(hdn::cv::cv2_times)) != hipSuccess) return -1;
+  if (clear) return hipMemsetAsync(sym, 0, sizeof(unsigned long long) * 4096 * 8, 0) == hipSuccess ? 0 : -1;
+  return hipMemcpy(dst_device, sym, sizeof(unsigned long long) * 4096 * 8, hipMemcpyDeviceToDevice) == hipSuccess ? 0 : -1;
+}
+#endif
+
+extern "C" int hdn_conv3x3_v2_pack_info(int S, int C, int* k_slices, int* k_steps) {
+  return cv2_dispatch(S, C, [&](auto cfg) {
+    if (k_slices) *k_slices = decltype(cfg)::WK;
+    if (k_steps) *k_steps = decltype(cfg)::KS;
+    return HDN_OK;
+  });
+}
+
+extern "C" long long hdn_conv3x3_v2_workspace_bytes(int B, int S, int C) {
+  if (B <= 0) return HDN_E_SHAPE;
+  long long out = 0;
+  const int rc = cv2_dispatch(S, C, [&](auto cfg) {
+    using Cf = decltype(cfg);
+    const int z = hdn::cv::k_slices_v2<Cf>(B);
+    out = z > 1 ? (long long)z * B * Cf::S * Cf::S * Cf::C * (long long)sizeof(float) : 0;
+    return HDN_OK;
+  });
+  return rc == HDN_OK ? out : rc;
+}
+
+extern "C" int hdn_conv3x3_v2_f32(const float* x, const void* wpacked, const float* bias, const float* residual, float* out, float* workspace,
+                                  long long workspace_bytes, int B, int S, int C, void* stream) {
+  if (B <= 0 || S <= 0 || C <= 0) return HDN_E_SHAPE;
+  const int rc = cv_check(x, wpacked, bias, out, (long long)B * S * S * C);
+  if (rc) return rc;
+  if (residual && !hdn::aligned16(residual)) return HDN_E_LIMIT;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return cv2_dispatch(S, C, [&](auto cfg) {
+    return hdn::cv::launch_v2<decltype(cfg)>(x, wpacked, bias, residual, out, workspace, workspace_bytes > 0 ? (size_t)workspace_bytes : 0, B, s);
   });
 }
 

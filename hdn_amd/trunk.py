@@ -176,6 +176,32 @@ def pack_conv3x3(weight):
     return _pack(weight, _MC_SIDE.get(C, 0), C, 1)
 
 
+def pack_conv3x3_v2(weight):
+    """[C, C, 3, 3] fp32 weights -> the fragment-ordered stream of hdn_conv3x3_v2_f32 (include/hdn_hip.h):
+    [C / 64][chunk][k slice][tap][k step of the slice][n tile][piece][k half][n][8] fp16 bit patterns."""
+    import ctypes
+
+    import torch
+
+    from . import _lib
+
+    C = weight.shape[0]
+    if tuple(weight.shape) != (C, C, 3, 3):
+        raise ValueError(f"pack_conv3x3_v2 takes [C, C, 3, 3] weights, got {tuple(weight.shape)}")
+    wk, ks = ctypes.c_int(0), ctypes.c_int(0)
+    if _lib.load().hdn_conv3x3_v2_pack_info(_MC_SIDE.get(C, 0), C, ctypes.byref(wk), ctypes.byref(ks)) != 0:
+        raise ValueError(f"no large-batch matrix-core kernel for {C} channels")
+    WK, KS = wk.value, ks.value
+    pieces = _split_f16(weight.detach().to(torch.float32).cpu()).reshape(SPLIT_PIECES, C, C, 9)        # [piece, co, ci, tap]
+    # co = nb * 64 + nt * 32 + n;  ci = chunk * 16 KS + (j * WK + slice) * 16 + g * 8 + e
+    t = pieces.reshape(SPLIT_PIECES, C // 64, 2, 32, C // (16 * KS), KS // WK, WK, 2, 8, 9)          # [pc, nb, nt, n, ch, j, wk, g, e, tap]
+    t = t.permute(1, 4, 6, 9, 5, 2, 0, 7, 3, 8).contiguous()                                           # [nb, ch, wk, tap, j, nt, pc, g, n, e]
+    return t.view(torch.int16).reshape(-1)
+
+
+V2_MIN_BATCH = 24      # below: the chained / K-sliced form of conv3x3_kernel (CHAIN_MAX_BATCH = 16 pairs and the sizes between)
+
+
 def pack_conv3x3s2_ds(weight, ds_weight):
     """[2C, C, 3, 3] weights of the stride-2 convolution + [2C, C, 1, 1] weights of the block's downsample branch -> the 4-tap layout of
     hdn_conv3x3s2_ds_f32: the 1x1 weights ride as a 4th tap of the middle kernel row."""
@@ -190,8 +216,9 @@ def pack_conv3x3s2_ds(weight, ds_weight):
     return _pack(w4, _MC_SIDE.get(CO, 0), CI, 2)
 
 
-def conv3x3_bias_relu(x, wpacked, bias, residual=None):
-    """relu(conv3x3(x) + bias (+ residual)) through hdn_conv3x3_bias_relu_f32; x / residual channels-last [B,C,S,S] float32."""
+def conv3x3_bias_relu(x, wpacked, bias, residual=None, wpacked_v2=None):
+    """relu(conv3x3(x) + bias (+ residual)) through hdn_conv3x3_bias_relu_f32 — or, given `wpacked_v2` (pack_conv3x3_v2) and a batch of
+    V2_MIN_BATCH or more, through hdn_conv3x3_v2_f32; x / residual channels-last [B,C,S,S] float32."""
     import torch
 
     from . import _lib
@@ -205,13 +232,17 @@ def conv3x3_bias_relu(x, wpacked, bias, residual=None):
         raise ValueError("conv3x3_bias_relu: weights must come from pack_conv3x3 for this channel count, on the input's device")
     out = torch.empty_like(x, memory_format=cl)
     lib = _lib.load()
-    nws = lib.hdn_conv3x3_workspace_bytes(B, S, C, 1)
+    v2 = wpacked_v2 is not None and B >= V2_MIN_BATCH
+    if v2 and (wpacked_v2.dtype != torch.int16 or wpacked_v2.device != dev or wpacked_v2.numel() != 9 * SPLIT_PIECES * C * C):
+        raise ValueError("conv3x3_bias_relu: wpacked_v2 must come from pack_conv3x3_v2 for this channel count, on the input's device")
+    nws = lib.hdn_conv3x3_v2_workspace_bytes(B, S, C) if v2 else lib.hdn_conv3x3_workspace_bytes(B, S, C, 1)
     if nws < 0:
         _lib.check(int(nws), "conv3x3_bias_relu")
     ws = torch.empty(nws // 4, dtype=torch.float32, device=dev) if nws else None   # (from torch's caching allocator: no sync, graph-safe)
     with _lib.device_guard(dev):
-        rc = lib.hdn_conv3x3_bias_relu_f32(_lib.ptr(x), _lib.ptr(wpacked), _lib.ptr(bias), _lib.ptr(residual) if residual is not None else None,
-                                           _lib.ptr(out), _lib.ptr(ws) if ws is not None else None, nws, B, S, C, _lib.stream_ptr(dev))
+        fn = lib.hdn_conv3x3_v2_f32 if v2 else lib.hdn_conv3x3_bias_relu_f32
+        rc = fn(_lib.ptr(x), _lib.ptr(wpacked_v2 if v2 else wpacked), _lib.ptr(bias), _lib.ptr(residual) if residual is not None else None,
+                _lib.ptr(out), _lib.ptr(ws) if ws is not None else None, nws, B, S, C, _lib.stream_ptr(dev))
     _lib.check(rc, "conv3x3_bias_relu")
     return out
 
@@ -375,6 +406,17 @@ class FusedBasicBlock(nn.Module):
         self.register_buffer("p1", pack_conv3x3(self.w1).to(dev) if use1 else None)
         self.register_buffer("p2", pack_conv3x3(self.w2).to(dev) if use2 else None)
         self.register_buffer("p1s2", pack_conv3x3s2_ds(self.w1, self.wd).to(dev) if use_s2 else None)
+        self._v2 = {}      # the large-batch packing of p1 / p2 (pack_conv3x3_v2), made at the first batch of V2_MIN_BATCH or more
+
+    def _packed_v2(self, which, batch):
+        if batch < V2_MIN_BATCH or FusedBasicBlock.v2_disabled:
+            return None
+        if which not in self._v2:
+            w = self.w1 if which == 1 else self.w2
+            self._v2[which] = pack_conv3x3_v2(w).to(w.device)
+        return self._v2[which]
+
+    v2_disabled = False        # A/B switch (tests, tools/experiments)
 
     def forward(self, x):
         import torch
@@ -393,12 +435,12 @@ class FusedBasicBlock(nn.Module):
             y, idt = conv3x3s2_ds(x, self.p1s2, self.b1)       # stride-2 convolution + the downsample branch from one staged input
         else:
             if self.p1 is not None and shape_ok(x):
-                y = conv3x3_bias_relu(x, self.p1, self.b1)
+                y = conv3x3_bias_relu(x, self.p1, self.b1, wpacked_v2=self._packed_v2(1, x.shape[0]))
             else:
                 y = bias_relu_(F.conv2d(x, self.w1, None, self.stride, 1), self.b1)
             idt = x if self.wd is None else F.conv2d(x, self.wd, None, self.ds_stride)
         if self.p2 is not None and shape_ok(y) and idt.is_contiguous(memory_format=torch.channels_last):
-            return conv3x3_bias_relu(y, self.p2, self.b2, idt)
+            return conv3x3_bias_relu(y, self.p2, self.b2, idt, wpacked_v2=self._packed_v2(2, y.shape[0]))
         return bias_relu_(F.conv2d(y, self.w2, None, 1, 1), self.b2, idt)
 
     chain_disabled = False     # A/B switch for every block at once (tests, tools/experiments)

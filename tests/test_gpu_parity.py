@@ -1127,6 +1127,45 @@ def test_conv3x3_matrix_core_vs_float64(dev, C, S, B):
         conv3x3_bias_relu(xd, wp[:-1], bd)
 
 
+@pytest.mark.parametrize("C,S", [(64, 32), (128, 16), (256, 8), (512, 4)])
+@pytest.mark.parametrize("B", [24, 33, 64])
+def test_conv3x3_v2_large_batch_form_vs_float64(dev, C, S, B):
+    """hdn_conv3x3_v2_f32 (round 5: 64 x 64 tiles per consumer wave, K split over the consumers, weights streamed L2 -> registers in
+    fragment order) against a float64 convolution — same bound as hdn_conv3x3_bias_relu_f32 (4x the error of PyTorch's own fp32
+    convolution + 1e-5 of the output scale) — and against that kernel (same arithmetic, different order of the fp32 partial sums);
+    ragged batches (33: partial last tiles; 24 / 33: K split over workgroups + reduction launch at several shapes), determinism."""
+    import torch.nn.functional as F
+    from hdn_amd.trunk import pack_conv3x3, pack_conv3x3_v2, conv3x3_bias_relu, V2_MIN_BATCH
+    assert B >= V2_MIN_BATCH
+    g = torch.Generator().manual_seed(7 * C + B)
+    w = torch.randn(C, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5
+    b = torch.randn(C, generator=g) * 0.1
+    nb = 3
+    x = torch.randn(B, C, S, S, generator=g).clamp_min_(0)
+    r = torch.randn(B, C, S, S, generator=g)
+    cl = torch.channels_last
+    wp, wp2, bd = pack_conv3x3(w).to(dev), pack_conv3x3_v2(w).to(dev), b.to(dev)
+    xd, rd = x.to(dev).contiguous(memory_format=cl), r.to(dev).contiguous(memory_format=cl)
+    y = conv3x3_bias_relu(xd, wp, bd, rd, wpacked_v2=wp2)
+    y0 = conv3x3_bias_relu(xd, wp, bd, wpacked_v2=wp2)
+    assert torch.equal(y, conv3x3_bias_relu(xd, wp, bd, rd, wpacked_v2=wp2))          # deterministic
+    assert y.is_contiguous(memory_format=cl) and y.shape == x.shape
+    y1 = conv3x3_bias_relu(xd, wp, bd, rd)                                            # the round-4 kernel
+    scale_all = float(y1.abs().max())
+    assert float((y - y1).abs().max()) <= 2e-6 * scale_all + 1e-6, float((y - y1).abs().max())
+    for sl in (slice(0, nb), slice(B - nb, B)):
+        conv = F.conv2d(x[sl].double(), w.double(), b.double(), padding=1)
+        t, t0 = torch.relu(conv + r[sl].double()), torch.relu(conv)
+        ref = torch.relu(F.conv2d(x[sl], w, b, padding=1) + r[sl])
+        e_ref = float((ref.double() - t).abs().max())
+        scale = float(t.abs().max())
+        for got, truth in ((y, t), (y0, t0)):
+            e = float((got[sl].cpu().double() - truth).abs().max())
+            assert e <= 4 * e_ref + 1e-5 * scale, (e, e_ref, scale)
+    with pytest.raises(ValueError):
+        conv3x3_bias_relu(xd, wp, bd, wpacked_v2=wp2[:-1])
+
+
 @pytest.mark.parametrize("CI,S", [(64, 16), (128, 8), (256, 4)])
 @pytest.mark.parametrize("B", [1, 3, 64])
 def test_conv3x3s2_ds_matrix_core_vs_float64(dev, CI, S, B):
