@@ -193,8 +193,9 @@ def main():
         return build_full_head(dev, d["imgs"], d["h4p"])
 
     from hdn_amd.homo_model import homo_stages
+    full_cpu_sd = None
     if args.workload == "full":
-        full_net, full_data, _ = build_full()
+        full_net, full_data, full_cpu_sd = build_full()
 
     def step_full(record, collective):
         st = homo_stages(full_net, full_data)
@@ -281,8 +282,15 @@ def main():
         elapsed = float(tt.item())
 
     if args.workload == "full":
+        coll = None
+        if world > 1:
+            x_local = homo_stages(full_net, full_data)["x"]
+            coll = collective_block(x_local, dev, rank, world, dist, hdist, comm)
+            if rank == 0:      # SURVEY 8d cfg 3: parity against the CPU on a 16-pair sample of this rank's shard
+                coll["parity_16"] = parity_16(x_local, d, full_cpu_sd)
         if rank == 0:
             print(json.dumps({
+                **({"collective": coll} if coll is not None else {}),
                 "metric": "frames/sec on 127/255 template/search pairs", "value": PAIRS * world * args.steps / elapsed,
                 "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -319,8 +327,8 @@ def main():
     X.xcorr_depthwise(d["north_x"], d["north_k"])
     north_variant = X.last_variant()
     north_kernel = {"north_fftc_61x61_31x31": "xcorr_north_fft4_kernel", "north_61x61_31x31": "xcorr_north_kernel"}[north_variant]
-    traffic, traffic_note = None, None
-    for rnd in ("round4", "round3", "round2", "round1"):  # the newest committed PMC measurement of this kernel
+    traffic, traffic_note, traffic_fresh = None, None, None
+    for rnd in ("round5", "round4", "round3", "round2", "round1"):  # the newest committed PMC measurement of this kernel
         path = os.path.join(ROOT, "profiles", rnd + "_pmc_hbm_traffic.json")
         if not os.path.exists(path) or traffic is not None:
             continue
@@ -329,6 +337,17 @@ def main():
                 if north_kernel in name and "traffic_calibrated_bytes" in rec and traffic is None:
                     traffic = rec["traffic_calibrated_bytes"]
                     traffic_note = rec.get("how", "profiles/%s_pmc_hbm_traffic.txt" % rnd)
+                    # the PMC passes are tied to the kernel source they measured (tools/pmc_traffic.py records its SHA-256)
+                    want = rec.get("kernel_source_sha256")
+                    if want:
+                        import hashlib
+                        src = os.path.join(ROOT, "hdn_amd", "csrc", rec.get("kernel_source", "xcorr_fft.hip"))
+                        have = hashlib.sha256(open(src, "rb").read()).hexdigest() if os.path.exists(src) else None
+                        traffic_fresh = have == want
+                        traffic_note += "; measured on %s sha256 %s" % (rec.get("kernel_source", "xcorr_fft.hip"), want[:16])
+                        if not traffic_fresh and rank == 0:
+                            print("bench.py: WARNING: hdn_amd/csrc/%s changed since %s measured `roofline.traffic` (re-run tools/profile_round.sh + "
+                                  "tools/pmc_traffic.py)" % (rec.get("kernel_source", "xcorr_fft.hip"), os.path.basename(path)), file=sys.stderr)
     if traffic is None:
         # a renamed / replaced kernel must not silently carry `traffic: null` (or a stale figure): re-run tools/profile_round.sh
         raise SystemExit("bench.py: no committed PMC traffic measurement under profiles/*_pmc_hbm_traffic.json names the kernel the "
@@ -373,6 +392,7 @@ def main():
             "frac": north_gbps / HBM_PEAK_GBPS,
             "traffic": traffic,
             "traffic_source": traffic_note,
+            "traffic_source_matches_kernel_source": traffic_fresh,   # None: the committed PMC file predates the source hash (round <= 4)
             "algorithmic_bytes_per_launch": NORTH_BYTES_PER_PAIR * PAIRS,
             "avg_launch_ms": north_ms,
             "min_launch_ms": float(solo.min()),
@@ -389,6 +409,14 @@ def main():
                                                "the parallel schedule the kernel shares the chip with the homography head there)"},
         },
     }
+    # The in-step brackets see the kernel at the step's duty cycle (~1/3 of the time; the chip cools between launches).  Ten launches
+    # back to back inside one hipGraph show what it sustains (round 4: 110 us = 0.42 against 92 us = 0.50 in the step): both are reported.
+    sustained_ms = graph_timed(lambda: X.xcorr_depthwise(d["north_x"], d["north_k"]))
+    result["roofline"].update({
+        "sustained_launch_ms": sustained_ms,
+        "sustained_frac": NORTH_BYTES_PER_PAIR * PAIRS / (sustained_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+        "sustained_note": "ten launches back to back in one hipGraph (100 % duty cycle: the power-limited clock of a dense packed-FMA stream); "
+                          "`frac` above is the same kernel at the step's duty cycle"})
     if north_variant.startswith("north_fft"):
         result["roofline"]["note"] = (
             "64x64 fp32 FFT per pair of planes in registers + LDS (~1,380 packed VALU ops per plane instead of the direct "
@@ -400,6 +428,8 @@ def main():
             "valu_achieved_tflops": north_tflops, "valu_peak_tflops": FP32_VALU_PEAK_TFLOPS,
             "valu_frac": north_tflops / FP32_VALU_PEAK_TFLOPS})
 
+    if world > 1:
+        result["collective"] = collective_block(d["off"], dev, rank, world, dist, hdist, comm)
     if rank == 0 and not args.no_breakdown and not args.only_north:
         result["kernels"] = breakdown(d, imgs2, tmpl, folded, X, SF, G)
     if not args.no_full_head and not args.only_north:
@@ -437,6 +467,55 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result), flush=True)
+
+
+def collective_block(x_local, dev, rank, world, dist, hdist, comm):
+    """What a driver needs to audit an N > 1 line (round-4 verdict): which exchange ran, how many ranks the communicator ITSELF reports,
+    whether every rank ended up with the same gathered [N * 64, 8] array, and whether this rank's rows arrived where they belong.
+    One extra exchange after the timed region; every rank calls this."""
+    kind = type(comm).__name__ if comm is not None else "torch.distributed." + dist.get_backend()
+    if comm is not None and hasattr(comm, "comm_count"):
+        comm_ranks = comm.comm_count()                     # ncclCommCount through the C ABI (hdn_rccl_comm_count)
+    elif comm is not None:
+        comm_ranks = int(comm.world)                       # the one-shot gather's window count
+    else:
+        comm_ranks = dist.get_world_size()
+    x_local = x_local.detach().to(torch.float32).contiguous()
+    got = hdist.all_gather_offsets(x_local, x_local.shape[0] * world, comm=comm)
+    torch.cuda.synchronize()
+    rows = x_local.shape[0]
+    own_ok = bool(torch.equal(got[rank * rows:(rank + 1) * rows], x_local))
+    stats = torch.tensor([got.double().sum().item(), got.double().abs().sum().item(), float(own_ok), float(comm_ranks)], dtype=torch.float64)
+    red_dev = dev if dist.get_backend() == "nccl" else "cpu"
+    lo, hi = stats.clone().to(red_dev), stats.clone().to(red_dev)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    lo, hi = lo.cpu(), hi.cpu()
+    return {"kind": {"RcclComm": "RCCL ncclAllGather through the C ABI (hdn_allgather_offsets)",
+                     "OneShotGather": "direct-write one-shot gather (hdn_gather_offsets_oneshot)"}.get(kind, kind),
+            "comm_ranks": comm_ranks, "comm_ranks_equal_across_ranks": bool(lo[3] == hi[3]), "world_size": world,
+            "gathered_shape": list(got.shape),
+            "checksum": float(stats[0]), "checksum_equal_across_ranks": bool(lo[0] == hi[0] and lo[1] == hi[1]),
+            "own_rows_in_place_on_every_rank": bool(lo[2] == 1.0),
+            "distinct_rows_per_rank": bool(rows < 2 or world < 2 or not torch.equal(got[:rows], got[rows:2 * rows]))}
+
+
+def parity_16(x_gpu, d, net_sd):
+    """max |x - CPU oracle| over the first 16 pairs of this rank's shard (full workload): the oracle's track_proj around a PyTorch-CPU
+    ResNet-34 with the same weights (the north star's bound on the corner offsets is 1e-4)."""
+    import hdn_amd
+    from oracle import hdn_oracle as O
+
+    n = 16
+    net = hdn_amd.HomoModelBuilder().eval()
+    net.load_state_dict(net_sd)
+    sf_sd = {k: v for k, v in net.ShareFeature.state_dict().items()}
+    imgs = d["imgs"][:n].detach().cpu()
+    data = {"org_imgs": imgs, "input_tensors": imgs, "h4p": d["h4p"][:n].detach().cpu()}
+    with torch.no_grad():
+        _, _, _, aux = O.track_proj(data, sf_sd, lambda f: net.fc(net.avgpool(net.backbone(f)).flatten(1)))
+    err = float((x_gpu[:n].detach().cpu() - aux["x"]).abs().max())
+    return {"pairs": n, "max_abs_err_px": err, "bound_px": 1e-4, "ok": bool(err <= 1e-4)}
 
 
 def run_config5(args, dev, rank, world, dist, hdist, comm, sf, folded):
@@ -537,31 +616,37 @@ def sequence_block(n_frames, dev):
     return res
 
 
+def graph_timed(fn, inner=10, iters=10):
+    """ms per launch of `fn`, `inner` launches captured as one hipGraph and replayed back to back between two events: no host side of a
+    call (output allocations, pointer tables of the multi-problem launches) and no per-replay fixed cost in the figure."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        keep = [fn() for _ in range(inner)]     # `inner` launches per graph: a replay's fixed ~10 us is not in the figure
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    del keep
+    return e0.elapsed_time(e1) / (iters * inner)
+
+
 def breakdown(d, imgs2, tmpl, folded, X, SF, G, iters=10):
     """Per-kernel timing outside the timed region (informational; algorithmic GB/s per kernel): ten launches captured as one
     hipGraph and replayed back to back between two events, so the host side of a call (output allocations, pointer tables of
     the multi-problem launches) is not in the figure."""
     def timed(fn, inner=10):
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                fn()
-        torch.cuda.current_stream().wait_stream(side)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            keep = [fn() for _ in range(inner)]     # `inner` launches per graph: a replay's fixed ~10 us is not in the figure
-        for _ in range(3):
-            g.replay()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            g.replay()
-        e1.record()
-        torch.cuda.synchronize()
-        del keep
-        return e0.elapsed_time(e1) / (iters * inner)
+        return graph_timed(fn, inner, iters)
 
     warped = G.dlt_warp(d["h4p"], d["off"], tmpl)[1]
     rows = {

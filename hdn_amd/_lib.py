@@ -66,6 +66,7 @@ SIGNATURES = {
     "hdn_rccl_available": (_i, []),
     "hdn_rccl_unique_id": (_i, [ctypes.c_void_p]),
     "hdn_rccl_comm_create": (_i, [ctypes.POINTER(ctypes.c_void_p), _i, _i, ctypes.c_void_p]),
+    "hdn_rccl_comm_count": (_i, [ctypes.c_void_p, ctypes.POINTER(_i)]),
     "hdn_rccl_comm_destroy": (_i, [ctypes.c_void_p]),
     "hdn_gather_create": (_i, [ctypes.POINTER(ctypes.c_void_p), _i, _i, ctypes.c_longlong]),
     "hdn_gather_handle": (_i, [ctypes.c_void_p, ctypes.c_void_p]),

@@ -101,6 +101,14 @@ __global__ __launch_bounds__(HDN_BLOCK) void gather_oneshot_kernel(const float4*
   const int p = blockIdx.x, tid = threadIdx.x;
   __shared__ int timed_out;
   if (tid == 0) timed_out = 0;
+  // A context whose status word is set (an earlier call gave up on a peer) is unusable: the host entry point refuses it, and a
+  // launch that reaches the device anyway — the replay of a hipGraph captured before the timeout — hands out NaN rows, never
+  // the slots' stale contents, and leaves the window alone.
+  if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {
+    const float qnan = __builtin_nanf("");
+    for (int i = tid; i < n16; i += HDN_BLOCK) all[size_t(p) * n16 + i] = float4{qnan, qnan, qnan, qnan};
+    return;
+  }
   char* mine = peers.win[rank];
   unsigned long long* ctl = reinterpret_cast<unsigned long long*>(mine);
   const unsigned long long epoch = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;   // the same for every workgroup
@@ -171,6 +179,14 @@ int hdn_rccl_comm_create(void** comm_out, int world, int rank, const void* id128
   const int rc = hdn::rccl_status(r.CommInitRank(&c, world, id, rank));  // binds the comm to the CURRENT device
   if (rc == HDN_OK) *comm_out = c;
   return rc;
+}
+
+// ranks in the communicator, as RCCL itself reports it (ncclCommCount): what bench.py --gpus N prints as collective.comm_ranks
+int hdn_rccl_comm_count(void* comm, int* count) {
+  if (!comm || !count) return HDN_E_NULL;
+  const hdn::Rccl& r = hdn::rccl();
+  if (!r.ok) return HDN_E_NORCCL;
+  return hdn::rccl_status(r.CommCount(static_cast<hdn::ncclComm_t>(comm), count));
 }
 
 int hdn_rccl_comm_destroy(void* comm) {

@@ -76,6 +76,14 @@ class RcclComm:
         _lib.check(rc, "hdn_allgather_offsets")
         return out
 
+    def comm_count(self) -> int:
+        """The number of ranks RCCL itself reports for this communicator (ncclCommCount through hdn_rccl_comm_count)."""
+        if self._h is None:
+            raise _lib.HdnHipError("communicator destroyed")
+        n = ctypes.c_int(0)
+        _lib.check(_lib.load().hdn_rccl_comm_count(self._h, ctypes.byref(n)), "hdn_rccl_comm_count")
+        return int(n.value)
+
     def destroy(self):
         if self._h is not None:
             h, self._h = self._h, None
@@ -102,22 +110,33 @@ class OneShotGather:
         self.world, self.rank, self.max_rows = int(world), int(rank), int(max_rows)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self._group = group
+        self._h = None
         h = ctypes.c_void_p()
         lib = _lib.load()
         with _lib.device_guard(self.device):
-            _lib.check(lib.hdn_gather_create(ctypes.byref(h), self.world, self.rank, self.max_rows * 32), "hdn_gather_create")
-            self._h = h
+            # exchange() is a collective of the caller's: it runs on EVERY rank exactly once, whatever happened before it on this
+            # one (a rank whose window could not be created hands out 64 zero bytes and raises afterwards), so that the ranks'
+            # collective sequences stay identical.
+            err, mine = None, ctypes.create_string_buffer(64)
             try:
-                mine = ctypes.create_string_buffer(64)
+                _lib.check(lib.hdn_gather_create(ctypes.byref(h), self.world, self.rank, self.max_rows * 32), "hdn_gather_create")
                 _lib.check(lib.hdn_gather_handle(h, mine), "hdn_gather_handle")
+            except Exception as e:
+                err = e
+            try:
                 handles = exchange(mine.raw)
+                if err is not None:
+                    raise err
                 if len(handles) != self.world or any(len(x) != 64 for x in handles):
                     raise ValueError("exchange() must return one 64-byte handle per rank")
+                if any(x == b"\0" * 64 for x in handles):
+                    raise _lib.HdnHipError("a peer could not create its gather window")
                 _lib.check(lib.hdn_gather_connect(h, ctypes.c_char_p(b"".join(handles))), "hdn_gather_connect")
             except Exception:
-                self._h = None                     # (the window is freed; peers that already mapped it must not use it)
-                lib.hdn_gather_destroy(h)
+                if h:                              # (the window is freed; peers that already mapped it must not use it)
+                    lib.hdn_gather_destroy(h)
                 raise
+            self._h = h
 
     @staticmethod
     def peers_reachable(device, group=None):
@@ -188,8 +207,10 @@ class OneShotGather:
             dist.all_gather_object(box, err, group=group)
             bad = [b for b in box if b]
             if bad:
+                # Ranks that built their object and ranks that did not must keep issuing the SAME collectives: nothing has been
+                # launched yet, so the survivors tear down locally (no barrier) and every rank goes on to the fallback together.
                 if obj is not None:
-                    obj.destroy()
+                    obj.destroy(collective=False)
                 return give_up("; ".join(bad))
         elif err:
             raise _lib.HdnHipError(err)
@@ -224,14 +245,35 @@ class OneShotGather:
             raise _lib.HdnHipError(f"one-shot gather: a peer did not deliver within 2 s (status {st}); the affected rows are NaN and "
                                    "this communicator is unusable — destroy it and rebuild, or fall back to RcclComm")
 
-    def destroy(self):
+    def destroy(self, collective: bool = True, timeout_s: float = None):
         """Collective when the object came from a process group: every rank drains its device, then all meet at a barrier, and only
-        then are the windows unmapped and freed (a peer's launch may still be storing into this rank's window before that)."""
+        then are the windows unmapped and freed (a peer's launch may still be storing into this rank's window before that).  The
+        barrier is BOUNDED (timeout_s, default HDN_GATHER_DESTROY_TIMEOUT_S or 30 s): the usual reason to destroy a poisoned object
+        is a peer that stopped answering, and a barrier with a dead peer never returns — after the timeout the teardown goes on
+        locally with a warning.  collective=False: local teardown only, for objects no launch has used yet (from_process_group's
+        failure path, where the ranks must keep issuing identical collectives)."""
         if self._h is not None:
             h, self._h = self._h, None
             torch.cuda.synchronize(self.device)
-            if self._group is not None or (dist.is_available() and dist.is_initialized() and self.world > 1 and dist.get_world_size() == self.world):
-                dist.barrier(group=self._group)
+            if collective and (self._group is not None or (dist.is_available() and dist.is_initialized() and self.world > 1
+                                                           and dist.get_world_size() == self.world)):
+                import os
+                import threading
+                if timeout_s is None:
+                    timeout_s = float(os.environ.get("HDN_GATHER_DESTROY_TIMEOUT_S", "30"))
+                done = threading.Event()
+
+                def meet():
+                    try:
+                        dist.barrier(group=self._group)
+                    finally:
+                        done.set()
+                t = threading.Thread(target=meet, daemon=True)
+                t.start()
+                if not done.wait(timeout_s):
+                    import warnings
+                    warnings.warn(f"hdn_amd: OneShotGather.destroy: the peers did not reach the barrier within {timeout_s:g} s; "
+                                  "freeing the gather window without them")
             with _lib.device_guard(self.device):
                 _lib.check(_lib.load().hdn_gather_destroy(h), "hdn_gather_destroy")
 

@@ -428,6 +428,7 @@ int hdn_allgather_offsets(const float* local, float* all, int Bl, void* rccl_com
 int hdn_rccl_available(void);
 int hdn_rccl_unique_id(void* id128);
 int hdn_rccl_comm_create(void** comm_out, int world, int rank, const void* id128);
+int hdn_rccl_comm_count(void* comm, int* count);   /* ncclCommCount: the ranks RCCL itself sees (ABI 6) */
 int hdn_rccl_comm_destroy(void* comm);
 
 /*

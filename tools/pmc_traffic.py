@@ -32,6 +32,16 @@ KERNELS = {
 }
 
 
+SOURCES = {"xcorr_north_fft": "xcorr_fft.hip"}     # kernel-name substring -> source file under hdn_amd/csrc (default: xcorr.hip)
+
+
+def source_hash(kernel_name):
+    import hashlib
+    fn = next((v for k, v in SOURCES.items() if k in kernel_name), "xcorr.hip")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "hdn_amd", "csrc", fn)
+    return fn, (hashlib.sha256(open(path, "rb").read()).hexdigest() if os.path.exists(path) else None)
+
+
 def main(src, dst):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True):
@@ -50,6 +60,7 @@ def main(src, dst):
             rd, wr, narrow = KERNELS[key]
             cal = 2 * (fetch - narrow) + narrow
             rec.update({"algorithmic_read_bytes": rd, "algorithmic_write_bytes": wr, "algorithmic_bytes": rd + wr,
+                        "kernel_source": source_hash(name)[0], "kernel_source_sha256": source_hash(name)[1],   # bench.py checks it against the tree it runs from
                         "fetch_calibrated_bytes": cal, "traffic_calibrated_bytes": cal + write,
                         "traffic_over_algorithmic": (cal + write) / (rd + wr),
                         "how": "profiles/%s.txt: 2*(FETCH_SIZE - narrow-load bytes) + narrow-load bytes + WRITE_SIZE, per launch "
