@@ -52,6 +52,7 @@ SIGNATURES = {
     "hdn_avgpool_fc_f32": (_i, [_c_float_p] * 4 + [_i] * 5 + [ctypes.c_void_p]),
     "hdn_head_tail_f32": (_i, [_c_float_p, ctypes.c_void_p] + [_c_float_p] * 4 + [_i] * 4 + [ctypes.c_void_p]),
     "hdn_head_conv3x3_f32": (_i, [ctypes.c_void_p, ctypes.c_void_p, _c_float_p, ctypes.c_void_p] + [_i] * 5 + [ctypes.c_void_p]),
+    "hdn_set_check_range": (_i, [_i]),
     "hdn_conv3x3_pack_info": (_i, [_i, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "hdn_conv3x3_workspace_bytes": (ctypes.c_longlong, [_i, _i, _i, _i]),
     "hdn_conv3x3s2_ds_f32": (_i, [_c_float_p] * 6 + [ctypes.c_longlong] + [_i] * 3 + [ctypes.c_void_p]),

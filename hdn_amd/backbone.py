@@ -17,7 +17,8 @@ launches, 1.1 ms of the 3.4 ms frame (profiles/round4_sequence.txt), none of the
 
 The modules keep their classes' names and parameters (state_dict unchanged): the object gets a subclass whose forward() uses the
 folded copy for CUDA float32 inputs in eval mode and the original forward() for anything else (training, CPU tensors).  The
-folded copy does not track later weight changes — call optimize_similarity_model again after loading another snapshot; a switched
+folded copy follows `load_state_dict` (of the module or of any parent: a post-hook re-folds INTO the existing buffers, so a hipGraph
+captured around them sees the new weights too); weights edited in place some other way need optimize_similarity_model again.  A switched
 module deep-copies and moves like any other, but pickling the MODULE object (torch.save(model), not state_dict) needs
 restore_similarity_model first, because the subclass exists only in this process.
 hdn_amd.tracker.DeviceTrackerHomo applies it to the model it is given (HDN_FOLD_BACKBONE=0 keeps the modules as they are).
@@ -173,7 +174,7 @@ def fold_sequentials(module: nn.Module) -> nn.Module:
 
 
 # ---------------------------------------------------------------------------------------------------------------- in-place switch
-_FUSED, _ORIG_CLASS = "_hdn_fused", "_hdn_orig_class"
+_FUSED, _ORIG_CLASS, _HOOK, _BUILD = "_hdn_fused", "_hdn_orig_class", "_hdn_reload_hook", "_hdn_fused_builder"
 
 
 def _use_fused(mod, x) -> bool:
@@ -183,9 +184,23 @@ def _use_fused(mod, x) -> bool:
             and next(fused.buffers()).device == x0.device)
 
 
-def _attach(mod: nn.Module, fused: nn.Module):
+def _refold(mod, incompatible_keys=None):
+    """load_state_dict post-hook: the folded copy is recomputed from the module's new weights and written INTO the existing folded buffers
+    (same storage: captured hipGraphs keep pointing at them).  Round-4 ADVICE: without it the folded weights silently stayed the old
+    snapshot's while state_dict() reported the new one."""
+    fused, build = mod.__dict__.get(_FUSED), mod.__dict__.get(_BUILD)
+    if fused is None or build is None:
+        return
+    with torch.no_grad():
+        fresh = build(mod)
+        dst = dict(fused.named_buffers())
+        for name, buf in fresh.named_buffers():
+            dst[name].copy_(buf.to(dst[name].device))
+
+
+def _attach(mod: nn.Module, fused: nn.Module, build=None):
     """mod(x) -> fused(x) for CUDA float32 inputs in eval mode, the class's own forward otherwise; parameters, buffers and state_dict of
-    `mod` are untouched (the folded copy is not a registered sub-module)."""
+    `mod` are untouched (the folded copy is not a registered sub-module).  build(mod) -> a fresh folded copy (for the reload hook)."""
     base = mod.__dict__.get(_ORIG_CLASS, type(mod))
 
     def forward(self, *args, **kw):
@@ -195,6 +210,8 @@ def _attach(mod: nn.Module, fused: nn.Module):
 
     object.__setattr__(mod, _FUSED, fused.eval())
     object.__setattr__(mod, _ORIG_CLASS, base)
+    object.__setattr__(mod, _BUILD, build)
+    object.__setattr__(mod, _HOOK, mod.register_load_state_dict_post_hook(_refold) if build is not None else None)
     mod.__class__ = type(base.__name__, (base,), {"forward": forward, "__module__": base.__module__})
 
 
@@ -202,7 +219,31 @@ def _detach(mod: nn.Module):
     base = mod.__dict__.get(_ORIG_CLASS)
     if base is not None:
         mod.__class__ = base
+        hook = mod.__dict__.pop(_HOOK, None)
+        if hook is not None:
+            hook.remove()
+        mod.__dict__.pop(_BUILD, None)
         del mod.__dict__[_ORIG_CLASS], mod.__dict__[_FUSED]
+
+
+def _original_view(mod):
+    """`mod` with its own class for the duration of a re-fold (the builders read attributes only, but fold_sequentials deep-copies: the
+    copy must not carry the switched class, whose folded attributes are plain dictionary entries)."""
+    import copy
+
+    m = copy.copy(mod)
+    m.__dict__ = {k: v for k, v in mod.__dict__.items() if k not in (_FUSED, _ORIG_CLASS, _HOOK, _BUILD)}
+    m.__class__ = mod.__dict__.get(_ORIG_CLASS, type(mod))
+    return m
+
+
+def _build_backbone(mod):
+    dev = next(mod.parameters()).device
+    return FusedAtrousResNet(_original_view(mod)).to(dev)
+
+
+def _build_neck(mod):
+    return fold_sequentials(_original_view(mod))
 
 
 def optimize_similarity_model(model, strict: bool = False) -> list:
@@ -215,7 +256,7 @@ def optimize_similarity_model(model, strict: bool = False) -> list:
         if isinstance(bb, nn.Module):
             try:
                 _detach(bb)
-                _attach(bb, FusedAtrousResNet(bb))
+                _attach(bb, FusedAtrousResNet(bb), build=_build_backbone)
                 done.append("backbone")
             except ValueError:
                 if strict:
@@ -226,7 +267,7 @@ def optimize_similarity_model(model, strict: bool = False) -> list:
                 _detach(nk)
                 folded = fold_sequentials(nk)
                 if any(isinstance(m, _FoldedConv) for m in folded.modules()):
-                    _attach(nk, folded)
+                    _attach(nk, folded, build=_build_neck)
                     done.append(name)
                 elif strict:
                     raise ValueError(f"{name}: no Sequential(Conv2d, BatchNorm2d) found")

@@ -1090,6 +1090,7 @@ extern "C" int hdn_conv3x3_bias_relu_f32(const float* x, const void* wpacked, co
   if (rc) return rc;
   if (residual && !hdn::aligned16(residual)) return HDN_E_LIMIT;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (const int rr = hdn::check_fp16_range(x, (long long)B * S * S * C, s)) return rr;
   return cv_dispatch(S, C, 1, B, [&](auto cfg) {
     return hdn::cv::launch<decltype(cfg)>(x, wpacked, bias, residual, out, nullptr, workspace, workspace_bytes > 0 ? (size_t)workspace_bytes : 0, B, s);
   });
@@ -1104,6 +1105,7 @@ extern "C" int hdn_conv3x3s2_ds_f32(const float* x, const void* wpacked, const f
   if (out_ds == out || out_ds == x) return HDN_E_ALIAS;
   if (!hdn::aligned16(out_ds)) return HDN_E_LIMIT;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (const int rr = hdn::check_fp16_range(x, (long long)B * S * S * CI * 4, s)) return rr;
   return cv_dispatch(S, CI, 2, B, [&](auto cfg) {
     return hdn::cv::launch<decltype(cfg)>(x, wpacked, bias, nullptr, out, out_ds, workspace, workspace_bytes > 0 ? (size_t)workspace_bytes : 0, B, s);
   });
@@ -1161,6 +1163,7 @@ extern "C" int hdn_conv3x3_v2_f32(const float* x, const void* wpacked, const flo
   if (rc) return rc;
   if (residual && !hdn::aligned16(residual)) return HDN_E_LIMIT;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (const int rr = hdn::check_fp16_range(x, (long long)B * S * S * C, s)) return rr;
   return cv2_dispatch(S, C, [&](auto cfg) {
     return hdn::cv::launch_v2<decltype(cfg)>(x, wpacked, bias, residual, out, workspace, workspace_bytes > 0 ? (size_t)workspace_bytes : 0, B, s);
   });
@@ -1185,6 +1188,10 @@ extern "C" int hdn_conv3x3_chain_f32(const float* x, int x_slices, const float* 
   for (const void* p : {(const void*)x, wpacked, (const void*)out_slices, (const void*)x_bias, (const void*)x_res, (const void*)x_out, (const void*)out_ds_slices})
     if (p && !hdn::aligned16(p)) return HDN_E_LIMIT;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  // (an activation is checked; an input still in K slices is finished inside the kernel and cannot be seen from here: the guard covers
+  //  the chain's first convolution and every un-chained call)
+  if (x_slices == 0)
+    if (const int rr = hdn::check_fp16_range(x, n_in, s)) return rr;
   const hdn::cv::LazyIn lz{x_bias, x_res, x_out, x_slices, res_slices};
   return cv_dispatch(S, CI, stride, B, [&](auto cfg) {
     return hdn::cv::launch_chain<decltype(cfg)>(x, lz, wpacked, out_slices, out_ds_slices, B, s);

@@ -259,6 +259,7 @@ extern "C" int hdn_head_conv3x3_f32(const float* const* xs, const void* w_packed
     if (static_cast<const void*>(xs[i]) == static_cast<const void*>(outs[i])) return HDN_E_ALIAS;
     P.x[i] = xs[i];
     P.out[i] = outs[i];
+    if (const int rr = hdn::check_fp16_range(xs[i], (long long)hdn::hc::CI * Hi * Wi, static_cast<hipStream_t>(stream))) return rr;
   }
   static hdn::PerDeviceOnce attr;
   const int dev_ = hdn::PerDeviceOnce::device();

@@ -260,6 +260,7 @@ extern "C" int hdn_head_tail_f32(const float* feats, const void* w1_packed, cons
   if (static_cast<const void*>(out) == static_cast<const void*>(feats)) return HDN_E_ALIAS;
   if (!hdn::aligned16(w1_packed)) return HDN_E_LIMIT;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (const int rr = hdn::check_fp16_range(feats, (long long)2 * n_levels * hidden * pixels, s)) return rr;
   return hidden == 256 ? hdn::ht::launch_levels<256>(feats, w1_packed, b1, wf, bf, out, n_levels, pixels, n_out, s)
                         : hdn::ht::launch_levels<128>(feats, w1_packed, b1, wf, bf, out, n_levels, pixels, n_out, s);
 }

@@ -235,9 +235,33 @@ class DeviceTrackerHomo(HomoTracker):
         # The backbone's convolutions are PyTorch-ROCm's, and their shapes are fixed for a whole sequence: let MIOpen search for its kernels once
         # (find mode; the search runs in the first frames / the capture warm-up).  Measured with the production-shaped model: 2.9 against 4.5 ms
         # per frame (profiles/round4_experiments.txt item 11).  The reference's inference scripts leave torch's default (off); HDN_MIOPEN_FIND=0 does too.
-        if os.environ.get("HDN_MIOPEN_FIND", "1") not in ("", "0") and next(model.parameters()).is_cuda:
-            torch.backends.cudnn.benchmark = True
+        # The flag is process-global in torch, so it is raised only AROUND this tracker's own calls (init / track_new, incl. the graph
+        # capture) and put back afterwards: other models in the process keep the setting they had (round-4 ADVICE).
+        self.miopen_find = os.environ.get("HDN_MIOPEN_FIND", "1") not in ("", "0") and next(model.parameters()).is_cuda
         # backbone + necks stay PyTorch-ROCm's convolutions; their BatchNorm / ReLU / add launches (a third of the B = 1 frame) are folded away
         from . import backbone as BB
         self.folded = BB.optimize_similarity_model(model) if (BB.enabled() if fold_backbone is None else fold_backbone) else []
         super().__init__(model.hm_net, iterations=iterations, similarity=DeviceSimilarity(model, cfg), graph=graph, cfg=cfg)
+        if (self.folded or self.miopen_find) and not DeviceTrackerHomo._announced:
+            import sys
+            DeviceTrackerHomo._announced = True      # once per process
+            print("hdn_amd: DeviceTrackerHomo" +
+                  (" switched %s of the model it was given to their BatchNorm-folded form (parameters / state_dict unchanged; "
+                   "hdn_amd.backbone.restore_similarity_model(model) or HDN_FOLD_BACKBONE=0 undoes it)" % " / ".join(self.folded) if self.folded else "") +
+                  (" and" if self.folded and self.miopen_find else "") +
+                  (" runs its networks under MIOpen find mode (torch.backends.cudnn.benchmark, raised around this tracker's calls only; "
+                   "HDN_MIOPEN_FIND=0: torch's setting as it is)" if self.miopen_find else ""), file=sys.stderr)
+
+    _announced = False
+
+    def _find_mode(self):
+        import contextlib
+        return torch.backends.cudnn.flags(enabled=torch.backends.cudnn.enabled, benchmark=True) if self.miopen_find else contextlib.nullcontext()
+
+    def init(self, img, bbox, poly, gt_points, first_point=None):
+        with self._find_mode():
+            return super().init(img, bbox, poly, gt_points, first_point)
+
+    def track_new(self, fr_idx, img, gt_box=None, gt_poly=None, gt_points=None, sync: bool = True):
+        with self._find_mode():
+            return super().track_new(fr_idx, img, gt_box, gt_poly, gt_points, sync=sync)

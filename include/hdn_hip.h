@@ -361,6 +361,16 @@ int hdn_head_conv3x3_f32(const float* const* xs, const void* w_packed, const flo
  * Replaces homo_estimator/Deep_homography/Oneline_DLTv1/backbone/resnet.py:78-94 and the downsample branch built at :162-169
  * (eval mode only).
  */
+/*
+ * Range guard of the two-fp16-piece kernels (ABI 6): hdn_conv3x3_bias_relu_f32, hdn_conv3x3s2_ds_f32, hdn_conv3x3_v2_f32,
+ * hdn_conv3x3_chain_f32 (activation inputs), hdn_head_conv3x3_f32 and hdn_head_tail_f32 need |x| < 65,504 on their fp32 INPUTS as
+ * well as on their weights (beyond it the first fp16 piece is inf and the result NaN, where the reference's fp32 convolution stays
+ * finite).  With HDN_CHECK_RANGE=1 in the environment, or after hdn_set_check_range(1) (returns the previous setting), each of those
+ * entry points first reduces max |x| over its input and returns HDN_E_LIMIT when it is >= 65,504 or NaN, launching nothing.  The check
+ * costs a reduction launch and a stream synchronisation per call: a debug switch, off by default, skipped inside stream captures.
+ */
+int hdn_set_check_range(int on);
+
 int hdn_conv3x3_pack_info(int S, int CI, int stride, int* block_n, int* k_steps);
 long long hdn_conv3x3_workspace_bytes(int B, int S, int CI, int stride);
 int hdn_conv3x3_bias_relu_f32(const float* x, const void* wpacked, const float* bias, const float* residual, float* out, float* workspace,

@@ -1476,6 +1476,81 @@ def test_head_conv_search_one_launch_vs_float64(dev, Hi, Wi, n, CO, nhwc):
     assert torch.equal(HD.head_conv_search(xd, pk).cpu().double(), got)          # deterministic
 
 
+# --------------------------------------------------------------------------- HDN_CHECK_RANGE: the fp16-piece kernels' input range
+def test_fp16_piece_range_guard(dev):
+    """The two-fp16-piece kernels need |x| < 65,504 on their fp32 inputs (beyond it the first piece is inf and the result NaN, where the
+    reference's fp32 convolutions stay finite: backbone/resnet.py:78-94, hdn/models/head/ban.py:55-66).  With the guard on
+    (hdn_set_check_range / HDN_CHECK_RANGE=1; the -m gpu suite runs with it, tests/conftest.py) an input of 7e4 is refused with HDN_E_LIMIT
+    by every entry point — nothing is launched, the output stays untouched — and an input of 6e4 still meets the float64 bound."""
+    import torch.nn.functional as F
+    from hdn_amd import _lib, heads as HD
+    from hdn_amd.trunk import pack_conv3x3, pack_conv3x3_v2, pack_conv3x3s2_ds, conv3x3_bias_relu, conv3x3s2_ds
+    lib = _lib.load()
+    prev = lib.hdn_set_check_range(1)
+    try:
+        g = torch.Generator().manual_seed(5)
+        cl = torch.channels_last
+        C, S, B = 256, 8, 24
+        w = torch.randn(C, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5
+        b = torch.randn(C, generator=g) * 0.1
+        wp, wp2, bd = pack_conv3x3(w).to(dev), pack_conv3x3_v2(w).to(dev), b.to(dev)
+        x = torch.randn(B, C, S, S, generator=g).clamp_min_(0)
+        for big, ok in ((7.0e4, False), (6.0e4, True), (float("nan"), False)):
+            xb = x.clone()
+            xb[B - 1, 17, 3, 5] = big
+            xd = xb.to(dev).contiguous(memory_format=cl)
+            for kw in ({}, {"wpacked_v2": wp2}):                      # the round-4 kernel and the large-batch form
+                if not ok:
+                    with pytest.raises(ValueError, match="HDN_E_LIMIT"):
+                        conv3x3_bias_relu(xd, wp, bd, **kw)
+                    continue
+                y = conv3x3_bias_relu(xd, wp, bd, **kw).cpu()
+                t = torch.relu(F.conv2d(xb.double(), w.double(), b.double(), padding=1))
+                ref = torch.relu(F.conv2d(xb, w, b, padding=1))
+                e_ref, scale = float((ref.double() - t).abs().max()), float(t.abs().max())
+                assert torch.isfinite(y).all() and float((y.double() - t).abs().max()) <= 4 * e_ref + 1e-5 * scale
+        # stride 2 + downsample
+        CI = 64
+        w2 = torch.randn(2 * CI, CI, 3, 3, generator=g) * 0.05
+        wd = torch.randn(2 * CI, CI, 1, 1, generator=g) * 0.1
+        x2 = torch.randn(3, CI, 32, 32, generator=g)
+        x2[1, 5, 7, 9] = -7.0e4                                          # (the magnitude counts)
+        with pytest.raises(ValueError, match="HDN_E_LIMIT"):
+            conv3x3s2_ds(x2.to(dev).contiguous(memory_format=cl), pack_conv3x3s2_ds(w2, wd).to(dev), torch.zeros(2 * CI, device=dev))
+        # the heads' two kernels
+        pk = HD._PackedHead()
+        pk.wsp = HD._pack_conv_search([(torch.randn(64, 256, 3, 3, generator=g) * 0.03).to(dev)])
+        pk.bsp = torch.zeros(1, 64, device=dev)
+        xs = torch.randn(1, 256, 9, 14, generator=g)
+        assert torch.isfinite(HD.head_conv_search([xs.to(dev)], pk)).all()
+        xs[0, 200, 8, 13] = 7.0e4
+        with pytest.raises(ValueError, match="HDN_E_LIMIT"):
+            HD.head_conv_search([xs.to(dev)], pk)
+        H, P, n = 256, 169, 3
+        pt = HD._PackedHead()
+        pt.w1 = (torch.randn(2 * n, H, H, generator=g) * 0.06).to(dev)
+        pt.b1 = torch.zeros(2 * n, H, 1, device=dev)
+        pt.wf = (torch.randn(2, 4, n * H, generator=g) * 0.05).to(dev)
+        pt.bf = torch.zeros(2, 4, 1, device=dev)
+        pt.w1p = HD._pack_w1(pt.w1)
+        feats = torch.randn(2 * n, H, P, 1, generator=g).relu_()
+        assert torch.isfinite(HD.head_tail(feats.to(dev), pt, n)).all()
+        feats[5, 255, 168, 0] = 7.0e4
+        with pytest.raises(ValueError, match="HDN_E_LIMIT"):
+            HD.head_tail(feats.to(dev), pt, n)
+        # off: the call goes through and is WRONG at that pixel (inf / NaN inside; the ReLU's fmax may even hand back a finite value): what
+        # the guard is for
+        lib.hdn_set_check_range(0)
+        y = HD.head_tail(feats.to(dev), pt, n).cpu().double()
+        f64 = lambda t: t.detach().cpu().double()
+        hid = torch.baddbmm(f64(pt.b1), f64(pt.w1), f64(feats).view(2 * n, H, -1)).relu()
+        ref = torch.baddbmm(f64(pt.bf), f64(pt.wf), hid.view(2, n * H, -1))
+        bad = ~torch.isfinite(y[:, :, 168]) | ((y[:, :, 168] - ref[:, :, 168]).abs() > 1e-2 * ref[:, :, 168].abs().max())
+        assert bool(bad.any()) and float((y[:, :, :168] - ref[:, :, :168]).abs().max()) <= 1e-3 * float(ref.abs().max())
+    finally:
+        lib.hdn_set_check_range(prev)
+
+
 # --------------------------------------------------------------------------- similarity backbone + necks: BatchNorm folded, epilogues fused
 @pytest.mark.parametrize("nhwc", [False, True])
 def test_backbone_folding_on_the_device(dev, nhwc):

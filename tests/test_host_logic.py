@@ -558,7 +558,26 @@ def test_backbone_switch_keeps_the_module_intact():
         assert vars(twin)["_hdn_fused"] is not fused and list(twin.state_dict().keys()) == keys and all(torch.equal(a, b) for a, b in zip(twin(x), ref))
         assert BB.optimize_similarity_model(model) == ["backbone", "neck"] and vars(bb)["_hdn_fused"] is not fused      # again: replaced, not stacked
         assert type(bb).__mro__[1] is Net
+        # another snapshot through load_state_dict (round-4 ADVICE: the folded copy used to stay the old snapshot's, silently): the
+        # post-hook re-folds into the SAME buffers (a captured hipGraph keeps pointing at them)
+        fused2 = vars(bb)["_hdn_fused"]
+        ptrs = [b.data_ptr() for b in fused2.buffers()]
+        other = Net().eval()
+        for m in other.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.running_mean.uniform_(-0.5, 0.5); m.running_var.uniform_(0.5, 2); m.weight.data.uniform_(0.5, 1.5); m.bias.data.uniform_(-0.5, 0.5)
+        ref_other = other(x)
+        bb.load_state_dict(other.state_dict())
+        assert vars(bb)["_hdn_fused"] is fused2 and [b.data_ptr() for b in fused2.buffers()] == ptrs
+        for a, b in zip(fused2(x), ref_other):
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+        assert all(float((a - b).abs().max()) > 1e-3 for a, b in zip(fused2(x), ref))        # (really different weights)
+        holder = nn.Module()                      # ... and through a parent's load_state_dict (ModelBuilder.load_state_dict in the reference's scripts)
+        holder.backbone = bb
+        holder.load_state_dict({"backbone." + k: v for k, v in Net().state_dict().items()})
+        assert float((fused2(x)[0] - bb(x)[0]).abs().max()) <= 1e-5 * float(bb(x)[0].abs().max())
         BB.restore_similarity_model(model)
+        assert len(bb._load_state_dict_post_hooks) == 0
         assert type(bb) is Net and "_hdn_fused" not in vars(bb) and type(model.neck) is Neck
         plain = types.SimpleNamespace(backbone=nn.Sequential(nn.Conv2d(3, 4, 3)), neck=None, neck_lp=None)
         assert BB.optimize_similarity_model(plain) == [] and type(plain.backbone) is nn.Sequential

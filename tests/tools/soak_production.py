@@ -14,7 +14,7 @@ dev = torch.device("cuda:0")
 frames, corners, init = make_sequence(n_frames=60, frame_hw=(720, 1280), target_wh=(300, 200), **LONG_WALK)
 model, _ = SB.build_production_model(frames, init, dev)
 trk = DeviceTrackerHomo(model)
-assert trk.use_graph and trk.folded == ["backbone", "neck", "neck_lp"] and torch.backends.cudnn.benchmark
+assert trk.use_graph and trk.folded == ["backbone", "neck", "neck_lp"] and trk.miopen_find and not torch.backends.cudnn.benchmark
 mem = []
 for seq in range(3):
     trk.init(frames[0], init["bbox"], init["poly"], init["gt_points"], init["first_point"])
