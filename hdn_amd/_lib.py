@@ -57,7 +57,7 @@ SIGNATURES = {
     "hdn_conv3x3_workspace_bytes": (ctypes.c_longlong, [_i, _i, _i, _i]),
     "hdn_conv3x3s2_ds_f32": (_i, [_c_float_p] * 6 + [ctypes.c_longlong] + [_i] * 3 + [ctypes.c_void_p]),
     "hdn_conv3x3_bias_relu_f32": (_i, [_c_float_p] * 6 + [ctypes.c_longlong] + [_i] * 3 + [ctypes.c_void_p]),
-    "hdn_conv3x3_v2_pack_info": (_i, [_i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+    "hdn_conv3x3_v2_pack_info": (_i, [_i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "hdn_conv3x3_v2_workspace_bytes": (ctypes.c_longlong, [_i, _i, _i]),
     "hdn_conv3x3_v2_f32": (_i, [_c_float_p] * 6 + [ctypes.c_longlong] + [_i] * 3 + [ctypes.c_void_p]),
     "hdn_conv3x3_chain_slices": (_i, [_i, _i, _i, _i]),

@@ -687,11 +687,14 @@ static int finish(const float* slices, int z, const float* bias, const float* re
 //     step, so that the next chunk's first fragments travel under them;
 //   * the producers also own the epilogue: they ask for the residual during the last chunk and, once the partial tiles are in LDS,
 //     add them in slice order + bias (+ residual), ReLU, 16-byte NHWC stores.
-template <int S_, int C_, int WM_, int WK_, int KS_>
+template <int S_, int C_, int WM_, int WK_, int KS_, int NT_ = 2>
 struct Cfg2 {
-  static constexpr int S = S_, C = C_, WM = WM_, WK = WK_, KS = KS_;
+  static constexpr int S = S_, C = C_, WM = WM_, WK = WK_, KS = KS_, NT = NT_;
   static_assert(WM * WK == 4 && KS % WK == 0, "four consumer waves: WM pixel tiles x WK k slices");
-  static constexpr int BM = 64 * WM, BN = 64, MT = 2, NT = 2, NP = 2;
+  // NT = 1 (32 output channels per workgroup, a 64 x 32 tile per wave, 6 MFMAs per step): twice the workgroups for the 4 x 4 stage, whose
+  // 1,024 pixels and 512 channels make 128 tiles of 64 x 64 (round 5 first split its K over two workgroups + a reduction launch instead)
+  static_assert(NT == 1 || NT == 2, "n tiles per wave");
+  static constexpr int BM = 64 * WM, BN = 32 * NT, MT = 2, NP = 2;
   static_assert(C % BN == 0 && C % (16 * KS) == 0, "channel blocking");
   static_assert((BM % S == 0) && ((S * S) % BM == 0 || BM % (S * S) == 0), "a tile is whole rows of one image, or whole images");
   static constexpr int IMGS = BM > S * S ? BM / (S * S) : 1;
@@ -704,8 +707,10 @@ struct Cfg2 {
   static constexpr int KG_BYTES = LP * 16, KSTEP_BYTES = 2 * KG_BYTES, PIECE_BYTES = KS * KSTEP_BYTES, A_BYTES = NP * PIECE_BYTES;
   static constexpr int NCHUNK = C / (16 * KS), NB = C / BN;
   static constexpr int SPW = KS / WK, NS = 9 * SPW;                  // k steps / steps (tap, k step) of one wave per chunk
-  static_assert(NS % 3 == 0, "three B register sets rotate with the step");
   static constexpr int PER = (NS % 2) ? 2 : 1;                       // chunks per unrolled period (two A register sets)
+  // B register sets: a step's fragments travel BSETS - 1 steps ahead.  Half-size steps (NT = 1: 6 MFMAs = 192 clk) need twice the distance.
+  static constexpr int BSETS = NT == 2 ? 3 : 6, PF = BSETS - 1;
+  static_assert((PER * NS) % BSETS == 0, "the B register sets rotate with the step");
   static constexpr int WSTEP = NT * NP * 64;                         // 16-byte words of one wave step: [n tile][piece][lane]
   static constexpr int WCHUNK = WK * NS * WSTEP;                     // ... of one (channel block, chunk): [k slice][step]
   static constexpr int EPI_STRIDE = BN + 4;
@@ -734,8 +739,11 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_v2_kernel(const float* 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool produce = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) != 0;
   const int li = lane & 31, g = lane >> 5;
-  const long long m0 = (long long)blockIdx.x * BM;
-  const int nb = blockIdx.y;
+  // blockIdx.x = output-channel block (fastest): workgroups are dealt to the 8 XCDs round-robin by their linear id, so an XCD sees
+  // NB / 8 (or one) of the channel blocks and its L2 holds that block's weight stream for all the pixel tiles that share it (the 4 x 4
+  // stage's 9.4 MB of weights do not fit one 4 MB L2; 1.2 MB per XCD do)
+  const long long m0 = (long long)blockIdx.y * BM;
+  const int nb = blockIdx.x;
   const int b0 = (int)(m0 / (S * S)), y0 = (int)((m0 % (S * S)) / S);
   const long long M = (long long)B * S * S;
   const int chunk0 = PARTIAL ? (int)blockIdx.z * cps : 0, nchunk = PARTIAL ? cps : Cf::NCHUNK;
@@ -842,21 +850,22 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_v2_kernel(const float* 
     const int img = i / (Cf::R * S), yy = (i / S) % Cf::R, xx = i % S;
     aoff[mt] = lds_addr(smem) + g * Cf::KG_BYTES + wk * Cf::KSTEP_BYTES + (img * Cf::IPITCH + yy * Cf::PW + xx) * 16;   // top-left tap, k step wk (+ WK j)
   }
-  f32x16 acc[2][2], accl[2][2];
+  constexpr int NT = Cf::NT, PF = Cf::PF;
+  f32x16 acc[2][NT], accl[2][NT];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = accl[mt][nt][r] = 0.f;
 
   // this wave's weight stream: [channel block][chunk][k slice][step][n tile][piece][lane] x 16 B
   const u32x4* const wbase = wp + ((size_t)nb * Cf::NCHUNK + chunk0) * Cf::WCHUNK + (size_t)wk * NS * Cf::WSTEP;
   const uint32_t voff = (uint32_t)lane * 16u;
-  u32x4 fb[3][2][2], fa[2][2][2];
+  u32x4 fb[Cf::BSETS][NT][2], fa[2][2][2];
   const int last_chunk = nchunk - 1;
   // B fragments of (chunk ch, step st); past the end: the last step again (keeps the count of outstanding loads static)
-  auto load_b = [&](u32x4 (&b)[2][2], int ch, int st) {
+  auto load_b = [&](u32x4 (&b)[NT][2], int ch, int st) {
 #if defined(HDN_ABLATION) && (defined(CV2_EXP_NOBLOAD) || defined(CV2_EXP_PURE))   // measurement build only
     if (ch + st > 1) { asm volatile("s_nop 0" ::: "memory"); return; }
 #endif
@@ -864,8 +873,10 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_v2_kernel(const float* 
     const u32x4* sp = wbase + (size_t)(past ? last_chunk : ch) * Cf::WCHUNK + (size_t)(past ? NS - 1 : st) * Cf::WSTEP;
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b[0][0]) : "v"(voff), "s"(sp));
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(b[0][1]) : "v"(voff), "s"(sp));
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(b[1][0]) : "v"(voff), "s"(sp));
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=v"(b[1][1]) : "v"(voff), "s"(sp));
+    if constexpr (NT == 2) {
+      asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(b[NT - 1][0]) : "v"(voff), "s"(sp));
+      asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=v"(b[NT - 1][1]) : "v"(voff), "s"(sp));
+    }
   };
   // A fragments of step ST (tap ST / SPW, the wave's k step wk + WK (ST % SPW)) of the image at `base` (+ IMG images, when the image
   // parity is static): the whole step-dependent part of the address is the instruction's offset field (no address arithmetic, and
@@ -887,8 +898,10 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_v2_kernel(const float* 
   using I1 = std::integral_constant<int, 1>;
   constexpr bool STATIC_IMG = Cf::PER == 2 && 2 * Cf::A_BYTES < 65536;   // two chunks per period: the image of a step is a constant of the offset field
 
-  load_b(fb[0], 0, 0);
-  load_b(fb[1], 0, 1);
+  static_for<PF>([&](auto Ic) {                         // the first PF steps' fragments (past a short K range: the last step again)
+    constexpr int i = decltype(Ic)::value;
+    load_b(fb[i], i / NS, i % NS);
+  });
   __builtin_amdgcn_s_barrier();                        // chunk 0 is staged
   CV2_STAMP(5);
   read_a(fa[0], aoff, I0{}, I0{});
@@ -898,7 +911,7 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_v2_kernel(const float* 
   for (int c0 = 0; c0 < nchunk; c0 += Cf::PER) {
     static_for<Cf::PER * NS>([&](auto Pc) {
       constexpr int p = decltype(Pc)::value, cp = p / NS, st = p % NS;
-      constexpr int as = p % 2, bs = p % 3;
+      constexpr int as = p % 2, bs = p % Cf::BSETS;
       const int chunk = c0 + cp;
       uint32_t cur[2] = {aoff[0], aoff[1]}, nxt[2] = {aoff[0], aoff[1]};     // this chunk's image, the next chunk's
       if constexpr (!STATIC_IMG) {
@@ -908,9 +921,9 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_v2_kernel(const float* 
       }
       using CurImg = std::integral_constant<int, STATIC_IMG ? (cp & 1) : 0>;
       using NxtImg = std::integral_constant<int, STATIC_IMG ? ((cp + 1) & 1) : 0>;
-      {  // the B fragments two steps ahead
-        constexpr int q = st + 2;
-        load_b(fb[(p + 2) % 3], chunk + q / NS, q % NS);
+      {  // the B fragments PF steps ahead
+        constexpr int q = st + PF;
+        load_b(fb[(p + PF) % Cf::BSETS], chunk + q / NS, q % NS);
       }
       if constexpr (st + 1 < NS) {
         read_a(fa[as ^ 1], cur, std::integral_constant<int, (st + 1) % NS>{}, CurImg{});
@@ -919,13 +932,13 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_v2_kernel(const float* 
 #elif defined(HDN_ABLATION) && defined(CV2_EXP_NOBLOAD)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(4)" ::: "memory");
 #else
-        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(4)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(4)" ::"n"(PF * NT * 2) : "memory");
 #endif
       } else {
 #if defined(HDN_ABLATION) && (defined(CV2_EXP_NOBLOAD) || defined(CV2_EXP_PURE))
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #else
-        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PF * NT * 2) : "memory");
 #endif
         // the chunk's last fragments are in registers: the producers may overwrite its image, and the next chunk's image is complete
         __builtin_amdgcn_s_barrier();
@@ -936,7 +949,7 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_v2_kernel(const float* 
 #pragma unroll
         for (int pc = 0; pc < 2; ++pc) asm volatile("" : "+v"(fa[as][mt][pc]));
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
+      for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int pc = 0; pc < 2; ++pc) asm volatile("" : "+v"(fb[bs][nt][pc]));
       // 12 MFMAs, the three products of an output tile two MFMAs apart
@@ -946,23 +959,23 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_v2_kernel(const float* 
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) accl[mt][nt] = mfma(fa[as][mt][1], fb[bs][nt][0], accl[mt][nt]);
+        for (int nt = 0; nt < NT; ++nt) accl[mt][nt] = mfma(fa[as][mt][1], fb[bs][nt][0], accl[mt][nt]);
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma(fa[as][mt][0], fb[bs][nt][0], acc[mt][nt]);
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma(fa[as][mt][0], fb[bs][nt][0], acc[mt][nt]);
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) accl[mt][nt] = mfma(fa[as][mt][0], fb[bs][nt][1], accl[mt][nt]);
+        for (int nt = 0; nt < NT; ++nt) accl[mt][nt] = mfma(fa[as][mt][0], fb[bs][nt][1], accl[mt][nt]);
     });
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the two surplus B loads at the tail)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the surplus B loads at the tail)
   CV2_STAMP(6);
   // ---- this wave's partial tile -> LDS (over the images: every consumer has passed the last chunk's barrier after its last read).
   // C/D layout of v_mfma_f32_32x32x16_f16: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
 #if defined(HDN_ABLATION) && defined(CV2_EXP_NOEPI)
-  if (lane == 0) out[blockIdx.x * 4 + wave] = acc[0][0][0] + accl[0][0][0] + acc[1][1][5] + accl[1][0][3] + acc[0][1][2] + acc[1][0][7];
+  if (lane == 0) out[blockIdx.y * 4 + wave] = acc[0][0][0] + accl[0][0][0] + acc[1][1][5] + accl[1][0][3] + acc[0][1][2] + acc[1][0][7];
   __syncthreads();
   return;
 #endif
@@ -974,8 +987,8 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_v2_kernel(const float* 
       constexpr int mt = decltype(MTc)::value, r = decltype(Rc)::value, i0 = (r & 3) + 8 * (r >> 2);
       constexpr int row0 = mt * 32 + mrow_to_pixel_s1<S>(i0), row1 = mt * 32 + mrow_to_pixel_s1<S>(i0 + 4);
       float* const q = rbase + (row0 + g * (row1 - row0)) * Cf::EPI_STRIDE;
-      q[0] = acc[mt][0][r] + accl[mt][0][r] * LO_UNSCALE;
-      q[32] = acc[mt][1][r] + accl[mt][1][r] * LO_UNSCALE;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) q[nt * 32] = acc[mt][nt][r] + accl[mt][nt][r] * LO_UNSCALE;
     });
   });
   CV2_STAMP(7);
@@ -1011,7 +1024,8 @@ static int launch_v2(const float* x, const void* wp, const float* bias, const fl
     }
     attr.set(dev_);
   }
-  const dim3 grid((unsigned)((M + Cf::BM - 1) / Cf::BM), Cf::NB, z), blk(2 * HDN_BLOCK);
+  if ((M + Cf::BM - 1) / Cf::BM > 65535) return HDN_E_LIMIT;
+  const dim3 grid(Cf::NB, (unsigned)((M + Cf::BM - 1) / Cf::BM), z), blk(2 * HDN_BLOCK);
   const u32x4* w4 = (const u32x4*)wp;
   if (z == 1) {
     if (res) hipLaunchKernelGGL((conv3x3_v2_kernel<Cf, 1>), grid, blk, Cf::LDS_BYTES, stream, x, w4, bias, res, out, B, Cf::NCHUNK);
@@ -1116,7 +1130,7 @@ extern "C" int hdn_conv3x3s2_ds_f32(const float* x, const void* wpacked, const f
 using CV2_L1 = hdn::cv::Cfg2<32, 64, 4, 1, 2>;    // 256 pixels (8 rows) x 64 channels per workgroup, chunks of 32 channels
 using CV2_L2 = hdn::cv::Cfg2<16, 128, 2, 2, 4>;   // 128 pixels (8 rows), two k slices, chunks of 64 channels
 using CV2_L3 = hdn::cv::Cfg2<8, 256, 1, 4, 4>;    // 64 pixels (one image), four k slices
-using CV2_L4 = hdn::cv::Cfg2<4, 512, 1, 4, 4>;    // 64 pixels (four images), four k slices; K split over two workgroups at B = 64
+using CV2_L4 = hdn::cv::Cfg2<4, 512, 1, 4, 4, 1>; // 64 pixels (four images) x 32 channels, four k slices: 256 workgroups at B = 64, no K split over workgroups
 
 template <class F>
 static int cv2_dispatch(int S, int C, F&& f) {
@@ -1136,10 +1150,11 @@ extern "C" int hdn_cv2_debug_times(void* dst_device, int clear) {   // measureme
 }
 #endif
 
-extern "C" int hdn_conv3x3_v2_pack_info(int S, int C, int* k_slices, int* k_steps) {
+extern "C" int hdn_conv3x3_v2_pack_info(int S, int C, int* k_slices, int* k_steps, int* n_tiles) {
   return cv2_dispatch(S, C, [&](auto cfg) {
     if (k_slices) *k_slices = decltype(cfg)::WK;
     if (k_steps) *k_steps = decltype(cfg)::KS;
+    if (n_tiles) *n_tiles = decltype(cfg)::NT;
     return HDN_OK;
   });
 }

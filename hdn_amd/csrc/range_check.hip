@@ -4,7 +4,9 @@
 // The packers check the WEIGHTS on the host; the ACTIVATIONS are device data, so checking them costs a reduction and a host round trip
 // per call — off by default (the trunk's BatchNorm-folded, ReLU'd activations are O(10)), on with HDN_CHECK_RANGE=1 or
 // hdn_set_check_range(1), and on in the -m gpu test suite.  Inside a stream capture the check is skipped (it synchronises).
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "hdn_common.h"
 
@@ -50,7 +52,13 @@ int check_fp16_range(const float* x, long long n, hipStream_t stream) {
   if (e == hipSuccess) e = hipStreamSynchronize(stream);
   (void)hipFreeAsync(word, stream);
   if (e != hipSuccess) return -(1000 + (int)e);
-  return host >= 0x477fe000u ? HDN_E_LIMIT : HDN_OK;           // 65,504.0f
+  if (host >= 0x477fe000u) {                                      // 65,504.0f
+    float v;
+    memcpy(&v, &host, sizeof v);
+    fprintf(stderr, "hdn_amd: HDN_CHECK_RANGE: max |x| = %g over %lld fp32 inputs of a two-fp16-piece kernel (limit 65,504): HDN_E_LIMIT\n", (double)v, n);
+    return HDN_E_LIMIT;
+  }
+  return HDN_OK;
 }
 
 }  // namespace hdn

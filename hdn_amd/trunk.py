@@ -178,7 +178,7 @@ def pack_conv3x3(weight):
 
 def pack_conv3x3_v2(weight):
     """[C, C, 3, 3] fp32 weights -> the fragment-ordered stream of hdn_conv3x3_v2_f32 (include/hdn_hip.h):
-    [C / 64][chunk][k slice][tap][k step of the slice][n tile][piece][k half][n][8] fp16 bit patterns."""
+    [C / (32 NT)][chunk][k slice][tap][k step of the slice][n tile][piece][k half][n][8] fp16 bit patterns."""
     import ctypes
 
     import torch
@@ -188,13 +188,13 @@ def pack_conv3x3_v2(weight):
     C = weight.shape[0]
     if tuple(weight.shape) != (C, C, 3, 3):
         raise ValueError(f"pack_conv3x3_v2 takes [C, C, 3, 3] weights, got {tuple(weight.shape)}")
-    wk, ks = ctypes.c_int(0), ctypes.c_int(0)
-    if _lib.load().hdn_conv3x3_v2_pack_info(_MC_SIDE.get(C, 0), C, ctypes.byref(wk), ctypes.byref(ks)) != 0:
+    wk, ks, nt = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    if _lib.load().hdn_conv3x3_v2_pack_info(_MC_SIDE.get(C, 0), C, ctypes.byref(wk), ctypes.byref(ks), ctypes.byref(nt)) != 0:
         raise ValueError(f"no large-batch matrix-core kernel for {C} channels")
-    WK, KS = wk.value, ks.value
+    WK, KS, NT = wk.value, ks.value, nt.value
     pieces = _split_f16(weight.detach().to(torch.float32).cpu()).reshape(SPLIT_PIECES, C, C, 9)        # [piece, co, ci, tap]
-    # co = nb * 64 + nt * 32 + n;  ci = chunk * 16 KS + (j * WK + slice) * 16 + g * 8 + e
-    t = pieces.reshape(SPLIT_PIECES, C // 64, 2, 32, C // (16 * KS), KS // WK, WK, 2, 8, 9)          # [pc, nb, nt, n, ch, j, wk, g, e, tap]
+    # co = nb * 32 NT + nt * 32 + n;  ci = chunk * 16 KS + (j * WK + slice) * 16 + g * 8 + e
+    t = pieces.reshape(SPLIT_PIECES, C // (32 * NT), NT, 32, C // (16 * KS), KS // WK, WK, 2, 8, 9)    # [pc, nb, nt, n, ch, j, wk, g, e, tap]
     t = t.permute(1, 4, 6, 9, 5, 2, 0, 7, 3, 8).contiguous()                                           # [nb, ch, wk, tap, j, nt, pc, g, n, e]
     return t.view(torch.int16).reshape(-1)
 

@@ -384,13 +384,13 @@ int hdn_conv3x3s2_ds_f32(const float* x, const void* wpacked, const float* bias,
  * consumer wave owns a 64 x 64 output tile, the four consumers of a workgroup are WM pixel tiles x WK slices of K, and the weights
  * stream L2 -> registers in fragment order (they never touch the LDS).  hdn_amd.trunk uses it from B = 24 pairs on (below that the
  * chained form is faster).
- * wpacked: [C / 64][C / (16 KS)][WK k slices][9 taps x KS / WK k steps][2 n tiles][2 pieces][64 lanes = k half x 32 + n][8] fp16
+ * wpacked: [C / (32 NT)][C / (16 KS)][WK k slices][9 taps x KS / WK k steps][NT n tiles][2 pieces][64 lanes = k half x 32 + n][8] fp16
  *   (hdn_amd.trunk.pack_conv3x3_v2), input channel = chunk * 16 KS + (j * WK + slice) * 16 + half * 8 + e for the j-th k step of a
- *   slice, output channel = block * 64 + tile * 32 + n; (WK, KS) = hdn_conv3x3_v2_pack_info(S, C); 16-byte aligned.
+ *   slice, output channel = block * 32 NT + tile * 32 + n; (WK, KS, NT) = hdn_conv3x3_v2_pack_info(S, C); 16-byte aligned.
  * Workspace as above (K split over workgroups when the tiles do not fill the chip: S = 4 at B = 64): hdn_conv3x3_v2_workspace_bytes.
  * Replaces homo_estimator/Deep_homography/Oneline_DLTv1/backbone/resnet.py:78-94 (eval mode only).
  */
-int hdn_conv3x3_v2_pack_info(int S, int C, int* k_slices, int* k_steps);
+int hdn_conv3x3_v2_pack_info(int S, int C, int* k_slices, int* k_steps, int* n_tiles);
 long long hdn_conv3x3_v2_workspace_bytes(int B, int S, int C);
 int hdn_conv3x3_v2_f32(const float* x, const void* wpacked, const float* bias, const float* residual, float* out, float* workspace,
                        long long workspace_bytes, int B, int S, int C, void* stream);
