@@ -687,9 +687,9 @@ static int finish(const float* slices, int z, const float* bias, const float* re
 //     step, so that the next chunk's first fragments travel under them;
 //   * the producers also own the epilogue: they ask for the residual during the last chunk and, once the partial tiles are in LDS,
 //     add them in slice order + bias (+ residual), ReLU, 16-byte NHWC stores.
-template <int S_, int C_, int WM_, int WK_, int KS_, int NT_ = 2>
+template <int S_, int C_, int WM_, int WK_, int KS_, int NT_ = 2, int TPW_ = 1>
 struct Cfg2 {
-  static constexpr int S = S_, C = C_, WM = WM_, WK = WK_, KS = KS_, NT = NT_;
+  static constexpr int S = S_, C = C_, WM = WM_, WK = WK_, KS = KS_, NT = NT_, TPW = TPW_;
   static_assert(WM * WK == 4 && KS % WK == 0, "four consumer waves: WM pixel tiles x WK k slices");
   // NT = 1 (32 output channels per workgroup, a 64 x 32 tile per wave, 6 MFMAs per step): twice the workgroups for the 4 x 4 stage, whose
   // 1,024 pixels and 512 channels make 128 tiles of 64 x 64 (round 5 first split its K over two workgroups + a reduction launch instead)
@@ -715,25 +715,19 @@ struct Cfg2 {
   static constexpr int WCHUNK = WK * NS * WSTEP;                     // ... of one (channel block, chunk): [k slice][step]
   static constexpr int EPI_STRIDE = BN + 4;
   static constexpr int RED_BYTES = WK * BM * EPI_STRIDE * 4;
-  static constexpr int LDS_BYTES = 2 * A_BYTES > RED_BYTES ? 2 * A_BYTES : RED_BYTES;
+  static constexpr int LDS_BYTES = TPW > 1 ? 2 * A_BYTES + RED_BYTES : (2 * A_BYTES > RED_BYTES ? 2 * A_BYTES : RED_BYTES);
   static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit the LDS");
+  static_assert(TPW == 1 || (C / (16 * KS)) % 2 == 0, "several tiles per workgroup: an even number of chunks per tile keeps the image parity");
   static constexpr int AITEMS = LP * 2 * KS, AITER = cdiv(AITEMS, HDN_BLOCK);
   static constexpr int E4 = BM * (BN / 4), EITER = cdiv(E4, HDN_BLOCK);   // 16-byte output items per tile / per producer thread
 };
-
-#if defined(HDN_ABLATION) && defined(CV2_EXP_TIME)   // measurement build only: s_memtime stamps per workgroup (tools/experiments/exp_conv3x3_v2_phases.py)
-__device__ unsigned long long cv2_times[4096 * 8];
-#define CV2_STAMP(slot) do { if (lane == 0 && (wave == 0)) { const unsigned wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); if (wg < 4096) cv2_times[wg * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } } while (0)
-#else
-#define CV2_STAMP(slot) do {} while (0)
-#endif
 
 // MODE 0: out = relu(conv + bias); 1: out = relu(conv + bias + res); 2: raw sums of the K slice blockIdx.z (`cps` chunks) to out[blockIdx.z][M][C]
 template <class Cf, int MODE>
 __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_v2_kernel(const float* __restrict__ x, const u32x4* __restrict__ wp, const float* __restrict__ bias,
                                                                const float* __restrict__ res, float* __restrict__ out, int B, int cps) {
   constexpr bool RES = MODE == 1, PARTIAL = MODE == 2;
-  constexpr int S = Cf::S, C = Cf::C, BM = Cf::BM, BN = Cf::BN, KS = Cf::KS, WK = Cf::WK, NS = Cf::NS, SPW = Cf::SPW;
+  constexpr int S = Cf::S, C = Cf::C, BM = Cf::BM, BN = Cf::BN, KS = Cf::KS, WK = Cf::WK, NS = Cf::NS, SPW = Cf::SPW, TPW = Cf::TPW;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x & (HDN_BLOCK - 1), lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -742,17 +736,24 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_v2_kernel(const float* 
   // blockIdx.x = output-channel block (fastest): workgroups are dealt to the 8 XCDs round-robin by their linear id, so an XCD sees
   // NB / 8 (or one) of the channel blocks and its L2 holds that block's weight stream for all the pixel tiles that share it (the 4 x 4
   // stage's 9.4 MB of weights do not fit one 4 MB L2; 1.2 MB per XCD do)
-  const long long m0 = (long long)blockIdx.y * BM;
   const int nb = blockIdx.x;
-  const int b0 = (int)(m0 / (S * S)), y0 = (int)((m0 % (S * S)) / S);
   const long long M = (long long)B * S * S;
+  // TPW consecutive pixel tiles per workgroup, one after the other: the producers stage tile t + 1 and store tile t - 1's output while the
+  // consumers multiply tile t (a launch's output no longer leaves all at once at its end, and only the first tile's staging is exposed)
+  const int tile0 = (int)blockIdx.y * TPW;
+  const int ntw = min(TPW, (int)((M + BM - 1) / BM) - tile0);
   const int chunk0 = PARTIAL ? (int)blockIdx.z * cps : 0, nchunk = PARTIAL ? cps : Cf::NCHUNK;
-  float* const red = reinterpret_cast<float*>(smem);
+  const int G = ntw * nchunk;                             // chunks of this workgroup, over its tiles
+  // the partial tiles meet in LDS: over the dead images when the workgroup has one tile, beside them otherwise
+  float* const red = reinterpret_cast<float*>(smem + (TPW > 1 ? 2 * Cf::A_BYTES : 0));
 
   if (produce) {
     // ------------------------------------------------------------------------------------------------ producers
     f4 av[Cf::AITER][2];
-    auto load_a = [&](int chunk) {
+    auto load_a = [&](int gc) {                            // global chunk gc = (tile, chunk)
+      const int tile = gc / nchunk, chunk = gc - tile * nchunk;
+      const long long m0 = (long long)(tile0 + tile) * BM;
+      const int b0 = (int)(m0 / (S * S)), y0 = (int)((m0 % (S * S)) / S);
 #pragma unroll
       for (int q = 0; q < Cf::AITER; ++q) {
         const int item = tid + q * HDN_BLOCK;
@@ -783,25 +784,9 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_v2_kernel(const float* 
       }
     };
     f4 rv[RES ? Cf::EITER : 1];
-    CV2_STAMP(0);
-    load_a(0);
-    store_a(0);
-    if (nchunk > 1) load_a(1);
-    CV2_STAMP(1);
-    __syncthreads();                                   // chunk 0 is staged
-#if defined(HDN_ABLATION) && defined(CV2_EXP_TWICE)   // measurement build only: the chunk loop twice (the difference to the shipping build = one loop)
-    for (int c = 0; c < nchunk; ++c) {
-      if (c + 1 < nchunk) { store_a((c + 1) & 1); if (c + 2 < nchunk) load_a(c + 2); }
-      __syncthreads();
-    }
-    load_a(0); store_a(0); if (nchunk > 1) load_a(1);
-#endif
-    for (int c = 0; c < nchunk; ++c) {
-      if (c + 1 < nchunk) {
-        store_a((c + 1) & 1);                          // that image was read last in chunk c - 1, one barrier ago
-        if (c + 2 < nchunk) load_a(c + 2);
-      }
-      if (RES && c + 1 == nchunk) {                    // the residual travels during the last chunk
+    auto load_res = [&](int tile) {                        // the residual travels during the tile's last chunk
+      if constexpr (RES) {
+        const long long m0 = (long long)(tile0 + tile) * BM;
 #pragma unroll
         for (int q = 0; q < Cf::EITER; ++q) {
           const int idx = tid + q * HDN_BLOCK, px = idx / (BN / 4), c4 = idx % (BN / 4);
@@ -809,35 +794,53 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_v2_kernel(const float* 
           rv[q] = *reinterpret_cast<const f4*>(res + m * C + nb * BN + c4 * 4);
         }
       }
-      __syncthreads();                                 // chunk c + 1 is staged; the consumers have read the last fragment of chunk c
-    }
-    CV2_STAMP(2);
-    __syncthreads();                                   // the partial tiles are in LDS
-    CV2_STAMP(3);
+    };
+    // sum of the WK partial tiles in slice order (+ bias (+ residual), ReLU), a pixel's BN channels = BN / 4 consecutive lanes
+    auto epilogue = [&](int tile) {
 #if defined(HDN_ABLATION) && defined(CV2_EXP_NOEPI)
-    return;
+      return;
 #endif
-    // ---- epilogue: sum of the WK partial tiles in slice order (+ bias (+ residual), ReLU), a pixel's 64 channels = 16 consecutive lanes
+      const long long m0 = (long long)(tile0 + tile) * BM;
 #pragma unroll
-    for (int q = 0; q < Cf::EITER; ++q) {
-      const int idx = tid + q * HDN_BLOCK, px = idx / (BN / 4), c4 = idx % (BN / 4);
-      const long long m = m0 + px;
-      if (idx < Cf::E4 && m < M) {
-        f4 v = *reinterpret_cast<const f4*>(red + px * Cf::EPI_STRIDE + c4 * 4);
+      for (int q = 0; q < Cf::EITER; ++q) {
+        const int idx = tid + q * HDN_BLOCK, px = idx / (BN / 4), c4 = idx % (BN / 4);
+        const long long m = m0 + px;
+        if (idx < Cf::E4 && m < M) {
+          f4 v = *reinterpret_cast<const f4*>(red + px * Cf::EPI_STRIDE + c4 * 4);
 #pragma unroll
-        for (int w = 1; w < WK; ++w) v = v + *reinterpret_cast<const f4*>(red + (w * BM + px) * Cf::EPI_STRIDE + c4 * 4);
-        if (PARTIAL) {
-          *reinterpret_cast<f4*>(out + ((long long)blockIdx.z * M + m) * C + nb * BN + c4 * 4) = v;
-        } else {
-          v = v + *reinterpret_cast<const f4*>(bias + nb * BN + c4 * 4);
-          if (RES) v = v + rv[q];
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-          *reinterpret_cast<f4*>(out + m * C + nb * BN + c4 * 4) = v;
+          for (int w = 1; w < WK; ++w) v = v + *reinterpret_cast<const f4*>(red + (w * BM + px) * Cf::EPI_STRIDE + c4 * 4);
+          if (PARTIAL) {
+            *reinterpret_cast<f4*>(out + ((long long)blockIdx.z * M + m) * C + nb * BN + c4 * 4) = v;
+          } else {
+            v = v + *reinterpret_cast<const f4*>(bias + nb * BN + c4 * 4);
+            if (RES) v = v + rv[q];
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            *reinterpret_cast<f4*>(out + m * C + nb * BN + c4 * 4) = v;
+          }
         }
       }
+    };
+    load_a(0);
+    store_a(0);
+    if (G > 1) load_a(1);
+    __syncthreads();                                   // chunk 0 is staged
+    for (int gc = 0, tile = 0, c = 0; gc < G; ++gc) {
+      if (gc + 1 < G) {
+        store_a((gc + 1) & 1);                         // that image was read last in chunk gc - 1, one barrier ago
+        if (gc + 2 < G) load_a(gc + 2);
+      }
+      if (TPW > 1 && c == 0 && tile > 0) epilogue(tile - 1);   // (its partial tiles arrived at the barrier that closed tile - 1; the consumers refill `red`
+                                                               //  behind this chunk's barrier at the earliest; rv is free again before load_res below)
+      if (c + 1 == nchunk) load_res(tile);
+      __syncthreads();                                 // chunk gc + 1 is staged; the consumers have read the last fragment of chunk gc
+      if (++c == nchunk) {
+        c = 0;
+        ++tile;
+        __syncthreads();                               // the tile's partial sums are in LDS
+      }
     }
+    epilogue(ntw - 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    CV2_STAMP(4);
     return;
   }
 
@@ -852,25 +855,23 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_v2_kernel(const float* 
   }
   constexpr int NT = Cf::NT, PF = Cf::PF;
   f32x16 acc[2][NT], accl[2][NT];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = accl[mt][nt][r] = 0.f;
 
-  // this wave's weight stream: [channel block][chunk][k slice][step][n tile][piece][lane] x 16 B
+  // this wave's weight stream: [channel block][chunk][k slice][step][n tile][piece][lane] x 16 B (the same for every tile of the workgroup)
   const u32x4* const wbase = wp + ((size_t)nb * Cf::NCHUNK + chunk0) * Cf::WCHUNK + (size_t)wk * NS * Cf::WSTEP;
   const uint32_t voff = (uint32_t)lane * 16u;
   u32x4 fb[Cf::BSETS][NT][2], fa[2][2][2];
-  const int last_chunk = nchunk - 1;
-  // B fragments of (chunk ch, step st); past the end: the last step again (keeps the count of outstanding loads static)
-  auto load_b = [&](u32x4 (&b)[NT][2], int ch, int st) {
+  // B fragments of (chunk ch, step st) of tile tt; a chunk index past the tile's is the next tile's first chunk — or, behind the last tile,
+  // the last step again (which keeps the count of outstanding loads static)
+  auto load_b = [&](u32x4 (&b)[NT][2], int tt, int ch, int st) {
 #if defined(HDN_ABLATION) && (defined(CV2_EXP_NOBLOAD) || defined(CV2_EXP_PURE))   // measurement build only
-    if (ch + st > 1) { asm volatile("s_nop 0" ::: "memory"); return; }
+    if (tt + ch + st > 1) { asm volatile("s_nop 0" ::: "memory"); return; }
 #endif
-    const bool past = ch > last_chunk;
-    const u32x4* sp = wbase + (size_t)(past ? last_chunk : ch) * Cf::WCHUNK + (size_t)(past ? NS - 1 : st) * Cf::WSTEP;
+    bool past = false;
+    if (ch >= nchunk) {
+      if (tt + 1 < ntw) ch -= nchunk;
+      else past = true;
+    }
+    const u32x4* sp = wbase + (size_t)(past ? nchunk - 1 : ch) * Cf::WCHUNK + (size_t)(past ? NS - 1 : st) * Cf::WSTEP;
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b[0][0]) : "v"(voff), "s"(sp));
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(b[0][1]) : "v"(voff), "s"(sp));
     if constexpr (NT == 2) {
@@ -895,109 +896,110 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_v2_kernel(const float* 
     }
   };
   using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
   constexpr bool STATIC_IMG = Cf::PER == 2 && 2 * Cf::A_BYTES < 65536;   // two chunks per period: the image of a step is a constant of the offset field
 
-  static_for<PF>([&](auto Ic) {                         // the first PF steps' fragments (past a short K range: the last step again)
+  static_for<PF>([&](auto Ic) {                         // the first PF steps' fragments
     constexpr int i = decltype(Ic)::value;
-    load_b(fb[i], i / NS, i % NS);
+    load_b(fb[i], 0, i / NS, i % NS);
   });
   __builtin_amdgcn_s_barrier();                        // chunk 0 is staged
-  CV2_STAMP(5);
   read_a(fa[0], aoff, I0{}, I0{});
-#if defined(HDN_ABLATION) && defined(CV2_EXP_TWICE)
-  for (int rep = 0; rep < 2; ++rep)
-#endif
-  for (int c0 = 0; c0 < nchunk; c0 += Cf::PER) {
-    static_for<Cf::PER * NS>([&](auto Pc) {
-      constexpr int p = decltype(Pc)::value, cp = p / NS, st = p % NS;
-      constexpr int as = p % 2, bs = p % Cf::BSETS;
-      const int chunk = c0 + cp;
-      uint32_t cur[2] = {aoff[0], aoff[1]}, nxt[2] = {aoff[0], aoff[1]};     // this chunk's image, the next chunk's
-      if constexpr (!STATIC_IMG) {
-        const uint32_t o = (uint32_t)(chunk & 1) * Cf::A_BYTES;
-        cur[0] += o; cur[1] += o;
-        nxt[0] += o ^ (uint32_t)Cf::A_BYTES; nxt[1] += o ^ (uint32_t)Cf::A_BYTES;
-      }
-      using CurImg = std::integral_constant<int, STATIC_IMG ? (cp & 1) : 0>;
-      using NxtImg = std::integral_constant<int, STATIC_IMG ? ((cp + 1) & 1) : 0>;
-      {  // the B fragments PF steps ahead
-        constexpr int q = st + PF;
-        load_b(fb[(p + PF) % Cf::BSETS], chunk + q / NS, q % NS);
-      }
-      if constexpr (st + 1 < NS) {
-        read_a(fa[as ^ 1], cur, std::integral_constant<int, (st + 1) % NS>{}, CurImg{});
-#if defined(HDN_ABLATION) && defined(CV2_EXP_PURE)
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#elif defined(HDN_ABLATION) && defined(CV2_EXP_NOBLOAD)
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(4)" ::: "memory");
-#else
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(4)" ::"n"(PF * NT * 2) : "memory");
-#endif
-      } else {
-#if defined(HDN_ABLATION) && (defined(CV2_EXP_NOBLOAD) || defined(CV2_EXP_PURE))
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#else
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PF * NT * 2) : "memory");
-#endif
-        // the chunk's last fragments are in registers: the producers may overwrite its image, and the next chunk's image is complete
-        __builtin_amdgcn_s_barrier();
-        if (chunk + 1 < nchunk) read_a(fa[as ^ 1], nxt, I0{}, NxtImg{});
-      }
+  for (int tt = 0; tt < ntw; ++tt) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int pc = 0; pc < 2; ++pc) asm volatile("" : "+v"(fa[as][mt][pc]));
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int pc = 0; pc < 2; ++pc) asm volatile("" : "+v"(fb[bs][nt][pc]));
-      // 12 MFMAs, the three products of an output tile two MFMAs apart
+        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = accl[mt][nt][r] = 0.f;
+    for (int c0 = 0; c0 < nchunk; c0 += Cf::PER) {
+      static_for<Cf::PER * NS>([&](auto Pc) {
+        constexpr int p = decltype(Pc)::value, cp = p / NS, st = p % NS;
+        constexpr int as = p % 2, bs = p % Cf::BSETS;
+        const int chunk = c0 + cp;
+        uint32_t cur[2] = {aoff[0], aoff[1]}, nxt[2] = {aoff[0], aoff[1]};     // this chunk's image, the next chunk's
+        if constexpr (!STATIC_IMG) {
+          const uint32_t o = (uint32_t)(chunk & 1) * Cf::A_BYTES;               // (a tile has an even number of chunks when the workgroup has several)
+          cur[0] += o; cur[1] += o;
+          nxt[0] += o ^ (uint32_t)Cf::A_BYTES; nxt[1] += o ^ (uint32_t)Cf::A_BYTES;
+        }
+        using CurImg = std::integral_constant<int, STATIC_IMG ? (cp & 1) : 0>;
+        using NxtImg = std::integral_constant<int, STATIC_IMG ? ((cp + 1) & 1) : 0>;
+        {  // the B fragments PF steps ahead
+          constexpr int q = st + PF;
+          load_b(fb[(p + PF) % Cf::BSETS], tt, chunk + q / NS, q % NS);
+        }
+        if constexpr (st + 1 < NS) {
+          read_a(fa[as ^ 1], cur, std::integral_constant<int, (st + 1) % NS>{}, CurImg{});
+#if defined(HDN_ABLATION) && defined(CV2_EXP_PURE)
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#elif defined(HDN_ABLATION) && defined(CV2_EXP_NOBLOAD)
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(4)" ::: "memory");
+#else
+          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(4)" ::"n"(PF * NT * 2) : "memory");
+#endif
+        } else {
+#if defined(HDN_ABLATION) && (defined(CV2_EXP_NOBLOAD) || defined(CV2_EXP_PURE))
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#else
+          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PF * NT * 2) : "memory");
+#endif
+          // the chunk's last fragments are in registers: the producers may overwrite its image, and the next chunk's image is complete
+          __builtin_amdgcn_s_barrier();
+          if (chunk + 1 < nchunk || tt + 1 < ntw) read_a(fa[as ^ 1], nxt, I0{}, NxtImg{});
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int pc = 0; pc < 2; ++pc) asm volatile("" : "+v"(fa[as][mt][pc]));
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int pc = 0; pc < 2; ++pc) asm volatile("" : "+v"(fb[bs][nt][pc]));
+        // 12 (NT = 1: 6) MFMAs, the three products of an output tile two MFMAs apart
 #if defined(HDN_ABLATION) && defined(CV2_EXP_NOMFMA)
-      return;
+        return;
 #endif
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) accl[mt][nt] = mfma(fa[as][mt][1], fb[bs][nt][0], accl[mt][nt]);
+          for (int nt = 0; nt < NT; ++nt) accl[mt][nt] = mfma(fa[as][mt][1], fb[bs][nt][0], accl[mt][nt]);
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma(fa[as][mt][0], fb[bs][nt][0], acc[mt][nt]);
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma(fa[as][mt][0], fb[bs][nt][0], acc[mt][nt]);
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) accl[mt][nt] = mfma(fa[as][mt][0], fb[bs][nt][1], accl[mt][nt]);
+          for (int nt = 0; nt < NT; ++nt) accl[mt][nt] = mfma(fa[as][mt][0], fb[bs][nt][1], accl[mt][nt]);
+      });
+    }
+    // ---- this wave's partial tile -> LDS.  One tile per workgroup: over the images (every consumer has passed the last chunk's barrier after
+    // its last read); several: into their own region, which the producers emptied during this tile's first chunk.
+    // C/D layout of v_mfma_f32_32x32x16_f16: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).  The pixel of accumulator row r
+    // is a compile-time constant for each of the two half waves: one multiply-add per store, not the mapping's dozen integer operations.
+#if defined(HDN_ABLATION) && defined(CV2_EXP_NOEPI)
+    if (lane == 0) out[blockIdx.y * 4 + wave] = acc[0][0][0] + accl[0][0][0] + acc[1][NT - 1][5] + accl[1][0][3] + acc[0][NT - 1][2] + acc[1][0][7];
+#else
+    float* const rbase = red + (wk * BM + wm * 64) * Cf::EPI_STRIDE + li;
+    static_for<2>([&](auto MTc) {
+      static_for<16>([&](auto Rc) {
+        constexpr int mt = decltype(MTc)::value, r = decltype(Rc)::value, i0 = (r & 3) + 8 * (r >> 2);
+        constexpr int row0 = mt * 32 + mrow_to_pixel_s1<S>(i0), row1 = mt * 32 + mrow_to_pixel_s1<S>(i0 + 4);
+        float* const q = rbase + (row0 + g * (row1 - row0)) * Cf::EPI_STRIDE;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) q[nt * 32] = acc[mt][nt][r] + accl[mt][nt][r] * LO_UNSCALE;
+      });
     });
+#endif
+    __syncthreads();                                   // the tile's partial sums are in LDS (the producers take them from there)
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the surplus B loads at the tail)
-  CV2_STAMP(6);
-  // ---- this wave's partial tile -> LDS (over the images: every consumer has passed the last chunk's barrier after its last read).
-  // C/D layout of v_mfma_f32_32x32x16_f16: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
-#if defined(HDN_ABLATION) && defined(CV2_EXP_NOEPI)
-  if (lane == 0) out[blockIdx.y * 4 + wave] = acc[0][0][0] + accl[0][0][0] + acc[1][1][5] + accl[1][0][3] + acc[0][1][2] + acc[1][0][7];
-  __syncthreads();
-  return;
-#endif
-  // The pixel of accumulator row r is a compile-time constant for each of the two half waves: one multiply-add per store, not the
-  // mapping's dozen integer operations.
-  float* const rbase = red + (wk * BM + wm * 64) * Cf::EPI_STRIDE + li;
-  static_for<2>([&](auto MTc) {
-    static_for<16>([&](auto Rc) {
-      constexpr int mt = decltype(MTc)::value, r = decltype(Rc)::value, i0 = (r & 3) + 8 * (r >> 2);
-      constexpr int row0 = mt * 32 + mrow_to_pixel_s1<S>(i0), row1 = mt * 32 + mrow_to_pixel_s1<S>(i0 + 4);
-      float* const q = rbase + (row0 + g * (row1 - row0)) * Cf::EPI_STRIDE;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) q[nt * 32] = acc[mt][nt][r] + accl[mt][nt][r] * LO_UNSCALE;
-    });
-  });
-  CV2_STAMP(7);
-  __syncthreads();
 }
 
 template <class Cf>
 static int k_slices_v2(int B) {
   const long long M = (long long)B * Cf::S * Cf::S;
+  if (Cf::TPW > 1) return 1;       // (several tiles per workgroup: the launch is long enough as it is)
   const long long tiles = ((M + Cf::BM - 1) / Cf::BM) * Cf::NB;
   static const int target = [] { const char* e = getenv("HDN_CV2_SLICE_TARGET"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 200; }();  // A/B switch
   int z = 1;
@@ -1024,8 +1026,9 @@ static int launch_v2(const float* x, const void* wp, const float* bias, const fl
     }
     attr.set(dev_);
   }
-  if ((M + Cf::BM - 1) / Cf::BM > 65535) return HDN_E_LIMIT;
-  const dim3 grid(Cf::NB, (unsigned)((M + Cf::BM - 1) / Cf::BM), z), blk(2 * HDN_BLOCK);
+  const long long wgs_m = ((M + Cf::BM - 1) / Cf::BM + Cf::TPW - 1) / Cf::TPW;
+  if (wgs_m > 65535) return HDN_E_LIMIT;
+  const dim3 grid(Cf::NB, (unsigned)wgs_m, z), blk(2 * HDN_BLOCK);
   const u32x4* w4 = (const u32x4*)wp;
   if (z == 1) {
     if (res) hipLaunchKernelGGL((conv3x3_v2_kernel<Cf, 1>), grid, blk, Cf::LDS_BYTES, stream, x, w4, bias, res, out, B, Cf::NCHUNK);
@@ -1127,28 +1130,22 @@ extern "C" int hdn_conv3x3s2_ds_f32(const float* x, const void* wpacked, const f
 
 
 // ---- round 5: the large-batch form (conv3x3_v2_kernel).                  S    C  WM WK KS
-using CV2_L1 = hdn::cv::Cfg2<32, 64, 4, 1, 2>;    // 256 pixels (8 rows) x 64 channels per workgroup, chunks of 32 channels
-using CV2_L2 = hdn::cv::Cfg2<16, 128, 2, 2, 4>;   // 128 pixels (8 rows), two k slices, chunks of 64 channels
+using CV2_L1 = hdn::cv::Cfg2<32, 64, 2, 2, 2, 2, 2>;   // 2 tiles of 128 pixels (4 rows) x 64 channels per workgroup, two k slices, chunks of 32 channels
+using CV2_L2 = hdn::cv::Cfg2<16, 128, 1, 4, 4, 2, 2>;  // 2 tiles of 64 pixels (4 rows), four k slices, chunks of 64 channels
+using CV2_L1S = hdn::cv::Cfg2<32, 64, 4, 1, 2>;        // (HDN_CV2_TPW=1: one tile of 256 pixels (8 rows) per workgroup, chunks of 32 channels)
+using CV2_L2S = hdn::cv::Cfg2<16, 128, 2, 2, 4>;       // (HDN_CV2_TPW=1: one tile of 128 pixels (8 rows), two k slices, chunks of 64 channels)
 using CV2_L3 = hdn::cv::Cfg2<8, 256, 1, 4, 4>;    // 64 pixels (one image), four k slices
 using CV2_L4 = hdn::cv::Cfg2<4, 512, 1, 4, 4, 1>; // 64 pixels (four images) x 32 channels, four k slices: 256 workgroups at B = 64, no K split over workgroups
 
 template <class F>
 static int cv2_dispatch(int S, int C, F&& f) {
-  if (S == 32 && C == 64) return f(CV2_L1{});
-  if (S == 16 && C == 128) return f(CV2_L2{});
+  static const bool single = [] { const char* e = getenv("HDN_CV2_TPW"); return e && atoi(e) == 1; }();   // A/B switch
+  if (S == 32 && C == 64) return single ? f(CV2_L1S{}) : f(CV2_L1{});
+  if (S == 16 && C == 128) return single ? f(CV2_L2S{}) : f(CV2_L2{});
   if (S == 8 && C == 256) return f(CV2_L3{});
   if (S == 4 && C == 512) return f(CV2_L4{});
   return HDN_E_LIMIT;
 }
-
-#if defined(HDN_ABLATION) && defined(CV2_EXP_TIME)
-extern "C" int hdn_cv2_debug_times(void* dst_device, int clear) {   // measurement build only
-  void* sym = nullptr;
-  if (hipGetSymbolAddress(&sym, HIP_SYMBOL(hdn::cv::cv2_times)) != hipSuccess) return -1;
-  if (clear) return hipMemsetAsync(sym, 0, sizeof(unsigned long long) * 4096 * 8, 0) == hipSuccess ? 0 : -1;
-  return hipMemcpy(dst_device, sym, sizeof(unsigned long long) * 4096 * 8, hipMemcpyDeviceToDevice) == hipSuccess ? 0 : -1;
-}
-#endif
 
 extern "C" int hdn_conv3x3_v2_pack_info(int S, int C, int* k_slices, int* k_steps, int* n_tiles) {
   return cv2_dispatch(S, C, [&](auto cfg) {
