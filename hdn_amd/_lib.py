@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libhdn_hip.so"
 LIB_PATH = os.environ.get("HDN_LIB_PATH", os.path.join(_HERE, LIB_NAME))  # override: A/B builds of the kernels
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _c_float_p = ctypes.c_void_p  # device pointers travel as integers
 _i = ctypes.c_int
@@ -48,6 +48,7 @@ SIGNATURES = {
     "hdn_track_prepare_f64": (_i, [_c_float_p] * 3 + [_i, ctypes.c_void_p]),
     "hdn_track_accumulate_f64": (_i, [_c_float_p] * 6 + [_i] + [_c_float_p] * 2 + [_i, ctypes.c_void_p]),
     "hdn_trunk_stem_f32": (_i, [_c_float_p] * 4 + [_i] * 4 + [ctypes.c_void_p]),
+    "hdn_trunk_stem_mfma_f32": (_i, [_c_float_p, ctypes.c_void_p, _c_float_p, _c_float_p] + [_i] * 3 + [ctypes.c_void_p]),
     "hdn_bias_relu_f32": (_i, [_c_float_p] * 3 + [_i] * 4 + [ctypes.c_void_p]),
     "hdn_avgpool_fc_f32": (_i, [_c_float_p] * 4 + [_i] * 5 + [ctypes.c_void_p]),
     "hdn_head_tail_f32": (_i, [_c_float_p, ctypes.c_void_p] + [_c_float_p] * 4 + [_i] * 4 + [ctypes.c_void_p]),

@@ -69,6 +69,23 @@ def resnet34_homo():
     return HomoResNet((3, 4, 6, 3))
 
 
+STEM_MFMA_MIN_BATCH = 32     # hdn_trunk_stem_mfma_f32 launches 4 workgroups per image: from here on they cover half the chip's 256 CUs
+
+
+def pack_stem_mfma(weight):
+    """[64, 2, 7, 7] fp32 weights (BatchNorm folded in) -> the fragment-ordered stream of hdn_trunk_stem_mfma_f32 (include/hdn_hip.h):
+    [7 k steps][2 n tiles][2 pieces][k half g][n][8] fp16 bit patterns, element j = w[32 tile + n][ci][ky][kx = j] with
+    ci * 7 + ky = 2 step + g, zero at j = 7."""
+    import torch
+
+    if tuple(weight.shape) != (64, 2, 7, 7):
+        raise ValueError(f"pack_stem_mfma takes [64, 2, 7, 7] weights, got {tuple(weight.shape)}")
+    w8 = torch.zeros(64, 14, 8, dtype=torch.float32)
+    w8[:, :, :7] = weight.detach().to(torch.float32).cpu().reshape(64, 14, 7)                # [co][r = ci * 7 + ky][kx]
+    t = _split_f16(w8).reshape(SPLIT_PIECES, 2, 32, 7, 2, 8)                                 # [pc, tile, n, step, g, j]
+    return t.permute(3, 1, 0, 4, 2, 5).contiguous().view(torch.int16).reshape(-1)            # [step, tile, pc, g, n, j]
+
+
 class FusedStem(nn.Module):
     """conv1 + folded bn1 + relu + maxpool of the trunk as ONE HIP kernel (hdn_trunk_stem_f32): the 64-channel 64 x 64 conv output
     never goes through HBM.  Built from a folded conv (weight [64,2,7,7], bias [64]); eval / no-grad only; CUDA tensors only."""
@@ -79,7 +96,9 @@ class FusedStem(nn.Module):
             raise ValueError("FusedStem replaces Conv2d(2, 64, 7, 2, 3) with a folded bias")
         self.register_buffer("wT", conv.weight.detach().permute(1, 2, 3, 0).contiguous())  # [ci][ky][kx][co]
         self.register_buffer("b", conv.bias.detach().clone())
+        self.register_buffer("wfrag", pack_stem_mfma(conv.weight))                           # the matrix-core form's weights (28 KB)
         self.channels_last = bool(channels_last)
+        self.mfma_disabled = False                                                           # A/B switch (tools/experiments, tests)
 
     def forward(self, x):
         from . import _lib
@@ -100,6 +119,12 @@ class FusedStem(nn.Module):
 
         out = torch.empty((B, 64, Hp, Wp), dtype=x.dtype, device=dev,
                           memory_format=torch.channels_last if self.channels_last else torch.contiguous_format)
+        if self.channels_last and H == 127 and W == 127 and B >= STEM_MFMA_MIN_BATCH and not self.mfma_disabled:
+            with _lib.device_guard(dev):
+                rc = _lib.load().hdn_trunk_stem_mfma_f32(_lib.ptr(xs), _lib.ptr(self.wfrag), _lib.ptr(self.b), _lib.ptr(out), B, H, W,
+                                                         _lib.stream_ptr(dev))
+            _lib.check(rc, "trunk_stem_mfma")
+            return out
         with _lib.device_guard(dev):
             rc = _lib.load().hdn_trunk_stem_f32(_lib.ptr(xs), _lib.ptr(self.wT), _lib.ptr(self.b), _lib.ptr(out), B, H, W,
                                                 1 if self.channels_last else 0, _lib.stream_ptr(dev))

@@ -33,7 +33,7 @@ extern "C" {
 /* RCCL failures are returned as -(2000 + ncclResult_t). */
 
 /* ABI version of this header; hdn_abi_version() of the loaded library must match. */
-#define HDN_ABI_VERSION 6
+#define HDN_ABI_VERSION 7
 int hdn_abi_version(void);
 
 /* Name of the kernel variant the last hdn_xcorr_* call on this thread dispatched to
@@ -284,6 +284,16 @@ int hdn_track_accumulate_f64(const double* Ht, const double* sim_state, const do
  * homo_estimator/Deep_homography/Oneline_DLTv1/backbone/resnet.py:141-147,183-186 (eval mode only).
  */
 int hdn_trunk_stem_f32(const float* x, const float* wT, const float* bias, float* out, int B, int H, int W, int nhwc, void* stream);
+
+/*
+ * The same stage on the matrix cores, for the batches that fill the chip (one workgroup per quarter image: B >= 32 at 127 px is where it pays;
+ * hdn_amd.trunk.FusedStem dispatches): x [B,2,127,127] (NCHW) -> out [B,32,32,64] (channels-last in memory).  H, W: 127 only (else
+ * HDN_E_LIMIT).  fp32 carried as two fp16 pieces, three piece products, fp32 accumulation: the error of an fp32 convolution.
+ * wfrag: the folded conv weights in MFMA-fragment order, [7 k steps][2 n tiles][2 pieces][64 lanes = (k half g, n)][8] fp16: element j is
+ * piece pc (p0 = fp16(w), p1 = fp16((w - p0) * 2048)) of w[co = 32 tile + n][ci][ky][kx = j], ci * 7 + ky = 2 * k step + g, and 0 at j = 7
+ * (hdn_amd.trunk.pack_stem_mfma); 16-byte aligned, 28,672 bytes.  bias[64] as above.  Same reference lines as hdn_trunk_stem_f32.
+ */
+int hdn_trunk_stem_mfma_f32(const float* x, const void* wfrag, const float* bias, float* out, int B, int H, int W, void* stream);
 
 /*
  * Residual-block epilogues of the same trunk, in place:

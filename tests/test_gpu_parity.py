@@ -15,6 +15,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from conftest import ROOT, golden_rng, load_golden, relu_normal
 from oracle import hdn_oracle as O
@@ -1044,6 +1045,34 @@ def test_trunk_fused_stem_vs_torch(dev, shape):
         assert float((y.cpu() - ref).abs().max()) <= 2e-5 + 2e-6 * float(ref.abs().max())
     with pytest.raises(ValueError):
         FusedStem(torch.nn.Conv2d(2, 64, 7, 2, 3, bias=False), False)
+
+
+@pytest.mark.parametrize("B", [32, 37, 64])
+def test_trunk_stem_matrix_core_form_vs_float64(dev, B):
+    """hdn_trunk_stem_mfma_f32 (the first stage as an implicit GEMM on the matrix cores, fp32 as two fp16 pieces; batches of 32 and more at
+    127 px, channels-last) against the same stage in float64 on the CPU, and against the vector-pipe kernel it stands in for: the error of
+    an fp32 convolution.  Inputs at the tracker's scale (crops are 0..255 minus a mean) as well as unit normal."""
+    from hdn_amd import trunk
+    from hdn_amd.trunk import FusedStem
+    g = torch.Generator().manual_seed(900 + B)
+    conv = torch.nn.Conv2d(2, 64, 7, 2, 3)
+    conv.weight.data = torch.randn(64, 2, 7, 7, generator=g) * 0.1
+    conv.bias.data = torch.randn(64, generator=g) * 0.5
+    st = FusedStem(conv, True).to(dev)
+    assert B >= trunk.STEM_MFMA_MIN_BATCH
+    for scale in (1.0, 120.0):
+        x = torch.randn(B, 2, 127, 127, generator=g) * scale
+        x[0, :, :, :5] = scale; x[1, :, -4:, :] = -scale                # (edges: the zero padding must not leak)
+        ref = F.max_pool2d(F.relu(F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), stride=2, padding=3)), 3, 2, 1)
+        y = st(x.to(dev))
+        assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+        st.mfma_disabled = True
+        y_valu = st(x.to(dev))
+        st.mfma_disabled = False
+        mag = float(ref.abs().max())
+        e, e_valu = float((y.cpu().double() - ref).abs().max()), float((y_valu.cpu().double() - ref).abs().max())
+        assert e <= 3e-6 * mag, (e, mag)
+        assert e <= 4 * e_valu + 1e-7 * mag, (e, e_valu)                 # no worse than the fp32 kernel's own rounding, to a small factor
 
 
 def test_folded_trunk_with_and_without_fused_stem(dev):

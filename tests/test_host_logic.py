@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_library_loads_and_reports_abi():
     lib = _lib.load()
-    assert lib.hdn_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.hdn_abi_version() == _lib.ABI_VERSION == 7
     assert lib.hdn_last_xcorr_variant() == b"none"
 
 
