@@ -8,15 +8,17 @@
 // convolution).  The k order makes an MFMA A fragment (lane = (pixel, k half), 8 consecutive k) EIGHT CONSECUTIVE INPUT PIXELS of one input row:
 // k = 16 s + 8 g + j  <->  row r = 2 s + g = ci * 7 + ky,  kx = j,  so lane (ox, g) of k step s needs x[ci][2 oy + ky - 3][2 ox - 3 + j], j = 0..7.
 //
-// Workgroup = 4 waves = (image, block of 16 conv rows = 8 pooled rows).  Per iteration every wave computes ONE conv row (64 pixels x 64 channels:
-// 2 x 2 MFMA tiles, 7 k steps x 12 MFMAs):
-//   * the input rows of the iteration (13, of which 8 are new) sit in an LDS ring as fp32, zero-padded (3 columns left, the out-of-range rows as zeros):
-//     no masking in the loop; a lane reads its 8 floats as four 8-byte ds_reads (column 2 ox: 8-byte aligned) and splits them in registers;
-//   * the weights are host-packed in fragment order ([k step][n tile][piece][lane] x 16 B, 28 KB) and copied to LDS once per workgroup;
-//   * the conv row (+ bias, ReLU) goes to an LDS ring of five rows [pixel][channel] fp32; after the barrier all 256 threads pool the two pooled rows the
-//     iteration completes (3 x 3 windows as 16-byte reads over 4 channels; a window always holds a real element and everything is >= 0 behind the ReLU, so
-//     the pool's -inf padding is a plain skip) and store them channels-last, 16 bytes per lane.
-// Iteration 0 computes the block's halo rows (only conv row 16 q - 1 is used): 5 iterations for 16 useful conv rows.
+// Workgroup = (image, ROWS conv rows).  Its 2 ROWS + 7 input rows are split ONCE into the two fp16 pieces while they are staged (LDS images
+// [ci][piece][row][192 halves], zero-padded: 3 columns left, rows outside the image as zeros - no masking later); an A fragment is then four dwords at a
+// 4-byte-aligned address (two ds_read2_b32), no arithmetic in the loop.  The row pitch of 96 dwords puts the two k halves of a wave (consecutive rows) on
+// disjoint LDS banks.  Weights: host-packed in fragment order, copied to LDS once.
+// Wave = (channel half h, stream of TILES tiles); a tile = 2 conv rows x 64 columns x 32 channels = 4 x 1 MFMA tiles, 7 k steps x 12 MFMAs.  The
+// 3 x 3 / stride-2 max pool never leaves the registers: rows 2p and 2p + 1 of a tile sit in the same lane / register of two accumulators, row 2p - 1 is
+// the carry from the stream's previous tile (a stream starts with the second row of the tile above its first: 6 MFMAs per k step), and in the 32 x 32
+// C / D layout a lane holds 4 consecutive columns - the one column to the left comes from lane ^ 32 (one ds_bpermute per 4 columns).  Everything is
+// >= 0 behind the ReLU and every window holds a real element, so the pool's -inf padding is a plain skip (a zero carry / zero left neighbour).
+// Two waves per SIMD (8 per workgroup at ROWS = 16): one wave's epilogue runs under the other's MFMAs.
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -30,21 +32,31 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
-typedef float f4 __attribute__((ext_vector_type(4)));
 
-constexpr int H = 127, W = 127, HC = 64, WC = 64, HP = 32, WP = 32, CO = 64, NSTEP = 7;
-constexpr int ROWS_PER_BLOCK = 16, NBLK = HC / ROWS_PER_BLOCK, NITER = ROWS_PER_BLOCK / 4 + 1;
-constexpr int IN_PITCH = 136;                                  // floats per staged input row: 3 zeros + 127 pixels + 6 zeros
-constexpr int IN_SLOTS = 16;                                   // input rows in the ring (13 are live)
-constexpr int IN_BYTES = IN_SLOTS * 2 * IN_PITCH * 4;          // [slot][ci][IN_PITCH]
+constexpr int H = 127, W = 127, HC = 64, HP = 32, WP = 32, CO = 64, NSTEP = 7;
+constexpr int PAIRS = 68;                                      // staged pairs of padded columns per row: 3 zeros + 127 pixels + 6 zeros
+constexpr int ROW_BYTES = 384;                                 // 96 dwords: consecutive rows 32 banks apart
 constexpr int W_WORDS = NSTEP * 2 * 2 * 64;                    // 16-byte words: [k step][n tile][piece][lane]
 constexpr int W_BYTES = W_WORDS * 16;
-constexpr int ROW_PITCH = CO + 4;                              // floats per pixel of a conv row in LDS
-constexpr int ROW_BYTES = WC * ROW_PITCH * 4;
-constexpr int ROW_SLOTS = 5;
-constexpr int LDS_BYTES = W_BYTES + IN_BYTES + ROW_SLOTS * ROW_BYTES;
-static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 constexpr float LO_SCALE = 2048.f, LO_UNSCALE = 1.f / 2048.f;
+
+template <int ROWS, int STREAMS>
+struct Geo {
+  static constexpr int THREADS = 128 * STREAMS;                // 2 channel halves x STREAMS waves
+  static constexpr int NBLK = HC / ROWS;                       // workgroups per image
+  static constexpr int NROWS = 2 * ROWS + 7;                   // input rows of ROWS conv rows + the conv row above them
+  static constexpr int TILES = ROWS / 2 / STREAMS;             // tiles (pooled rows) per stream
+  static constexpr int PIECE_BYTES = NROWS * ROW_BYTES;
+  static constexpr int A_BYTES = 4 * PIECE_BYTES;              // [ci][piece]
+  static constexpr int LDS_BYTES = W_BYTES + A_BYTES;
+  static constexpr int ITEMS = NROWS * 2 * PAIRS;
+  static_assert(ROWS % (2 * STREAMS) == 0 && HC % ROWS == 0, "geometry");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+struct __attribute__((packed, aligned(4))) Frag {              // 8 halves at a 4-byte-aligned LDS address
+  unsigned d[4];
+};
 
 template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
@@ -57,170 +69,159 @@ __device__ __forceinline__ void static_for(F&& f) {
 __device__ __forceinline__ f32x16 mfma(const u32x4& a, const u32x4& b, const f32x16& c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
-__device__ __forceinline__ void split2x2(f2 v, unsigned& p0, unsigned& p1) {
+__device__ __forceinline__ void split2(f2 v, unsigned& p0, unsigned& p1) {
   const f16x2 h = __builtin_convertvector(v, f16x2);
   p0 = __builtin_bit_cast(unsigned, h);
   const f2 r = (v - __builtin_convertvector(h, f2)) * LO_SCALE;
   p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
 }
+__device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
-__global__ __launch_bounds__(HDN_BLOCK) void trunk_stem_mfma_kernel(const float* __restrict__ x, const u32x4* __restrict__ wfrag, const float* __restrict__ bias,
-                                                                    float* __restrict__ out) {
+template <int ROWS, int STREAMS>
+__global__ __launch_bounds__(128 * STREAMS) void trunk_stem_mfma_kernel(const float* __restrict__ x, const u32x4* __restrict__ wfrag,
+                                                                        const float* __restrict__ bias, float* __restrict__ out) {
+  using G = Geo<ROWS, STREAMS>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32x4* const sW = reinterpret_cast<u32x4*>(smem);
-  float* const sIn = reinterpret_cast<float*>(smem + W_BYTES);
-  float* const sRow = reinterpret_cast<float*>(smem + W_BYTES + IN_BYTES);
+  unsigned char* const sA = smem + W_BYTES;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = wave & 1, rr = wave >> 1;
   const int li = lane & 31, g = lane >> 5;
-  const int b = blockIdx.x / NBLK, q = blockIdx.x % NBLK;
+  const int b = blockIdx.x / G::NBLK, q = blockIdx.x % G::NBLK;
+  const int R0 = q * ROWS;                                     // first conv row of the workgroup
   const float* const xb = x + (size_t)b * 2 * H * W;
 
-  for (int i = tid; i < W_WORDS; i += HDN_BLOCK) sW[i] = wfrag[i];
-  // bias of this lane's two channels (C/D layout: column = lane & 31)
-  const float bias0 = bias[li], bias1 = bias[32 + li];
-
-  // input rows [y_lo, y_lo + nrow) (both channels) -> the ring: slot = row mod 16, zeros outside the image.  Work item = (row, channel, 4 padded columns)
-  auto load_item = [&](int item, int y_lo) -> f4 {
-    const int c4 = item % (IN_PITCH / 4), rc = item / (IN_PITCH / 4), ci = rc & 1, y = y_lo + (rc >> 1);
-    f4 v = f4{0.f, 0.f, 0.f, 0.f};
-    if (y >= 0 && y < H) {
-      const float* src = xb + ((size_t)ci * H + y) * W;
-      const int x0 = c4 * 4 - 3;                                         // image column of the first of the four floats
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (x0 + j >= 0 && x0 + j < W) v[j] = src[x0 + j];
-    }
-    return v;
-  };
-  auto store_item = [&](int item, int y_lo, f4 v) {
-    const int c4 = item % (IN_PITCH / 4), rc = item / (IN_PITCH / 4), ci = rc & 1, y = y_lo + (rc >> 1);
-    *reinterpret_cast<f4*>(sIn + ((size_t)((y & (IN_SLOTS - 1)) * 2 + ci)) * IN_PITCH + c4 * 4) = v;
-  };
-  constexpr int NEW_ITEMS = 8 * 2 * (IN_PITCH / 4), NPRE = cdiv(NEW_ITEMS, HDN_BLOCK);       // the 8 new rows of an iteration
-  f4 pre[NPRE];
-
-  f32x16 acc[2][2], accl[2][2];
-  int carry_slot = 0;                                                    // ring slot of conv row (first row of the iteration) - 1
+  // ---- weights -> LDS; input rows 2 R0 - 5 .. 2 R0 + 2 ROWS + 1 -> fp16 pieces in LDS (every load in flight before the first use)
+  for (int i = tid; i < W_WORDS; i += G::THREADS) sW[i] = wfrag[i];
   {
-    const int y_lo = 2 * (q * ROWS_PER_BLOCK - 4) - 3;                   // iteration 0 (the halo rows): all 13 input rows
-#if !(defined(HDN_ABLATION) && defined(STEM_EXP_NOSTAGE0))
-    for (int item = tid; item < 13 * 2 * (IN_PITCH / 4); item += HDN_BLOCK) store_item(item, y_lo, load_item(item, y_lo));
-#endif
-  }
-  __syncthreads();
-  for (int it = 0; it < NITER; ++it) {
-    const int c0 = q * ROWS_PER_BLOCK + (it - 1) * 4;                    // first conv row of the iteration; its input rows are 2 c0 - 3 .. 2 c0 + 9
-    // the next iteration's 8 new input rows (2 c0 + 10 .. 2 c0 + 17) start their way to registers under this iteration's MFMAs
-#if defined(HDN_ABLATION) && defined(STEM_EXP_NOPRE)
-    for (int k = 0; k < NPRE; ++k) pre[k] = f4{0.f, 0.f, 0.f, 0.f};
-#else
-    if (it + 1 < NITER) {
+    constexpr int NIT = cdiv(G::ITEMS, G::THREADS);
+    f2 v[NIT];
+    const int y_lo = 2 * R0 - 5;
 #pragma unroll
-      for (int k = 0; k < NPRE; ++k) {
-        const int item = tid + k * HDN_BLOCK;
-        if (item < NEW_ITEMS) pre[k] = load_item(item, 2 * c0 + 10);
+    for (int k = 0; k < NIT; ++k) {
+      const int item = min(tid + k * G::THREADS, G::ITEMS - 1);
+      const int pr = item % PAIRS, rc = item / PAIRS, ci = rc & 1, y = y_lo + (rc >> 1);
+      const int x0 = 2 * pr - 3;                               // image column of the pair's first element
+      const float* src = xb + ((size_t)ci * H + min(max(y, 0), H - 1)) * W;
+      const float a = src[min(max(x0, 0), W - 1)], c = src[min(max(x0 + 1, 0), W - 1)];
+      const bool yin = y >= 0 && y < H;
+      v[k] = f2{yin && x0 >= 0 && x0 < W ? a : 0.f, yin && x0 + 1 >= 0 && x0 + 1 < W ? c : 0.f};
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int item = tid + k * G::THREADS;
+      if (item < G::ITEMS) {
+        const int pr = item % PAIRS, rc = item / PAIRS, ci = rc & 1, slot = rc >> 1;
+        unsigned p0, p1;
+        split2(v[k], p0, p1);
+        unsigned char* dst = sA + (size_t)(ci * 2) * G::PIECE_BYTES + slot * ROW_BYTES + pr * 4;
+        *reinterpret_cast<unsigned*>(dst) = p0;
+        *reinterpret_cast<unsigned*>(dst + G::PIECE_BYTES) = p1;
       }
     }
-#endif
-    const int oy = c0 + wave;
-#if defined(HDN_ABLATION) && defined(STEM_EXP_NOMFMA)
-    const bool live = false;
-#else
-    const bool live = oy >= 0 && oy < HC && (it > 0 || wave == 3);       // (iteration 0: only the last halo row is ever read)
-#endif
-    if (live) {
+  }
+  const float bias_c = bias[32 * h + li];                      // C / D layout: column (channel) = lane & 31
+  __syncthreads();
+
+  // ---- per-lane A address pieces: k step s, half g -> r = 2 s + g = ci * 7 + ky; input row slot of conv row oy, tap ky = 2 (oy - R0) + ky + 2
+  const int Rw = R0 + rr * 2 * G::TILES;                       // the stream's first conv row
+  const unsigned char* const a_lane = sA + 4 * li + (2 * (Rw - R0)) * ROW_BYTES;
+  f32x16 carry[2];                                             // conv row above the current tile, [column half], after the ReLU
+  f32x16 acc[4], accl[4];                                      // [row of the pair * 2 + column half]
+
+  auto tile = [&](auto HaloC, int t) {
+    constexpr bool HALO = decltype(HaloC)::value;              // only the second row of the pair (the stream's carry-in)
+    constexpr int M0 = HALO ? 2 : 0;
+    const unsigned char* const a_tile = a_lane + (4 * t + 2) * ROW_BYTES;
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+    for (int mt = M0; mt < 4; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+      for (int r = 0; r < 16; ++r) {
+        acc[mt][r] = bias_c;
+        accl[mt][r] = 0.f;
+      }
+    static_for<NSTEP>([&](auto Sc) {
+      constexpr int s = decltype(Sc)::value;
+      constexpr int r0 = 2 * s, r1 = 2 * s + 1;
+      constexpr int o0 = ((r0 / 7) * 2 * G::NROWS + (r0 % 7)) * ROW_BYTES, o1 = ((r1 / 7) * 2 * G::NROWS + (r1 % 7)) * ROW_BYTES;
+      const unsigned char* const pa = a_tile + (g ? o1 : o0);
+      u32x4 a[4][2], bf[2];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[mt][nt][r] = accl[mt][nt][r] = 0.f;
-      static_for<NSTEP>([&](auto Sc) {
-        constexpr int s = decltype(Sc)::value;
-        const int r = 2 * s + g, ci = r >= 7 ? 1 : 0, ky = r - 7 * ci;
-        const int y = 2 * oy + ky - 3;
-        const float* row = sIn + ((size_t)((y & (IN_SLOTS - 1)) * 2 + ci)) * IN_PITCH;
-        u32x4 a[2][2], bf[2][2];
+      for (int mt = M0; mt < 4; ++mt)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-          const f2* p = reinterpret_cast<const f2*>(row + 2 * (32 * mt + li));      // columns 2 ox .. 2 ox + 7 of the padded row = x_in 2 ox - 3 ..
-          const f2 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
-          unsigned h[4], l[4];
-          split2x2(v0, h[0], l[0]);
-          split2x2(v1, h[1], l[1]);
-          split2x2(v2, h[2], l[2]);
-          split2x2(v3, h[3], l[3]);
-          a[mt][0] = u32x4{h[0], h[1], h[2], h[3]};
-          a[mt][1] = u32x4{l[0], l[1], l[2], l[3]};
+        for (int pc = 0; pc < 2; ++pc) {
+          const Frag f = *reinterpret_cast<const Frag*>(pa + pc * G::PIECE_BYTES + (mt >> 1) * 2 * ROW_BYTES + (mt & 1) * 128);
+          a[mt][pc] = u32x4{f.d[0], f.d[1], f.d[2], f.d[3]};
         }
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+      for (int pc = 0; pc < 2; ++pc) bf[pc] = sW[((s * 2 + h) * 2 + pc) * 64 + lane];
 #pragma unroll
-          for (int pc = 0; pc < 2; ++pc) bf[nt][pc] = sW[((s * 2 + nt) * 2 + pc) * 64 + lane];
+      for (int mt = M0; mt < 4; ++mt) accl[mt] = mfma(a[mt][1], bf[0], accl[mt]);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+      for (int mt = M0; mt < 4; ++mt) acc[mt] = mfma(a[mt][0], bf[0], acc[mt]);
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt) accl[mt][nt] = mfma(a[mt][1], bf[nt][0], accl[mt][nt]);
+      for (int mt = M0; mt < 4; ++mt) accl[mt] = mfma(a[mt][0], bf[1], accl[mt]);
+    });
+    if constexpr (HALO) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+      for (int ch = 0; ch < 2; ++ch)
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma(a[mt][0], bf[nt][0], acc[mt][nt]);
+        for (int r = 0; r < 16; ++r) carry[ch][r] = fmaxf(acc[2 + ch][r] + accl[2 + ch][r] * LO_UNSCALE, 0.f);
+    } else {
+      // rows 2p - 1 (carry), 2p, 2p + 1 -> vertical max; then columns 2 px - 1 .. 2 px + 1.  Lane (li, g) holds columns 32 ch + 8 j + 4 g + (0..3).
+      const int p = (Rw >> 1) + t;
+      float* const orow = out + (((size_t)b * HP + p) * WP + 2 * g) * CO + 32 * h + li;
+      float left0 = 0.f;                                       // column 31's value for column-half 1, j = 0 (lanes g = 0)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt) accl[mt][nt] = mfma(a[mt][0], bf[nt][1], accl[mt][nt]);
-      });
-      // ---- conv row (+ bias, ReLU) -> ring slot.  C/D layout: column (channel) = lane & 31, row (pixel) = (r & 3) + 8 (r >> 2) + 4 g
-      float* const dst = sRow + (size_t)((carry_slot + 1 + wave) % ROW_SLOTS) * (WC * ROW_PITCH) + li;
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int ch = 0; ch < 2; ++ch) {
+        float v[16], tl[4];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int px = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-          dst[px * ROW_PITCH] = fmaxf(acc[mt][0][r] + accl[mt][0][r] * LO_UNSCALE + bias0, 0.f);
-          dst[px * ROW_PITCH + 32] = fmaxf(acc[mt][1][r] + accl[mt][1][r] * LO_UNSCALE + bias1, 0.f);
+          const float v0 = acc[ch][r] + accl[ch][r] * LO_UNSCALE, v1 = acc[2 + ch][r] + accl[2 + ch][r] * LO_UNSCALE;
+          v[r] = max3(v0, v1, carry[ch][r]);                   // (carry >= 0: the ReLU of all three)
+          carry[ch][r] = fmaxf(v1, 0.f);
         }
-    }
-    __syncthreads();
-    // ---- pooling: iteration it >= 1 completes pooled rows p = 8 q + 2 (it - 1) and p + 1 (conv rows c0 - 1 .. c0 + 3 = slots carry .. carry + 4)
-#if defined(HDN_ABLATION) && defined(STEM_EXP_NOPOOL)
-    if (it > 0 && x == nullptr) {
-#else
-    if (it > 0) {
-#endif
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int item = tid + k * HDN_BLOCK;                              // (pooled row of the pair, pooled column, channel quad)
-        const int c4 = item & 15, px = (item >> 4) & 31, pr = item >> 9;
-        f4 m = f4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) tl[j] = __shfl_xor(v[4 * j + 3], 32);          // the other k half's last column of group j
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-          const int crow = c0 - 1 + 2 * pr + dy;                           // conv row 2 p - 1 + dy
-          if (crow < 0) continue;                                          // (the pool's padding row: every window holds a real element, all >= 0)
-          const float* rowp = sRow + (size_t)((carry_slot + 2 * pr + dy) % ROW_SLOTS) * (WC * ROW_PITCH) + c4 * 4;
-#pragma unroll
-          for (int dx = 0; dx < 3; ++dx) {
-            const int cx = 2 * px - 1 + dx;
-            if (cx < 0) continue;
-            const f4 v = *reinterpret_cast<const f4*>(rowp + cx * ROW_PITCH);
-            m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
-          }
+        for (int j = 0; j < 4; ++j) {
+          const float left = g ? tl[j] : (j > 0 ? tl[j - 1] : left0);               // column 32 ch + 8 j + 4 g - 1 (image column -1: 0)
+          float* const o = orow + (size_t)(16 * ch + 4 * j) * CO;
+          o[0] = max3(left, v[4 * j], v[4 * j + 1]);
+          o[CO] = max3(v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
         }
-        const int p = q * (ROWS_PER_BLOCK / 2) + 2 * (it - 1) + pr;
-        *reinterpret_cast<f4*>(out + (((size_t)b * HP + p) * WP + px) * CO + c4 * 4) = m;
+        left0 = tl[3];
       }
     }
-    if (it + 1 < NITER) {                                                  // (every wave is past its A reads: the dead ring slots can be refilled)
+  };
+
+  if (Rw > 0) {
+    tile(std::true_type{}, -1);
+  } else {
 #pragma unroll
-      for (int k = 0; k < NPRE; ++k) {
-        const int item = tid + k * HDN_BLOCK;
-        if (item < NEW_ITEMS) store_item(item, 2 * c0 + 10, pre[k]);
-      }
-    }
-    carry_slot = (carry_slot + 4) % ROW_SLOTS;                             // the iteration's last row becomes the next one's row - 1
-    __syncthreads();                                                       // (the next iteration writes conv-row slots the pool just read)
+    for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) carry[ch][r] = 0.f;
   }
+#pragma unroll 1
+  for (int t = 0; t < G::TILES; ++t) tile(std::false_type{}, t);
+}
+
+template <int ROWS, int STREAMS>
+int launch(const float* x, const void* wfrag, const float* bias, float* out, int B, hipStream_t stream) {
+  using G = Geo<ROWS, STREAMS>;
+  static PerDeviceOnce attr;
+  const int dev_ = PerDeviceOnce::device();
+  if (!attr.done(dev_)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&trunk_stem_mfma_kernel<ROWS, STREAMS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       G::LDS_BYTES);
+    if (e != hipSuccess) return -(1000 + (int)e);
+    attr.set(dev_);
+  }
+  hipLaunchKernelGGL((trunk_stem_mfma_kernel<ROWS, STREAMS>), dim3((unsigned)B * G::NBLK), dim3(G::THREADS), G::LDS_BYTES, stream, x,
+                     static_cast<const u32x4*>(wfrag), bias, out);
+  return launch_status();
 }
 
 }  // namespace stem_mc
@@ -234,15 +235,13 @@ extern "C" int hdn_trunk_stem_mfma_f32(const float* x, const void* wfrag, const 
   if (H != hdn::stem_mc::H || W != hdn::stem_mc::W || B > (1 << 20)) return HDN_E_LIMIT;       // 127-px crops only; hdn_trunk_stem_f32 takes the rest
   if (static_cast<const void*>(out) == static_cast<const void*>(x)) return HDN_E_ALIAS;
   if (!hdn::aligned16(wfrag) || !hdn::aligned16(out)) return HDN_E_LIMIT;
-  static hdn::PerDeviceOnce attr;
-  const int dev_ = hdn::PerDeviceOnce::device();
-  if (!attr.done(dev_)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hdn::stem_mc::trunk_stem_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       hdn::stem_mc::LDS_BYTES);
-    if (e != hipSuccess) return -(1000 + (int)e);
-    attr.set(dev_);
-  }
-  hipLaunchKernelGGL(hdn::stem_mc::trunk_stem_mfma_kernel, dim3((unsigned)B * hdn::stem_mc::NBLK), dim3(HDN_BLOCK), hdn::stem_mc::LDS_BYTES,
-                     static_cast<hipStream_t>(stream), x, static_cast<const hdn::stem_mc::u32x4*>(wfrag), bias, out);
-  return hdn::launch_status();
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (int rc = hdn::check_fp16_range(x, (long long)B * 2 * H * W, st)) return rc;
+  static const int rows_env = [] {
+    const char* e = getenv("HDN_STEM_ROWS");                   // A/B switch (tools/experiments): conv rows per workgroup
+    return e ? atoi(e) : 0;
+  }();
+  const int rows = rows_env ? rows_env : (B >= 48 ? 16 : 8);  // 4 workgroups per image from 48 images on, 8 below: the chip's 256 CUs covered either way
+  if (rows == 16) return hdn::stem_mc::launch<16, 4>(x, wfrag, bias, out, B, st);
+  return hdn::stem_mc::launch<8, 2>(x, wfrag, bias, out, B, st);
 }

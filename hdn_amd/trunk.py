@@ -69,7 +69,9 @@ def resnet34_homo():
     return HomoResNet((3, 4, 6, 3))
 
 
-STEM_MFMA_MIN_BATCH = 32     # hdn_trunk_stem_mfma_f32 launches 4 workgroups per image: from here on they cover half the chip's 256 CUs
+# hdn_trunk_stem_mfma_f32 from this batch on (measured, rocprofv3 kernel time, MI355X: B = 8 10.6 us against 12.8 on the vector pipe, 16: 10.8 / 18.9,
+# 32: 12.5 / 31.9, 64: 17.4 / 53.0; B = 4 is a draw); HDN_STEM_MFMA_MIN_BATCH: A/B switch
+STEM_MFMA_MIN_BATCH = int(__import__("os").environ.get("HDN_STEM_MFMA_MIN_BATCH", "8"))
 
 
 def pack_stem_mfma(weight):
@@ -96,7 +98,7 @@ class FusedStem(nn.Module):
             raise ValueError("FusedStem replaces Conv2d(2, 64, 7, 2, 3) with a folded bias")
         self.register_buffer("wT", conv.weight.detach().permute(1, 2, 3, 0).contiguous())  # [ci][ky][kx][co]
         self.register_buffer("b", conv.bias.detach().clone())
-        self.register_buffer("wfrag", pack_stem_mfma(conv.weight))                           # the matrix-core form's weights (28 KB)
+        self.register_buffer("wfrag", pack_stem_mfma(conv.weight).to(conv.weight.device))                           # the matrix-core form's weights (28 KB)
         self.channels_last = bool(channels_last)
         self.mfma_disabled = False                                                           # A/B switch (tools/experiments, tests)
 
@@ -111,7 +113,9 @@ class FusedStem(nn.Module):
 
             y = F.conv2d(x, self.wT.permute(3, 0, 1, 2), self.b, stride=2, padding=3)
             return F.max_pool2d(F.relu(y), 3, 2, 1)
-        dev = _lib.require_device(x, self.wT)
+        dev = _lib.require_device(x, self.wT, self.b)
+        if self.wfrag.device != dev:
+            raise _lib.HdnHipError(f"FusedStem weights on {self.wfrag.device}, input on {dev}")
         xs = x.detach().contiguous()  # NCHW
         Hc, Wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         Hp, Wp = (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1

@@ -1047,10 +1047,10 @@ def test_trunk_fused_stem_vs_torch(dev, shape):
         FusedStem(torch.nn.Conv2d(2, 64, 7, 2, 3, bias=False), False)
 
 
-@pytest.mark.parametrize("B", [32, 37, 64])
+@pytest.mark.parametrize("B", [8, 13, 37, 48, 64])
 def test_trunk_stem_matrix_core_form_vs_float64(dev, B):
-    """hdn_trunk_stem_mfma_f32 (the first stage as an implicit GEMM on the matrix cores, fp32 as two fp16 pieces; batches of 32 and more at
-    127 px, channels-last) against the same stage in float64 on the CPU, and against the vector-pipe kernel it stands in for: the error of
+    """hdn_trunk_stem_mfma_f32 (the first stage as an implicit GEMM on the matrix cores, fp32 as two fp16 pieces; batches of 8 and more at
+    127 px, channels-last; 8 conv rows per workgroup below 48 images, 16 from there on) against the same stage in float64 on the CPU, and against the vector-pipe kernel it stands in for: the error of
     an fp32 convolution.  Inputs at the tracker's scale (crops are 0..255 minus a mean) as well as unit normal."""
     from hdn_amd import trunk
     from hdn_amd.trunk import FusedStem
@@ -1063,7 +1063,8 @@ def test_trunk_stem_matrix_core_form_vs_float64(dev, B):
     for scale in (1.0, 120.0):
         x = torch.randn(B, 2, 127, 127, generator=g) * scale
         x[0, :, :, :5] = scale; x[1, :, -4:, :] = -scale                # (edges: the zero padding must not leak)
-        ref = F.max_pool2d(F.relu(F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), stride=2, padding=3)), 3, 2, 1)
+        with torch.no_grad():
+            ref = F.max_pool2d(F.relu(F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), stride=2, padding=3)), 3, 2, 1)
         y = st(x.to(dev))
         assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
         st.mfma_disabled = True
@@ -1546,6 +1547,14 @@ def test_fp16_piece_range_guard(dev):
         x2[1, 5, 7, 9] = -7.0e4                                          # (the magnitude counts)
         with pytest.raises(ValueError, match="HDN_E_LIMIT"):
             conv3x3s2_ds(x2.to(dev).contiguous(memory_format=cl), pack_conv3x3s2_ds(w2, wd).to(dev), torch.zeros(2 * CI, device=dev))
+        # the trunk's first stage on the matrix cores
+        from hdn_amd.trunk import FusedStem
+        st = FusedStem(torch.nn.Conv2d(2, 64, 7, 2, 3), True).to(dev)
+        xs0 = torch.randn(8, 2, 127, 127, generator=g)
+        assert torch.isfinite(st(xs0.to(dev))).all()
+        xs0[7, 1, 126, 126] = -7.0e4
+        with pytest.raises(ValueError, match="HDN_E_LIMIT"):
+            st(xs0.to(dev))
         # the heads' two kernels
         pk = HD._PackedHead()
         pk.wsp = HD._pack_conv_search([(torch.randn(64, 256, 3, 3, generator=g) * 0.03).to(dev)])

@@ -66,6 +66,8 @@ def test_c_abi_argument_errors_need_no_gpu():
     assert lib.hdn_rccl_unique_id(None) == -1 and lib.hdn_rccl_available() in (0, 1)
     assert lib.hdn_bias_relu_f32(one, None, None, 1, 4, 4, 1, None) == -1 and lib.hdn_bias_relu_f32(one, one, None, 1, 0, 4, 1, None) == -2
     assert lib.hdn_bias_relu_f32(one, one, one, 1, 4, 4, 1, None) == -4 and lib.hdn_bias_relu_f32(one, one, None, 65536, 512, 4096, 1, None) == -3
+    assert lib.hdn_trunk_stem_mfma_f32(one, None, one, one, 8, 127, 127, None) == -1 and lib.hdn_trunk_stem_mfma_f32(one, one, one, ctypes.c_void_p(32), 0, 127, 127, None) == -2
+    assert lib.hdn_trunk_stem_mfma_f32(one, one, one, ctypes.c_void_p(32), 8, 126, 127, None) == -3 and lib.hdn_trunk_stem_mfma_f32(one, one, one, one, 8, 127, 127, None) == -4
     assert lib.hdn_conv3x3_bias_relu_f32(one, one, one, None, None, None, 0, 1, 32, 64, None) == -1
     assert lib.hdn_conv3x3_bias_relu_f32(one, one, one, None, ctypes.c_void_p(32), None, 0, 1, 30, 64, None) == -3      # unsupported (S, C)
     assert lib.hdn_conv3x3_bias_relu_f32(one, one, one, None, ctypes.c_void_p(32), None, 0, 1, 32, 64, None) == -1      # needs a workspace at B = 1
@@ -717,3 +719,16 @@ def test_fused_stem_host_side():
         st(torch.randn(1, 2, 9, 9))  # in range: needs the GPU library, never a CPU fallback
     g = fold_for_inference(resnet34_homo().eval(), channels_last=False, fused_stem=True)
     assert isinstance(g.conv1, FusedStem) and isinstance(g.maxpool, torch.nn.Identity)
+    # the matrix-core form's weight stream (include/hdn_hip.h, hdn_trunk_stem_mfma_f32): [k step][n tile][piece][k half][n][8] fp16
+    from hdn_amd.trunk import pack_stem_mfma
+    w = f.conv1.weight.detach()
+    fr = pack_stem_mfma(w).view(torch.float16).reshape(7, 2, 2, 2, 32, 8)
+    assert st.wfrag.dtype == torch.int16 and st.wfrag.numel() == 7 * 2 * 2 * 64 * 8
+    for s_, tile, g_, n, j in ((0, 0, 0, 0, 0), (3, 1, 1, 17, 6), (6, 1, 1, 31, 2), (3, 0, 0, 5, 3)):
+        r = 2 * s_ + g_
+        wv = w[32 * tile + n, r // 7, r % 7, j]
+        p0 = wv.to(torch.float16)
+        assert fr[s_, tile, 0, g_, n, j] == p0 and fr[s_, tile, 1, g_, n, j] == ((wv - p0.float()) * 2048.0).to(torch.float16)
+    assert float(fr[:, :, :, :, :, 7].abs().max()) == 0.0                       # kx = 7: the zero tap that pads K to 112
+    with pytest.raises(ValueError):
+        pack_stem_mfma(torch.zeros(64, 3, 7, 7))
