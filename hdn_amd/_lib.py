@@ -43,8 +43,8 @@ SIGNATURES = {
     "hdn_frame_warp_perspective_u8": (_i, [_c_float_p] * 3 + [_i] * 3 + [ctypes.c_void_p]),
     "hdn_frame_warp_affine_cubic_u8": (_i, [_c_float_p] * 3 + [_i] * 3 + [ctypes.c_void_p]),
     "hdn_remap_linear_f32": (_i, [_c_float_p] * 4 + [_i] * 5 + [ctypes.c_void_p]),
-    "hdn_similarity_translation_f32": (_i, [_c_float_p] * 6 + [_i, _i, ctypes.c_double, ctypes.c_float, ctypes.c_double, ctypes.c_void_p]),
-    "hdn_similarity_logpolar_f32": (_i, [_c_float_p] * 5 + [_i, _i, ctypes.c_float, ctypes.c_double, ctypes.c_float, ctypes.c_void_p]),
+    "hdn_similarity_translation_f32": (_i, [_c_float_p] * 6 + [_i, _i, ctypes.c_double, ctypes.c_float, ctypes.c_double, _i, ctypes.c_void_p]),
+    "hdn_similarity_logpolar_f32": (_i, [_c_float_p] * 5 + [_i, _i, ctypes.c_float, ctypes.c_double, ctypes.c_float, _i, ctypes.c_void_p]),
     "hdn_track_prepare_f64": (_i, [_c_float_p] * 3 + [_i, ctypes.c_void_p]),
     "hdn_track_accumulate_f64": (_i, [_c_float_p] * 6 + [_i] + [_c_float_p] * 2 + [_i, ctypes.c_void_p]),
     "hdn_trunk_stem_f32": (_i, [_c_float_p] * 4 + [_i] * 4 + [ctypes.c_void_p]),

@@ -28,6 +28,14 @@ __device__ __forceinline__ float softmax2_class1(float x0, float x1) {
   return rn_mul(e1, rn_div(1.0f, rn_add(e0, e1)));
 }
 
+// score.sigmoid() of a 1-channel logit map (hdnTracker._convert_score, hdn_tracker.py:85-87) as ATen's CPU kernel forms it: 1 / (1 + exp(0 - x)).
+__device__ __forceinline__ float sigmoid1(float x) { return rn_div(1.0f, rn_add(1.0f, expf(rn_sub(0.0f, x)))); }
+
+// _convert_score of anchor i: cls_out_channels == 2 -> softmax class 1 of planes (0, 1); == 1 -> sigmoid of the single plane
+__device__ __forceinline__ float class_score(const float* __restrict__ cls, int n, int i, int cls_channels) {
+  return cls_channels == 1 ? sigmoid1(cls[i]) : softmax2_class1(cls[i], cls[n + i]);
+}
+
 // np.argmax: the largest value, the lowest index among equals.
 __device__ __forceinline__ void wave_argmax(double& v, int& i) {
 #pragma unroll
@@ -41,9 +49,10 @@ __device__ __forceinline__ void wave_argmax(double& v, int& i) {
 __global__ __launch_bounds__(HDN_WAVE) void similarity_translation_kernel(const float* __restrict__ cls, const float* __restrict__ loc_c,
                                                                           const double* __restrict__ window, const float* __restrict__ points,
                                                                           const double* __restrict__ seq, double* __restrict__ state, int S,
-                                                                          double window_influence, float stride_c, double exemplar) {
+                                                                          double window_influence, float stride_c, double exemplar,
+                                                                          int cls_channels) {
   const int b = blockIdx.x, lane = threadIdx.x, n = S * S;
-  cls += size_t(b) * 2 * n;
+  cls += size_t(b) * cls_channels * n;
   loc_c += size_t(b) * 2 * n;
   seq += size_t(b) * HDN_SIM_SEQ_DOUBLES;
   state += size_t(b) * HDN_SIM_STATE_DOUBLES;
@@ -51,7 +60,7 @@ __global__ __launch_bounds__(HDN_WAVE) void similarity_translation_kernel(const 
   double best = -INFINITY;
   int best_i = 0x7fffffff;
   for (int i = lane; i < n; i += HDN_WAVE) {
-    const float sc = softmax2_class1(cls[i], cls[n + i]);
+    const float sc = class_score(cls, n, i, cls_channels);
     const double ps = (double)rn_mul(sc, keep) + window[i] * window_influence;
     if (ps > best) { best = ps; best_i = i; }  // ascending i per lane: the first maximum stays
   }
@@ -69,7 +78,7 @@ __global__ __launch_bounds__(HDN_WAVE) void similarity_translation_kernel(const 
     }
     const double cx = dcx + seq[0], cy = dcy + seq[1];
     state[0] = dcx; state[1] = dcy; state[2] = cx; state[3] = cy; state[4] = stop;
-    state[5] = (double)softmax2_class1(cls[best_i], cls[n + best_i]);  // best_score = score[best_idx] (:205)
+    state[5] = (double)class_score(cls, n, best_i, cls_channels);  // best_score = score[best_idx] (:205)
     state[6] = (double)best_i; state[7] = best;
     // parameters of the second search crop, get_subwindow(img, self.center_pos, INSTANCE_SIZE, s_x, avg) (:191-193)
     state[8] = cx; state[9] = cy; state[10] = seq[3]; state[11] = seq[5]; state[12] = seq[6]; state[13] = seq[7];
@@ -86,16 +95,16 @@ __device__ __forceinline__ void mat3_mul(const double* a, const double* b, doubl
 __global__ __launch_bounds__(HDN_WAVE) void similarity_logpolar_kernel(const float* __restrict__ cls_lp, const float* __restrict__ loc_lp,
                                                                        const float* __restrict__ points_lp, const double* __restrict__ seq,
                                                                        double* __restrict__ state, int S, float stride_lp, double mag,
-                                                                       float rot_unit) {
+                                                                       float rot_unit, int cls_channels) {
   const int b = blockIdx.x, lane = threadIdx.x, n = S * S;
-  cls_lp += size_t(b) * 2 * n;
+  cls_lp += size_t(b) * cls_channels * n;
   loc_lp += size_t(b) * 4 * n;
   seq += size_t(b) * HDN_SIM_SEQ_DOUBLES;
   state += size_t(b) * HDN_SIM_STATE_DOUBLES;
   double best = -INFINITY;  // (float32 scores compared as doubles: exact)
   int best_i = 0x7fffffff;
   for (int i = lane; i < n; i += HDN_WAVE) {
-    const double sc = (double)softmax2_class1(cls_lp[i], cls_lp[n + i]);
+    const double sc = (double)class_score(cls_lp, n, i, cls_channels);
     if (sc > best) { best = sc; best_i = i; }
   }
   wave_argmax(best, best_i);
@@ -217,22 +226,22 @@ __global__ __launch_bounds__(HDN_WAVE) void track_accumulate_kernel(const double
 
 extern "C" int hdn_similarity_translation_f32(const float* cls, const float* loc_c, const double* window, const float* points,
                                               const double* seq, double* state, int B, int S, double window_influence, float stride_c,
-                                              double exemplar_size, void* stream) {
+                                              double exemplar_size, int cls_channels, void* stream) {
   if (!cls || !loc_c || !window || !points || !seq || !state) return HDN_E_NULL;
-  if (B <= 0 || S <= 0 || !(exemplar_size > 0)) return HDN_E_SHAPE;
+  if (B <= 0 || S <= 0 || !(exemplar_size > 0) || (cls_channels != 1 && cls_channels != 2)) return HDN_E_SHAPE;
   if (S > 1024) return HDN_E_LIMIT;
   hipLaunchKernelGGL(hdn::similarity_translation_kernel, dim3(B), dim3(HDN_WAVE), 0, (hipStream_t)stream, cls, loc_c, window, points, seq, state,
-                     S, window_influence, stride_c, exemplar_size);
+                     S, window_influence, stride_c, exemplar_size, cls_channels);
   return hdn::launch_status();
 }
 
 extern "C" int hdn_similarity_logpolar_f32(const float* cls_lp, const float* loc_lp, const float* points_lp, const double* seq, double* state,
-                                           int B, int S, float stride_lp, double mag, float rot_unit, void* stream) {
+                                           int B, int S, float stride_lp, double mag, float rot_unit, int cls_channels, void* stream) {
   if (!cls_lp || !loc_lp || !points_lp || !seq || !state) return HDN_E_NULL;
-  if (B <= 0 || S <= 0) return HDN_E_SHAPE;
+  if (B <= 0 || S <= 0 || (cls_channels != 1 && cls_channels != 2)) return HDN_E_SHAPE;
   if (S > 1024) return HDN_E_LIMIT;
   hipLaunchKernelGGL(hdn::similarity_logpolar_kernel, dim3(B), dim3(HDN_WAVE), 0, (hipStream_t)stream, cls_lp, loc_lp, points_lp, seq, state, S,
-                     stride_lp, mag, rot_unit);
+                     stride_lp, mag, rot_unit, cls_channels);
   return hdn::launch_status();
 }
 

@@ -36,13 +36,15 @@ class TrackerConfig:
     output_size_lp: int = 13          # cfg.TRAIN.OUTPUT_SIZE_LP
     context_amount: float = 0.5       # cfg.TRACK.CONTEXT_AMOUNT
     window_influence: float = 0.1632532824922313   # cfg.TRACK.WINDOW_INFLUENCE (config.py default: 0.45)
+    cls_out_channels: int = 2         # cfg.BAN.KWARGS.cls_out_channels: 2 = softmax class 1, 1 = sigmoid (hdn_tracker.py:84-91)
 
     @classmethod
     def from_reference(cls, cfg):
         """From the reference's yacs node (hdn.core.config.cfg) after the experiment YAML was merged."""
         return cls(exemplar_size=int(cfg.TRACK.EXEMPLAR_SIZE), instance_size=int(cfg.TRACK.INSTANCE_SIZE), base_size=int(cfg.TRACK.BASE_SIZE),
                    stride=int(cfg.POINT.STRIDE), stride_lp=int(cfg.POINT.STRIDE_LP), output_size_lp=int(cfg.TRAIN.OUTPUT_SIZE_LP),
-                   context_amount=float(cfg.TRACK.CONTEXT_AMOUNT), window_influence=float(cfg.TRACK.WINDOW_INFLUENCE))
+                   context_amount=float(cfg.TRACK.CONTEXT_AMOUNT), window_influence=float(cfg.TRACK.WINDOW_INFLUENCE),
+                   cls_out_channels=int(cfg.BAN.KWARGS.cls_out_channels))
 
     @property
     def score_size(self) -> int:      # hdn_tracker_proj_e2e.py:24-25
@@ -76,6 +78,8 @@ class SimilarityDecoder:
         self.dev = torch.device(device)
         c = self.cfg
         self.S, self.S_lp = c.score_size, c.output_size_lp
+        if c.cls_out_channels not in (1, 2):                          # hdn_tracker.py:84-91 has exactly these two decodes
+            raise ValueError(f"cls_out_channels must be 1 (sigmoid) or 2 (softmax), got {c.cls_out_channels}")
         hanning = np.hanning(self.S)                                  # hdn_tracker_proj_e2e.py:26-29
         self.window = torch.from_numpy(np.outer(hanning, hanning).flatten()).to(self.dev)
         self.points = torch.from_numpy(generate_points(c.stride, self.S)).to(self.dev)
@@ -98,28 +102,28 @@ class SimilarityDecoder:
                 raise ValueError(f"{name} must be a contiguous float64 GPU tensor of {B} x {n}")
 
     def translation(self, cls, loc_c, seq, state):
-        """cls [B,2,S,S], loc_c [B,2,S,S] -> state[:, 0:14] (include/hdn_hip.h)."""
+        """cls [B,cls_out_channels,S,S], loc_c [B,2,S,S] -> state[:, 0:14] (include/hdn_hip.h)."""
         dev = _lib.require_device(cls, loc_c)
         B = cls.shape[0]
-        cls, loc_c = self._maps(cls, 2, self.S, "cls"), self._maps(loc_c, 2, self.S, "loc_c")
+        cls, loc_c = self._maps(cls, self.cfg.cls_out_channels, self.S, "cls"), self._maps(loc_c, 2, self.S, "loc_c")
         self._records(seq, state, B)
         c = self.cfg
         with _lib.device_guard(dev):
             rc = _lib.load().hdn_similarity_translation_f32(_lib.ptr(cls), _lib.ptr(loc_c), _lib.ptr(self.window), _lib.ptr(self.points),
                                                             _lib.ptr(seq), _lib.ptr(state), B, self.S, c.window_influence, 8.0,
-                                                            float(c.exemplar_size), _lib.stream_ptr(dev))   # (_convert_c hard-codes 8)
+                                                            float(c.exemplar_size), c.cls_out_channels, _lib.stream_ptr(dev))   # (_convert_c hard-codes 8)
         _lib.check(rc, "similarity translation decode")
 
     def logpolar(self, cls_lp, loc_lp, seq, state):
-        """cls_lp [B,2,S,S], loc_lp [B,4,S,S] + the record the translation call wrote -> state[:, 16:46]."""
+        """cls_lp [B,cls_out_channels,S,S], loc_lp [B,4,S,S] + the record the translation call wrote -> state[:, 16:46]."""
         dev = _lib.require_device(cls_lp, loc_lp)
         B = cls_lp.shape[0]
-        cls_lp, loc_lp = self._maps(cls_lp, 2, self.S_lp, "cls_lp"), self._maps(loc_lp, 4, self.S_lp, "loc_lp")
+        cls_lp, loc_lp = self._maps(cls_lp, self.cfg.cls_out_channels, self.S_lp, "cls_lp"), self._maps(loc_lp, 4, self.S_lp, "loc_lp")
         self._records(seq, state, B)
         with _lib.device_guard(dev):
             rc = _lib.load().hdn_similarity_logpolar_f32(_lib.ptr(cls_lp), _lib.ptr(loc_lp), _lib.ptr(self.points_lp), _lib.ptr(seq),
                                                          _lib.ptr(state), B, self.S_lp, float(self.cfg.stride_lp), self.mag, self.rot_unit,
-                                                         _lib.stream_ptr(dev))
+                                                         self.cfg.cls_out_channels, _lib.stream_ptr(dev))
         _lib.check(rc, "similarity log-polar decode")
 
 

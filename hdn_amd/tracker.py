@@ -215,19 +215,13 @@ class DeviceTrackerHomo(HomoTracker):
     BatchNorm-folded, epilogue-fused form (hdn_amd.backbone; fold_backbone=False or HDN_FOLD_BACKBONE=0: left as they are)."""
 
     def __init__(self, model, graph: bool = None, iterations: int = 1, cfg: TrackerConfig = None, fold_backbone: bool = None):
-        cls_out = 2
         if cfg is None:
             cfg = TrackerConfig()
             try:
                 from hdn.core.config import cfg as ref_cfg     # the reference's node, after tools/test.py merged the YAML
-                cfg = TrackerConfig.from_reference(ref_cfg)
-                cls_out = int(ref_cfg.BAN.KWARGS.cls_out_channels)
+                cfg = TrackerConfig.from_reference(ref_cfg)    # (incl. cfg.BAN.KWARGS.cls_out_channels: 2 = softmax, 1 = sigmoid decode)
             except ImportError:
                 pass
-        if cls_out != 2:
-            # hdnTracker._convert_score's sigmoid branch (hdn_tracker.py:85-87); the shipped configurations use the 2-class softmax
-            raise NotImplementedError("hdn_amd's device decode implements cfg.BAN.KWARGS.cls_out_channels == 2 (softmax); run the "
-                                      "reference's host tracker for the 1-channel sigmoid head (python -m hdn_amd.run --host-tracker ...)")
         if graph is None:
             graph = os.environ.get("HDN_TRACKER_GRAPH", "1") not in ("", "0")
         model.eval()

@@ -236,19 +236,21 @@ int hdn_remap_linear_f32(const float* src, const float* mapx, const float* mapy,
  *   log-polar call:   [16] scale_delta [17] rot_delta [18] best_idx_lp [19] score_lp[best_idx_lp]  [20..28] H_sim (row major)
  *                     [32..37] 2x3 matrix of img_rot_around_center(img, cx, cy, w, h, -rot_delta) (transform.py:69-100)
  *                     [40..45] hdn_subwindow_f32 params of the homography crop (cx, cy, init_s_z_sm * scale_delta, avg)
- * cls[B,2,S,S], loc_c[B,2,S,S], cls_lp[B,2,S,S], loc_lp[B,4,S,S]: the heads' outputs (ModelBuilder.track_new / track_new_lp,
+ * cls[B,cls_channels,S,S], loc_c[B,2,S,S], cls_lp[B,cls_channels,S,S], loc_lp[B,4,S,S]: the heads' outputs (ModelBuilder.track_new / track_new_lp,
  * hdn/models/model_builder_e2e_unconstrained_v2.py:131-158).  window[S*S] float64 and points[S*S,2] float32: the tables the
  * reference's constructor builds (hdn_tracker_proj_e2e.py:26-32).  mag = log(EXEMPLAR / 2) / EXEMPLAR and
  * rot_unit = (float)(2 pi / EXEMPLAR) are passed in as the host computed them.  The log-polar call reads the state record the
  * translation call wrote.  np.argmax semantics (first maximum); NaN logits are not ordered the way numpy orders them.
+ * cls_channels = cfg.BAN.KWARGS.cls_out_channels: 2 -> score = softmax over the two planes, class 1 (every shipped configuration);
+ * 1 -> score = sigmoid of the single plane (hdn_tracker.py:85-87); anything else HDN_E_SHAPE.
  */
 #define HDN_SIM_SEQ_DOUBLES 8
 #define HDN_SIM_STATE_DOUBLES 48
 int hdn_similarity_translation_f32(const float* cls, const float* loc_c, const double* window, const float* points, const double* seq,
                                    double* state, int B, int S, double window_influence, float stride_c, double exemplar_size,
-                                   void* stream);
+                                   int cls_channels, void* stream);
 int hdn_similarity_logpolar_f32(const float* cls_lp, const float* loc_lp, const float* points_lp, const double* seq, double* state, int B,
-                                int S, float stride_lp, double mag, float rot_unit, void* stream);
+                                int S, float stride_lp, double mag, float rot_unit, int cls_channels, void* stream);
 
 /*
  * The tracker's 3x3 float64 bookkeeping, one lane per sequence (BASELINE configs[3]): the numpy lines of

@@ -33,8 +33,12 @@ def hanning_window(score_size):
 
 
 def convert_score(score):
-    """hdnTracker._convert_score (hdn_tracker.py:84-91), cls_out_channels = 2: softmax over the two classes, class 1."""
-    score = score.permute(1, 2, 3, 0).contiguous().view(2, -1).permute(1, 0)
+    """hdnTracker._convert_score (hdn_tracker.py:84-91): cls_out_channels = 2 (every shipped configuration) -> softmax over the two
+    classes, class 1; cls_out_channels = 1 -> sigmoid of the single map (:85-87).  The channel count is the map's own."""
+    ch = score.shape[1]
+    if ch == 1:
+        return score.permute(1, 2, 3, 0).contiguous().view(-1).sigmoid().detach().cpu().numpy()
+    score = score.permute(1, 2, 3, 0).contiguous().view(ch, -1).permute(1, 0)
     return score.softmax(1).detach()[:, 1].cpu().numpy()
 
 

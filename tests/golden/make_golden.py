@@ -631,6 +631,57 @@ def gen_similarity(ref_te, cfg):
     save("similarity", **out)
 
 
+def gen_similarity_sigmoid(ref_te, cfg):
+    """The decode of gen_similarity under cfg.BAN.KWARGS.cls_out_channels = 1: hdnTracker._convert_score takes its sigmoid branch
+    (hdn_tracker.py:85-87) on 1-channel score maps, for both heads.  No shipped YAML selects it; the reference's code has it, so the
+    device decode has it too (hdn_similarity_*_f32, cls_channels = 1).  The tracker is built under the switched configuration (its
+    constructor reads the key, hdn_tracker_proj_e2e.py:28) and track_new is EXECUTED as in gen_similarity."""
+    g = rng(1010)
+    wi_prod = float(cfg.TRACK.WINDOW_INFLUENCE)
+
+    def maps(peak=None, peak_lp=None, cls_bias=0.0, lp_bias=0.0, loc_sigma=0.4, lp_sigma=0.3):
+        cls = g.standard_normal((1, 1, 25, 25)).astype(np.float32) + np.float32(cls_bias)
+        loc = (loc_sigma * g.standard_normal((1, 2, 25, 25))).astype(np.float32)
+        cls_lp = g.standard_normal((1, 1, 13, 13)).astype(np.float32) + np.float32(lp_bias)
+        loc_lp = (lp_sigma * g.standard_normal((1, 4, 13, 13))).astype(np.float32)
+        if peak is not None:
+            cls[0, 0, peak[0], peak[1]] += np.float32(6.0)
+        if peak_lp is not None:
+            cls_lp[0, 0, peak_lp[0], peak_lp[1]] += np.float32(6.0)
+        return cls, loc, cls_lp, loc_lp
+
+    cases = []
+    # 0 / 1: clear peaks (centre / border); 2: translation gate (window influence 0, sigmoid < 0.05 everywhere); 3: log-polar gate
+    # (every sigmoid < 0.25); 4: exact ties on a symmetric pair of cells; 5: saturated logits (sigmoid rounds to 1.0f: the first of them wins)
+    cases.append(dict(m=maps((13, 11), (6, 7)), size=(150.0, 100.0), pos=(320.0, 180.0), wi=wi_prod))
+    cases.append(dict(m=maps((3, 21), (1, 11), loc_sigma=1.5, lp_sigma=1.0), size=(201.0, 77.0), pos=(611.5, 402.25), wi=wi_prod))
+    cases.append(dict(m=maps(None, (5, 5), cls_bias=-9.0), size=(150.0, 100.0), pos=(300.0, 200.0), wi=0.0))
+    cases.append(dict(m=maps((12, 12), None, lp_bias=-6.0), size=(90.0, 120.0), pos=(100.0, 80.0), wi=wi_prod))
+    c4 = maps(None, None, cls_bias=-1.0, lp_bias=-1.0)
+    for (i, j) in ((9, 15), (15, 9)):
+        c4[0][0, 0, i, j] = np.float32(5.0)
+    for (i, j) in ((8, 3), (3, 8)):
+        c4[2][0, 0, i, j] = np.float32(7.0)
+    cases.append(dict(m=c4, size=(150.0, 100.0), pos=(320.0, 180.0), wi=wi_prod))
+    c5 = maps((12, 12), (6, 6))
+    c5[0][0, 0, 12, 12] = np.float32(40.0)
+    c5[2][0, 0, 4:7, 6] = np.float32(30.0)
+    cases.append(dict(m=c5, size=(150.0, 100.0), pos=(320.0, 180.0), wi=wi_prod))
+
+    prev = int(cfg.BAN.KWARGS.cls_out_channels)
+    cfg.BAN.KWARGS.cls_out_channels = 1
+    try:
+        trk = ref_te.hdnTrackerHomo(torch.nn.Module())
+        assert trk.cls_out_channels == 1
+        out = {"window": trk.window, "points": trk.points, "points_lp": trk.points_lp, "n_cases": np.array(len(cases)),
+               "window_influence_production": np.array(wi_prod)}
+        out.update(_similarity_cases_through_track_new(ref_te, cfg, cases))
+    finally:
+        cfg.BAN.KWARGS.cls_out_channels = prev
+        cfg.TRACK.WINDOW_INFLUENCE = wi_prod
+    save("similarity_sigmoid", **out)
+
+
 def gen_config5(ref_te, ref_ban, ref_bt, cfg):
     """BASELINE configs[4] at the tracker level: cfg.TRACK.INSTANCE_SIZE = 303 (score map 31 x 31, hdn_tracker_proj_e2e.py:24-25;
     37 x 37 search features -> conv_search 35 x 35 -> 31 x 31, ban.py:73-78).
@@ -1005,6 +1056,9 @@ def main():
     if want("similarity"):
         import hdn.tracker.hdn_tracker_proj_e2e as ref_te
         gen_similarity(ref_te, cfg)
+    if want("similarity_sigmoid"):
+        import hdn.tracker.hdn_tracker_proj_e2e as ref_te
+        gen_similarity_sigmoid(ref_te, cfg)
     if want("similarity303", "heads256_cfg5", "frame303"):
         import hdn.models.head.ban as ref_ban
         import hdn.tracker.base_tracker as ref_bt

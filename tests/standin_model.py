@@ -40,14 +40,14 @@ def _seed_head(head, seed, loc_scale):
 
 
 class StandInSiamese(nn.Module):
-    def __init__(self, hm_net, seed: int = 11, loc_scale: float = 0.4, loc_scale_lp: float = 0.05):
+    def __init__(self, hm_net, seed: int = 11, loc_scale: float = 0.4, loc_scale_lp: float = 0.05, cls_out: int = 2):
         super().__init__()
         from hdn_amd import heads as HD
         from hdn_amd.logpolar import STN_Polar
         torch.manual_seed(seed)
         self.backbone = _levels(seed + 1)
-        self.head = _seed_head(HD.MultiBAN([C] * 3, 2, weighted=True), seed + 2, loc_scale)
-        self.head_lp = _seed_head(HD.MultiCircBAN([C] * 3, 2, weighted=True), seed + 3, loc_scale_lp)
+        self.head = _seed_head(HD.MultiBAN([C] * 3, cls_out, weighted=True), seed + 2, loc_scale)
+        self.head_lp = _seed_head(HD.MultiCircBAN([C] * 3, cls_out, weighted=True), seed + 3, loc_scale_lp)
         self.logpolar_instance = STN_Polar(255)
         self.hm_net = hm_net
         yy, xx = torch.meshgrid(torch.arange(25.0), torch.arange(25.0), indexing="ij")
@@ -55,9 +55,17 @@ class StandInSiamese(nn.Module):
         yy, xx = torch.meshgrid(torch.arange(13.0), torch.arange(13.0), indexing="ij")
         self.register_buffer("cls_prior_lp", 6.0 * torch.exp(-((yy - 6.2) ** 2 + (xx - 5.9) ** 2) / 8.0).reshape(1, 1, 13, 13))
         self.zf = self.zf_lp = None
+        self.cls_out = cls_out     # cfg.BAN.KWARGS.cls_out_channels: 2 (shipped) or 1 (the sigmoid decode, hdn_tracker.py:85-87)
 
     def feature_extractor(self, x):
         return [F.relu(cv(x)) for cv in self.backbone]
+
+    @staticmethod
+    def with_prior(cls, prior):
+        """The centre prior on the class-1 logits (2 channels) / on the single logit map (1 channel; -3: sigmoid stays low off the peak)."""
+        if cls.shape[1] == 1:
+            return cls + prior - 3.0
+        return torch.cat([cls[:, 0:1], cls[:, 1:2] + prior], dim=1)
 
     @staticmethod
     def neck(feats):   # AdjustLayer's centre crop for maps smaller than 20 (hdn/models/neck/neck.py): 15 -> 7
@@ -69,8 +77,7 @@ class StandInSiamese(nn.Module):
 
     def track_new(self, x, delta=[0, 0]):
         cls, loc_c = self.head(self.zf, self.neck(self.feature_extractor(x)))
-        cls = torch.cat([cls[:, 0:1], cls[:, 1:2] + self.cls_prior], dim=1)
-        return {"cls": cls, "loc_c": loc_c}
+        return {"cls": self.with_prior(cls, self.cls_prior), "loc_c": loc_c}
 
     def track_new_lp(self, x, delta=[0, 0]):
         polar = getattr(self, "_polar0", None)
@@ -79,8 +86,7 @@ class StandInSiamese(nn.Module):
             self._polar0 = polar
         x_lp, grid = self.logpolar_instance(x, polar, delta)
         cls_lp, loc_lp = self.head_lp(self.zf_lp, self.feature_extractor(x_lp))
-        cls_lp = torch.cat([cls_lp[:, 0:1], cls_lp[:, 1:2] + self.cls_prior_lp], dim=1)
-        return {"x_lp": x_lp, "cls_lp": cls_lp, "loc_lp": loc_lp, "grid": grid}
+        return {"x_lp": x_lp, "cls_lp": self.with_prior(cls_lp, self.cls_prior_lp), "loc_lp": loc_lp, "grid": grid}
 
 
 class StandInSiameseCPU:
@@ -103,9 +109,9 @@ class StandInSiameseCPU:
 
     def track_new(self, x, delta=[0, 0]):
         cls, loc_c = self.O.multi_ban(self.zf, StandInSiamese.neck(self.feature_extractor(x)), self.sd, circular=False)
-        return {"cls": torch.cat([cls[:, 0:1], cls[:, 1:2] + self.cls_prior], dim=1), "loc_c": loc_c}
+        return {"cls": StandInSiamese.with_prior(cls, self.cls_prior), "loc_c": loc_c}
 
     def track_new_lp(self, x, delta=[0, 0]):
         x_lp, grid = self.O.logpolar_sample(x, torch.zeros((x.shape[0], 2)), delta, image_sz=255)
         cls_lp, loc_lp = self.O.multi_ban(self.zf_lp, self.feature_extractor(x_lp), self.sd_lp, circular=True)
-        return {"x_lp": x_lp, "cls_lp": torch.cat([cls_lp[:, 0:1], cls_lp[:, 1:2] + self.cls_prior_lp], dim=1), "loc_lp": loc_lp, "grid": grid}
+        return {"x_lp": x_lp, "cls_lp": StandInSiamese.with_prior(cls_lp, self.cls_prior_lp), "loc_lp": loc_lp, "grid": grid}

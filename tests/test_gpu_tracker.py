@@ -86,7 +86,8 @@ def _decode_case(dev, g, n, dec_cache, instance_size=255):
     k = f"c{n}__"
     wi = float(g[k + "window_influence"])
     if wi not in dec_cache:
-        dec_cache[wi] = SimilarityDecoder(dev, TrackerConfig(window_influence=wi, instance_size=instance_size))
+        dec_cache[wi] = SimilarityDecoder(dev, TrackerConfig(window_influence=wi, instance_size=instance_size,
+                                                             cls_out_channels=int(g[k + "cls"].shape[1])))
     dec = dec_cache[wi]
     size = g[k + "size"]
     seq = sequence_constants(g[k + "center_pos"], float(g[k + "init_s_z"]), float(np.floor(np.sqrt(size[0] * size[1]))), [10.0, 20.0, 30.0], dec.cfg)
@@ -98,11 +99,12 @@ def _decode_case(dev, g, n, dec_cache, instance_size=255):
     return {kk: v.cpu().numpy() for kk, v in state_fields(state.view(-1)).items()}, seq
 
 
-@pytest.mark.parametrize("fixture,instance_size,S", [("similarity", 255, 25), ("similarity303", 303, 31)])
+@pytest.mark.parametrize("fixture,instance_size,S", [("similarity", 255, 25), ("similarity303", 303, 31), ("similarity_sigmoid", 255, 25)])
 def test_similarity_decode_golden(dev, fixture, instance_size, S):
     """hdn_similarity_translation_f32 / hdn_similarity_logpolar_f32 against the reference's own decode
     (tests/golden/similarity.npz: hdn_tracker_proj_e2e.py:169-214 on seeded head maps, both gates, exact argmax ties;
-    similarity303.npz: the same from a tracker the reference built under INSTANCE_SIZE = 303 — BASELINE configs[4], S = 31).
+    similarity303.npz: the same from a tracker the reference built under INSTANCE_SIZE = 303 — BASELINE configs[4], S = 31;
+    similarity_sigmoid.npz: a tracker built under cls_out_channels = 1, _convert_score's sigmoid branch hdn_tracker.py:85-87).
     Indices, gates and the centre are exact; scores / scale / rotation within 1e-6 (expf / exp of the device library vs the
     host's: at most an ulp of float32); H_sim within 1e-9 relative to its largest entry."""
     from conftest import load_golden
@@ -228,7 +230,9 @@ def _similarity_pair(dev, fc_bias_scale=1.0, **standin_kw):
     sd = {k: v.clone() for k, v in net_cpu.ShareFeature.state_dict().items()}
     ref = HomoTrackerOracle(sd, lambda f: net_cpu.fc(net_cpu.avgpool(net_cpu.backbone(f)).flatten(1)), similarity=SimilarityOracle(cpu))
     twin = twin.to(dev)
-    make = lambda **kw: HomoTracker(twin.hm_net, similarity=DeviceSimilarity(twin), **kw)
+    from hdn_amd.similarity import TrackerConfig
+    cfg = TrackerConfig(cls_out_channels=twin.cls_out)
+    make = lambda **kw: HomoTracker(twin.hm_net, similarity=DeviceSimilarity(twin, cfg), cfg=cfg, **kw)
     return ref, make, twin
 
 
@@ -266,6 +270,34 @@ def test_sequence_stream_with_similarity_device_vs_cpu(dev):
     assert max(errs) <= 2e-3, errs
     assert trk.host_syncs - syncs0 == len(frames) - 1          # ONE read (4 corners + best_score) per frame
     print("similarity sequence corner errors (px):", " ".join(f"{e:.2e}" for e in errs))
+
+
+def test_sequence_stream_sigmoid_heads_device_vs_cpu(dev):
+    """cfg.BAN.KWARGS.cls_out_channels = 1: 1-channel classification maps decoded with a sigmoid (hdnTracker._convert_score,
+    hdn_tracker.py:85-87) instead of the 2-class softmax.  The whole frame loop on the device (eager and as one hipGraph) against the
+    CPU restatement, as in the 2-class test above; the decode itself is pinned to the executed reference by similarity_sigmoid.npz."""
+    from synth_sequence import make_sequence, success_4pts_error
+    frames, corners, init = make_sequence(n_frames=8, frame_hw=(360, 640), target_wh=(150, 100), seed=9)
+    ref, make, twin = _similarity_pair(dev, cls_out=1)
+    assert twin.head.box2.cls.head[3].weight.shape[0] == 1
+    trk, trk_g = make(), make(graph=True)
+    for t_ in (ref, trk, trk_g):
+        t_.init(frames[0], init["bbox"], init["poly"], init["gt_points"], init["first_point"])
+    errs, moved = [], 0
+    for t in range(1, len(frames)):
+        a, ag, b = trk.track_new(t, frames[t]), trk_g.track_new(t, frames[t]), ref.track_new(t, frames[t])
+        s = b["similarity"]
+        st = trk.similarity.state.view(-1).cpu().numpy()
+        assert abs(st[0] - s["dcx"]) <= 2e-2 and abs(st[1] - s["dcy"]) <= 2e-2, (t, st[:2], s["dcx"], s["dcy"])
+        assert abs(st[16] - s["scale_delta"]) <= 1e-3 and abs(st[17] - s["rot_delta"]) <= 1e-3, (t, st[16:18], s)
+        moved += int(abs(s["dcx"]) + abs(s["dcy"]) > 0.05 and abs(s["scale_delta"] - 1) > 1e-3 and abs(s["rot_delta"]) > 1e-3)
+        assert abs(float(a["best_score"]) - s["best_score"]) <= 1e-4 and 0.0 < s["best_score"] < 1.0
+        errs.append(success_4pts_error(a["points"], b["points"]))
+        assert success_4pts_error(a["points"], ag["points"]) <= 1e-3
+    assert moved == len(frames) - 1
+    assert errs[0] <= 2e-4 and max(errs) <= 2e-3, errs
+    assert trk_g._graph is not None
+    print("sigmoid-head sequence corner errors (px):", " ".join(f"{e:.2e}" for e in errs))
 
 
 def test_graphed_tracker_with_similarity_matches_eager(dev):

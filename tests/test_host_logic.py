@@ -93,10 +93,12 @@ def test_c_abi_argument_errors_need_no_gpu():
     assert lib.hdn_conv3x3_finish_f32(one, 4, None, None, 0, two, 1, 32, 64, None) == -1 and lib.hdn_conv3x3_finish_f32(one, 4, one, None, 0, one, 1, 32, 64, None) == -4
     assert lib.hdn_conv3x3_finish_f32(one, 4, one, None, 2, two, 1, 32, 64, None) == -2 and lib.hdn_conv3x3_finish_f32(one, 4, one, None, 0, two, 1, 32, 66, None) == -2
     assert lib.hdn_avgpool_fc_f32(one, one, None, two, 1, 512, 16, 17, 1, None) == -3 and lib.hdn_avgpool_fc_f32(one, one, None, None, 1, 512, 16, 8, 1, None) == -1
-    assert lib.hdn_similarity_translation_f32(one, one, one, one, one, None, 1, 25, 0.16, 8.0, 127.0, None) == -1
-    assert lib.hdn_similarity_translation_f32(one, one, one, one, one, one, 1, 0, 0.16, 8.0, 127.0, None) == -2
-    assert lib.hdn_similarity_logpolar_f32(one, one, None, one, one, 1, 13, 8.0, 0.03, 0.05, None) == -1
-    assert lib.hdn_similarity_logpolar_f32(one, one, one, one, one, 0, 13, 8.0, 0.03, 0.05, None) == -2
+    assert lib.hdn_similarity_translation_f32(one, one, one, one, one, None, 1, 25, 0.16, 8.0, 127.0, 2, None) == -1
+    assert lib.hdn_similarity_translation_f32(one, one, one, one, one, one, 1, 0, 0.16, 8.0, 127.0, 2, None) == -2
+    assert lib.hdn_similarity_logpolar_f32(one, one, None, one, one, 1, 13, 8.0, 0.03, 0.05, 2, None) == -1
+    assert lib.hdn_similarity_logpolar_f32(one, one, one, one, one, 0, 13, 8.0, 0.03, 0.05, 2, None) == -2
+    assert lib.hdn_similarity_translation_f32(one, one, one, one, one, one, 1, 25, 0.16, 8.0, 127.0, 3, None) == -2      # cls_out_channels: 1 or 2
+    assert lib.hdn_similarity_logpolar_f32(one, one, one, one, one, 1, 13, 8.0, 0.03, 0.05, 0, None) == -2
     with pytest.raises(_lib.HdnHipError, match="ncclResult_t 3"):
         _lib.check(-2003, "x")
     with pytest.raises(ValueError):

@@ -305,13 +305,14 @@ def test_refine_step_composes_normalised_inverse():
     np.testing.assert_array_equal(w[:, :4], np.repeat(img[:, :1], 4, axis=1))
 
 
-@pytest.mark.parametrize("fixture,S,n_expected", [("similarity", 25, 7), ("similarity303", 31, 5)])
+@pytest.mark.parametrize("fixture,S,n_expected", [("similarity", 25, 7), ("similarity303", 31, 5), ("similarity_sigmoid", 25, 6)])
 def test_similarity_decode_oracle_vs_reference(fixture, S, n_expected):
     """oracle.tracker_oracle's restatement of hdn_tracker_proj_e2e.py:164-214 against tests/golden/similarity.npz (the
     reference's own _convert_score / _convert_c / _convert_logpolar_simi / window / rot_scale_around_center_shift_tran on
     seeded head maps: both gates, exact argmax ties, the identity branches of H_sim) and similarity303.npz (the same on a
-    tracker built under INSTANCE_SIZE = 303: 31 x 31 score map, BASELINE configs[4]).  Same numpy / ATen calls in the same
-    order: bit-exact."""
+    tracker built under INSTANCE_SIZE = 303: 31 x 31 score map, BASELINE configs[4]) and similarity_sigmoid.npz (a tracker built under
+    cfg.BAN.KWARGS.cls_out_channels = 1: 1-channel maps through _convert_score's sigmoid branch, hdn_tracker.py:85-87; exact ties and
+    saturated scores included).  Same numpy / ATen calls in the same order: bit-exact."""
     from oracle import tracker_oracle as TO
     g = load_golden(fixture)
     np.testing.assert_array_equal(TO.hanning_window(S), g["window"])
