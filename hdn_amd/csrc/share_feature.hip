@@ -418,6 +418,29 @@ __global__ __launch_bounds__(HDN_BLOCK) void share_feature_rows_kernel(const flo
     st.ab[ch] = float2v{prm[SF_ALPHA + ch], prm[SF_BETA + ch]};
     asm volatile("" : "+v"(st.ab[ch]));  // resident in VGPRs (the compiler would keep the uniform values in SGPRs and copy per use)
   }
+  if (rows_per_strip == 1) {
+    // one output row per wave (the tracker's B = 1 calls: most SIMDs hold a single wave, nothing hides a load): all seven input rows of the
+    // strip are asked for at once - one round trip instead of seven in a row (10.9 -> see profiles/round5_conv3x3.txt, B = 1, cold caches)
+    float2v xr[7];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) xr[q] = load_row(c, c.ra - 3 + q);
+#if defined(HDN_ABLATION) && defined(SF_EXP_NOSTEPS)   // measurement build: launch + the rows' round trip only
+    if (c.m0) c.dst[size_t(c.ra) * c.W + c.col0] = xr[0].x + xr[1].x + xr[2].x + xr[3].x + xr[4].x + xr[5].x + xr[6].x;
+    return;
+#endif
+#if defined(HDN_ABLATION) && defined(SF_EXP_ONESTEP)   // measurement build: one of the seven steps
+    step<0, false>(st, c, c.ra + 3, xr[6]);
+    return;
+#endif
+    step<0, false>(st, c, c.ra - 3, xr[0]);
+    step<1, false>(st, c, c.ra - 2, xr[1]);
+    step<2, false>(st, c, c.ra - 1, xr[2]);
+    step<0, false>(st, c, c.ra, xr[3]);
+    step<1, false>(st, c, c.ra + 1, xr[4]);
+    step<2, false>(st, c, c.ra + 2, xr[5]);
+    step<0, false>(st, c, c.ra + 3, xr[6]);
+    return;
+  }
   const int last = c.rb + 2;  // output row rb-1 is finished by step rb+2
   const int full_lo = c.ra + 3, full_hi = min(c.rb + 2, H - 1);
   int i = c.ra - 3;

@@ -241,7 +241,10 @@ extern "C" int hdn_trunk_stem_mfma_f32(const float* x, const void* wfrag, const 
     const char* e = getenv("HDN_STEM_ROWS");                   // A/B switch (tools/experiments): conv rows per workgroup
     return e ? atoi(e) : 0;
   }();
-  const int rows = rows_env ? rows_env : (B >= 48 ? 16 : 8);  // 4 workgroups per image from 48 images on, 8 below: the chip's 256 CUs covered either way
+  // 4 workgroups per image from 48 images on, 8 from 8 on, 16 for the tracker's few-image calls (B = 1, cold: 8.8 us against 11.7 at 8 rows, 12.0 on
+  // the vector pipe): the shorter the workgroup's chain of dependent steps the better when nothing else is on the chip
+  const int rows = rows_env ? rows_env : (B >= 48 ? 16 : B >= 8 ? 8 : 4);
   if (rows == 16) return hdn::stem_mc::launch<16, 4>(x, wfrag, bias, out, B, st);
+  if (rows == 4) return hdn::stem_mc::launch<4, 2>(x, wfrag, bias, out, B, st);
   return hdn::stem_mc::launch<8, 2>(x, wfrag, bias, out, B, st);
 }

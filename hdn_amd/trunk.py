@@ -71,7 +71,7 @@ def resnet34_homo():
 
 # hdn_trunk_stem_mfma_f32 from this batch on (measured, rocprofv3 kernel time, MI355X: B = 8 10.6 us against 12.8 on the vector pipe, 16: 10.8 / 18.9,
 # 32: 12.5 / 31.9, 64: 17.4 / 53.0; B = 4 is a draw); HDN_STEM_MFMA_MIN_BATCH: A/B switch
-STEM_MFMA_MIN_BATCH = int(__import__("os").environ.get("HDN_STEM_MFMA_MIN_BATCH", "8"))
+STEM_MFMA_MIN_BATCH = int(__import__("os").environ.get("HDN_STEM_MFMA_MIN_BATCH", "1"))
 
 
 def pack_stem_mfma(weight):
