@@ -1,6 +1,6 @@
 // Experiment (round 5): what does a grid-wide barrier cost on MI355X (256 workgroups x 512 threads, one per CU)?  It prices a persistent
 // B = 1 trunk kernel (33 dependent convolutions in one launch) against today's 4.6 us per dependent graph node.
-//   hipcc --offload-arch=gfx950 -O3 -o grid_barrier_cost grid_barrier_cost.hip && ./grid_barrier_cost
+//   hipcc --offload-arch=gfx950 -O3 -o tools/experiments/grid_barrier_cost tools/experiments/grid_barrier_cost.hip (then through gpurun)
 #include <hip/hip_runtime.h>
 #include <hip/hip_cooperative_groups.h>
 #include <cstdio>
