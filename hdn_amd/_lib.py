@@ -48,6 +48,7 @@ SIGNATURES = {
     "hdn_track_prepare_f64": (_i, [_c_float_p] * 3 + [_i, ctypes.c_void_p]),
     "hdn_track_accumulate_f64": (_i, [_c_float_p] * 6 + [_i] + [_c_float_p] * 2 + [_i, ctypes.c_void_p]),
     "hdn_trunk_stem_f32": (_i, [_c_float_p] * 4 + [_i] * 4 + [ctypes.c_void_p]),
+    "hdn_conv3x3s2_v2_f32": (_i, [_c_float_p, ctypes.c_void_p, _c_float_p, _c_float_p, _c_float_p] + [_i] * 3 + [ctypes.c_void_p]),
     "hdn_trunk_stem_mfma_f32": (_i, [_c_float_p, ctypes.c_void_p, _c_float_p, _c_float_p] + [_i] * 3 + [ctypes.c_void_p]),
     "hdn_bias_relu_f32": (_i, [_c_float_p] * 3 + [_i] * 4 + [ctypes.c_void_p]),
     "hdn_avgpool_fc_f32": (_i, [_c_float_p] * 4 + [_i] * 5 + [ctypes.c_void_p]),

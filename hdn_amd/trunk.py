@@ -245,6 +245,22 @@ def pack_conv3x3s2_ds(weight, ds_weight):
     return _pack(w4, _MC_SIDE.get(CO, 0), CI, 2)
 
 
+def pack_conv3x3s2_ds_v2(weight, ds_weight):
+    """[2C, C, 3, 3] + [2C, C, 1, 1] fp32 weights -> the fragment-ordered stream of hdn_conv3x3s2_v2_f32 (include/hdn_hip.h):
+    [2C / 64][C / 32 chunks][2 k steps][10 steps: nine taps + the downsample branch][2 n tiles][piece][k half][n][8] fp16 bit patterns."""
+    import torch
+
+    CO, CI = weight.shape[0], weight.shape[1]
+    if tuple(weight.shape) != (2 * CI, CI, 3, 3) or tuple(ds_weight.shape) != (2 * CI, CI, 1, 1) or CI % 32 or CO % 64:
+        raise ValueError(f"pack_conv3x3s2_ds_v2 takes [2C, C, 3, 3] and [2C, C, 1, 1] weights, got {tuple(weight.shape)}, {tuple(ds_weight.shape)}")
+    w10 = torch.zeros(CO, CI, 10, dtype=torch.float32)
+    w10[:, :, :9] = weight.detach().float().cpu().reshape(CO, CI, 9)
+    w10[:, :, 9] = ds_weight.detach().float().cpu()[:, :, 0, 0]
+    # co = nb * 64 + nt * 32 + n;  ci = chunk * 32 + wk * 16 + g * 8 + e
+    t = _split_f16(w10).reshape(SPLIT_PIECES, CO // 64, 2, 32, CI // 32, 2, 2, 8, 10)      # [pc, nb, nt, n, chunk, wk, g, e, step]
+    return t.permute(1, 4, 5, 8, 2, 0, 6, 3, 7).contiguous().view(torch.int16).reshape(-1)  # [nb, chunk, wk, step, nt, pc, g, n, e]
+
+
 def conv3x3_bias_relu(x, wpacked, bias, residual=None, wpacked_v2=None):
     """relu(conv3x3(x) + bias (+ residual)) through hdn_conv3x3_bias_relu_f32 — or, given `wpacked_v2` (pack_conv3x3_v2) and a batch of
     V2_MIN_BATCH or more, through hdn_conv3x3_v2_f32; x / residual channels-last [B,C,S,S] float32."""
@@ -282,8 +298,9 @@ MATRIX_CORE_CHANNELS = (64, 128, 256, 512)
 _MC_SIDE = {64: 32, 128: 16, 256: 8, 512: 4}
 
 
-def conv3x3s2_ds(x, wpacked, bias):
-    """(relu(conv3x3/s2(x) + bias), conv1x1/s2(x)) through hdn_conv3x3s2_ds_f32; x channels-last [B,C,2S,2S] -> two [B,2C,S,S]."""
+def conv3x3s2_ds(x, wpacked, bias, wpacked_v2=None):
+    """(relu(conv3x3/s2(x) + bias), conv1x1/s2(x)) through hdn_conv3x3s2_ds_f32 - or, given `wpacked_v2` (pack_conv3x3s2_ds_v2) and a batch of
+    V2_MIN_BATCH or more, through hdn_conv3x3s2_v2_f32; x channels-last [B,C,2S,2S] -> two [B,2C,S,S]."""
     import torch
 
     from . import _lib
@@ -294,6 +311,16 @@ def conv3x3s2_ds(x, wpacked, bias):
     if H != W or H % 2 or not x.is_contiguous(memory_format=cl):
         raise ValueError("conv3x3s2_ds: square, even-sided channels-last input")
     S, CO = H // 2, 2 * CI
+    if wpacked_v2 is not None and B >= V2_MIN_BATCH:
+        if wpacked_v2.dtype != torch.int16 or wpacked_v2.device != dev or wpacked_v2.numel() != SPLIT_PIECES * 10 * CI * CO or bias.numel() != CO:
+            raise ValueError("conv3x3s2_ds: v2 weights must come from pack_conv3x3s2_ds_v2 for this channel count, on the input's device")
+        out = torch.empty((B, CO, S, S), dtype=torch.float32, device=dev, memory_format=cl)
+        out_ds = torch.empty_like(out, memory_format=cl)
+        with _lib.device_guard(dev):
+            rc = _lib.load().hdn_conv3x3s2_v2_f32(_lib.ptr(x), _lib.ptr(wpacked_v2), _lib.ptr(bias), _lib.ptr(out), _lib.ptr(out_ds), B, S, CI,
+                                                  _lib.stream_ptr(dev))
+        _lib.check(rc, "conv3x3s2_v2")
+        return out, out_ds
     if wpacked.dtype != torch.int16 or wpacked.device != dev or wpacked.numel() != SPLIT_PIECES * 3 * 4 * CI * CO or bias.numel() != CO:
         raise ValueError("conv3x3s2_ds: weights must come from pack_conv3x3s2_ds for this channel count, on the input's device")
     out = torch.empty((B, CO, S, S), dtype=torch.float32, device=dev, memory_format=cl)
@@ -438,14 +465,19 @@ class FusedBasicBlock(nn.Module):
         self._v2 = {}      # the large-batch packing of p1 / p2 (pack_conv3x3_v2), made at the first batch of V2_MIN_BATCH or more
 
     def _packed_v2(self, which, batch):
-        if batch < V2_MIN_BATCH or FusedBasicBlock.v2_disabled:
+        """which: 1 / 2 = the block's stride-1 convolutions, "s2" = the stride-2 convolution + downsample branch."""
+        if batch < V2_MIN_BATCH or FusedBasicBlock.v2_disabled or (which == "s2" and FusedBasicBlock.v2_s2_disabled):
             return None
         if which not in self._v2:
-            w = self.w1 if which == 1 else self.w2
-            self._v2[which] = pack_conv3x3_v2(w).to(w.device)
+            if which == "s2":
+                self._v2[which] = pack_conv3x3s2_ds_v2(self.w1, self.wd).to(self.w1.device)
+            else:
+                w = self.w1 if which == 1 else self.w2
+                self._v2[which] = pack_conv3x3_v2(w).to(w.device)
         return self._v2[which]
 
     v2_disabled = False        # A/B switch (tests, tools/experiments)
+    v2_s2_disabled = False     # ... of the stride-2 stages' large-batch form alone
 
     def forward(self, x):
         import torch
@@ -461,7 +493,7 @@ class FusedBasicBlock(nn.Module):
             x = x.finish()
         if (self.p1s2 is not None and x.is_contiguous(memory_format=torch.channels_last)
                 and x.shape[2] == x.shape[3] == 2 * _MC_SIDE.get(2 * x.shape[1], -1)):
-            y, idt = conv3x3s2_ds(x, self.p1s2, self.b1)       # stride-2 convolution + the downsample branch from one staged input
+            y, idt = conv3x3s2_ds(x, self.p1s2, self.b1, wpacked_v2=self._packed_v2("s2", x.shape[0]))   # stride-2 convolution + the downsample branch from one staged input
         else:
             if self.p1 is not None and shape_ok(x):
                 y = conv3x3_bias_relu(x, self.p1, self.b1, wpacked_v2=self._packed_v2(1, x.shape[0]))

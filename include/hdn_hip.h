@@ -408,6 +408,18 @@ int hdn_conv3x3_v2_f32(const float* x, const void* wpacked, const float* bias, c
                        long long workspace_bytes, int B, int S, int C, void* stream);
 
 /*
+ * hdn_conv3x3s2_ds_f32's large-batch form (round 5, conv3x3s2.hip; hdn_amd.trunk dispatches from B = 24): the same two outputs,
+ *   out = relu(conv3x3/s2/p1(x, w) + bias),  out_ds = conv1x1/s2(x, w_ds) (raw),  x [B,2S,2S,CI] -> out, out_ds [B,S,S,2 CI] (channels-last),
+ * (S, CI) = (16, 64), (8, 128), (4, 256) (else HDN_E_LIMIT), no workspace.  Same arithmetic as above (two fp16 pieces, three products, hi / lo
+ * fp32 accumulators; summation order: chunks of 32 input channels, inside a chunk the 9 taps, the two 16-channel k steps added last).
+ * wpacked: [2 CI / 64][CI / 32][2 k steps][10 steps][2 n tiles][2 pieces][k half g][n][8] fp16 - element e of lane (g, n) = piece of
+ * w[co = 64 block + 32 tile + n][ci = 32 chunk + 16 k step + 8 g + e][tap t = 3 ky + kx] for step t < 9, of w_ds[co][ci] for step 9
+ * (hdn_amd.trunk.pack_conv3x3s2_ds_v2); 16-byte aligned.  Replaces conv1 + bn1 + relu and downsample(x) of a BasicBlock with stride 2,
+ * backbone/resnet.py:78-94.
+ */
+int hdn_conv3x3s2_v2_f32(const float* x, const void* wpacked, const float* bias, float* out, float* out_ds, int B, int S, int CI, void* stream);
+
+/*
  * The same convolutions chained (ABI 5, the tracker's B = 1, where every launch is a dependent step of ~5 us and the launches that only
  * add K slices up were half of the trunk's): a convolution writes its raw K-slice sums and the NEXT convolution finishes them while it
  * stages its input, so a BasicBlock is two launches instead of four.

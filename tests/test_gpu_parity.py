@@ -1226,6 +1226,42 @@ def test_conv3x3s2_ds_matrix_core_vs_float64(dev, CI, S, B):
             assert e <= 4 * e_ref + 1e-5 * scale, (e, e_ref, scale)
 
 
+@pytest.mark.parametrize("CI,S", [(64, 16), (128, 8), (256, 4)])
+@pytest.mark.parametrize("B", [24, 33, 64])
+def test_conv3x3s2_v2_large_batch_form_vs_float64(dev, CI, S, B):
+    """hdn_conv3x3s2_v2_f32 (round 5: the stride-2 stages in the producer / consumer form, even / odd column images, the downsample branch as a
+    tenth tap step) against float64 convolutions and against hdn_conv3x3s2_ds_f32: the same bound as every other convolution kernel here; partial
+    tiles (B = 33: the 4 x 4 stage's tiles hold four images), borders, both outputs; bit-reproducible."""
+    from hdn_amd.trunk import pack_conv3x3s2_ds, pack_conv3x3s2_ds_v2, conv3x3s2_ds, V2_MIN_BATCH
+    assert B >= V2_MIN_BATCH
+    g = torch.Generator().manual_seed(3 * CI + B)
+    CO = 2 * CI
+    w = torch.randn(CO, CI, 3, 3, generator=g) * (2.0 / (9 * CI)) ** 0.5
+    wd = torch.randn(CO, CI, 1, 1, generator=g) * (1.0 / CI) ** 0.5
+    b = torch.randn(CO, generator=g) * 0.1
+    x = torch.randn(B, CI, 2 * S, 2 * S, generator=g).clamp_min_(0)
+    x[0, :, 0, :] = 3.0; x[B - 1, :, :, 2 * S - 1] = 2.0                 # (borders: the padding row / column must stay zero)
+    cl = torch.channels_last
+    wp, wp2 = pack_conv3x3s2_ds(w, wd).to(dev), pack_conv3x3s2_ds_v2(w, wd).to(dev)
+    xd = x.to(dev).contiguous(memory_format=cl)
+    y, yd = conv3x3s2_ds(xd, wp, b.to(dev), wpacked_v2=wp2)
+    y2, yd2 = conv3x3s2_ds(xd, wp, b.to(dev), wpacked_v2=wp2)
+    y1, yd1 = conv3x3s2_ds(xd, wp, b.to(dev))
+    assert torch.equal(y, y2) and torch.equal(yd, yd2) and y.shape == (B, CO, S, S) and yd.is_contiguous(memory_format=cl)
+    nb = min(B, 5)
+    for sl in (slice(0, nb), slice(B - nb, B)):
+        t = torch.relu(F.conv2d(x[sl].double(), w.double(), b.double(), stride=2, padding=1))
+        td = F.conv2d(x[sl].double(), wd.double(), None, stride=2)
+        ref = torch.relu(F.conv2d(x[sl], w, b, stride=2, padding=1))
+        refd = F.conv2d(x[sl], wd, None, stride=2)
+        for got, got1, truth, r32 in ((y, y1, t, ref), (yd, yd1, td, refd)):
+            e, e_ref, scale = float((got[sl].cpu().double() - truth).abs().max()), float((r32.double() - truth).abs().max()), float(truth.abs().max())
+            assert e <= 4 * e_ref + 1e-5 * scale, (e, e_ref, scale)
+            assert float((got[sl] - got1[sl]).abs().max()) <= 2e-6 * scale        # the round-4 kernel: another summation order, same pieces
+    with pytest.raises(ValueError):
+        conv3x3s2_ds(xd, wp, b.to(dev), wpacked_v2=wp2[:-8])
+
+
 @pytest.mark.parametrize("C,S", [(64, 32), (128, 16), (256, 8), (512, 4)])
 @pytest.mark.parametrize("B", [1, 2, 3, 9, 16])
 def test_conv3x3_chain_vs_unchained_and_float64(dev, C, S, B):
