@@ -68,6 +68,10 @@ def test_c_abi_argument_errors_need_no_gpu():
     assert lib.hdn_bias_relu_f32(one, one, one, 1, 4, 4, 1, None) == -4 and lib.hdn_bias_relu_f32(one, one, None, 65536, 512, 4096, 1, None) == -3
     assert lib.hdn_trunk_stem_mfma_f32(one, None, one, one, 8, 127, 127, None) == -1 and lib.hdn_trunk_stem_mfma_f32(one, one, one, ctypes.c_void_p(32), 0, 127, 127, None) == -2
     assert lib.hdn_trunk_stem_mfma_f32(one, one, one, ctypes.c_void_p(32), 8, 126, 127, None) == -3 and lib.hdn_trunk_stem_mfma_f32(one, one, one, one, 8, 127, 127, None) == -4
+    assert lib.hdn_conv3x3s2_v2_f32(one, one, one, ctypes.c_void_p(32), None, 24, 16, 64, None) == -1
+    assert lib.hdn_conv3x3s2_v2_f32(one, one, one, ctypes.c_void_p(32), ctypes.c_void_p(48), 0, 16, 64, None) == -2
+    assert lib.hdn_conv3x3s2_v2_f32(one, one, one, ctypes.c_void_p(32), ctypes.c_void_p(32), 24, 16, 64, None) == -4   # the two outputs alias
+    assert lib.hdn_conv3x3s2_v2_f32(one, one, one, ctypes.c_void_p(32), ctypes.c_void_p(48), 24, 16, 128, None) == -3  # not one of the trunk's stages
     assert lib.hdn_conv3x3_bias_relu_f32(one, one, one, None, None, None, 0, 1, 32, 64, None) == -1
     assert lib.hdn_conv3x3_bias_relu_f32(one, one, one, None, ctypes.c_void_p(32), None, 0, 1, 30, 64, None) == -3      # unsupported (S, C)
     assert lib.hdn_conv3x3_bias_relu_f32(one, one, one, None, ctypes.c_void_p(32), None, 0, 1, 32, 64, None) == -1      # needs a workspace at B = 1
@@ -703,6 +707,23 @@ def test_committed_bench_line_follows_the_contract(name):
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["value"] > 0
+
+
+def test_stride2_v2_weight_stream_layout():
+    """pack_conv3x3s2_ds_v2: the fragment order include/hdn_hip.h documents for hdn_conv3x3s2_v2_f32, checked entry by entry."""
+    from hdn_amd.trunk import pack_conv3x3s2_ds_v2
+    g = torch.Generator().manual_seed(3)
+    CI, CO = 64, 128
+    w, wd = torch.randn(CO, CI, 3, 3, generator=g), torch.randn(CO, CI, 1, 1, generator=g)
+    fr = pack_conv3x3s2_ds_v2(w, wd).view(torch.float16).reshape(CO // 64, CI // 32, 2, 10, 2, 2, 2, 32, 8)   # [nb, chunk, wk, step, nt, pc, g, n, e]
+    assert fr.numel() == 2 * 10 * CI * CO
+    for nb, ch, wk, st, nt, g_, n, e in ((0, 0, 0, 0, 0, 0, 0, 0), (1, 1, 1, 9, 1, 1, 31, 7), (0, 1, 0, 4, 1, 0, 5, 3), (1, 0, 1, 8, 0, 1, 17, 6)):
+        co, ci = 64 * nb + 32 * nt + n, 32 * ch + 16 * wk + 8 * g_ + e
+        wv = wd[co, ci, 0, 0] if st == 9 else w[co, ci, st // 3, st % 3]
+        p0 = wv.to(torch.float16)
+        assert fr[nb, ch, wk, st, nt, 0, g_, n, e] == p0 and fr[nb, ch, wk, st, nt, 1, g_, n, e] == ((wv - p0.float()) * 2048.0).to(torch.float16)
+    with pytest.raises(ValueError):
+        pack_conv3x3s2_ds_v2(w, wd[:, :32])
 
 
 def test_fused_stem_host_side():
