@@ -8,6 +8,8 @@ so its state_dict loads unchanged.  This is a dense MFMA-bound contraction and l
 """
 from __future__ import annotations
 
+import os
+
 import torch.nn as nn
 
 
@@ -69,9 +71,9 @@ def resnet34_homo():
     return HomoResNet((3, 4, 6, 3))
 
 
-# hdn_trunk_stem_mfma_f32 from this batch on (measured, rocprofv3 kernel time, MI355X: B = 8 10.6 us against 12.8 on the vector pipe, 16: 10.8 / 18.9,
-# 32: 12.5 / 31.9, 64: 17.4 / 53.0; B = 4 is a draw); HDN_STEM_MFMA_MIN_BATCH: A/B switch
-STEM_MFMA_MIN_BATCH = int(__import__("os").environ.get("HDN_STEM_MFMA_MIN_BATCH", "1"))
+# hdn_trunk_stem_mfma_f32 from this batch on (measured, rocprofv3 kernel time, MI355X, matrix cores / vector pipe: B = 1 8.8 / 12.0 us with cold caches,
+# 8: 10.6 / 12.8, 16: 10.8 / 18.9, 32: 12.5 / 31.9, 64: 17.4 / 53.0); HDN_STEM_MFMA_MIN_BATCH: A/B switch
+STEM_MFMA_MIN_BATCH = int(os.environ.get("HDN_STEM_MFMA_MIN_BATCH", "1"))
 
 
 def pack_stem_mfma(weight):
