@@ -36,6 +36,7 @@ SIGNATURES = {
     "hdn_warp_f32": (_i, [_c_float_p] * 3 + [_i] * 4 + [ctypes.c_void_p]),
     "hdn_warp_count_f32": (_i, [_c_float_p] * 4 + [_i] * 4 + [ctypes.c_void_p]),
     "hdn_dlt_warp_f32": (_i, [_c_float_p] * 5 + [_i] * 3 + [ctypes.c_void_p]),
+    "hdn_dlt_warp_strided_f32": (_i, [_c_float_p] * 3 + [ctypes.c_longlong] + [_c_float_p] * 2 + [_i] * 3 + [ctypes.c_void_p]),
     "hdn_refine_warp_f32": (_i, [_c_float_p] * 4 + [_i] * 3 + [ctypes.c_void_p]),
     "hdn_l1_score_f32": (_i, [_c_float_p] * 3 + [_i, ctypes.c_float, ctypes.c_void_p]),
     "hdn_l1_score2_f32": (_i, [_c_float_p] * 4 + [_i, ctypes.c_float, ctypes.c_void_p]),

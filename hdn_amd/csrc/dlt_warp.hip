@@ -242,7 +242,7 @@ __global__ __launch_bounds__(HDN_BLOCK) void dlt_warp_kernel(const float* __rest
                                                              const float* __restrict__ off,
                                                              const float* __restrict__ img,
                                                              float* __restrict__ H_out, float* __restrict__ warped,
-                                                             int H, int W) {
+                                                             int H, int W, long long img_batch_stride) {
   __shared__ float sH[9];
   __shared__ double sA[72];
   const int b = blockIdx.y;
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(HDN_BLOCK) void dlt_warp_kernel(const float* __rest
 #pragma unroll
   for (int q = 0; q < WARP_PX_PER_THREAD; ++q) {
     const int pix = base + q * HDN_BLOCK;
-    if (pix < H * W) warp_pixel(img + size_t(b) * HW, th, warped + size_t(b) * HW, pix / W, pix - (pix / W) * W, 1, H, W);
+    if (pix < H * W) warp_pixel(img + size_t(b) * img_batch_stride, th, warped + size_t(b) * HW, pix / W, pix - (pix / W) * W, 1, H, W);
   }
 }
 
@@ -338,16 +338,21 @@ int hdn_warp_f32(const float* img, const float* theta, float* out, int B, int C,
   return hdn_warp_count_f32(img, theta, out, nullptr, B, C, H, W, stream);
 }
 
-int hdn_dlt_warp_f32(const float* h4p, const float* off, const float* img, float* H_out, float* warped, int B, int H,
-                     int W, void* stream) {
+int hdn_dlt_warp_strided_f32(const float* h4p, const float* off, const float* img, long long img_batch_stride, float* H_out, float* warped, int B,
+                             int H, int W, void* stream) {
   if (!h4p || !off || !img || !H_out || !warped) return HDN_E_NULL;
-  if (B <= 0 || H <= 1 || W <= 1) return HDN_E_SHAPE;
+  if (B <= 0 || H <= 1 || W <= 1 || img_batch_stride < (long long)H * W) return HDN_E_SHAPE;
   if (B > 65535 || (long long)H * W > (1LL << 30)) return HDN_E_LIMIT;
   if (warped == img) return HDN_E_ALIAS;
   dim3 grid(hdn::cdiv(H * W, hdn::WARP_PX_PER_BLOCK), B);
   hipLaunchKernelGGL(hdn::dlt_warp_kernel, grid, dim3(HDN_BLOCK), 0, static_cast<hipStream_t>(stream), h4p, off, img,
-                     H_out, warped, H, W);
+                     H_out, warped, H, W, img_batch_stride);
   return hdn::launch_status();
+}
+
+int hdn_dlt_warp_f32(const float* h4p, const float* off, const float* img, float* H_out, float* warped, int B, int H,
+                     int W, void* stream) {
+  return hdn_dlt_warp_strided_f32(h4p, off, img, (long long)H * W, H_out, warped, B, H, W, stream);
 }
 
 int hdn_l1_score_f32(const float* a, const float* b, float* out, int n, float scale, void* stream) {

@@ -98,12 +98,16 @@ def dlt_warp(h4p: torch.Tensor, off_set: torch.Tensor, img: torch.Tensor):
     if tuple(h4p.shape) != (B, 8) or tuple(off_set.shape) != (B, 8):
         raise ValueError(f"h4p / off_set must be [{B},8], got {tuple(h4p.shape)} and {tuple(off_set.shape)}")
     dev = _lib.require_device(h4p, off_set, img)
-    p, o, im = h4p.detach().contiguous(), off_set.detach().contiguous(), img.detach().contiguous()
+    p, o, im = h4p.detach().contiguous(), off_set.detach().contiguous(), img.detach()
+    # one channel of a [B,C,H,W] tensor (HomoModelBuilder.forward: org_imgs[:, :1]) is read in place: rows and pixels contiguous, images C * H * W apart
+    if not (im.stride(3) == 1 and im.stride(2) == W) or (B > 1 and im.stride(0) < H * W):
+        im = im.contiguous()
+    bstride = im.stride(0) if B > 1 else H * W
     Hm = torch.empty((B, 9), dtype=torch.float32, device=dev)
     warped = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
     with _lib.device_guard(dev):
-        rc = _lib.load().hdn_dlt_warp_f32(_lib.ptr(p), _lib.ptr(o), _lib.ptr(im), _lib.ptr(Hm), _lib.ptr(warped), B, H, W,
-                                          _lib.stream_ptr(dev))
+        rc = _lib.load().hdn_dlt_warp_strided_f32(_lib.ptr(p), _lib.ptr(o), _lib.ptr(im), bstride, _lib.ptr(Hm), _lib.ptr(warped), B, H, W,
+                                                  _lib.stream_ptr(dev))
     _lib.check(rc, "dlt_warp")
     return Hm.view(B, 3, 3), warped
 

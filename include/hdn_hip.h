@@ -150,6 +150,10 @@ int hdn_warp_count_f32(const float* img, const float* theta, float* out, unsigne
  */
 int hdn_dlt_warp_f32(const float* h4p, const float* off, const float* img, float* H_out, float* warped,
                      int B, int H, int W, void* stream);
+/* The same with the images `img_batch_stride` floats apart (>= H * W): one channel of a [B,C,H,W] tensor without a copy (HomoModelBuilder.forward
+ * warps channel 0 of the pair, homo_model_builder.py:166-170). */
+int hdn_dlt_warp_strided_f32(const float* h4p, const float* off, const float* img, long long img_batch_stride, float* H_out, float* warped, int B,
+                             int H, int W, void* stream);
 
 /*
  * One step of the tracker's refinement loop (hdn/tracker/hdn_tracker_proj_e2e.py:242-250; trip count 1 in the shipped

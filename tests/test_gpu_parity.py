@@ -548,6 +548,15 @@ def test_dlt_warp_fused_golden_and_full_batch(dev):
     pidx, base = O.full_patch_indices(64, 127, 127)
     two = hdn_amd.transform(127, 127, Minv, Hm, M, img.to(dev), pidx.to(dev), base.to(dev))
     assert float((two - w).abs().max()) < 1e-5
+    # one channel of a [B,2,H,W] pair read in place (hdn_dlt_warp_strided_f32: no copy of org_imgs[:, :1]); odd views still work
+    pair = torch.stack([img[:, 0], torch.full_like(img[:, 0], 7.0)], dim=1).to(dev)          # channel 1 must never be sampled
+    Hs, ws = hdn_amd.dlt_warp(h4p.to(dev), off.to(dev), pair[:, :1])
+    assert torch.equal(ws, w) and torch.equal(Hs, Hm)
+    Ht, wt = hdn_amd.dlt_warp(h4p.to(dev), off.to(dev), pair.transpose(2, 3)[:, :1].transpose(2, 3))  # same view, round-tripped strides
+    assert torch.equal(wt, w)
+    wide = torch.zeros(64, 1, 127, 130, device=dev)
+    wide[..., :127] = img.to(dev)
+    assert torch.equal(hdn_amd.dlt_warp(h4p.to(dev), off.to(dev), wide[..., :127])[1], w)      # (row pitch != W: copied first)
 
 
 # --------------------------------------------------------------------------- correlation heads (§8a row 11, §8f rank 1)
@@ -1047,10 +1056,10 @@ def test_trunk_fused_stem_vs_torch(dev, shape):
         FusedStem(torch.nn.Conv2d(2, 64, 7, 2, 3, bias=False), False)
 
 
-@pytest.mark.parametrize("B", [8, 13, 37, 48, 64])
+@pytest.mark.parametrize("B", [1, 5, 8, 13, 37, 48, 64])
 def test_trunk_stem_matrix_core_form_vs_float64(dev, B):
-    """hdn_trunk_stem_mfma_f32 (the first stage as an implicit GEMM on the matrix cores, fp32 as two fp16 pieces; batches of 8 and more at
-    127 px, channels-last; 8 conv rows per workgroup below 48 images, 16 from there on) against the same stage in float64 on the CPU, and against the vector-pipe kernel it stands in for: the error of
+    """hdn_trunk_stem_mfma_f32 (the first stage as an implicit GEMM on the matrix cores, fp32 as two fp16 pieces; every batch size at
+    127 px, channels-last; 4 conv rows per workgroup below 8 images, 8 below 48, 16 from there on) against the same stage in float64 on the CPU, and against the vector-pipe kernel it stands in for: the error of
     an fp32 convolution.  Inputs at the tracker's scale (crops are 0..255 minus a mean) as well as unit normal."""
     from hdn_amd import trunk
     from hdn_amd.trunk import FusedStem
@@ -1062,7 +1071,7 @@ def test_trunk_stem_matrix_core_form_vs_float64(dev, B):
     assert B >= trunk.STEM_MFMA_MIN_BATCH
     for scale in (1.0, 120.0):
         x = torch.randn(B, 2, 127, 127, generator=g) * scale
-        x[0, :, :, :5] = scale; x[1, :, -4:, :] = -scale                # (edges: the zero padding must not leak)
+        x[0, :, :, :5] = scale; x[B - 1, :, -4:, :] = -scale            # (edges: the zero padding must not leak)
         with torch.no_grad():
             ref = F.max_pool2d(F.relu(F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), stride=2, padding=3)), 3, 2, 1)
         y = st(x.to(dev))

@@ -61,6 +61,7 @@ def test_c_abi_argument_errors_need_no_gpu():
     assert lib.hdn_dlt_solve_f32(one, one, None, 1, None) == -1
     assert lib.hdn_warp_f32(one, one, ctypes.c_void_p(32), 1, 1, 1, 5, None) == -2  # linspace(-1,1,1)
     assert lib.hdn_dlt_warp_f32(one, one, one, one, ctypes.c_void_p(32), 70000, 5, 5, None) == -3
+    assert lib.hdn_dlt_warp_strided_f32(one, one, one, 24, one, ctypes.c_void_p(32), 2, 5, 5, None) == -2      # images closer than H * W
     assert lib.hdn_allgather_offsets(one, one, 4, None, None) == -1 and lib.hdn_allgather_offsets(one, one, 0, one, None) == -2
     assert lib.hdn_rccl_comm_create(ctypes.byref(ctypes.c_void_p()), 2, 2, ctypes.c_char_p(b"\0" * 128)) == -2
     assert lib.hdn_rccl_unique_id(None) == -1 and lib.hdn_rccl_available() in (0, 1)
