@@ -98,8 +98,15 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3s2_v2_kernel(const float
 
   if (produce) {
     // ------------------------------------------------------------------------------------------------ producers
-    f4 av[Cf::AITER][2];
-    auto load_a = [&](int chunk) {
+    // two register sets: a chunk's pixels are asked for TWO chunks before they are split into the LDS image (a chunk is 10 steps of 6 MFMAs = under a
+    // microsecond, less than a round trip to the previous launch's output).  Measured: no change against one set - what a chunk costs here is the
+    // producers' own instruction stream (address arithmetic + 32 conversions per item, 6 items per thread: ablations in profiles/round5_conv3x3.txt)
+    f4 av[2][Cf::AITER][2];
+    auto load_a = [&](int chunk, auto SETc) {
+      constexpr int set = decltype(SETc)::value;
+#if defined(HDN_ABLATION) && defined(S2_EXP_NOALOAD)
+      if (chunk > 0) return;
+#endif
 #pragma unroll
       for (int q = 0; q < Cf::AITER; ++q) {
         const int item = tid + q * HDN_BLOCK;
@@ -109,40 +116,49 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3s2_v2_kernel(const float
         const int b = b0 + img, y = 2 * y0 + ry - 1, xx = pc - 1;
         const bool ok = item < Cf::AITEMS && item / (2 * KS) < Cf::LPV && sl < Cf::NE + Cf::NO && b < B && y >= 0 && y < SI && xx >= 0 && xx < SI;
         const f4* src = reinterpret_cast<const f4*>(x + (((size_t)(ok ? b : 0) * SI + (ok ? y : 0)) * SI + (ok ? xx : 0)) * CI + chunk * (16 * KS) + sub * 8);
-        av[q][0] = ok ? src[0] : f4{0.f, 0.f, 0.f, 0.f};
-        av[q][1] = ok ? src[1] : f4{0.f, 0.f, 0.f, 0.f};
+        av[set][q][0] = ok ? src[0] : f4{0.f, 0.f, 0.f, 0.f};
+        av[set][q][1] = ok ? src[1] : f4{0.f, 0.f, 0.f, 0.f};
       }
     };
-    auto store_a = [&](int ab) {
+    auto store_a = [&](int ab, auto SETc) {
+      constexpr int set = decltype(SETc)::value;
 #pragma unroll
       for (int q = 0; q < Cf::AITER; ++q) {
         const int item = tid + q * HDN_BLOCK;
         if (item < Cf::AITEMS) {
           const int px = item / (2 * KS), sub = item % (2 * KS);
           unsigned q0[4], q1[4];
-          split2x2(av[q][0].x, av[q][0].y, q0[0], q1[0]);
-          split2x2(av[q][0].z, av[q][0].w, q0[1], q1[1]);
-          split2x2(av[q][1].x, av[q][1].y, q0[2], q1[2]);
-          split2x2(av[q][1].z, av[q][1].w, q0[3], q1[3]);
+          split2x2(av[set][q][0].x, av[set][q][0].y, q0[0], q1[0]);
+          split2x2(av[set][q][0].z, av[set][q][0].w, q0[1], q1[1]);
+          split2x2(av[set][q][1].x, av[set][q][1].y, q0[2], q1[2]);
+          split2x2(av[set][q][1].z, av[set][q][1].w, q0[3], q1[3]);
           unsigned char* dst = smem + ab * Cf::A_BYTES + sub * Cf::KG_BYTES + px * 16;
           *reinterpret_cast<u32x4*>(dst) = u32x4{q0[0], q0[1], q0[2], q0[3]};
           *reinterpret_cast<u32x4*>(dst + Cf::PIECE_BYTES) = u32x4{q1[0], q1[1], q1[2], q1[3]};
         }
       }
     };
-    load_a(0);
-    store_a(0);
-    if (Cf::NCHUNK > 1) load_a(1);
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    load_a(0, S0{});
+    if (Cf::NCHUNK > 1) load_a(1, S1{});
+    store_a(0, S0{});
+    if (Cf::NCHUNK > 2) load_a(2, S0{});
     __syncthreads();                                   // chunk 0 is staged
-    for (int c = 0; c < Cf::NCHUNK; ++c) {
-      if (c + 1 < Cf::NCHUNK) {
-        store_a((c + 1) & 1);                          // that image was read last in chunk c - 1, one barrier ago
-        if (c + 2 < Cf::NCHUNK) load_a(c + 2);
+    static_for<Cf::NCHUNK>([&](auto Cc) {              // chunk c + 1 -> its image (read last in chunk c - 1, one barrier ago); chunk c + 3 on its way
+      constexpr int c = decltype(Cc)::value;
+      using Set = std::integral_constant<int, (c + 1) & 1>;
+      if constexpr (c + 1 < Cf::NCHUNK) {
+        store_a((c + 1) & 1, Set{});
+        if constexpr (c + 3 < Cf::NCHUNK) load_a(c + 3, Set{});
       }
       __syncthreads();                                 // chunk c + 1 is staged; the consumers have read the last fragment of chunk c
-    }
+    });
     __syncthreads();                                   // both outputs' partial tiles are in LDS
     // sum of the WK partial tiles in k order; the 3 x 3 output + bias, ReLU; the downsample branch raw.  A pixel's 64 channels = 16 consecutive lanes
+#if defined(HDN_ABLATION) && defined(S2_EXP_NOEPI)
+    return;
+#endif
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
       const float* const rd = red + o * Cf::RED_FLOATS;
@@ -185,6 +201,9 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3s2_v2_kernel(const float
   const uint32_t voff = (uint32_t)lane * 16u;
   u32x4 fb[Cf::BSETS][NT][2], fa[2][2];
   auto load_b = [&](u32x4 (&b)[NT][2], int ch, int st) {    // a step past the last chunk: the last step again (keeps the count of loads in flight static)
+#if defined(HDN_ABLATION) && defined(S2_EXP_NOBLOAD)        // measurement build only
+    if (ch + st > 0) { asm volatile("s_nop 0" ::: "memory"); return; }
+#endif
     const bool past = ch >= Cf::NCHUNK;
     const u32x4* sp = wbase + (size_t)(past ? Cf::NCHUNK - 1 : ch) * Cf::WCHUNK + (size_t)(past ? NS - 1 : st) * Cf::WSTEP;
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b[0][0]) : "v"(voff), "s"(sp));
@@ -218,9 +237,17 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3s2_v2_kernel(const float
       }
       if constexpr (st + 1 < NS) {
         read_a(fa[as ^ 1], cur, std::integral_constant<int, st + 1>{});
+#if defined(HDN_ABLATION) && defined(S2_EXP_NOBLOAD)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(2)" ::: "memory");
+#else
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(2)" ::"n"(PF * NT * 2) : "memory");
+#endif
       } else {
+#if defined(HDN_ABLATION) && defined(S2_EXP_NOBLOAD)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#else
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PF * NT * 2) : "memory");
+#endif
         // the chunk's last fragments are in registers: the producers may overwrite its image, and the next chunk's image is complete
         __builtin_amdgcn_s_barrier();
         if (chunk + 1 < Cf::NCHUNK) read_a(fa[as ^ 1], nxt, I0{});
@@ -231,6 +258,9 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3s2_v2_kernel(const float
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int pc = 0; pc < 2; ++pc) asm volatile("" : "+v"(fb[bs][nt][pc]));
+#if defined(HDN_ABLATION) && defined(S2_EXP_NOMFMA)
+      return;
+#endif
       if constexpr (st < 9) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) accl[nt] = mfma(fa[as][1], fb[bs][nt][0], accl[nt]);
