@@ -102,6 +102,21 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3s2_v2_kernel(const float
     // microsecond, less than a round trip to the previous launch's output).  Measured: no change against one set - what a chunk costs here is the
     // producers' own instruction stream (address arithmetic + 32 conversions per item, 6 items per thread: ablations in profiles/round5_conv3x3.txt)
     f4 av[2][Cf::AITER][2];
+    // an item = (pixel slot, 8-channel group of the chunk): its source offset, validity and LDS address do not depend on the chunk - worked out once
+    // (two divisions by constants per item and chunk otherwise: the producers' instruction stream is what paces a chunk, not the loads' latency)
+    uint32_t a_src[Cf::AITER], a_dst[Cf::AITER];
+    bool a_ok[Cf::AITER];
+#pragma unroll
+    for (int q = 0; q < Cf::AITER; ++q) {
+      const int item = tid + q * HDN_BLOCK;
+      const int px = min(item / (2 * KS), Cf::LPV - 1), sub = item % (2 * KS);
+      const int img = px / Cf::IPITCH, ry = (px % Cf::IPITCH) / Cf::PW, sl = px % Cf::IPITCH % Cf::PW;
+      const int pc = sl < Cf::NE ? 2 * sl : 2 * (sl - Cf::NE) + 1;                 // padded column of the slot
+      const int b = b0 + img, y = 2 * y0 + ry - 1, xx = pc - 1;
+      a_ok[q] = item < Cf::AITEMS && item / (2 * KS) < Cf::LPV && sl < Cf::NE + Cf::NO && b < B && y >= 0 && y < SI && xx >= 0 && xx < SI;
+      a_src[q] = a_ok[q] ? (uint32_t)(((b * SI + y) * SI + xx) * CI + sub * 8) : 0u;       // (floats; the whole input is < 2^31 of them)
+      a_dst[q] = (uint32_t)((item % (2 * KS)) * Cf::KG_BYTES + (item / (2 * KS)) * 16);
+    }
     auto load_a = [&](int chunk, auto SETc) {
       constexpr int set = decltype(SETc)::value;
 #if defined(HDN_ABLATION) && defined(S2_EXP_NOALOAD)
@@ -109,30 +124,22 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3s2_v2_kernel(const float
 #endif
 #pragma unroll
       for (int q = 0; q < Cf::AITER; ++q) {
-        const int item = tid + q * HDN_BLOCK;
-        const int px = min(item / (2 * KS), Cf::LPV - 1), sub = item % (2 * KS);
-        const int img = px / Cf::IPITCH, ry = (px % Cf::IPITCH) / Cf::PW, sl = px % Cf::IPITCH % Cf::PW;
-        const int pc = sl < Cf::NE ? 2 * sl : 2 * (sl - Cf::NE) + 1;                 // padded column of the slot
-        const int b = b0 + img, y = 2 * y0 + ry - 1, xx = pc - 1;
-        const bool ok = item < Cf::AITEMS && item / (2 * KS) < Cf::LPV && sl < Cf::NE + Cf::NO && b < B && y >= 0 && y < SI && xx >= 0 && xx < SI;
-        const f4* src = reinterpret_cast<const f4*>(x + (((size_t)(ok ? b : 0) * SI + (ok ? y : 0)) * SI + (ok ? xx : 0)) * CI + chunk * (16 * KS) + sub * 8);
-        av[set][q][0] = ok ? src[0] : f4{0.f, 0.f, 0.f, 0.f};
-        av[set][q][1] = ok ? src[1] : f4{0.f, 0.f, 0.f, 0.f};
+        const f4* src = reinterpret_cast<const f4*>(x + a_src[q] + chunk * (16 * KS));
+        av[set][q][0] = a_ok[q] ? src[0] : f4{0.f, 0.f, 0.f, 0.f};
+        av[set][q][1] = a_ok[q] ? src[1] : f4{0.f, 0.f, 0.f, 0.f};
       }
     };
     auto store_a = [&](int ab, auto SETc) {
       constexpr int set = decltype(SETc)::value;
 #pragma unroll
       for (int q = 0; q < Cf::AITER; ++q) {
-        const int item = tid + q * HDN_BLOCK;
-        if (item < Cf::AITEMS) {
-          const int px = item / (2 * KS), sub = item % (2 * KS);
+        if (tid + q * HDN_BLOCK < Cf::AITEMS) {
           unsigned q0[4], q1[4];
           split2x2(av[set][q][0].x, av[set][q][0].y, q0[0], q1[0]);
           split2x2(av[set][q][0].z, av[set][q][0].w, q0[1], q1[1]);
           split2x2(av[set][q][1].x, av[set][q][1].y, q0[2], q1[2]);
           split2x2(av[set][q][1].z, av[set][q][1].w, q0[3], q1[3]);
-          unsigned char* dst = smem + ab * Cf::A_BYTES + sub * Cf::KG_BYTES + px * 16;
+          unsigned char* dst = smem + ab * Cf::A_BYTES + a_dst[q];
           *reinterpret_cast<u32x4*>(dst) = u32x4{q0[0], q0[1], q0[2], q0[3]};
           *reinterpret_cast<u32x4*>(dst + Cf::PIECE_BYTES) = u32x4{q1[0], q1[1], q1[2], q1[3]};
         }
