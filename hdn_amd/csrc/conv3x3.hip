@@ -32,41 +32,13 @@
 #include <utility>
 
 #include "hdn_common.h"
+#include "mfma_split.h"
 
 namespace hdn {
 namespace cv {
+using namespace hdn::mc;
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef float f4 __attribute__((ext_vector_type(4)));
-
-// compile-time loop: f(std::integral_constant<int, I>{}) for I = 0 .. N - 1
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
-  (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
-}
-
-__device__ __forceinline__ f32x16 mfma(const u32x4& a, const u32x4& b, const f32x16& c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-}
-
-// two fp32 values -> their two fp16 pieces (round-to-nearest-even by v_cvt_pk_f16_f32), packed (lo = first value):
-// x = p0 + 2^-11 p1 up to 2^-23 |x|; the residual x - p0 is exact in fp32, and so is its product with 2^11 (6 VALU ops per pair)
-constexpr float LO_SCALE = 2048.f, LO_UNSCALE = 1.f / 2048.f;
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef float f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split2x2(float x, float y, unsigned& p0, unsigned& p1) {
-  const f2 v = {x, y};
-  const f16x2 h = __builtin_convertvector(v, f16x2);
-  p0 = __builtin_bit_cast(unsigned, h);
-  const f2 r = (v - __builtin_convertvector(h, f2)) * LO_SCALE;
-  p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
-}
+// vector types, the MFMA, the fp32 -> two-fp16-piece split (x = p0 + 2^-11 p1) and static_for: mfma_split.h
 
 // S = OUTPUT side, CI -> CO channels, STRIDE 1 or 2 (input side S * STRIDE); DS: the block's 1x1 / stride-2 downsample branch is
 // computed alongside from the same staged activations (it is the centre tap with its own weights) into a second output.

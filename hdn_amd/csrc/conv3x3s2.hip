@@ -18,36 +18,11 @@
 #include <utility>
 
 #include "hdn_common.h"
+#include "mfma_split.h"
 
 namespace hdn {
 namespace cvs {
-
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef float f4 __attribute__((ext_vector_type(4)));
-typedef float f2 __attribute__((ext_vector_type(2)));
-
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
-  (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
-}
-__device__ __forceinline__ f32x16 mfma(const u32x4& a, const u32x4& b, const f32x16& c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-}
-constexpr float LO_SCALE = 2048.f, LO_UNSCALE = 1.f / 2048.f;
-__device__ __forceinline__ void split2x2(float x, float y, unsigned& p0, unsigned& p1) {
-  const f2 v = {x, y};
-  const f16x2 h = __builtin_convertvector(v, f16x2);
-  p0 = __builtin_bit_cast(unsigned, h);
-  const f2 r = (v - __builtin_convertvector(h, f2)) * LO_SCALE;
-  p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
-}
+using namespace hdn::mc;
 
 template <int SO_, int CI_>
 struct CfgS {

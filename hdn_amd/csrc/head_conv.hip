@@ -19,16 +19,12 @@
 #include <utility>
 
 #include "hdn_common.h"
+#include "mfma_split.h"
 
 namespace hdn {
 namespace hc {
+using namespace hdn::mc;
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef float f4 __attribute__((ext_vector_type(4)));
 
 constexpr int MAX_PROBLEMS = 4, CI = 256, CHUNK = 64, NCHUNK = CI / CHUNK, TILE_M = 32, TILE_N = 64, NTAP = 9;
 constexpr int LP_MAX = 224;                                   // patch pixels an LDS image holds
@@ -37,33 +33,12 @@ constexpr int LP_MAX = 224;                                   // patch pixels an
 constexpr int KH_BYTES = (LP_MAX + 1) * 16, KSTEP_BYTES = 2 * KH_BYTES, PIECE_BYTES = 4 * KSTEP_BYTES, IMG_BYTES = 2 * PIECE_BYTES;   // [piece][k step][k half][pixel] x 16 B
 constexpr int RED_BYTES = 4 * TILE_M * TILE_N * 4;
 constexpr int LDS_BYTES = 2 * IMG_BYTES > RED_BYTES ? 2 * IMG_BYTES : RED_BYTES;
-constexpr float LO_SCALE = 2048.f, LO_UNSCALE = 1.f / 2048.f;
-
-// compile-time loop: f(std::integral_constant<int, I>{}) for I = 0 .. N - 1
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
-  (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
-}
 
 struct Ptrs {
   const float* x[MAX_PROBLEMS];
   float* out[MAX_PROBLEMS];
 };
 
-__device__ __forceinline__ f32x16 mfma(const u32x4& a, const u32x4& b, const f32x16& c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-}
-__device__ __forceinline__ void split2x2(float x, float y, unsigned& p0, unsigned& p1) {
-  const f2 v = {x, y};
-  const f16x2 h = __builtin_convertvector(v, f16x2);
-  p0 = __builtin_bit_cast(unsigned, h);
-  const f2 r = (v - __builtin_convertvector(h, f2)) * LO_SCALE;
-  p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
-}
 
 // the 18 A fragments (9 taps x 2 pieces) of one (chunk, k slice): contiguous in the packed weights, 1 KB each
 __device__ __forceinline__ void load_a(u32x4 (&a)[NTAP][2], const u32x4* wa) {

@@ -23,22 +23,17 @@
 #include <utility>
 
 #include "hdn_common.h"
+#include "mfma_split.h"
 
 namespace hdn {
 namespace stem_mc {
-
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef float f2 __attribute__((ext_vector_type(2)));
+using namespace hdn::mc;
 
 constexpr int H = 127, W = 127, HC = 64, HP = 32, WP = 32, CO = 64, NSTEP = 7;
 constexpr int PAIRS = 68;                                      // staged pairs of padded columns per row: 3 zeros + 127 pixels + 6 zeros
 constexpr int ROW_BYTES = 384;                                 // 96 dwords: consecutive rows 32 banks apart
 constexpr int W_WORDS = NSTEP * 2 * 2 * 64;                    // 16-byte words: [k step][n tile][piece][lane]
 constexpr int W_BYTES = W_WORDS * 16;
-constexpr float LO_SCALE = 2048.f, LO_UNSCALE = 1.f / 2048.f;
 
 template <int ROWS, int STREAMS>
 struct Geo {
@@ -58,23 +53,6 @@ struct __attribute__((packed, aligned(4))) Frag {              // 8 halves at a 
   unsigned d[4];
 };
 
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
-  (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
-}
-__device__ __forceinline__ f32x16 mfma(const u32x4& a, const u32x4& b, const f32x16& c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-}
-__device__ __forceinline__ void split2(f2 v, unsigned& p0, unsigned& p1) {
-  const f16x2 h = __builtin_convertvector(v, f16x2);
-  p0 = __builtin_bit_cast(unsigned, h);
-  const f2 r = (v - __builtin_convertvector(h, f2)) * LO_SCALE;
-  p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
-}
 __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
 template <int ROWS, int STREAMS>
