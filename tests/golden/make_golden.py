@@ -27,6 +27,7 @@ import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT_DIR = None      # --out: write the fixtures somewhere else (to compare a regeneration with the committed files)
 SEED = 20260928
 
 
@@ -128,7 +129,7 @@ def t(a):
 
 
 def save(name, **arrs):
-    path = os.path.join(HERE, name + ".npz")
+    path = os.path.join(OUT_DIR or HERE, name + ".npz")
     np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
     print(f"  wrote {name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
 
@@ -1012,7 +1013,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
     ap.add_argument("--only", default="", help="comma-separated fixture names to regenerate (default: all)")
+    ap.add_argument("--out", default="", help="directory to write the .npz files to (default: next to this script)")
     args = ap.parse_args()
+    if args.out:
+        global OUT_DIR
+        OUT_DIR = os.path.abspath(args.out)
+        os.makedirs(OUT_DIR, exist_ok=True)
     only = set(x for x in args.only.split(",") if x)
     want = lambda *names: not only or bool(only & set(names))
     if not os.path.isdir(args.reference):
