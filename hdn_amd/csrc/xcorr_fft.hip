@@ -854,7 +854,13 @@ __global__ __launch_bounds__(64 * WPG) void xcorr_north_fft4_kernel(const float*
             sa[f] = a;
             sb2[f] = b;
           }
+#if defined(HDN_ABLATION) && defined(NF4_EXP_SPECW) && NF4_EXP_SPECW == 1   // measurement build only (wrong results): half of the 32 KB spectrum write
+          if constexpr (f > 0) lw64<(f - 1) * 8>(a_row, sa[f - 1]);
+#elif defined(HDN_ABLATION) && defined(NF4_EXP_SPECW) && NF4_EXP_SPECW == 2 // ... none of it
+          if constexpr (f == 32) lw64<0>(a_row, cf{sa[0].x + sb2[31].y + sa[17].y, sb2[3].x + sa[29].x + sb2[11].y});
+#else
           if constexpr (f > 0) lw2x64<f - 1, 32 + f - 1>(a_row, sa[f - 1], sb2[f - 1]);
+#endif
         });
       }
     }
