@@ -286,6 +286,7 @@ static int launch(const float* x, const void* wp, const float* bias, float* out,
     if (e != hipSuccess) return -(1000 + (int)e);
     attr.set(dev_);
   }
+  if ((M + Cf::BM - 1) / Cf::BM > 65535) return HDN_E_LIMIT;      // grid.y (as launch_v2 of conv3x3.hip)
   const dim3 grid(Cf::NB, (unsigned)((M + Cf::BM - 1) / Cf::BM)), blk(2 * HDN_BLOCK);
   hipLaunchKernelGGL((conv3x3s2_v2_kernel<Cf>), grid, blk, Cf::LDS_BYTES, stream, x, static_cast<const u32x4*>(wp), bias, out, out_ds, B);
   return launch_status();

@@ -36,7 +36,7 @@ bool check_range_enabled() {
   return v > 0;
 }
 
-// HDN_OK, or HDN_E_LIMIT when some |x[i]| >= 65,504 (or is NaN).  No-op when the guard is off or the stream is capturing.
+// HDN_OK, or HDN_E_LIMIT when some |x[i]| >= 65,520 (or is NaN).  No-op when the guard is off or the stream is capturing.
 int check_fp16_range(const float* x, long long n, hipStream_t stream) {
   if (!check_range_enabled() || !x || n <= 0) return HDN_OK;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -52,10 +52,10 @@ int check_fp16_range(const float* x, long long n, hipStream_t stream) {
   if (e == hipSuccess) e = hipStreamSynchronize(stream);
   (void)hipFreeAsync(word, stream);
   if (e != hipSuccess) return -(1000 + (int)e);
-  if (host >= 0x477fe000u) {                                      // 65,504.0f
+  if (host >= 0x477ff000u) {                                      // 65,520.0f: the first value v_cvt_f16_f32 (round-to-nearest-even) turns into inf
     float v;
     memcpy(&v, &host, sizeof v);
-    fprintf(stderr, "hdn_amd: HDN_CHECK_RANGE: max |x| = %g over %lld fp32 inputs of a two-fp16-piece kernel (limit 65,504): HDN_E_LIMIT\n", (double)v, n);
+    fprintf(stderr, "hdn_amd: HDN_CHECK_RANGE: max |x| = %g over %lld fp32 inputs of a two-fp16-piece kernel (they need |x| < 65,520): HDN_E_LIMIT\n", (double)v, n);
     return HDN_E_LIMIT;
   }
   return HDN_OK;

@@ -250,7 +250,8 @@ class OneShotGather:
         then are the windows unmapped and freed (a peer's launch may still be storing into this rank's window before that).  The
         barrier is BOUNDED (timeout_s, default HDN_GATHER_DESTROY_TIMEOUT_S or 30 s): the usual reason to destroy a poisoned object
         is a peer that stopped answering, and a barrier with a dead peer never returns — after the timeout the teardown goes on
-        locally with a warning.  collective=False: local teardown only, for objects no launch has used yet (from_process_group's
+        locally with a warning, and the process group the barrier was issued on must not be used again (the orphaned barrier stays
+        queued on it; any later collective there would be out of sequence with the peers).  collective=False: local teardown only, for objects no launch has used yet (from_process_group's
         failure path, where the ranks must keep issuing identical collectives)."""
         if self._h is not None:
             h, self._h = self._h, None
@@ -265,6 +266,9 @@ class OneShotGather:
 
                 def meet():
                     try:
+                        # a new thread's current device is 0: bind this rank's, or an RCCL barrier on a group that has not used a
+                        # device yet would pick GPU 0 (and create a context there)
+                        torch.cuda.set_device(self.device)
                         dist.barrier(group=self._group)
                     finally:
                         done.set()
@@ -273,7 +277,9 @@ class OneShotGather:
                 if not done.wait(timeout_s):
                     import warnings
                     warnings.warn(f"hdn_amd: OneShotGather.destroy: the peers did not reach the barrier within {timeout_s:g} s; "
-                                  "freeing the gather window without them")
+                                  "freeing the gather window without them.  The barrier this rank issued is still queued on the process "
+                                  "group: do NOT issue another collective on that group (it would pair with the peers out of sequence) — "
+                                  "tear the group down, or rebuild it")
             with _lib.device_guard(self.device):
                 _lib.check(_lib.load().hdn_gather_destroy(h), "hdn_gather_destroy")
 

@@ -250,7 +250,22 @@ class DeviceTrackerHomo(HomoTracker):
 
     def _find_mode(self):
         import contextlib
-        return torch.backends.cudnn.flags(enabled=torch.backends.cudnn.enabled, benchmark=True) if self.miopen_find else contextlib.nullcontext()
+        if not self.miopen_find:
+            return contextlib.nullcontext()
+
+        @contextlib.contextmanager
+        def only_benchmark():
+            # torch.backends.cudnn.flags() sets EVERY flag (the ones not named fall to its defaults: deterministic=False,
+            # allow_tf32=True), which would override a user's settings for the backbone's convolutions and bake them into the
+            # captured graph (round-5 ADVICE).  Only `benchmark` is touched here.
+            before = torch.backends.cudnn.benchmark
+            torch.backends.cudnn.benchmark = True
+            try:
+                yield
+            finally:
+                torch.backends.cudnn.benchmark = before
+
+        return only_benchmark()
 
     def init(self, img, bbox, poly, gt_points, first_point=None):
         with self._find_mode():

@@ -464,19 +464,18 @@ class FusedBasicBlock(nn.Module):
         self.register_buffer("p1", pack_conv3x3(self.w1).to(dev) if use1 else None)
         self.register_buffer("p2", pack_conv3x3(self.w2).to(dev) if use2 else None)
         self.register_buffer("p1s2", pack_conv3x3s2_ds(self.w1, self.wd).to(dev) if use_s2 else None)
-        self._v2 = {}      # the large-batch packing of p1 / p2 (pack_conv3x3_v2), made at the first batch of V2_MIN_BATCH or more
+        # the large-batch packing of the same weights (pack_conv3x3_v2 / pack_conv3x3s2_ds_v2): buffers like p1 / p2 / p1s2, so that
+        # .to() / .cuda() move them with the module and no host round trip happens at the first batch of V2_MIN_BATCH or more
+        # (which a stream capture could not hold); non-persistent: state_dict stays the reference's
+        self.register_buffer("p1v2", pack_conv3x3_v2(self.w1).to(dev) if use1 else None, persistent=False)
+        self.register_buffer("p2v2", pack_conv3x3_v2(self.w2).to(dev) if use2 else None, persistent=False)
+        self.register_buffer("p1s2v2", pack_conv3x3s2_ds_v2(self.w1, self.wd).to(dev) if use_s2 else None, persistent=False)
 
     def _packed_v2(self, which, batch):
         """which: 1 / 2 = the block's stride-1 convolutions, "s2" = the stride-2 convolution + downsample branch."""
         if batch < V2_MIN_BATCH or FusedBasicBlock.v2_disabled or (which == "s2" and FusedBasicBlock.v2_s2_disabled):
             return None
-        if which not in self._v2:
-            if which == "s2":
-                self._v2[which] = pack_conv3x3s2_ds_v2(self.w1, self.wd).to(self.w1.device)
-            else:
-                w = self.w1 if which == 1 else self.w2
-                self._v2[which] = pack_conv3x3_v2(w).to(w.device)
-        return self._v2[which]
+        return {1: self.p1v2, 2: self.p2v2, "s2": self.p1s2v2}[which]
 
     v2_disabled = False        # A/B switch (tests, tools/experiments)
     v2_s2_disabled = False     # ... of the stride-2 stages' large-batch form alone

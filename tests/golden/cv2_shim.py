@@ -29,13 +29,25 @@ from oracle import frame_oracle as _F
 from oracle import hdn_oracle as _O
 from oracle import tracker_oracle as _T
 
+# A REAL OpenCV wins (round-6 VERDICT item 1): when `cv2` is importable, every entry point below logs the call and forwards it to the real
+# module, so that a fixture regenerated in such an image is pinned on OpenCV itself, not on the oracle.  (Probed in round 6: neither the
+# build container nor the MI355X box has it; tests/test_cv2_pin.py holds the direct comparisons and skips until one does.)
+try:
+    import importlib as _il
+    _cv = _il.import_module("cv2")
+    if getattr(_cv, "__file__", None) == __file__ or not hasattr(_cv, "getBuildInformation"):
+        _cv = None
+except ImportError:
+    _cv = None
+REAL = _cv is not None
+
 # OpenCV 4.x constant values (imgproc.hpp / core/base.hpp)
 INTER_NEAREST, INTER_LINEAR, INTER_CUBIC, INTER_AREA, INTER_LANCZOS4 = 0, 1, 2, 3, 4
 WARP_FILL_OUTLIERS, WARP_INVERSE_MAP = 8, 16
 WARP_POLAR_LINEAR, WARP_POLAR_LOG = 0, 256
 BORDER_CONSTANT, BORDER_REPLICATE, BORDER_REFLECT, BORDER_WRAP, BORDER_REFLECT_101 = 0, 1, 2, 3, 4
 COLOR_BGR2GRAY, RANSAC = 6, 8
-__version__ = "0.0-oracle-shim"
+__version__ = (_cv.__version__ + "+logged") if REAL else "0.0-oracle-shim"
 
 CALLS = []
 
@@ -50,6 +62,8 @@ def resize(src, dsize, dst=None, fx=0, fy=0, interpolation=INTER_LINEAR):
         raise NotImplementedError(f"cv2 shim: resize of {src.dtype} {src.shape} interpolation {interpolation}")
     dw, dh = int(dsize[0]), int(dsize[1])
     _log("resize", src=src.shape, dsize=(dw, dh))
+    if REAL:
+        return _cv.resize(src, (dw, dh))
     return _F.resize_linear_u8(src, dw, dh)
 
 
@@ -60,6 +74,8 @@ def warpPerspective(src, M, dsize, dst=None, flags=INTER_LINEAR, borderMode=BORD
     if flags != INTER_LINEAR or borderMode != BORDER_REPLICATE or (dh, dw) != src.shape[:2]:
         raise NotImplementedError(f"cv2 shim: warpPerspective flags {flags} border {borderMode} dsize {dsize} of {src.shape}")
     _log("warpPerspective", src=src.shape, dtype=str(src.dtype))
+    if REAL:
+        return _cv.warpPerspective(src, M, (dw, dh), flags=flags, borderMode=borderMode)
     if src.dtype == np.uint8 and src.ndim == 3:
         return _F.warp_perspective_u8(src, M)
     if src.dtype in (np.float32, np.float64) and src.ndim == 2:
@@ -72,6 +88,8 @@ def warpAffine(src, M, dsize, dst=None, flags=INTER_LINEAR, borderMode=BORDER_CO
     M = np.asarray(M, np.float64).reshape(2, 3)
     dw, dh = int(dsize[0]), int(dsize[1])
     _log("warpAffine", src=src.shape, dtype=str(src.dtype), flags=flags, border=borderMode)
+    if REAL:
+        return _cv.warpAffine(src, M, (dw, dh), flags=flags, borderMode=borderMode)
     if src.dtype == np.uint8 and src.ndim == 3 and flags == INTER_CUBIC and borderMode == BORDER_REPLICATE and (dh, dw) == src.shape[:2]:
         return _F.warp_affine_cubic_u8(src, M)
     if src.dtype == np.float32 and src.ndim == 2 and flags == INTER_LINEAR and borderMode == BORDER_CONSTANT:
@@ -84,6 +102,8 @@ def logPolar(src, center, M, flags):
     if src.dtype != np.uint8 or src.ndim != 3 or flags != WARP_FILL_OUTLIERS + INTER_LINEAR:
         raise NotImplementedError(f"cv2 shim: logPolar of {src.dtype} {src.shape} flags {flags}")
     _log("logPolar", src=src.shape, center=tuple(float(c) for c in center), M=float(M))
+    if REAL:
+        return _cv.logPolar(src, center, M, flags)
     h, w = src.shape[:2]
     mx, my = _F.log_polar_maps(w, h, (float(center[0]), float(center[1])), float(M))
     return _F.remap_linear_u8(src, mx, my)     # WARP_FILL_OUTLIERS: BORDER_CONSTANT, value 0
@@ -94,6 +114,8 @@ def perspectiveTransform(src, m, dst=None):
     if src.dtype != np.float32 or src.ndim != 3 or src.shape[2] != 2:
         raise NotImplementedError(f"cv2 shim: perspectiveTransform of {src.dtype} {src.shape}")
     _log("perspectiveTransform", n=src.shape[1])
+    if REAL:
+        return _cv.perspectiveTransform(src, np.asarray(m))
     return _T.perspective_transform(src.reshape(-1, 2), np.asarray(m, np.float64)).reshape(src.shape)
 
 
