@@ -328,7 +328,7 @@ def main():
     north_variant = X.last_variant()
     north_kernel = {"north_fftc_61x61_31x31": "xcorr_north_fft4_kernel", "north_61x61_31x31": "xcorr_north_kernel"}[north_variant]
     traffic, traffic_note, traffic_fresh = None, None, None
-    for rnd in ("round5", "round4", "round3", "round2", "round1"):  # the newest committed PMC measurement of this kernel
+    for rnd in ("round6", "round5", "round4", "round3", "round2", "round1"):  # the newest committed PMC measurement of this kernel
         path = os.path.join(ROOT, "profiles", rnd + "_pmc_hbm_traffic.json")
         if not os.path.exists(path) or traffic is not None:
             continue
@@ -417,7 +417,10 @@ def main():
         "sustained_frac": NORTH_BYTES_PER_PAIR * PAIRS / (sustained_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
         "sustained_note": "ten launches back to back in one hipGraph (100 % duty cycle: the power-limited clock of a dense packed-FMA stream); "
                           "`frac` above is the same kernel at the step's duty cycle"})
+    # the practical ceiling beside the nominal peak: a 16-byte-per-lane nontemporal copy of the launch's own byte count
+    result["roofline"].update(measured_copy(dev))
     if north_variant.startswith("north_fft"):
+        result["roofline"].update(north_issue_fractions(north_ms, sustained_ms, lambda: X.xcorr_depthwise(d["north_x"], d["north_k"]), dev, rank))
         result["roofline"]["note"] = (
             "64x64 fp32 FFT per pair of planes in registers + LDS (~1,380 packed VALU ops per plane instead of the direct "
             "sum's 7,688); one wave per SIMD (32 KB of LDS per wave), issue-bound: DESIGN.md section 4/6")
@@ -639,6 +642,114 @@ def graph_timed(fn, inner=10, iters=10):
     torch.cuda.synchronize()
     del keep
     return e0.elapsed_time(e1) / (iters * inner)
+
+
+def measured_copy(dev, mbytes=370):
+    """`roofline.measured_copy_GBps`: hdn_ubench_copy_f32 (csrc/ubench.hip) over ~the 31x31 launch's byte count (read + write = 2 x 185 MB),
+    ten launches per hipGraph, HIP events around the replays.  The 8 TB/s `peak` stays the denominator of `frac`; this is the figure a
+    pure copy reaches on THIS box in THIS run."""
+    from hdn_amd import _lib
+    n = (mbytes * 1000 * 1000 // 2 // 4) // 4 * 4
+    src = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+    dst = torch.empty_like(src)
+    lib = _lib.load()
+
+    def launch():
+        _lib.check(lib.hdn_ubench_copy_f32(_lib.ptr(src), _lib.ptr(dst), n, _lib.stream_ptr(dev)), "ubench copy")
+    ms = graph_timed(launch)
+    assert torch.equal(src, dst)
+    return {"measured_copy_GBps": 2 * 4 * n / (ms * 1e-3) / 1e9, "measured_copy_bytes": 2 * 4 * n, "measured_copy_ms": ms,
+            "measured_copy_note": "hdn_ubench_copy_f32: 16 B per lane, nontemporal loads and stores, 8,192 workgroups; read + write bytes / time, "
+                                  "ten launches back to back in one hipGraph (csrc/ubench.hip)"}
+
+
+def _sclk_sampler():
+    """(start, stop) around a region: shader clock in MHz from hwmon every 10 ms -> list (empty when the box does not expose it)."""
+    import glob
+    import threading
+    hw = (glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input") or [None])[0]
+    samples, halt = [], threading.Event()
+
+    def run():
+        while not halt.is_set():
+            try:
+                samples.append(float(open(hw).read()) / 1e6)
+            except Exception:
+                return
+            time.sleep(0.01)
+    th = threading.Thread(target=run, daemon=True)
+
+    def start():
+        if hw:
+            th.start()
+
+    def stop():
+        halt.set()
+        if hw:
+            th.join(timeout=1.0)
+        return samples
+    return start, stop
+
+
+def north_issue_fractions(in_step_ms, sustained_ms, launch, dev, rank):
+    """SURVEY.md section 8d "report both fractions" for the FFT form of the 31x31 (x) 61x61 kernel, which is neither HBM- nor FMA-bound but
+    ISSUE-bound: one wave per SIMD, one issue slot per 4 clocks.
+        issue_frac = 4 clk x instructions issued per pair / clocks a pair takes          (1.0 = the lone wave never waits)
+        valu_frac  = 4 clk x packed fp32 VALU instructions per pair / clocks a pair takes (the share of issue slots that is arithmetic)
+    clocks per pair = launch time x shader clock / pairs per SIMD (64 x 256 planes / 2 per pair / 1,024 SIMDs = 8).  Instruction counts:
+    static, from the shipped code object (tools/north_instr_count.py -> profiles/round6_north_instr.json, tied to the kernel source by
+    SHA-256).  Shader clock: hwmon samples (10 ms) during 0.3 s of back-to-back launches; the in-step launch runs at a higher clock than
+    that (the chip boosts between launches), so the in-step fractions computed with this clock are UPPER bounds; the sustained_ pair
+    (sustained time, sustained clock) is the matched one."""
+    import hashlib
+    path = os.path.join(ROOT, "profiles", "round6_north_instr.json")
+    if not os.path.exists(path):
+        return {"issue_frac": None, "issue_note": "profiles/round6_north_instr.json missing (tools/north_instr_count.py)"}
+    rec = json.load(open(path))
+    src = os.path.join(ROOT, "hdn_amd", "csrc", rec["kernel_source"])
+    fresh = hashlib.sha256(open(src, "rb").read()).hexdigest() == rec["kernel_source_sha256"] if os.path.exists(src) else None
+    if fresh is False and rank == 0:
+        print("bench.py: WARNING: hdn_amd/csrc/%s changed since tools/north_instr_count.py counted its instructions" % rec["kernel_source"], file=sys.stderr)
+    # shader clock under the kernel, sustained
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        launch()
+    torch.cuda.current_stream().wait_stream(side)
+    with torch.cuda.graph(g):
+        keep = [launch() for _ in range(10)]
+    start, stop = _sclk_sampler()
+    g.replay()
+    torch.cuda.synchronize()
+    start()
+    t_end = time.perf_counter() + 0.3
+    while time.perf_counter() < t_end:
+        for _ in range(10):
+            g.replay()
+        torch.cuda.synchronize()
+    mhz = stop()
+    del keep
+    if len(mhz) >= 5:
+        clock_ghz, clock_src = float(np.median(mhz)) / 1e3, "hwmon freq1_input, median of %d samples over 0.3 s of back-to-back launches" % len(mhz)
+    else:
+        clock_ghz, clock_src = 2.0, "not readable on this box; 2.0 GHz = GRBM_GUI_ACTIVE / duration of profiles/round3_north_experiments.txt"
+    pairs_per_simd = PAIRS * C / 2 / 1024.0
+    out = {"instructions_per_pair": rec["issued_per_pair"], "valu_packed_per_pair": rec["valu_packed_per_pair"],
+           "instruction_count_source": "profiles/round6_north_instr.json (static, hot loop of the shipped code object)",
+           "instruction_count_matches_kernel_source": fresh, "pairs_per_simd": pairs_per_simd,
+           "shader_clock_GHz": clock_ghz, "shader_clock_source": clock_src}
+    for tag, ms in (("", in_step_ms), ("sustained_", sustained_ms)):
+        clocks = ms * 1e-3 * clock_ghz * 1e9 / pairs_per_simd
+        out[tag + "clocks_per_pair"] = clocks
+        out[tag + "issue_frac"] = 4.0 * rec["issued_per_pair"] / clocks
+        out[tag + "valu_frac"] = 4.0 * rec["valu_packed_per_pair"] / clocks
+    tflops = rec["flops_per_pair"] * PAIRS * C / 2 / (in_step_ms * 1e-3) / 1e12
+    out.update({"valu_achieved_tflops": tflops, "valu_peak_tflops": FP32_VALU_PEAK_TFLOPS, "valu_flops_frac": tflops / FP32_VALU_PEAK_TFLOPS,
+                "issue_note": "issue_frac / valu_frac: share of a lone wave's issue slots (one per 4 clocks) that hold an instruction / a packed fp32 "
+                              "math instruction; the in-step pair uses the SUSTAINED clock sample (the step's clock is higher and not observable at "
+                              "microsecond resolution), so the in-step fractions are upper bounds and the sustained_ ones are the matched pair"})
+    return out
 
 
 def breakdown(d, imgs2, tmpl, folded, X, SF, G, iters=10):

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libhdn_hip.so"
 LIB_PATH = os.environ.get("HDN_LIB_PATH", os.path.join(_HERE, LIB_NAME))  # override: A/B builds of the kernels
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _c_float_p = ctypes.c_void_p  # device pointers travel as integers
 _i = ctypes.c_int
@@ -43,6 +43,10 @@ SIGNATURES = {
     "hdn_subwindow_f32": (_i, [_c_float_p] * 3 + [_i] * 5 + [ctypes.c_void_p]),
     "hdn_frame_warp_perspective_u8": (_i, [_c_float_p] * 3 + [_i] * 3 + [ctypes.c_void_p]),
     "hdn_frame_warp_affine_cubic_u8": (_i, [_c_float_p] * 3 + [_i] * 3 + [ctypes.c_void_p]),
+    "hdn_subwindow_batch_f32": (_i, [_c_float_p] * 2 + [_i, _c_float_p] + [_i] * 6 + [ctypes.c_void_p]),
+    "hdn_frame_warp_perspective_batch_u8": (_i, [_c_float_p] * 2 + [_i, _c_float_p] + [_i] * 4 + [ctypes.c_void_p]),
+    "hdn_frame_warp_affine_cubic_batch_u8": (_i, [_c_float_p] * 2 + [_i, _c_float_p] + [_i] * 4 + [ctypes.c_void_p]),
+    "hdn_l1_score2_batch_f32": (_i, [_c_float_p] * 4 + [_i, ctypes.c_longlong, _i, ctypes.c_float, ctypes.c_void_p]),
     "hdn_remap_linear_f32": (_i, [_c_float_p] * 4 + [_i] * 5 + [ctypes.c_void_p]),
     "hdn_similarity_translation_f32": (_i, [_c_float_p] * 6 + [_i, _i, ctypes.c_double, ctypes.c_float, ctypes.c_double, _i, ctypes.c_void_p]),
     "hdn_similarity_logpolar_f32": (_i, [_c_float_p] * 5 + [_i, _i, ctypes.c_float, ctypes.c_double, ctypes.c_float, _i, ctypes.c_void_p]),
@@ -56,6 +60,7 @@ SIGNATURES = {
     "hdn_head_tail_f32": (_i, [_c_float_p, ctypes.c_void_p] + [_c_float_p] * 4 + [_i] * 4 + [ctypes.c_void_p]),
     "hdn_head_conv3x3_f32": (_i, [ctypes.c_void_p, ctypes.c_void_p, _c_float_p, ctypes.c_void_p] + [_i] * 5 + [ctypes.c_void_p]),
     "hdn_set_check_range": (_i, [_i]),
+    "hdn_ubench_copy_f32": (_i, [_c_float_p] * 2 + [ctypes.c_longlong, ctypes.c_void_p]),
     "hdn_conv3x3_pack_info": (_i, [_i, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "hdn_conv3x3_workspace_bytes": (ctypes.c_longlong, [_i, _i, _i, _i]),
     "hdn_conv3x3s2_ds_f32": (_i, [_c_float_p] * 6 + [ctypes.c_longlong] + [_i] * 3 + [ctypes.c_void_p]),

@@ -34,6 +34,29 @@
 #include "hdn_common.h"
 #include "mfma_split.h"
 
+// Measurement hooks (tools/build_variant.sh ... -DHDN_ABLATION -D<experiment>): every site below expands to its production text; the
+// experiments' replacement bodies live in ablation/conv3x3.inc and are compiled in only under -DHDN_ABLATION, so that editing or adding an
+// experiment leaves this translation unit's text (and the hash the committed PMC record carries) unchanged.
+#define HDN_ABL_CONV3X3_0(...) __VA_ARGS__
+#define HDN_ABL_CONV3X3_1(...) __VA_ARGS__
+#define HDN_ABL_CONV3X3_2(...) __VA_ARGS__
+#define HDN_ABL_CONV3X3_3(...) __VA_ARGS__
+#define HDN_ABL_CONV3X3_4(...) __VA_ARGS__
+#define HDN_ABL_CONV3X3_5(...) __VA_ARGS__
+#define HDN_ABL_CONV3X3_6(...) __VA_ARGS__
+#define HDN_ABL_CONV3X3_7(...) __VA_ARGS__
+#define HDN_ABL_CONV3X3_8(...) __VA_ARGS__
+#define HDN_ABL_CONV3X3_9(...) __VA_ARGS__
+#define HDN_ABL_CONV3X3_10(...) __VA_ARGS__
+#define HDN_ABL_CONV3X3_11(...) __VA_ARGS__
+#define HDN_ABL_CONV3X3_12(...) __VA_ARGS__
+#define HDN_ABL_CONV3X3_13(...) __VA_ARGS__
+#define HDN_ABL_CONV3X3_14_BEGIN
+#define HDN_ABL_CONV3X3_14_END
+#ifdef HDN_ABLATION
+#include "ablation/conv3x3.inc"
+#endif
+
 namespace hdn {
 namespace cv {
 using namespace hdn::mc;
@@ -199,9 +222,7 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __r
   u32x4 wr[2][Cf::WITER];   // two stages in flight: stage t travels in wr[t & 1] from stage t - 4 (load) to stage t - 2 (LDS store)
   auto load_w = [&](int stage, auto P) {
     constexpr int p = decltype(P)::value;
-#if defined(HDN_ABLATION) && defined(CV_EXP_NOWLOAD)   // measurement build only: tools/build_variant.sh -DHDN_ABLATION -DCV_EXP_NOWLOAD
-    if (stage > 3) return;
-#endif
+    HDN_ABL_CONV3X3_0()
     const u32x4* src = wblock + (size_t)stage * Cf::W4;
 #pragma unroll
     for (int q = 0; q < Cf::WITER; ++q) wr[p][q] = src[min(tid + q * HDN_BLOCK, Cf::W4 - 1)];
@@ -216,9 +237,7 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __r
   // input chunk: (pixel, k step, k half) items of 8 channels = 32 bytes
   f4 av[Cf::AITER][2];
   auto load_a = [&](int chunk) {
-#if defined(HDN_ABLATION) && defined(CV_EXP_NOALOAD)   // measurement build only: tools/build_variant.sh -DHDN_ABLATION -DCV_EXP_NOALOAD
-    if (chunk > 0) return;
-#endif
+    HDN_ABL_CONV3X3_1()
 #pragma unroll
     for (int q = 0; q < Cf::AITER; ++q) {
       const int item = tid + q * HDN_BLOCK;
@@ -232,9 +251,7 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __r
     }
   };
   auto store_a = [&](int ab) {
-#if defined(HDN_ABLATION) && defined(CV_EXP_NOSTAGE)   // measurement build only: tools/build_variant.sh -DHDN_ABLATION -DCV_EXP_NOSTAGE
-    return;
-#endif
+    HDN_ABL_CONV3X3_2()
 #pragma unroll
     for (int q = 0; q < Cf::AITER; ++q) {
       const int item = tid + q * HDN_BLOCK;
@@ -299,9 +316,7 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __r
   };
   // fragments of step (tap t of the stage's kernel row ky, k step ks) from W buffer `buf`
   auto read_frags = [&](Frags& f, int ky, int t, int ks, int buf, int ab) {
-#if defined(HDN_ABLATION) && defined(CV_EXP_NOREAD)   // measurement build only: tools/build_variant.sh -DHDN_ABLATION -DCV_EXP_NOREAD
-    if (ky + t + ks + buf >= 0) return;
-#endif
+    HDN_ABL_CONV3X3_3()
     const int toff = (t == 3 ? 0 : ((ky - 1) * Cf::PW + (t - 1)) * 16) + ks * Cf::KSTEP_BYTES + ab * Cf::A_BYTES;   // (tap 3: the downsample branch reads the centre)
     const uint32_t wb = boff + buf * Cf::WSTAGE_BYTES + (t * KS + ks) * Cf::WSTEP_BYTES;
 #pragma unroll
@@ -316,9 +331,7 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __r
         asm volatile("ds_read_b128 %0, %1" : "=v"(f.b[nt][s]) : "v"(wb + s * Cf::WPIECE_BYTES + nt * 32 * 16));
   };
   auto mma = [&](const Frags& f, auto TODS) {
-#if defined(HDN_ABLATION) && defined(CV_EXP_NOMFMA)   // measurement build only: tools/build_variant.sh -DHDN_ABLATION -DCV_EXP_NOMFMA
-    return;
-#endif
+    HDN_ABL_CONV3X3_4()
     constexpr bool tods = decltype(TODS)::value;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -370,9 +383,7 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __r
       if (stage + 1 < nstage) __syncthreads();
     };
     int c2 = 0;
-#if defined(HDN_ABLATION) && defined(CV_EXP_NOLOOP)   // measurement build only: prologue + epilogue of a launch
-    c2 = nchunk;
-#endif
+    HDN_ABL_CONV3X3_5()
 #pragma unroll 1
     for (; c2 + 1 < nchunk; c2 += 2) static_for<6>([&](auto Jc) { stage_p(c2, Jc); });
     if (c2 < nchunk) static_for<3>([&](auto Jc) { stage_p(c2, Jc); });   // an odd chunk count: one more chunk, at position 0 of the period again
@@ -429,9 +440,7 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __r
       if (stage + 1 < nstage) __syncthreads();
     };
     int c2 = 0;
-#if defined(HDN_ABLATION) && defined(CV_EXP_NOLOOP)
-    c2 = nchunk;
-#endif
+    HDN_ABL_CONV3X3_6()
 #pragma unroll 1
     for (; c2 + 1 < nchunk; c2 += 2) static_for<6>([&](auto Jc) { stage_c(c2, Jc); });
     if (c2 < nchunk) static_for<3>([&](auto Jc) { stage_c(c2, Jc); });
@@ -441,10 +450,7 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __r
   // The tile goes through LDS once ([pixel][BN] fp32) so that the residual is read and the result written as 16 bytes per lane,
   // a pixel's BN channels (contiguous in NHWC) by BN / 4 consecutive lanes.
   __syncthreads();  // every wave is done with the A / W images
-#if defined(HDN_ABLATION) && defined(CV_EXP_NOEPI)   // measurement build only: no output staging, residual read or store (one float per workgroup keeps the loop alive)
-  if (threadIdx.x == 0) out[blockIdx.x] = acc[0][0][0] + accl[0][0][0];
-  return;
-#endif
+  HDN_ABL_CONV3X3_7()
   float* const sO = reinterpret_cast<float*>(smem);
   // (the pixel of accumulator row r is a compile-time constant for each of the two half waves: one multiply-add per store instead of
   //  the mapping's dozen integer operations - round 5)
@@ -769,9 +775,7 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_v2_kernel(const float* 
     };
     // sum of the WK partial tiles in slice order (+ bias (+ residual), ReLU), a pixel's BN channels = BN / 4 consecutive lanes
     auto epilogue = [&](int tile) {
-#if defined(HDN_ABLATION) && defined(CV2_EXP_NOEPI)
-      return;
-#endif
+      HDN_ABL_CONV3X3_8()
       const long long m0 = (long long)(tile0 + tile) * BM;
 #pragma unroll
       for (int q = 0; q < Cf::EITER; ++q) {
@@ -835,9 +839,7 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_v2_kernel(const float* 
   // B fragments of (chunk ch, step st) of tile tt; a chunk index past the tile's is the next tile's first chunk — or, behind the last tile,
   // the last step again (which keeps the count of outstanding loads static)
   auto load_b = [&](u32x4 (&b)[NT][2], int tt, int ch, int st) {
-#if defined(HDN_ABLATION) && (defined(CV2_EXP_NOBLOAD) || defined(CV2_EXP_PURE))   // measurement build only
-    if (tt + ch + st > 1) { asm volatile("s_nop 0" ::: "memory"); return; }
-#endif
+    HDN_ABL_CONV3X3_9()
     bool past = false;
     if (ch >= nchunk) {
       if (tt + 1 < ntw) ch -= nchunk;
@@ -858,9 +860,7 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_v2_kernel(const float* 
     constexpr int ST = decltype(STc)::value, IMG = decltype(IMGc)::value, t = ST / SPW;
     constexpr int OFF = ((t / 3) * Cf::PW + (t % 3)) * 16 + WK * (ST % SPW) * Cf::KSTEP_BYTES + IMG * Cf::A_BYTES;
     static_assert(OFF + Cf::PIECE_BYTES < 65536, "ds_read offset field");
-#if defined(HDN_ABLATION) && defined(CV2_EXP_PURE)      // measurement build only: MFMAs and barriers, nothing else
-    if (ST > 0) return;
-#endif
+    HDN_ABL_CONV3X3_10()
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[mt][0]) : "v"(base[mt]), "n"(OFF));
@@ -902,19 +902,9 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_v2_kernel(const float* 
         }
         if constexpr (st + 1 < NS) {
           read_a(fa[as ^ 1], cur, std::integral_constant<int, (st + 1) % NS>{}, CurImg{});
-#if defined(HDN_ABLATION) && defined(CV2_EXP_PURE)
-          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#elif defined(HDN_ABLATION) && defined(CV2_EXP_NOBLOAD)
-          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(4)" ::: "memory");
-#else
-          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(4)" ::"n"(PF * NT * 2) : "memory");
-#endif
+          HDN_ABL_CONV3X3_11(asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(4)" ::"n"(PF * NT * 2) : "memory");)
         } else {
-#if defined(HDN_ABLATION) && (defined(CV2_EXP_NOBLOAD) || defined(CV2_EXP_PURE))
-          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#else
-          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PF * NT * 2) : "memory");
-#endif
+          HDN_ABL_CONV3X3_12(asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PF * NT * 2) : "memory");)
           // the chunk's last fragments are in registers: the producers may overwrite its image, and the next chunk's image is complete
           __builtin_amdgcn_s_barrier();
           if (chunk + 1 < nchunk || tt + 1 < ntw) read_a(fa[as ^ 1], nxt, I0{}, NxtImg{});
@@ -928,9 +918,7 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_v2_kernel(const float* 
 #pragma unroll
           for (int pc = 0; pc < 2; ++pc) asm volatile("" : "+v"(fb[bs][nt][pc]));
         // 12 (NT = 1: 6) MFMAs, the three products of an output tile two MFMAs apart
-#if defined(HDN_ABLATION) && defined(CV2_EXP_NOMFMA)
-        return;
-#endif
+        HDN_ABL_CONV3X3_13()
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -949,9 +937,7 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_v2_kernel(const float* 
     // its last read); several: into their own region, which the producers emptied during this tile's first chunk.
     // C/D layout of v_mfma_f32_32x32x16_f16: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).  The pixel of accumulator row r
     // is a compile-time constant for each of the two half waves: one multiply-add per store, not the mapping's dozen integer operations.
-#if defined(HDN_ABLATION) && defined(CV2_EXP_NOEPI)
-    if (lane == 0) out[blockIdx.y * 4 + wave] = acc[0][0][0] + accl[0][0][0] + acc[1][NT - 1][5] + accl[1][0][3] + acc[0][NT - 1][2] + acc[1][0][7];
-#else
+    HDN_ABL_CONV3X3_14_BEGIN
     float* const rbase = red + (wk * BM + wm * 64) * Cf::EPI_STRIDE + li;
     static_for<2>([&](auto MTc) {
       static_for<16>([&](auto Rc) {
@@ -962,7 +948,7 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_v2_kernel(const float* 
         for (int nt = 0; nt < NT; ++nt) q[nt * 32] = acc[mt][nt][r] + accl[mt][nt][r] * LO_UNSCALE;
       });
     });
-#endif
+    HDN_ABL_CONV3X3_14_END
     __syncthreads();                                   // the tile's partial sums are in LDS (the producers take them from there)
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the surplus B loads at the tail)

@@ -20,6 +20,19 @@
 #include "hdn_common.h"
 #include "mfma_split.h"
 
+// Measurement hooks (tools/build_variant.sh ... -DHDN_ABLATION -D<experiment>): every site below expands to its production text; the
+// experiments' replacement bodies live in ablation/conv3x3s2.inc and are compiled in only under -DHDN_ABLATION, so that editing or adding an
+// experiment leaves this translation unit's text (and the hash the committed PMC record carries) unchanged.
+#define HDN_ABL_CONV3X3S2_0(...) __VA_ARGS__
+#define HDN_ABL_CONV3X3S2_1(...) __VA_ARGS__
+#define HDN_ABL_CONV3X3S2_2(...) __VA_ARGS__
+#define HDN_ABL_CONV3X3S2_3(...) __VA_ARGS__
+#define HDN_ABL_CONV3X3S2_4(...) __VA_ARGS__
+#define HDN_ABL_CONV3X3S2_5(...) __VA_ARGS__
+#ifdef HDN_ABLATION
+#include "ablation/conv3x3s2.inc"
+#endif
+
 namespace hdn {
 namespace cvs {
 using namespace hdn::mc;
@@ -94,9 +107,7 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3s2_v2_kernel(const float
     }
     auto load_a = [&](int chunk, auto SETc) {
       constexpr int set = decltype(SETc)::value;
-#if defined(HDN_ABLATION) && defined(S2_EXP_NOALOAD)
-      if (chunk > 0) return;
-#endif
+      HDN_ABL_CONV3X3S2_0()
 #pragma unroll
       for (int q = 0; q < Cf::AITER; ++q) {
         const f4* src = reinterpret_cast<const f4*>(x + a_src[q] + chunk * (16 * KS));
@@ -138,9 +149,7 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3s2_v2_kernel(const float
     });
     __syncthreads();                                   // both outputs' partial tiles are in LDS
     // sum of the WK partial tiles in k order; the 3 x 3 output + bias, ReLU; the downsample branch raw.  A pixel's 64 channels = 16 consecutive lanes
-#if defined(HDN_ABLATION) && defined(S2_EXP_NOEPI)
-    return;
-#endif
+    HDN_ABL_CONV3X3S2_1()
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
       const float* const rd = red + o * Cf::RED_FLOATS;
@@ -183,9 +192,7 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3s2_v2_kernel(const float
   const uint32_t voff = (uint32_t)lane * 16u;
   u32x4 fb[Cf::BSETS][NT][2], fa[2][2];
   auto load_b = [&](u32x4 (&b)[NT][2], int ch, int st) {    // a step past the last chunk: the last step again (keeps the count of loads in flight static)
-#if defined(HDN_ABLATION) && defined(S2_EXP_NOBLOAD)        // measurement build only
-    if (ch + st > 0) { asm volatile("s_nop 0" ::: "memory"); return; }
-#endif
+    HDN_ABL_CONV3X3S2_2()
     const bool past = ch >= Cf::NCHUNK;
     const u32x4* sp = wbase + (size_t)(past ? Cf::NCHUNK - 1 : ch) * Cf::WCHUNK + (size_t)(past ? NS - 1 : st) * Cf::WSTEP;
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b[0][0]) : "v"(voff), "s"(sp));
@@ -219,17 +226,9 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3s2_v2_kernel(const float
       }
       if constexpr (st + 1 < NS) {
         read_a(fa[as ^ 1], cur, std::integral_constant<int, st + 1>{});
-#if defined(HDN_ABLATION) && defined(S2_EXP_NOBLOAD)
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(2)" ::: "memory");
-#else
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(2)" ::"n"(PF * NT * 2) : "memory");
-#endif
+        HDN_ABL_CONV3X3S2_3(asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(2)" ::"n"(PF * NT * 2) : "memory");)
       } else {
-#if defined(HDN_ABLATION) && defined(S2_EXP_NOBLOAD)
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#else
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PF * NT * 2) : "memory");
-#endif
+        HDN_ABL_CONV3X3S2_4(asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PF * NT * 2) : "memory");)
         // the chunk's last fragments are in registers: the producers may overwrite its image, and the next chunk's image is complete
         __builtin_amdgcn_s_barrier();
         if (chunk + 1 < Cf::NCHUNK) read_a(fa[as ^ 1], nxt, I0{});
@@ -240,9 +239,7 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3s2_v2_kernel(const float
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int pc = 0; pc < 2; ++pc) asm volatile("" : "+v"(fb[bs][nt][pc]));
-#if defined(HDN_ABLATION) && defined(S2_EXP_NOMFMA)
-      return;
-#endif
+      HDN_ABL_CONV3X3S2_5()
       if constexpr (st < 9) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) accl[nt] = mfma(fa[as][1], fb[bs][nt][0], accl[nt]);

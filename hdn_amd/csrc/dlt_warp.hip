@@ -274,9 +274,12 @@ constexpr int L1_THREADS = 1024, L1_PER_THREAD = 16;
 // Workgroup j scores a against (j ? b1 : b0) into out[j]: the two scores of a frame are one launch.
 __global__ __launch_bounds__(L1_THREADS) void l1_score_kernel(const float* __restrict__ a, const float* __restrict__ b0,
                                                               const float* __restrict__ b1, float* __restrict__ out, int n,
-                                                              float scale) {
+                                                              float scale, long long plane_stride) {
   __shared__ float part[L1_THREADS / HDN_WAVE];
-  const float* __restrict__ b = blockIdx.x ? b1 : b0;
+  // blockIdx.y = the sample of a batch (hdn_l1_score2_batch_f32): the three planes `plane_stride` floats further, its two scores at out[2 y]
+  a += (size_t)blockIdx.y * plane_stride;
+  out += 2 * blockIdx.y;
+  const float* __restrict__ b = (blockIdx.x ? b1 : b0) + (size_t)blockIdx.y * plane_stride;
   float s = 0.f;
   for (int base = 0; base < n; base += L1_THREADS * L1_PER_THREAD) {
     float av[L1_PER_THREAD], bv[L1_PER_THREAD];
@@ -359,7 +362,7 @@ int hdn_l1_score_f32(const float* a, const float* b, float* out, int n, float sc
   if (!a || !b || !out) return HDN_E_NULL;
   if (n <= 0) return HDN_E_SHAPE;
   hipLaunchKernelGGL(hdn::l1_score_kernel, dim3(1), dim3(hdn::L1_THREADS), 0, static_cast<hipStream_t>(stream), a, b, b, out,
-                     n, scale);
+                     n, scale, 0LL);
   return hdn::launch_status();
 }
 
@@ -367,7 +370,17 @@ int hdn_l1_score2_f32(const float* a, const float* b0, const float* b1, float* o
   if (!a || !b0 || !b1 || !out2) return HDN_E_NULL;
   if (n <= 0) return HDN_E_SHAPE;
   hipLaunchKernelGGL(hdn::l1_score_kernel, dim3(2), dim3(hdn::L1_THREADS), 0, static_cast<hipStream_t>(stream), a, b0, b1, out2,
-                     n, scale);
+                     n, scale, 0LL);
+  return hdn::launch_status();
+}
+
+int hdn_l1_score2_batch_f32(const float* a, const float* b0, const float* b1, float* out, int n, long long plane_stride, int B, float scale,
+                            void* stream) {
+  if (!a || !b0 || !b1 || !out) return HDN_E_NULL;
+  if (n <= 0 || B <= 0 || plane_stride < n) return HDN_E_SHAPE;
+  if (B > 65535) return HDN_E_LIMIT;
+  hipLaunchKernelGGL(hdn::l1_score_kernel, dim3(2, B), dim3(hdn::L1_THREADS), 0, static_cast<hipStream_t>(stream), a, b0, b1, out, n, scale,
+                     plane_stride);
   return hdn::launch_status();
 }
 

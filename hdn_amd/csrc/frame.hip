@@ -45,8 +45,14 @@ __device__ __forceinline__ ResizeAxis resize_axis(int d, int dn, int sn) {
 }
 
 // params (device, float64): [cx, cy, original_sz, avg_0 .. avg_{C-1}]
+// blockIdx.y = the frame of a batch (one sequence each, hdn_subwindow_batch_f32): frames contiguous [B,H,W,C], the parameter records
+// `params_stride` doubles apart (they may be columns of a wider per-sequence record), the crops contiguous [B, C | 1, model_sz, model_sz].
 __global__ __launch_bounds__(HDN_BLOCK) void subwindow_kernel(const uint8_t* __restrict__ frame, const double* __restrict__ params,
-                                                              float* __restrict__ out, int H, int W, int C, int model_sz, int mode) {
+                                                              float* __restrict__ out, int H, int W, int C, int model_sz, int mode,
+                                                              int params_stride) {
+  frame += size_t(blockIdx.y) * H * W * C;
+  params += size_t(blockIdx.y) * params_stride;
+  out += size_t(blockIdx.y) * (mode ? 1 : C) * model_sz * model_sz;
   const double cx = params[0], cy = params[1], sz = params[2];
   const double c = (sz - 1.0) / 2.0;
   const double xmin_d = floor(cx - c + 0.5), ymin_d = floor(cy - c + 0.5);
@@ -113,7 +119,11 @@ __device__ __forceinline__ void inv3(const double* m, double* o) {
 __device__ __forceinline__ int cv_round_sat(double v) { return (int)rint(fmax(-2147483648.0, fmin(2147483647.0, v))); }
 
 __global__ __launch_bounds__(HDN_BLOCK) void frame_warp_perspective_kernel(const uint8_t* __restrict__ src, const double* __restrict__ M,
-                                                                           uint8_t* __restrict__ dst, int H, int W, int C, int bw) {
+                                                                           uint8_t* __restrict__ dst, int H, int W, int C, int bw,
+                                                                           int m_stride) {
+  src += size_t(blockIdx.y) * H * W * C;      // (blockIdx.y = the frame of a batch, each with its own matrix: hdn_frame_warp_perspective_batch_u8)
+  dst += size_t(blockIdx.y) * H * W * C;
+  M += size_t(blockIdx.y) * m_stride;
   double m[9], mi[9];
 #pragma unroll
   for (int q = 0; q < 9; ++q) m[q] = M[q];
@@ -163,7 +173,10 @@ __global__ __launch_bounds__(HDN_BLOCK) void frame_warp_perspective_kernel(const
 __device__ short g_cubic_itab[32 * 32 * 16];
 
 __global__ __launch_bounds__(HDN_BLOCK) void frame_warp_affine_cubic_kernel(const uint8_t* __restrict__ src, const double* __restrict__ M,
-                                                                            uint8_t* __restrict__ dst, int H, int W, int C) {
+                                                                            uint8_t* __restrict__ dst, int H, int W, int C, int m_stride) {
+  src += size_t(blockIdx.y) * H * W * C;      // (blockIdx.y = the frame of a batch: hdn_frame_warp_affine_cubic_batch_u8)
+  dst += size_t(blockIdx.y) * H * W * C;
+  M += size_t(blockIdx.y) * m_stride;
   // invert the 2x3 matrix as cv::warpAffine does
   double m00 = M[0], m01 = M[1], m02 = M[2], m10 = M[3], m11 = M[4], m12 = M[5];
   double D = m00 * m11 - m01 * m10;
@@ -302,45 +315,70 @@ static int frame_grid(size_t n) {
 
 extern "C" {
 
+int hdn_subwindow_batch_f32(const unsigned char* frames, const double* params, int params_stride, float* out, int B, int H, int W, int C,
+                            int model_sz, int mode, void* stream) {
+  if (!frames || !params || !out) return HDN_E_NULL;
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || model_sz <= 0 || (mode != 0 && mode != 1) || (mode == 1 && C != 3)) return HDN_E_SHAPE;
+  if (params_stride < 3 + C) return HDN_E_SHAPE;
+  if (C > hdn::FR_MAXC || model_sz > 4096 || (long long)H * W > (1LL << 30) || B > 65535) return HDN_E_LIMIT;
+  hipLaunchKernelGGL(hdn::subwindow_kernel, dim3(hdn::frame_grid((size_t)model_sz * model_sz), B), dim3(HDN_BLOCK), 0,
+                     static_cast<hipStream_t>(stream), frames, params, out, H, W, C, model_sz, mode, params_stride);
+  return hdn::launch_status();
+}
+
 int hdn_subwindow_f32(const unsigned char* frame, const double* params, float* out, int H, int W, int C, int model_sz, int mode,
                       void* stream) {
-  if (!frame || !params || !out) return HDN_E_NULL;
-  if (H <= 0 || W <= 0 || C <= 0 || model_sz <= 0 || (mode != 0 && mode != 1) || (mode == 1 && C != 3)) return HDN_E_SHAPE;
-  if (C > hdn::FR_MAXC || model_sz > 4096 || (long long)H * W > (1LL << 30)) return HDN_E_LIMIT;
-  hipLaunchKernelGGL(hdn::subwindow_kernel, dim3(hdn::frame_grid((size_t)model_sz * model_sz)), dim3(HDN_BLOCK), 0,
-                     static_cast<hipStream_t>(stream), frame, params, out, H, W, C, model_sz, mode);
+  return hdn_subwindow_batch_f32(frame, params, 3 + (C > 0 ? C : 0), out, 1, H, W, C, model_sz, mode, stream);
+}
+
+int hdn_frame_warp_perspective_batch_u8(const unsigned char* src, const double* M, int m_stride, unsigned char* dst, int B, int H, int W, int C,
+                                        void* stream) {
+  if (!src || !M || !dst) return HDN_E_NULL;
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || m_stride < 9) return HDN_E_SHAPE;
+  if (C > hdn::FR_MAXC || (long long)H * W > (1LL << 30) || B > 65535) return HDN_E_LIMIT;
+  {
+    const unsigned char* const se = src + (size_t)B * H * W * C;
+    const unsigned char* const de = dst + (size_t)B * H * W * C;
+    if (src < de && dst < se) return HDN_E_ALIAS;
+  }
+  int bh = H < 16 ? H : 16;                      // OpenCV's block walk (BLOCK_SZ 32): it fixes the summation order of x
+  int bw = 1024 / bh < W ? 1024 / bh : W;
+  hipLaunchKernelGGL(hdn::frame_warp_perspective_kernel, dim3(hdn::frame_grid((size_t)H * W), B), dim3(HDN_BLOCK), 0,
+                     static_cast<hipStream_t>(stream), src, M, dst, H, W, C, bw, m_stride);
   return hdn::launch_status();
 }
 
 int hdn_frame_warp_perspective_u8(const unsigned char* src, const double* M, unsigned char* dst, int H, int W, int C, void* stream) {
+  return hdn_frame_warp_perspective_batch_u8(src, M, 9, dst, 1, H, W, C, stream);
+}
+
+int hdn_frame_warp_affine_cubic_batch_u8(const unsigned char* src, const double* M, int m_stride, unsigned char* dst, int B, int H, int W, int C,
+                                         void* stream) {
   if (!src || !M || !dst) return HDN_E_NULL;
-  if (H <= 0 || W <= 0 || C <= 0) return HDN_E_SHAPE;
-  if (C > hdn::FR_MAXC || (long long)H * W > (1LL << 30)) return HDN_E_LIMIT;
-  if (src == dst) return HDN_E_ALIAS;
-  int bh = H < 16 ? H : 16;                      // OpenCV's block walk (BLOCK_SZ 32): it fixes the summation order of x
-  int bw = 1024 / bh < W ? 1024 / bh : W;
-  hipLaunchKernelGGL(hdn::frame_warp_perspective_kernel, dim3(hdn::frame_grid((size_t)H * W)), dim3(HDN_BLOCK), 0,
-                     static_cast<hipStream_t>(stream), src, M, dst, H, W, C, bw);
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || m_stride < 6) return HDN_E_SHAPE;
+  if (C > hdn::FR_MAXC || (long long)H * W > (1LL << 30) || B > 65535) return HDN_E_LIMIT;
+  {
+    const unsigned char* const se = src + (size_t)B * H * W * C;
+    const unsigned char* const de = dst + (size_t)B * H * W * C;
+    if (src < de && dst < se) return HDN_E_ALIAS;
+  }
+  const int rc = hdn::ensure_cubic_tab();
+  if (rc != HDN_OK) return rc;
+  hipLaunchKernelGGL(hdn::frame_warp_affine_cubic_kernel, dim3(hdn::frame_grid((size_t)H * W), B), dim3(HDN_BLOCK), 0,
+                     static_cast<hipStream_t>(stream), src, M, dst, H, W, C, m_stride);
   return hdn::launch_status();
 }
 
 int hdn_frame_warp_affine_cubic_u8(const unsigned char* src, const double* M, unsigned char* dst, int H, int W, int C, void* stream) {
-  if (!src || !M || !dst) return HDN_E_NULL;
-  if (H <= 0 || W <= 0 || C <= 0) return HDN_E_SHAPE;
-  if (C > hdn::FR_MAXC || (long long)H * W > (1LL << 30)) return HDN_E_LIMIT;
-  if (src == dst) return HDN_E_ALIAS;
-  const int rc = hdn::ensure_cubic_tab();
-  if (rc != HDN_OK) return rc;
-  hipLaunchKernelGGL(hdn::frame_warp_affine_cubic_kernel, dim3(hdn::frame_grid((size_t)H * W)), dim3(HDN_BLOCK), 0,
-                     static_cast<hipStream_t>(stream), src, M, dst, H, W, C);
-  return hdn::launch_status();
+  return hdn_frame_warp_affine_cubic_batch_u8(src, M, 6, dst, 1, H, W, C, stream);
 }
 
 int hdn_remap_linear_f32(const float* src, const float* mapx, const float* mapy, float* dst, int C, int Hs, int Ws, int Hd, int Wd,
                          void* stream) {
   if (!src || !mapx || !mapy || !dst) return HDN_E_NULL;
   if (C <= 0 || Hs <= 0 || Ws <= 0 || Hd <= 0 || Wd <= 0) return HDN_E_SHAPE;
-  if (C > hdn::FR_MAXC || (long long)Hs * Ws > (1LL << 30) || (long long)Hd * Wd > (1LL << 30)) return HDN_E_LIMIT;
+  // (C counts planes that share the maps: the channels of one crop, or of a whole batch of crops)
+  if (C > 4096 || (long long)Hs * Ws > (1LL << 30) || (long long)Hd * Wd > (1LL << 30)) return HDN_E_LIMIT;
   if (src == dst) return HDN_E_ALIAS;
   hipLaunchKernelGGL(hdn::remap_linear_kernel, dim3(hdn::frame_grid((size_t)Hd * Wd)), dim3(HDN_BLOCK), 0,
                      static_cast<hipStream_t>(stream), src, mapx, mapy, dst, C, Hs, Ws, Hd, Wd);

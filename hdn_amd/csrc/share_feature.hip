@@ -14,6 +14,16 @@
 
 #include "hdn_common.h"
 
+// Measurement hooks (tools/build_variant.sh ... -DHDN_ABLATION -D<experiment>): every site below expands to its production text; the
+// experiments' replacement bodies live in ablation/share_feature.inc and are compiled in only under -DHDN_ABLATION, so that editing or adding an
+// experiment leaves this translation unit's text (and the hash the committed PMC record carries) unchanged.
+#define HDN_ABL_SHARE_FEATURE_0(...) __VA_ARGS__
+#define HDN_ABL_SHARE_FEATURE_1(...) __VA_ARGS__
+#define HDN_ABL_SHARE_FEATURE_2(...) __VA_ARGS__
+#ifdef HDN_ABLATION
+#include "ablation/share_feature.inc"
+#endif
+
 namespace hdn {
 
 constexpr int SF_ROWS = 4;    // output rows per workgroup
@@ -384,9 +394,7 @@ __global__ __launch_bounds__(HDN_BLOCK) void share_feature_rows_kernel(const flo
                                                                        float* __restrict__ out, int H, int W, int rows_per_strip,
                                                                        int strips_per_img, int total_strips) {
   using namespace sfv;
-#if defined(HDN_ABLATION) && defined(SF_EXP_PRIO)   // measurement build only: tools/build_variant.sh -DHDN_ABLATION -DSF_EXP_PRIO=3
-  __builtin_amdgcn_s_setprio(SF_EXP_PRIO);
-#endif
+  HDN_ABL_SHARE_FEATURE_0()
   const int lane = threadIdx.x & 63;
   const int strip = __builtin_amdgcn_readfirstlane(blockIdx.x * (HDN_BLOCK / 64) + (threadIdx.x >> 6));
   if (strip >= total_strips) return;
@@ -424,14 +432,8 @@ __global__ __launch_bounds__(HDN_BLOCK) void share_feature_rows_kernel(const flo
     float2v xr[7];
 #pragma unroll
     for (int q = 0; q < 7; ++q) xr[q] = load_row(c, c.ra - 3 + q);
-#if defined(HDN_ABLATION) && defined(SF_EXP_NOSTEPS)   // measurement build: launch + the rows' round trip only
-    if (c.m0) c.dst[size_t(c.ra) * c.W + c.col0] = xr[0].x + xr[1].x + xr[2].x + xr[3].x + xr[4].x + xr[5].x + xr[6].x;
-    return;
-#endif
-#if defined(HDN_ABLATION) && defined(SF_EXP_ONESTEP)   // measurement build: one of the seven steps
-    step<0, false>(st, c, c.ra + 3, xr[6]);
-    return;
-#endif
+    HDN_ABL_SHARE_FEATURE_1()
+    HDN_ABL_SHARE_FEATURE_2()
     step<0, false>(st, c, c.ra - 3, xr[0]);
     step<1, false>(st, c, c.ra - 2, xr[1]);
     step<2, false>(st, c, c.ra - 1, xr[2]);

@@ -27,6 +27,15 @@
 
 #include <cstdlib>
 
+// Measurement hooks (tools/build_variant.sh ... -DHDN_ABLATION -D<experiment>): every site below expands to its production text; the
+// experiments' replacement bodies live in ablation/xcorr.inc and are compiled in only under -DHDN_ABLATION, so that editing or adding an
+// experiment leaves this translation unit's text (and the hash the committed PMC record carries) unchanged.
+#define HDN_ABL_XCORR_0(...) __VA_ARGS__
+#define HDN_ABL_XCORR_1(...) __VA_ARGS__
+#ifdef HDN_ABLATION
+#include "ablation/xcorr.inc"
+#endif
+
 namespace hdn {
 
 constexpr int XC_MAX_PROBLEMS = 8;
@@ -61,9 +70,7 @@ constexpr int ITER = cdiv(N4, HDN_BLOCK);
 
 __global__ __launch_bounds__(HDN_BLOCK) void xcorr_prod29_kernel(XcorrPtrs P, int planes) {
   using namespace prod29;
-#if defined(HDN_ABLATION) && defined(XC_EXP_PRIO)   // measurement build only: tools/build_variant.sh -DHDN_ABLATION -DXC_EXP_PRIO=3
-  __builtin_amdgcn_s_setprio(XC_EXP_PRIO);
-#endif
+  HDN_ABL_XCORR_0()
   __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
   float* sx = smem;
   float* so = smem + XFLOATS;
@@ -652,9 +659,7 @@ __device__ __forceinline__ void planes_out(const float* lds, float* __restrict__
 
 __global__ __launch_bounds__(HDN_BLOCK, 3) void xcorr_circ13f_kernel(XcorrPtrs P, int planes, int groups_per_problem, int total_groups) {
   using namespace circ13f;
-#if defined(HDN_ABLATION) && defined(XC_EXP_PRIO)
-  __builtin_amdgcn_s_setprio(XC_EXP_PRIO);
-#endif
+  HDN_ABL_XCORR_1()
   __shared__ __attribute__((aligned(16))) float smem[WAVES * WAVE_FLOATS];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

@@ -401,6 +401,15 @@ int launch_north_fft(const float* x, const float* k, float* out, int planes, int
 // =======================================================================================
 #include <type_traits>
 
+// Measurement hooks (tools/build_variant.sh ... -DHDN_ABLATION -D<experiment>): every site below expands to its production text; the
+// experiments' replacement bodies live in ablation/xcorr_fft.inc and are compiled in only under -DHDN_ABLATION, so that editing or adding an
+// experiment leaves this translation unit's text (and the hash the committed PMC record carries) unchanged.
+#define HDN_ABL_XCORR_FFT_0(...) __VA_ARGS__
+#define HDN_ABL_XCORR_FFT_1(...) __VA_ARGS__
+#ifdef HDN_ABLATION
+#include "ablation/xcorr_fft.inc"
+#endif
+
 namespace hdn {
 namespace nf2 {
 using nfft::bitrev;
@@ -720,9 +729,7 @@ __global__ __launch_bounds__(64 * WPG) void xcorr_north_fft4_kernel(const float*
     if (worker == tail_worker) north_fft_v1_body(smem, x, k, out, planes, npairs, 0, 1, tab, lane);
     return;  // (a surplus wave of the last workgroup)
   }
-#if defined(HDN_ABLATION) && defined(NF4_EXP_SOLO)   // measurement build only   // measurement only: NF4_EXP_SOLO of a workgroup's 4 waves work, the others leave (their pairs are skipped)
-  if (wave >= NF4_EXP_SOLO) return;
-#endif
+  HDN_ABL_XCORR_FFT_0()
   const uint32_t sb = lds_addr(smem);
 
   const int fc = lane & 31;
@@ -854,13 +861,7 @@ __global__ __launch_bounds__(64 * WPG) void xcorr_north_fft4_kernel(const float*
             sa[f] = a;
             sb2[f] = b;
           }
-#if defined(HDN_ABLATION) && defined(NF4_EXP_SPECW) && NF4_EXP_SPECW == 1   // measurement build only (wrong results): half of the 32 KB spectrum write
-          if constexpr (f > 0) lw64<(f - 1) * 8>(a_row, sa[f - 1]);
-#elif defined(HDN_ABLATION) && defined(NF4_EXP_SPECW) && NF4_EXP_SPECW == 2 // ... none of it
-          if constexpr (f == 32) lw64<0>(a_row, cf{sa[0].x + sb2[31].y + sa[17].y, sb2[3].x + sa[29].x + sb2[11].y});
-#else
-          if constexpr (f > 0) lw2x64<f - 1, 32 + f - 1>(a_row, sa[f - 1], sb2[f - 1]);
-#endif
+          HDN_ABL_XCORR_FFT_1(if constexpr (f > 0) lw2x64<f - 1, 32 + f - 1>(a_row, sa[f - 1], sb2[f - 1]);)
         });
       }
     }

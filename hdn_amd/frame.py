@@ -42,11 +42,24 @@ def upload(img) -> torch.Tensor:
 
 
 def _check_frame(frame):
-    if not isinstance(frame, torch.Tensor) or frame.dtype != torch.uint8 or frame.dim() != 3 or not frame.is_cuda:
-        raise _lib.HdnHipError("frame must be a uint8 [H,W,C] tensor on the GPU (hdn_amd.frame.upload); there is no CPU fallback")
+    """-> (H, W, C) of a frame [H,W,C], or of every frame of a batch [B,H,W,C] (B sequences in lock step: hdn_amd.batched_tracker)."""
+    if not isinstance(frame, torch.Tensor) or frame.dtype != torch.uint8 or frame.dim() not in (3, 4) or not frame.is_cuda:
+        raise _lib.HdnHipError("frame must be a uint8 [H,W,C] (or [B,H,W,C]) tensor on the GPU (hdn_amd.frame.upload); there is no CPU fallback")
     if not frame.is_contiguous():
         raise ValueError("frame must be contiguous")
-    return frame.shape
+    return frame.shape[-3:]
+
+
+def _records(t, B, width, what):
+    """A float64 device array of B parameter records of `width` doubles -> (tensor to keep alive, pointer, stride in doubles).  The records
+    may be a column slice of a wider per-sequence array (state[:, 8:14]): only the rows' stride has to be uniform."""
+    if t.dtype != torch.float64 or not t.is_cuda:
+        raise TypeError(f"{what} must be a float64 GPU tensor")
+    if t.dim() == 1 and B == 1:
+        t = t.reshape(1, -1)
+    if t.dim() != 2 or t.shape[0] != B or t.shape[1] != width or t.stride(1) != 1 or (B > 1 and t.stride(0) < width):
+        raise ValueError(f"{what} must be [{B}, {width}] with unit column stride, got {tuple(t.shape)} strides {tuple(t.stride())}")
+    return t, t.data_ptr(), (t.stride(0) if B > 1 else width)
 
 
 def _dev_f64(values, dev) -> torch.Tensor:
@@ -73,21 +86,26 @@ def crop_points(pos, original_sz, im_h, im_w):
 def _subwindow(frame, pos, model_sz, original_sz, avg_chans, mode, params=None):
     H, W, C = _check_frame(frame)
     dev = frame.device
+    B = frame.shape[0] if frame.dim() == 4 else 1
     if params is None:
+        if B != 1:
+            raise ValueError("a batch of frames takes its crop parameters as a float64 device tensor [B, 3 + C] (`params`)")
         params = _dev_f64([pos[0], pos[1], original_sz] + [float(a) for a in np.asarray(avg_chans).reshape(-1)], dev)
-    if params.numel() != 3 + C:
+    if B == 1 and params.numel() != 3 + C:
         raise ValueError(f"params must be [cx, cy, original_sz, avg x {C}]")
+    keep, pp, stride = _records(params, B, 3 + C, "params")
     m = int(model_sz)
-    out = torch.empty((1, 1 if mode else C, m, m), dtype=torch.float32, device=dev)
+    out = torch.empty((B, 1 if mode else C, m, m), dtype=torch.float32, device=dev)
     with _lib.device_guard(dev):
-        rc = _lib.load().hdn_subwindow_f32(_lib.ptr(frame), _lib.ptr(params), _lib.ptr(out), H, W, C, m, mode, _lib.stream_ptr(dev))
+        rc = _lib.load().hdn_subwindow_batch_f32(_lib.ptr(frame), pp, stride, _lib.ptr(out), B, H, W, C, m, mode, _lib.stream_ptr(dev))
     _lib.check(rc, "get_subwindow")
     return out
 
 
 def get_subwindow(frame, pos, model_sz, original_sz, avg_chans, params=None, islog: int = 0):
     """-> float32 [1, C, model_sz, model_sz] (uint8-valued), on the device; islog=1 appends the C log-polar channels
-    (np.concatenate((im_patch, getPolarImg(im_patch)), 2), base_tracker.py:119-126) -> [1, 2C, model_sz, model_sz]."""
+    (np.concatenate((im_patch, getPolarImg(im_patch)), 2), base_tracker.py:119-126) -> [1, 2C, model_sz, model_sz].
+    A batch of frames [B,H,W,C] with `params` [B, 3 + C] gives [B, ...]: one launch, frame b cut with record b."""
     out = _subwindow(frame, pos, model_sz, original_sz, avg_chans, 0, params)
     if islog == 1:
         return torch.cat([out, get_polar_img(out)], dim=1)
@@ -116,10 +134,11 @@ _polar_maps = {}
 def get_polar_img(patch: torch.Tensor, original=None) -> torch.Tensor:
     """getPolarImg (hdn/models/logpolar.py:11-29) on a device crop [1, C, S, S] (uint8-valued float32): cv2.logPolar about
     (S // 2, S // 2) (or round(original)) with M = S / log(S / 2), INTER_LINEAR, outliers filled with 0.  Restated OpenCV."""
-    if patch.dim() != 4 or patch.shape[0] != 1 or patch.dtype != torch.float32:
-        raise ValueError("get_polar_img takes a float32 [1, C, H, W] crop")
+    if patch.dim() != 4 or patch.dtype != torch.float32:
+        raise ValueError("get_polar_img takes a float32 [B, C, H, W] crop")
     dev = _lib.require_device(patch)
-    _, C, H, W = patch.shape
+    Bp, C, H, W = patch.shape
+    C = Bp * C          # the maps are the same for every plane: a batch of crops is just more planes
     center = (float(np.round(original[0])), float(np.round(original[1]))) if original is not None else (float(H // 2), float(W // 2))
     key = (dev, H, W, center)
     if key not in _polar_maps:
@@ -145,28 +164,39 @@ def get_search_info(frame, pos, original_sz, avg_chans, model_sz: int = 127, par
     return _subwindow(frame, pos, model_sz, original_sz, avg_chans, 1, params)
 
 
+def _matrices(frame, M, width, what):
+    B = frame.shape[0] if frame.dim() == 4 else 1
+    if isinstance(M, torch.Tensor):
+        m = M if (B > 1 or M.dim() == 2) else M.contiguous().reshape(1, -1)
+        if B == 1 and m.numel() != width:
+            raise ValueError(f"M must be {what}")
+    else:
+        a = np.asarray(M, np.float64)
+        if a.size != B * width:
+            raise ValueError(f"M must be {what}" + (f" per frame ({B} frames)" if B > 1 else ""))
+        m = _dev_f64(a.reshape(-1), frame.device).reshape(B, width)
+    return (B,) + _records(m, B, width, "M")
+
+
 def warp_perspective(frame, M):
-    """cv2.warpPerspective(frame, M, (W, H), borderMode=cv2.BORDER_REPLICATE); M: 3x3 (host array or float64 device tensor)."""
+    """cv2.warpPerspective(frame, M, (W, H), borderMode=cv2.BORDER_REPLICATE); M: 3x3 (host array or float64 device tensor).
+    A batch [B,H,W,C] takes B matrices [B, 9] (rows of a wider float64 device array are fine) and is one launch."""
     H, W, C = _check_frame(frame)
-    m = _dev_f64(np.asarray(M, np.float64).reshape(-1) if not isinstance(M, torch.Tensor) else M, frame.device)
-    if m.numel() != 9:
-        raise ValueError("M must be 3x3")
+    B, keep, mp, stride = _matrices(frame, M, 9, "3x3")
     out = torch.empty_like(frame)
     with _lib.device_guard(frame.device):
-        rc = _lib.load().hdn_frame_warp_perspective_u8(_lib.ptr(frame), _lib.ptr(m), _lib.ptr(out), H, W, C, _lib.stream_ptr(frame.device))
+        rc = _lib.load().hdn_frame_warp_perspective_batch_u8(_lib.ptr(frame), mp, stride, _lib.ptr(out), B, H, W, C, _lib.stream_ptr(frame.device))
     _lib.check(rc, "warp_perspective")
     return out
 
 
 def warp_affine_cubic(frame, M):
-    """cv2.warpAffine(frame, M, (W, H), flags=cv2.INTER_CUBIC, borderMode=cv2.BORDER_REPLICATE); M: 2x3."""
+    """cv2.warpAffine(frame, M, (W, H), flags=cv2.INTER_CUBIC, borderMode=cv2.BORDER_REPLICATE); M: 2x3 (a batch: [B, 6])."""
     H, W, C = _check_frame(frame)
-    m = _dev_f64(np.asarray(M, np.float64).reshape(-1) if not isinstance(M, torch.Tensor) else M, frame.device)
-    if m.numel() != 6:
-        raise ValueError("M must be 2x3")
+    B, keep, mp, stride = _matrices(frame, M, 6, "2x3")
     out = torch.empty_like(frame)
     with _lib.device_guard(frame.device):
-        rc = _lib.load().hdn_frame_warp_affine_cubic_u8(_lib.ptr(frame), _lib.ptr(m), _lib.ptr(out), H, W, C, _lib.stream_ptr(frame.device))
+        rc = _lib.load().hdn_frame_warp_affine_cubic_batch_u8(_lib.ptr(frame), mp, stride, _lib.ptr(out), B, H, W, C, _lib.stream_ptr(frame.device))
     _lib.check(rc, "warp_affine_cubic")
     return out
 

@@ -121,11 +121,12 @@ def track_proj(net, data, tmp_mask=None, cached_patch_1=None):
     return st["H_mat"], score, score_simi
 
 
-def track_proj_pair(net, template, search, h4p, patch_1):
+def track_proj_pair(net, template, search, h4p, patch_1, per_sample: bool = False):
     """track_proj for the tracker's per-frame call, where the two crops are separate tensors and ShareFeature(template) is cached
     (SURVEY §3d): the same stages as homo_stages(..., cached_patch_1) without building the [B,2,H,W] pair first (one concatenation
     and one strided copy per call less - launches that are pure latency at B = 1).
-    template / search: [B,1,H,W] contiguous fp32; patch_1 = ShareFeature(template)."""
+    template / search: [B,1,H,W] contiguous fp32; patch_1 = ShareFeature(template).
+    per_sample: the two scores of EVERY sample ([B] each) instead of sample 0's (the reference's `[0][0]`): B independent sequences."""
     if template.shape != search.shape or template.dim() != 4 or template.shape[1] != 1:
         raise ValueError(f"template / search must both be [B,1,H,W], got {tuple(template.shape)} / {tuple(search.shape)}")
     with torch.no_grad():
@@ -133,7 +134,10 @@ def track_proj_pair(net, template, search, h4p, patch_1):
         x = _regress(net, torch.cat((patch_1, p2), dim=1))
         H_mat, pred = G.dlt_warp(h4p, x, template.contiguous())
         pf = _share(net, pred)
-    score, score_simi = G.l1_score2(p2[0, 0], pf[0, 0], patch_1[0, 0], 1.0 / (127 * 127))
+    if per_sample:
+        score, score_simi = G.l1_score2_batch(p2, pf, patch_1, 1.0 / (127 * 127))
+    else:
+        score, score_simi = G.l1_score2(p2[0, 0], pf[0, 0], patch_1[0, 0], 1.0 / (127 * 127))
     return H_mat, score, score_simi
 
 

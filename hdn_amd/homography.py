@@ -138,3 +138,21 @@ def l1_score2(a: torch.Tensor, b0: torch.Tensor, b1: torch.Tensor, scale: float)
                                            _lib.stream_ptr(dev))
     _lib.check(rc, "l1_score2")
     return out[0], out[1]
+
+
+def l1_score2_batch(a: torch.Tensor, b0: torch.Tensor, b1: torch.Tensor, scale: float):
+    """Per-sample scores of a batch: a, b0, b1 [B,1,H,W] (channel 0 of every sample, as track_proj scores it) -> two [B] device tensors
+    from ONE launch (hdn_l1_score2_batch_f32); entry s is bit-identical to l1_score2 on sample s alone.  The reference scores sample 0
+    only (`[0][0]`, model_builder_e2e_unconstrained_v2.py:213-216): its tracker holds one sequence.  The lock-step multi-sequence
+    tracker needs every sequence's own gate value."""
+    dev = _lib.require_device(a, b0, b1)
+    if a.dim() != 4 or a.shape[1] != 1 or a.shape != b0.shape or a.shape != b1.shape or a.numel() == 0:
+        raise ValueError("l1_score2_batch needs three [B,1,H,W] tensors of equal shape")
+    B, n = a.shape[0], a.shape[2] * a.shape[3]
+    ac, b0c, b1c = a.detach().contiguous(), b0.detach().contiguous(), b1.detach().contiguous()
+    out = torch.empty((B, 2), dtype=torch.float32, device=dev)
+    with _lib.device_guard(dev):
+        rc = _lib.load().hdn_l1_score2_batch_f32(_lib.ptr(ac), _lib.ptr(b0c), _lib.ptr(b1c), _lib.ptr(out), n, n, B, float(scale), _lib.stream_ptr(dev))
+    _lib.check(rc, "l1_score2_batch")
+    return out[:, 0], out[:, 1]
+

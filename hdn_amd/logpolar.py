@@ -32,8 +32,12 @@ def logpolar_sample(x: torch.Tensor, polar: torch.Tensor, tabs, want_grid: bool 
     B, C, H, W = x.shape
     rho, c, s = tabs
     S = rho.numel()
+    if tuple(polar.shape) == (1, 2) and B > 1:
+        # the reference broadcasts one origin over the batch (`x.repeat([batch, 1, 1]) + polar[:, 0]...`, hdn/models/logpolar.py:113-114;
+        # ModelBuilder.track_new_lp always passes a [1, 2] zero origin, model_builder_e2e_unconstrained_v2.py:145)
+        polar = polar.expand(B, 2)
     if tuple(polar.shape) != (B, 2):
-        raise ValueError(f"polar must be [{B},2], got {tuple(polar.shape)}")
+        raise ValueError(f"polar must be [{B},2] (or [1,2], broadcast), got {tuple(polar.shape)}")
     dev = _lib.require_device(x, polar, rho, c, s)
     xc, pc = x.detach().contiguous(), polar.detach().contiguous()
     out = torch.empty((B, C, S, S), dtype=torch.float32, device=dev)

@@ -53,13 +53,15 @@ def _constants(dev, B, H, W):
     return _CONST[key]
 
 
-def homo_refine(net, template: torch.Tensor, search: torch.Tensor, iterations: int = 2, cache_template: bool = True, patch_1: torch.Tensor = None):
+def homo_refine(net, template: torch.Tensor, search: torch.Tensor, iterations: int = 2, cache_template: bool = True, patch_1: torch.Tensor = None,
+                per_sample: bool = False):
     """template / search: [B,1,127,127] normalised gray crops on the device (get_template_info / get_search_info output).
 
     Returns (H_comp [B,3,3] float64 = product of the normalised inverse homographies, as the tracker composes it,
     similarity_norm, similarity_norm_simi of the LAST iteration — the values the tracker's `> 2.5` gate sees).
     ShareFeature(template) is computed once (it is constant: SURVEY §3d) — or not at all when the caller hands it in as `patch_1`
-    (the tracker keeps it for the whole sequence: the template crop is cut once, in init)."""
+    (the tracker keeps it for the whole sequence: the template crop is cut once, in init).
+    per_sample: scores of every sample ([B]) instead of sample 0's — B independent sequences (hdn_amd.batched_tracker)."""
     if iterations < 1:
         raise ValueError("iterations must be >= 1")
     B, _, H, W = template.shape
@@ -67,6 +69,8 @@ def homo_refine(net, template: torch.Tensor, search: torch.Tensor, iterations: i
     h4p, pidx, eye = _constants(dev, B, H, W)
     H_comp = eye.clone()
     cur = search
+    if per_sample and patch_1 is None and not cache_template:
+        raise ValueError("per_sample scores need the cached-template form (cache_template=True or patch_1)")
     if patch_1 is not None:
         if patch_1.shape != template.shape or patch_1.device != template.device:
             raise ValueError(f"patch_1 must be ShareFeature(template): {tuple(template.shape)} on {template.device}, got {tuple(patch_1.shape)}")
@@ -76,7 +80,7 @@ def homo_refine(net, template: torch.Tensor, search: torch.Tensor, iterations: i
     score = score_simi = None
     for _ in range(iterations):
         if p1 is not None:
-            H_mat, score, score_simi = track_proj_pair(net, template, cur, h4p, p1)
+            H_mat, score, score_simi = track_proj_pair(net, template, cur, h4p, p1, per_sample=per_sample)
         else:
             imgs = torch.cat((template, cur), dim=1)
             data = {"org_imgs": imgs, "input_tensors": imgs, "h4p": h4p, "patch_indices": pidx}

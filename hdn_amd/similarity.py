@@ -160,15 +160,35 @@ class DeviceSimilarity:
 
     def init(self, frame, init_pos, init_s_z, init_s_z_sm, channel_average):
         """hdnTrackerHomo.init's model side (:99-107): z_crop = get_subwindow_for_homo(img, center_pos, EXEMPLAR_SIZE, s_z, avg,
-        islog=1); model.template(z_crop) — plus the records the per-frame kernels read."""
+        islog=1); model.template(z_crop) — plus the records the per-frame kernels read.
+        A batch of B sequences in lock step (hdn_amd.batched_tracker): frame [B,H,W,3], init_pos [B,2], init_s_z / init_s_z_sm [B],
+        channel_average [B,3]; the model then holds B templates (its zf has batch B) and every per-frame call runs at batch B."""
         dev = frame.device
         dec = self.decoder(dev)
-        host = sequence_constants(init_pos, init_s_z, init_s_z_sm, channel_average, self.cfg)
+        if frame.dim() == 4:
+            B = frame.shape[0]
+            pos, sz, szs, avg = (np.asarray(a, np.float64) for a in (init_pos, init_s_z, init_s_z_sm, channel_average))
+            if pos.shape != (B, 2) or sz.shape != (B,) or szs.shape != (B,) or avg.shape != (B, 3):
+                raise ValueError(f"a batch of {B} sequences takes init_pos [{B},2], init_s_z / init_s_z_sm [{B}], channel_average [{B},3]")
+            host = np.stack([sequence_constants(pos[b], sz[b], szs[b], avg[b], self.cfg) for b in range(B)])
+            tparams = np.concatenate([pos, sz[:, None], avg], axis=1)          # the template crop: about init_pos, side init_s_z
+        else:
+            B = 1
+            host = sequence_constants(init_pos, init_s_z, init_s_z_sm, channel_average, self.cfg).reshape(1, -1)
+            tparams = None
+        self.batch, self.batched = B, frame.dim() == 4
         self.seq = torch.from_numpy(host).to(dev)
+        if not self.batched:
+            self.seq = self.seq.reshape(-1)
         # get_subwindow(img, init_pos, INSTANCE_SIZE, s_x, avg) (:164-166): the first search crop never moves
-        self._params0 = torch.from_numpy(host[[0, 1, 3, 5, 6, 7]].copy()).to(dev)
-        self.state = dec.new_state(1)
-        z_crop, _ = FR.get_subwindow_for_homo(frame, init_pos, self.cfg.exemplar_size, init_s_z, channel_average, islog=1)
+        self._params0 = torch.from_numpy(np.ascontiguousarray(host[:, [0, 1, 3, 5, 6, 7]])).to(dev)
+        if not self.batched:
+            self._params0 = self._params0.reshape(-1)
+        self.state = dec.new_state(B)
+        if not self.batched:
+            z_crop, _ = FR.get_subwindow_for_homo(frame, init_pos, self.cfg.exemplar_size, init_s_z, channel_average, islog=1)
+        else:
+            z_crop = FR.get_subwindow(frame, None, self.cfg.exemplar_size, None, None, params=torch.from_numpy(tparams).to(dev), islog=1)
         with torch.no_grad():
             self.model.template(z_crop)
         return z_crop
@@ -176,15 +196,21 @@ class DeviceSimilarity:
     def __call__(self, frame):
         if self.seq is None:
             raise RuntimeError("DeviceSimilarity.init() has not been called for this sequence")
-        c, dec, row = self.cfg, self.decoder(frame.device), self.state.view(-1)
+        c, dec = self.cfg, self.decoder(frame.device)
+        B, batched = getattr(self, "batch", 1), getattr(self, "batched", False)
+        if (frame.shape[0] if frame.dim() == 4 else 1) != B or batched != (frame.dim() == 4):
+            raise ValueError(f"init() was given {B} sequence(s); this call has {frame.shape[0] if frame.dim() == 4 else 1}")
+        seq = self.seq.view(B, -1)
         # 1. translation (:164-186)
         x_crop = FR.get_subwindow(frame, None, c.instance_size, None, None, params=self._params0)
         with torch.no_grad():
             out = self.model.track_new(x_crop)
-        dec.translation(out["cls"], out["loc_c"], self.seq, self.state)
+        dec.translation(out["cls"], out["loc_c"], seq, self.state)
         # 2. scale / rotation (:189-214): crop about the moved centre, log-polar head
-        x_moved = FR.get_subwindow(frame, None, c.instance_size, None, None, params=row[8:14])
+        x_moved = FR.get_subwindow(frame, None, c.instance_size, None, None, params=self.state[:, 8:14] if batched else self.state.view(-1)[8:14])
         with torch.no_grad():
             out = self.model.track_new_lp(x_moved, [0, 0])
-        dec.logpolar(out["cls_lp"], out["loc_lp"], self.seq, self.state)
-        return state_fields(row)
+        dec.logpolar(out["cls_lp"], out["loc_lp"], seq, self.state)
+        if batched:    # column views of the [B, 48] record (the kernels take them with the rows' stride)
+            return {"rot_matrix": self.state[:, 32:38], "params_homo": self.state[:, 40:46], "H_sim": self.state[:, 20:29]}
+        return state_fields(self.state.view(-1))

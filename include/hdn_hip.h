@@ -33,7 +33,7 @@ extern "C" {
 /* RCCL failures are returned as -(2000 + ncclResult_t). */
 
 /* ABI version of this header; hdn_abi_version() of the loaded library must match. */
-#define HDN_ABI_VERSION 7
+#define HDN_ABI_VERSION 8
 int hdn_abi_version(void);
 
 /* Name of the kernel variant the last hdn_xcorr_* call on this thread dispatched to
@@ -178,6 +178,13 @@ int hdn_l1_score_f32(const float* a, const float* b, float* out, int n, float sc
  * of hdn_l1_score_f32). */
 int hdn_l1_score2_f32(const float* a, const float* b0, const float* b1, float* out2, int n, float scale, void* stream);
 
+/* The same for B samples in one launch (the lock-step multi-sequence tracker, hdn_amd.batched_tracker): sample s reads its three planes
+ * `plane_stride` floats (>= n) after sample s - 1's and writes out[2 s], out[2 s + 1]; every sample's sums run in the order of
+ * hdn_l1_score2_f32, so each is bit-identical to its own single call.  The reference scores sample 0 only
+ * (model_builder_e2e_unconstrained_v2.py:213-216: `[0][0]`), because its tracker holds one sequence per process. */
+int hdn_l1_score2_batch_f32(const float* a, const float* b0, const float* b1, float* out, int n, long long plane_stride, int B, float scale,
+                            void* stream);
+
 /*
  * Log-polar resample of the search crop: out[b,c,a,r] = bilinear(img[b,c], p(a,r)) with
  *   g = (rho[r]*cos_theta[a] + polar[b,0], rho[r]*sin_theta[a] + polar[b,1]) / (size//2)   (the reference's grid)
@@ -219,6 +226,18 @@ int hdn_subwindow_f32(const unsigned char* frame, const double* params, float* o
                       void* stream);
 int hdn_frame_warp_perspective_u8(const unsigned char* src, const double* M, unsigned char* dst, int H, int W, int C, void* stream);
 int hdn_frame_warp_affine_cubic_u8(const unsigned char* src, const double* M, unsigned char* dst, int H, int W, int C, void* stream);
+/*
+ * The three calls above for B frames at once (B independent sequences advancing in lock step; the reference's only inference-time
+ * parallelism is several videos at once, tools/test.py:91-103): frames / crops contiguous [B, ...]; frame b takes its parameter record /
+ * matrix at params + b * params_stride (>= 3 + C doubles) / M + b * m_stride (>= 9 / 6 doubles), so the records may be columns of a wider
+ * per-sequence array (the similarity state record).  Per frame bit-identical to the single-frame call (same kernel, blockIdx.y = b).
+ */
+int hdn_subwindow_batch_f32(const unsigned char* frames, const double* params, int params_stride, float* out, int B, int H, int W, int C,
+                            int model_sz, int mode, void* stream);
+int hdn_frame_warp_perspective_batch_u8(const unsigned char* src, const double* M, int m_stride, unsigned char* dst, int B, int H, int W, int C,
+                                        void* stream);
+int hdn_frame_warp_affine_cubic_batch_u8(const unsigned char* src, const double* M, int m_stride, unsigned char* dst, int B, int H, int W, int C,
+                                         void* stream);
 int hdn_remap_linear_f32(const float* src, const float* mapx, const float* mapy, float* dst, int C, int Hs, int Ws, int Hd, int Wd,
                          void* stream);
 
@@ -468,6 +487,13 @@ int hdn_rccl_unique_id(void* id128);
 int hdn_rccl_comm_create(void** comm_out, int world, int rank, const void* id128);
 int hdn_rccl_comm_count(void* comm, int* count);   /* ncclCommCount: the ranks RCCL itself sees (ABI 6) */
 int hdn_rccl_comm_destroy(void* comm);
+
+/*
+ * Measurement aid (bench.py `roofline.measured_copy_GBps`; SURVEY.md section 8d asks for a measured device-copy bandwidth beside the
+ * nominal 8 TB/s): dst[0..n) = src[0..n), 16 bytes per lane, nontemporal on both sides, 8,192 workgroups.  n % 4 == 0, 16-byte aligned
+ * pointers, no overlap.  Asynchronous on `stream`; moves 2 * 4 * n bytes.
+ */
+int hdn_ubench_copy_f32(const float* src, float* dst, long long n, void* stream);
 
 /*
  * The same exchange as ONE kernel per rank and one xGMI hop, for a fully connected node (for 2 KB per rank a

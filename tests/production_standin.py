@@ -193,7 +193,7 @@ class ProductionStandIn(nn.Module):
 
     def track_new_lp(self, x, delta=[0, 0]):
         polar = self._polar0
-        if polar is None or polar.device != x.device:
+        if polar is None or polar.device != x.device or polar.shape[0] != x.shape[0]:
             polar = self._polar0 = torch.zeros((x.shape[0], 2), dtype=torch.float32, device=x.device)
         x_lp, grid = self.logpolar_instance(x, polar, delta)
         cls_lp, loc_lp = self.head_lp(self.zf_lp, self.neck_lp(self.feature_extractor(x_lp)))

@@ -81,7 +81,7 @@ class StandInSiamese(nn.Module):
 
     def track_new_lp(self, x, delta=[0, 0]):
         polar = getattr(self, "_polar0", None)
-        if polar is None or polar.device != x.device:
+        if polar is None or polar.device != x.device or polar.shape[0] != x.shape[0]:
             polar = torch.zeros((x.shape[0], 2), dtype=torch.float32, device=x.device)
             self._polar0 = polar
         x_lp, grid = self.logpolar_instance(x, polar, delta)
