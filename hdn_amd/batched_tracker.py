@@ -17,7 +17,7 @@ Parity.  Every kernel computes sequence b of a batch exactly as it computes it a
 selects the data); what may differ from N separate B = 1 runs is the rounding of the PyTorch-ROCm convolutions (MIOpen picks other
 algorithms at another batch size) and of the B = 1-only packed head / chained trunk forms.  tests/test_gpu_tracker.py holds every
 sequence of a batch to its own B = 1 run (<= 1e-4 px on the corners with the stand-in networks; bit-exact frame kernels) and to the CPU
-oracle loop.
+restatement of the loop.
 
 Frames of all sequences of a step must have one size (they share the [N,H,W,3] buffer); sequences of different lengths: keep feeding
 the last frame of a finished one (its results are simply not read).

@@ -287,6 +287,77 @@ def run_production(n_frames=501, n_parity=0, nchw=False, components=True, dev=No
     return res
 
 
+# --------------------------------------------------------------------------------------------------- n sequences in lock step
+def init_from_corners(c0, target_wh):
+    """The init record tools/synth_sequence.make_sequence builds for frame 0, for ANY frame of the sequence (its ground-truth corners)."""
+    tw, th = target_wh
+    c0 = np.asarray(c0, np.float32)
+    return {"bbox": [float(c0[:, 0].min()), float(c0[:, 1].min()), float(tw), float(th)],
+            "poly": [float(c0[:, 0].mean()), float(c0[:, 1].mean()), float(tw), float(th), 0.0],
+            "gt_points": c0.reshape(-1).tolist(), "first_point": c0[0].tolist()}
+
+
+def run_multi(ns=(1, 4, 16, 32), n_steps=60, dev=None, quiet=False, offset=3, distinct_steps=8, kprofile_n=None):
+    """hdn_amd.batched_tracker.BatchedDeviceTracker(model, n) over n sequences in lock step on ONE GPU, production-shaped model.
+    Sequence b = the synthetic 1280x720 sequence started `offset * b` frames later (its own first frame, template, corners, H_total).
+    A step's n frames arrive as ONE pinned uint8 [n,720,1280,3] buffer (what a decoder / loader thread hands over); the timed loop
+    does, per step: one host->device copy, one hipGraph replay, one host read of [n, 9].  `distinct_steps` pinned step buffers are
+    cycled (the seeded stand-in does not track, so which frame follows which does not matter for the timing).
+    -> rows {n, ms_per_step, frames_per_s, ms_per_step_frames_resident, ...}."""
+    from hdn_amd.batched_tracker import BatchedDeviceTracker
+    dev = dev or torch.device("cuda:0")
+    log = (lambda *a: None) if quiet else (lambda *a: print(*a, file=sys.stderr, flush=True))
+    nmax = max(ns)
+    target = (300, 200)
+    frames, corners, init = make_sequence(n_frames=distinct_steps + 1 + (nmax - 1) * offset, frame_hw=(720, 1280), target_wh=target, **LONG_WALK)
+    torch.backends.cudnn.benchmark = os.environ.get("HDN_SEQ_FIND", "1") != "0"
+    model, _ = build_production_model(frames, init, dev)
+    rows = []
+    for n in ns:
+        t0 = time.perf_counter()
+        offs = [b * offset for b in range(n)]
+        inits = [init_from_corners(corners[o], target) for o in offs]
+        trk = BatchedDeviceTracker(model, n)
+        trk.init([frames[o] for o in offs], [i["bbox"] for i in inits], [i["poly"] for i in inits], [i["gt_points"] for i in inits])
+        steps = [torch.from_numpy(np.stack([frames[o + 1 + k] for o in offs])).pin_memory() for k in range(distinct_steps)]
+        for k in range(6):                                  # MIOpen find at this batch size, graph capture, clocks
+            trk.track_new(k, steps[k % distinct_steps])
+        torch.cuda.synchronize(); s0 = trk.host_syncs
+        per = []
+        t1 = time.perf_counter()
+        for k in range(n_steps):
+            a = time.perf_counter(); res = trk.track_new(k, steps[k % distinct_steps]); per.append(time.perf_counter() - a)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t1) / n_steps * 1e3
+        assert len(res) == n and all(np.isfinite(r["points"]).all() for r in res)
+        # the same with the frames already on the device (no PCIe in the step): what the kernels + networks alone sustain
+        dsteps = [s.to(dev) for s in steps[:4]]
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        for k in range(n_steps):
+            trk.track_new(k, dsteps[k % len(dsteps)])
+        torch.cuda.synchronize()
+        ms_res = (time.perf_counter() - t2) / n_steps * 1e3
+        row = {"n": n, "ms_per_step": ms, "frames_per_s": n * 1e3 / ms, "ms_per_frame": ms / n, "p99_ms_per_step": float(np.percentile(per, 99) * 1e3),
+               "host_syncs_per_step": (trk.host_syncs - s0) / n_steps, "graph": trk._graph is not None,
+               "ms_per_step_frames_resident": ms_res, "frames_per_s_frames_resident": n * 1e3 / ms_res,
+               "upload_MB_per_step": steps[0].numel() / 1e6}
+        if kprofile_n is not None and n == kprofile_n:
+            row["kernel_profile"] = kernel_profile(trk, [None] + [dsteps[k % len(dsteps)] for k in range(30)], n=20)
+        rows.append(row)
+        log(f"[multi] n={n:3d}: {ms:8.3f} ms per step = {n * 1e3 / ms:8.1f} frames/s  (frames resident: {ms_res:8.3f} ms = {n * 1e3 / ms_res:8.1f} frames/s)  "
+            f"graph={row['graph']}  [{time.perf_counter() - t0:.1f} s]")
+        del trk, steps, dsteps
+        torch.cuda.empty_cache()
+    base = next((r for r in rows if r["n"] == 1), rows[0])
+    for r in rows:
+        r["speedup_vs_n1"] = r["frames_per_s"] / base["frames_per_s"] * (base["n"] if base["n"] != 1 else 1)
+    return {"tracker": "hdn_amd.batched_tracker.BatchedDeviceTracker(model, n): n independent sequences advance one frame per step; one pinned "
+                       "[n,720,1280,3] upload, one hipGraph replay, one host read of [n, 9] per step",
+            "model": "tests/production_standin.py (ResNet-50 stride-8 dilated backbone x2, 256-channel heads, ResNet-34 estimator; seeded; fp32; channels-last; MIOpen find)",
+            "steps_timed": n_steps, "rows": rows}
+
+
+
 def format_table(res):
     lines = [f"{res['frames']} frames, {res['ms_per_frame']:.3f} ms per frame as one hipGraph ({res['fps']:.0f} frames/s), {res['ms_per_frame_eager']:.3f} ms eager",
              f"{'stage':<100s} {'ms':>8s}  owner"]
@@ -315,7 +386,20 @@ def main():
     ap.add_argument("--production-shape", action="store_true"); ap.add_argument("--nchw", action="store_true")
     ap.add_argument("--no-components", action="store_true", help="skip the per-stage table (profiling runs)")
     ap.add_argument("--kernel-profile", action="store_true", help="torch.profiler over 20 graph frames: device time per kernel, hdn:: vs library")
+    ap.add_argument("--multi", type=str, default=None, help="comma-separated n: BatchedDeviceTracker over n sequences in lock step (production-shaped model)")
+    ap.add_argument("--multi-profile", type=int, default=None, help="with --multi: torch.profiler kernel table at this n")
     args = ap.parse_args()
+    if args.multi:
+        res = run_multi(tuple(int(x) for x in args.multi.split(",")), n_steps=args.frames or 60, kprofile_n=args.multi_profile)
+        for r in res["rows"]:
+            k = r.get("kernel_profile")
+            if k:
+                print(f"n={r['n']}: device time {k['device_ms_per_frame']:.3f} ms per step in {k['launches_per_frame']:.0f} launches = hdn:: {k['hdn_kernels_ms_per_frame']:.3f} ms "
+                      f"({k['hdn_kernel_launches_per_frame']:.0f}) + library {k['library_kernels_ms_per_frame']:.3f} ms + copies {k['copies_ms_per_frame']:.3f} ms", file=sys.stderr)
+                for t in k["top"]:
+                    print(f"  {t['kernel']:<120s} {t['us_per_frame']:9.2f} us  x{t['calls_per_frame']}", file=sys.stderr)
+        print(json.dumps(res))
+        return
     if args.production_shape:
         res = run_production(args.frames or 501, 61 if args.parity is None else args.parity, nchw=args.nchw, components=not args.no_components, kprofile=args.kernel_profile)
         print(format_table(res), file=sys.stderr)
