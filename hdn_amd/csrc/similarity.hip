@@ -111,12 +111,15 @@ __global__ __launch_bounds__(HDN_WAVE) void similarity_logpolar_kernel(const flo
   if (lane == 0) {
     const double dcx = state[0], dcy = state[1], cx = state[2], cy = state[3];
     double scale_delta = 1.0, rot_delta = 0.0;  // sim_lp = [1, 1, 0, 0]: 1 * cur_sz / init_s_z == 1 exactly
+    double sim0 = 1.0, gated = 1.0;             // what hdnTracker.track_new (hdn_tracker.py:245-248) reads: sim_lp[0] itself and whether it is the gate's [1, 1, 0, 0]
     if (!(state[4] != 0.0 || best < 0.25)) {
       const float d0 = rn_sub(points_lp[2 * best_i], rn_mul(loc_lp[best_i], stride_lp));
       const float d2 = rn_sub(points_lp[2 * best_i + 1], rn_mul(loc_lp[2 * n + best_i], stride_lp));
       const float sc = (float)exp((double)d0 * mag);  // np.exp(float32 * np.float64) stored into the float32 array
       scale_delta = ((double)sc * seq[2]) / seq[2];   // sim_lp[0] * cur_sz / self.init_s_z, cur_sz = init_s_z (:158,206)
       rot_delta = (double)rn_mul(d2, rot_unit);
+      sim0 = (double)sc;
+      gated = 0.0;
     }
     // rot_scale_around_center_shift_tran(cx, cy, rot_delta, scale_delta, delta_cx, delta_cy)
     double tran[9] = {1, 0, dcx, 0, 1, dcy, 0, 0, 1}, tmp[9];
@@ -142,7 +145,100 @@ __global__ __launch_bounds__(HDN_WAVE) void similarity_logpolar_kernel(const flo
     state[35] = ss; state[36] = cc;  state[37] = (cy - cy * cc) - cx * ss;
     // get_subwindow_for_homo(rot_img_homo, self.center_pos, EXEMPLAR_SIZE, self.init_s_z_sm * scale_delta, avg) (:224-227)
     state[40] = cx; state[41] = cy; state[42] = seq[4] * scale_delta; state[43] = seq[5]; state[44] = seq[6]; state[45] = seq[7];
+    state[46] = sim0; state[47] = gated;
   }
+}
+
+// ---- hdnTracker.track_new after the two decodes (hdn/tracker/hdn_tracker.py:213-301): TRACKS['hdnTracker'], the similarity-only tracker ----
+// One lane per sequence, float64 as numpy computes these lines — except the two accumulators numpy itself turns into float32:
+// `self.rot += sim_lp[2]` and `self.lp_shift[1] += sim_lp[2]` add an np.float32 to a python number, which NumPy 2 evaluates (and keeps) in
+// float32 from the first un-gated frame on; a gated frame adds the python int 0 and changes neither value nor type.  tr[11] / tr[12] carry that type.
+__device__ __forceinline__ void acc_f32(double& v, double& is_f32, float x) {
+  v = (double)rn_add((float)v, x);
+  is_f32 = 1.0;
+}
+
+__device__ __forceinline__ void wrap_2pi(double& v, double is_f32, double sign) {   // v -= sign * (math.pi * 2) in v's own type
+  const double two_pi = 6.283185307179586;
+  v = is_f32 != 0.0 ? (double)rn_sub((float)v, (float)(sign * two_pi)) : v - sign * two_pi;
+}
+
+__global__ __launch_bounds__(HDN_WAVE) void simi_track_update_kernel(const double* __restrict__ state, double* __restrict__ tr,
+                                                                     double* __restrict__ seq, double* __restrict__ out, int B, double img_w,
+                                                                     double img_h, double scale_score_thresh, double context_amount,
+                                                                     double ratio) {
+  const int b = blockIdx.x * HDN_WAVE + threadIdx.x;
+  if (b >= B) return;
+  const double* S = state + size_t(b) * HDN_SIM_STATE_DOUBLES;
+  double* T = tr + size_t(b) * HDN_SIMI_TRACK_DOUBLES;
+  double* O = out + size_t(b) * HDN_SIMI_OUT_DOUBLES;
+  const double dcx = S[0], dcy = S[1], cx = S[2], cy = S[3], best_score = S[5], pscore = S[7];
+  // :214-222  the "lost" bookkeeping (its only product, the next window_scale_factor, is overwritten by `= 1` at :183 before it is read)
+  double new_wsf = 1.0, lost_count = T[9], last_lost = T[10];
+  if (pscore < scale_score_thresh) {
+    new_wsf = 1.5;
+    if (lost_count == 0.0) last_lost = 1.0;
+    lost_count += 1.0;
+    if (last_lost == 0.0 && lost_count < 5.0) { lost_count = 0.0; last_lost = 0.0; }
+  }
+  // :224-227  (center = pred_c / scale_z * window_scale_factor with window_scale_factor = s_x / (s_z * ratio) == 1 exactly: s_z and ratio are
+  //           integer-valued doubles, s_x = floor(s_z * ratio * 1) is their exact product — the translation decode's delta IS center)
+  const double d = sqrt(dcx * dcx + dcy * dcy);
+  T[7] = (T[13] == 0.0) ? d : (T[7] + d) / 2.0;      // fr_idx == 1  <=>  the first tracked frame of the sequence
+  T[13] += 1.0;
+  T[0] = cx; T[1] = cy;                                // :229-233
+  // :247-252  size update, clamped
+  const double sim0 = S[46];
+  double width = T[2] * sim0, height = T[3] * sim0;    // (* window_scale_factor == 1.0; sim_lp[1] is the same float32 as sim_lp[0])
+  const double lo = (10.0 * T[14]) / T[15];
+  double m = (img_w < width) ? img_w : width;          // python min(width, W) / max(lo, .): the SECOND argument only if it is strictly smaller / larger
+  width = (m > lo) ? m : lo;
+  m = (img_h < height) ? img_h : height;
+  height = (m > 10.0) ? m : 10.0;
+  T[2] = width; T[3] = height;
+  // :256-258
+  double rot = T[4], lp = T[5], rot_f32 = T[11], lp_f32 = T[12];
+  if (S[47] == 0.0) {
+    const float rd = (float)S[17];
+    acc_f32(lp, lp_f32, rd);
+    acc_f32(rot, rot_f32, rd);
+  }
+  T[6] = width / T[14];
+  O[0] = cx - width / 2.0; O[1] = cy - height / 2.0; O[2] = width; O[3] = height;
+  // :264-269  (a float32 rot is compared with the python float rounded to float32, as NumPy 2 compares a float32 scalar with a weak python float)
+  const double two_pi = 6.283185307179586;
+  const double hi = rot_f32 != 0.0 ? (double)(float)two_pi : two_pi, lw = rot_f32 != 0.0 ? (double)(float)(-two_pi) : -two_pi;
+  if (rot >= hi) { wrap_2pi(rot, rot_f32, 1.0); wrap_2pi(lp, lp_f32, 1.0); }
+  else if (rot < lw) { wrap_2pi(rot, rot_f32, -1.0); wrap_2pi(lp, lp_f32, -1.0); }
+  T[4] = rot; T[5] = lp; T[11] = rot_f32; T[12] = lp_f32;
+  // :271-280  polygon = roll(transformPoly(cetner2poly([cx, cy, w, h]), getRotMatrix(cx, cy, rot)), 4 - poly_shift_l); np.cos / np.sin in rot's dtype
+  const double cc = rot_f32 != 0.0 ? (double)(float)cos(rot) : cos(rot), ss = rot_f32 != 0.0 ? (double)(float)sin(rot) : sin(rot);
+  const double tx = (cx - cx * cc) + cy * ss, ty = (cy - cy * cc) - cx * ss;
+  const double x1 = cx - width * 0.5, y1 = cy - height * 0.5, x2 = cx + width * 0.5, y2 = cy + height * 0.5;
+  const double px[4] = {x1, x2, x2, x1}, py[4] = {y1, y1, y2, y2};
+  const int shift = (4 - (int)T[19]) & 3;
+  double mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const double qx = (px[i] * cc + py[i] * (-ss)) + tx, qy = (px[i] * ss + py[i] * cc) + ty;
+    const int j = (i + shift) & 3;
+    O[10 + 2 * j] = qx; O[11 + 2 * j] = qy;
+    mnx = fmin(mnx, qx); mny = fmin(mny, qy); mxx = fmax(mxx, qx); mxy = fmax(mxy, qy);
+  }
+  O[4] = mnx; O[5] = mny; O[6] = mxx - mnx; O[7] = mxy - mny;
+  O[8] = best_score; O[9] = rot; O[18] = S[4]; O[19] = pscore;
+  // :156-162  update_template: img_rot_around_center(init_img, init_pos, lp_shift[1]) (math.cos / math.sin: double, transform.py:80-97)
+  const double ix = T[17], iy = T[18], c2 = cos(lp), s2 = sin(lp);
+  T[32] = c2; T[33] = -s2; T[34] = (ix - ix * c2) + iy * s2;
+  T[35] = s2; T[36] = c2;  T[37] = (iy - iy * c2) - ix * s2;
+  // :283  window_scale_factor = new_window_scale_factor; then the next frame's :180-192: s_z, s_x and the first search crop
+  T[8] = new_wsf; T[9] = lost_count; T[10] = last_lost;
+  const double sum = width + height;
+  const double w_z = width + context_amount * sum, h_z = height + context_amount * sum;
+  const double s_z = floor(sqrt(w_z * h_z)), s_x = floor(s_z * ratio);
+  double* q = seq + size_t(b) * HDN_SIM_SEQ_DOUBLES;
+  q[0] = cx; q[1] = cy; q[2] = s_z; q[3] = s_x; q[4] = 0.0; q[5] = T[20]; q[6] = T[21]; q[7] = T[22];
+  T[24] = cx; T[25] = cy; T[26] = s_x; T[27] = T[20]; T[28] = T[21]; T[29] = T[22];
 }
 
 // ---- the tracker's 3x3 bookkeeping (hdn_tracker_proj_e2e.py:150-155 and :251-272), one lane per sequence ----------------------
@@ -242,6 +338,15 @@ extern "C" int hdn_similarity_logpolar_f32(const float* cls_lp, const float* loc
   if (S > 1024) return HDN_E_LIMIT;
   hipLaunchKernelGGL(hdn::similarity_logpolar_kernel, dim3(B), dim3(HDN_WAVE), 0, (hipStream_t)stream, cls_lp, loc_lp, points_lp, seq, state, S,
                      stride_lp, mag, rot_unit, cls_channels);
+  return hdn::launch_status();
+}
+
+extern "C" int hdn_simi_track_update_f64(const double* state, double* tr, double* seq, double* out, int B, int img_w, int img_h,
+                                         double scale_score_thresh, double context_amount, double instance_exemplar_ratio, void* stream) {
+  if (!state || !tr || !seq || !out) return HDN_E_NULL;
+  if (B <= 0 || img_w <= 0 || img_h <= 0 || !(instance_exemplar_ratio > 0)) return HDN_E_SHAPE;
+  hipLaunchKernelGGL(hdn::simi_track_update_kernel, dim3(hdn::cdiv(B, HDN_WAVE)), dim3(HDN_WAVE), 0, (hipStream_t)stream, state, tr, seq, out, B,
+                     (double)img_w, (double)img_h, scale_score_thresh, context_amount, instance_exemplar_ratio);
   return hdn::launch_status();
 }
 

@@ -183,4 +183,7 @@ def install(strict: bool = False, modules: dict = None, tracker: bool = False) -
             from .tracker import DeviceTrackerHomo
             _rebind(tb.TRACKS, "hdnTrackerHomoProje2e", DeviceTrackerHomo, item=True)
             done.append(("hdn.tracker.tracker_builder", "TRACKS['hdnTrackerHomoProje2e']"))
+            from .simi_tracker import DeviceTrackerSimi
+            _rebind(tb.TRACKS, "hdnTracker", DeviceTrackerSimi, item=True)
+            done.append(("hdn.tracker.tracker_builder", "TRACKS['hdnTracker']"))
     return done

@@ -33,7 +33,7 @@ extern "C" {
 /* RCCL failures are returned as -(2000 + ncclResult_t). */
 
 /* ABI version of this header; hdn_abi_version() of the loaded library must match. */
-#define HDN_ABI_VERSION 8
+#define HDN_ABI_VERSION 9
 int hdn_abi_version(void);
 
 /* Name of the kernel variant the last hdn_xcorr_* call on this thread dispatched to
@@ -259,6 +259,7 @@ int hdn_remap_linear_f32(const float* src, const float* mapx, const float* mapy,
  *   log-polar call:   [16] scale_delta [17] rot_delta [18] best_idx_lp [19] score_lp[best_idx_lp]  [20..28] H_sim (row major)
  *                     [32..37] 2x3 matrix of img_rot_around_center(img, cx, cy, w, h, -rot_delta) (transform.py:69-100)
  *                     [40..45] hdn_subwindow_f32 params of the homography crop (cx, cy, init_s_z_sm * scale_delta, avg)
+ *                     [46] sim_lp[0] as hdnTracker.track_new reads it (the float32 scale, 1 when gated) [47] 1 when the 0.25 / stop gate replaced sim_lp
  * cls[B,cls_channels,S,S], loc_c[B,2,S,S], cls_lp[B,cls_channels,S,S], loc_lp[B,4,S,S]: the heads' outputs (ModelBuilder.track_new / track_new_lp,
  * hdn/models/model_builder_e2e_unconstrained_v2.py:131-158).  window[S*S] float64 and points[S*S,2] float32: the tables the
  * reference's constructor builds (hdn_tracker_proj_e2e.py:26-32).  mag = log(EXEMPLAR / 2) / EXEMPLAR and
@@ -274,6 +275,29 @@ int hdn_similarity_translation_f32(const float* cls, const float* loc_c, const d
                                    int cls_channels, void* stream);
 int hdn_similarity_logpolar_f32(const float* cls_lp, const float* loc_lp, const float* points_lp, const double* seq, double* state, int B,
                                 int S, float stride_lp, double mag, float rot_unit, int cls_channels, void* stream);
+
+/*
+ * hdn_simi_track_update_f64: the numpy lines of hdnTracker.track_new behind the two decodes (hdn/tracker/hdn_tracker.py:213-301) and the first
+ * lines of the NEXT frame's (:176-192) — TRACKS['hdnTracker'] (hdn/tracker/tracker_builder.py:13), the similarity-only tracker whose search
+ * window follows the target and whose template is refreshed every frame (update_template, :156-162).  One lane per sequence; nothing leaves
+ * the device, so hdn_amd.simi_tracker replays a frame as one hipGraph.  Reads the state record of the two decode calls above (which were
+ * given THIS frame's seq record), updates the track record, writes the next frame's seq record and the result.
+ *   tr[B][HDN_SIMI_TRACK_DOUBLES] float64: [0..1] center_pos [2..3] size [4] rot [5] lp_shift[1] [6] scale [7] v [8] window_scale_factor
+ *     [9] lost_count [10] last_lost [11] rot is np.float32 [12] lp_shift[1] is np.float32 (NumPy 2 turns both into float32 at the first un-gated
+ *     frame: python number += np.float32) [13] frames tracked [14..15] init_size [16] init_s_z [17..18] init_pos [19] poly_shift_l
+ *     [20..22] channel average [24..29] hdn_subwindow_f32 params of the next frame's first search crop (center_pos, s_x, avg)
+ *     [32..37] 2x3 matrix of img_rot_around_center(init_img, init_pos, lp_shift[1]) (hdn/utils/transform.py:69-100) for update_template
+ *     [40..45] hdn_subwindow_f32 params of the template crop (init_pos, init_s_z, avg; written by the host at init)
+ *   seq[B][HDN_SIM_SEQ_DOUBLES]: rewritten for the next frame (center_pos, s_z, s_x, -, avg)
+ *   out[B][HDN_SIMI_OUT_DOUBLES] float64: [0..3] bbox [4..7] bbox_aligned [8] best_score [9] rot [10..17] polygon (4 x (x, y), rolled by
+ *     4 - poly_shift_l) [18] stop_update_flag [19] pscore[best_idx]
+ * img_w / img_h: the frame's size (the clamps of :249-250); scale_score_thresh = cfg.TRACK.SCALE_SCORE_THRESH; context_amount =
+ * cfg.TRACK.CONTEXT_AMOUNT; instance_exemplar_ratio = np.round(INSTANCE_SIZE / EXEMPLAR_SIZE).
+ */
+#define HDN_SIMI_TRACK_DOUBLES 48
+#define HDN_SIMI_OUT_DOUBLES 20
+int hdn_simi_track_update_f64(const double* state, double* tr, double* seq, double* out, int B, int img_w, int img_h, double scale_score_thresh,
+                              double context_amount, double instance_exemplar_ratio, void* stream);
 
 /*
  * The tracker's 3x3 float64 bookkeeping, one lane per sequence (BASELINE configs[3]): the numpy lines of

@@ -266,3 +266,151 @@ class HomoTrackerOracle:
         self.trace = {"H_homo": H_homo, "img": img, "rot_img": rot_img, "x_crop_homo": crop, "crop_points": crop_points, "search": search, "H_hm": steps[-1][1],
                       "H_mat": steps[-1][0], "H_hm_comp": H_comp, "homo_score": score, "H_sim": H_sim, "scale_delta": scale_delta, "rot_delta": rot_delta}
         return {"points": pts, "polygon": pts, "score": float(np.asarray(score).reshape(-1)[0]), "best_score": best_score, "similarity": sim}
+
+
+# ------------------------------------------------------------------------------------------------ TRACKS['hdnTracker'] (similarity only)
+SCALE_SCORE_THRESH = 0.5    # cfg.TRACK.SCALE_SCORE_THRESH (hdn/core/config.py:527, experiments/siamban_r50_l234_pot/config.yaml:48)
+
+
+def center2poly(c):
+    """cetner2poly (hdn/utils/bbox.py:40-56): (cx, cy, w, h) -> (x1, y1, x2, y1, x2, y2, x1, y2)."""
+    x, y, w, h = c[0], c[1], c[2], c[3]
+    x1, y1, x2, y2 = x - w * 0.5, y - h * 0.5, x + w * 0.5, y + h * 0.5
+    return np.array([x1, y1, x2, y1, x2, y2, x1, y2])
+
+
+def get_rot_matrix(cx, cy, rot):
+    """getRotMatrix (hdn/utils/bbox.py:58-75): np.cos / np.sin of `rot` in ITS dtype (float32 once the accumulated rotation is)."""
+    cc, ss = np.cos(rot), np.sin(rot)
+    return np.array([[cc, -ss, cx - cx * cc + cy * ss], [ss, cc, cy - cy * cc - cx * ss], [0, 0, 1]])
+
+
+def transform_poly(polygon, m):
+    """transformPoly (hdn/utils/bbox.py:77-90)."""
+    polygon = polygon.reshape(-1, 2)
+    out = np.ones([polygon.shape[0], 3])
+    out[:, 0:2] = polygon
+    out = out @ m.transpose(1, 0)
+    return out[:, 0:2]
+
+
+class SimiTrackerOracle:
+    """TEST INFRASTRUCTURE: hdnTracker (hdn/tracker/hdn_tracker.py:18-301) on the CPU — the similarity-only tracker with a template
+    refresh every frame, TRACKS['hdnTracker'] (hdn/tracker/tracker_builder.py:13), the default cfg.TRACK.TYPE (hdn/core/config.py:517).
+    `model` exposes ModelBuilder.template / track_new / track_new_lp.  Statement by statement as the reference, with numpy's scalar types
+    left to fall where they fall under NumPy 2 (e.g. `self.rot += sim_lp[2]` turns a python number into np.float32 on the first un-gated
+    frame); tests/test_oracle_golden.py holds it to tests/golden/tracker_loop_simi.npz = the reference's own init / track_new executed."""
+
+    def __init__(self, model, window_influence=WINDOW_INFLUENCE, instance_size=INSTANCE_SIZE, scale_score_thresh=SCALE_SCORE_THRESH):
+        self.model, self.window_influence, self.instance_size, self.scale_score_thresh = model, window_influence, int(instance_size), scale_score_thresh
+        self.score_size = (self.instance_size - EXEMPLAR_SIZE) // STRIDE + 1 + BASE_SIZE
+        self.window = hanning_window(self.score_size)
+        self.points = generate_points(STRIDE, self.score_size)
+        self.points_lp = generate_points(STRIDE_LP, OUTPUT_SIZE_LP)
+        self.trace = {}
+
+    def _template(self, img, s_z):
+        z = F.get_subwindow(img, self.init_pos, EXEMPLAR_SIZE, s_z, self.channel_average)
+        z_log = F.get_polar_img(z[0].transpose(1, 2, 0).astype(np.uint8)).transpose(2, 0, 1)[None].astype(np.float32)
+        z_crop = np.concatenate([z, z_log], axis=1)                       # islog=1 (base_tracker.py:119-126)
+        with torch.no_grad():
+            self.model.template(torch.from_numpy(z_crop))
+        return z_crop
+
+    def init(self, img, bbox, poly, first_point):
+        """hdn_tracker.py:109-154."""
+        self.center_pos = np.array([poly[0], poly[1]])
+        self.init_rot = poly[4]
+        self.rot = poly[4]
+        polygon = transform_poly(center2poly(poly[:4]), get_rot_matrix(poly[0], poly[1], poly[4]))
+        fir_dis = (polygon - first_point) ** 2
+        self.poly_shift_l = np.argmin(fir_dis[:, 0] + fir_dis[:, 1])
+        self.scale, self.lp_shift, self.v = 1, [0, 0], 0
+        self.size = np.array([poly[2], poly[3]])
+        self.align_size = np.array([bbox[2], bbox[3]])
+        w_z = self.size[0] + CONTEXT_AMOUNT * np.sum(self.size)
+        h_z = self.size[1] + CONTEXT_AMOUNT * np.sum(self.size)
+        s_z = np.floor(np.sqrt(w_z * h_z))
+        self.channel_average = np.mean(img, axis=(0, 1))
+        self.init_pos = np.array([poly[0], poly[1]])
+        self.init_img, self.init_size, self.init_s_z = img, self.size, s_z
+        self.window_scale_factor, self.lost_count, self.last_lost = 1.0, 0, False
+        self.trace = {"z_crop": self._template(img, s_z)}
+
+    def update_template(self):
+        """:156-162: the FIRST frame rotated about init_pos by the accumulated rotation, cropped again, model.template again."""
+        # (img_rot_around_center takes math.cos / math.sin of the angle: double arithmetic on the float32 sum's value, transform.py:80-81)
+        img = F.warp_affine_cubic_u8(self.init_img, F.rot_matrix_2x3(self.init_pos[0], self.init_pos[1], float(self.lp_shift[1])))
+        return self._template(img, self.init_s_z), img
+
+    def track_new(self, fr_idx, img, gt_box=None, gt_poly=None):
+        """:174-301."""
+        import math
+        w_z = self.size[0] + CONTEXT_AMOUNT * np.sum(self.size)
+        h_z = self.size[1] + CONTEXT_AMOUNT * np.sum(self.size)
+        self.window_scale_factor = 1
+        s_z = np.floor(np.sqrt(w_z * h_z))
+        ratio = np.round(self.instance_size / EXEMPLAR_SIZE)
+        scale_z = EXEMPLAR_SIZE / s_z
+        s_x = np.floor(s_z * ratio * self.window_scale_factor)
+        self.window_scale_factor = s_x / (s_z * ratio)
+        x_crop = F.get_subwindow(img, self.center_pos, self.instance_size, s_x, self.channel_average)
+        with torch.no_grad():
+            out = self.model.track_new(torch.from_numpy(x_crop))
+        score = convert_score(out["cls"])
+        pred_c = convert_c(out["loc_c"], self.points)
+        pscore = score * (1 - self.window_influence) + self.window * self.window_influence
+        best_idx = np.argmax(pscore)
+        stop = 0
+        if pscore[best_idx] < 0.05:
+            center, stop = [0, 0], 1
+        else:
+            center = pred_c[:, best_idx] / scale_z * self.window_scale_factor
+        new_wsf = 1
+        if pscore[best_idx] < self.scale_score_thresh:
+            new_wsf = 1.5
+            if self.lost_count == 0:
+                self.last_lost = True
+            self.lost_count += 1
+            if not self.last_lost and self.lost_count < 5:
+                self.lost_count, self.last_lost = 0, False
+        d = math.sqrt(center[0] * center[0] + center[1] * center[1])
+        self.v = d if fr_idx == 1 else (self.v + d) / 2
+        cx, cy = center[0] + self.center_pos[0], center[1] + self.center_pos[1]
+        self.center_pos = np.array([cx, cy])
+        x_moved = F.get_subwindow(img, self.center_pos, self.instance_size, s_x, self.channel_average)
+        with torch.no_grad():
+            out = self.model.track_new_lp(torch.from_numpy(x_moved), [0, 0])
+        score_lp = convert_score(out["cls_lp"])
+        pred_lp = convert_logpolar_simi(out["loc_lp"], self.points_lp)
+        best_idx_lp = np.argmax(score_lp)
+        sim_lp = pred_lp[:, best_idx_lp]
+        if stop or score_lp[best_idx_lp] < 0.25:
+            sim_lp = [1, 1, 0, 0]
+        width = self.size[0] * sim_lp[0] * self.window_scale_factor
+        height = self.size[1] * sim_lp[1] * self.window_scale_factor
+        width = max(10 * self.init_size[0] / self.init_size[1], min(width, img.shape[:2][1]))
+        height = max(10, min(height, img.shape[:2][0]))
+        self.size = np.array([width, height])
+        self.lp_shift[1] += sim_lp[2]
+        self.rot += sim_lp[2]
+        self.scale = width / self.init_size[0]
+        bbox = [cx - width / 2, cy - height / 2, width, height]
+        if self.rot >= 2 * math.pi:
+            self.rot -= math.pi * 2
+            self.lp_shift[1] -= math.pi * 2
+        elif self.rot < -2 * math.pi:
+            self.rot += math.pi * 2
+            self.lp_shift[1] += math.pi * 2
+        best_score = score[best_idx]
+        polygon = transform_poly(center2poly([cx, cy, width, height]), get_rot_matrix(cx, cy, self.rot))
+        polygon = np.roll(polygon, 4 - self.poly_shift_l, 0)
+        max_p, min_p = np.max(polygon, 0), np.min(polygon, 0)
+        align_bbox = [min_p[0], min_p[1], max_p[0] - min_p[0], max_p[1] - min_p[1]]
+        self.align_size = [align_bbox[2], align_bbox[3]]
+        z_crop, rot_img = self.update_template()
+        self.window_scale_factor = new_wsf
+        self.trace = {"s_x": s_x, "s_z": s_z, "x_crop": x_crop, "x_crop_moved": x_moved, "best_idx": int(best_idx), "stop": stop,
+                      "pscore_best": pscore[best_idx], "center": np.asarray(center, np.float64), "best_idx_lp": int(best_idx_lp),
+                      "score_lp_best": score_lp[best_idx_lp], "sim_lp": np.asarray(sim_lp, np.float64), "z_crop": z_crop, "rot_init_img": rot_img}
+        return {"bbox": bbox, "bbox_aligned": align_bbox, "best_score": best_score, "rot": self.rot, "polygon": polygon}

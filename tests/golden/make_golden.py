@@ -804,36 +804,10 @@ TRACKER_LOOP_SEQ = dict(n_frames=13, frame_hw=(360, 640), target_wh=(150, 100)) 
 TRACKER_LOOP_EVENTS = {"gate_frame": 5, "singular_frame": 9}
 
 
-def gen_tracker_loop(ref_te, ref_mb, cfg):
-    """hdnTrackerHomo.init / track_new (hdn/tracker/hdn_tracker_proj_e2e.py:60-120,141-285) EXECUTED, verbatim, around the reference's
-    real ModelBuilder (83.6 M parameters, production YAML) over a synthetic sequence (tools/synth_sequence.py) -> tracker_loop.npz.
-
-    What runs is the reference's own code: init's size arithmetic, get_subwindow / get_subwindow_for_homo (crop, padding),
-    getPolarImg, _convert_score / _convert_c / _convert_logpolar_simi, the window blend and both gates, img_rot_around_center,
-    get_search_info / get_template_info / merge_tmp_search, ModelBuilder.template / track_new / track_new_lp / track_proj, the
-    inverse / normalise / compose of the residual, the un-scale / un-shift block, the `> 2.5` gate, the H_total recurrence, the singular
-    reset.  The only stand-ins are the six OpenCV entry points (tests/golden/cv2_shim.py -> oracle restatements; parity-unpinned).
-
-    The model is seeded, not trained (no snapshot exists in the image), so it is prepared to behave like a tracker's model:
-      * hm_net: BatchNorm statistics / fc as gen_homo_model seeds them (corner offsets of a few pixels);
-      * similarity branch: BatchNorm running statistics calibrated on the first frame's crops (default statistics let a random
-        50-layer network's activations grow to 1e6); loc_scale 0.5 / 0.05; and a fixed Gaussian prior added to the class-1 logit maps by
-        a subclass of the reference's ModelBuilder (an untrained head has no peak; with the prior the argmax sits near the centre and
-        moves between neighbouring cells with the data).
-    Two events exercise the rarely taken branches: at frame `gate_frame` the homography score returned by track_proj is raised by 10
-    (the `homo_score > 2.5` branch, :261-262), before frame `singular_frame` the generator sets tracker.H_total to a singular matrix
-    (the reset, :150-153).
-
-    Stored per frame: the four head maps and track_proj's outputs (so that tests can replay the networks), the trunk output x, and what the
-    reference computed from them — read from track_new's own local variables when it returns (s_x, best_idx, centre, sim_lp, scale_delta,
-    rot_delta, H_sim, H_hm, crop_points, H_hm_comp) and from the tracker object (H_total, center_pos, scale, rot) — plus CRC-32 of the
-    stabilised frame, the rotated frame and the three crops (frame 1: the crops themselves).  A second, shorter run under
-    cfg.TRACK.INSTANCE_SIZE = 303 (BASELINE configs[4]: 31 x 31 score map; the model keeps its STN_Polar(255), the reference's own
-    log-polar branch cannot run at 303, DESIGN §2) is stored under the prefix `b__`."""
-    root = os.path.dirname(os.path.dirname(HERE))
-    if root not in sys.path:
-        sys.path.insert(0, root)
-    import cv2_shim
+def _conditioned_model(ref_te, ref_mb, cfg):
+    """The reference's real ModelBuilder, seeded and conditioned as gen_tracker_loop's docstring describes, plus the synthetic sequence it was
+    calibrated on and the header entries of a tracker-loop fixture.  Shared by gen_tracker_loop (hdnTrackerHomo) and gen_tracker_loop_simi
+    (hdnTracker): both loops run around the same model.  -> (mb, frames, corners, init, out)"""
     from tools.synth_sequence import make_sequence
 
     class _Conditioned(ref_mb.ModelBuilder):
@@ -841,15 +815,16 @@ def gen_tracker_loop(ref_te, ref_mb, cfg):
         the homography score of one call."""
 
         score_bias = 0.0
+        cls_bias = cls_lp_bias = 0.0      # (gen_tracker_loop_simi lowers one frame's class-1 logits to take the two gates' branches)
 
         def track_new(self, x, delta=[0, 0]):
             o = super().track_new(x)
-            o["cls"] = torch.cat([o["cls"][:, 0:1], o["cls"][:, 1:2] + self.cls_prior[o["cls"].shape[-1]]], dim=1)
+            o["cls"] = torch.cat([o["cls"][:, 0:1], o["cls"][:, 1:2] + self.cls_prior[o["cls"].shape[-1]] + self.cls_bias], dim=1)
             return o
 
         def track_new_lp(self, x, delta=[0, 0]):
             o = super().track_new_lp(x, delta)
-            o["cls_lp"] = torch.cat([o["cls_lp"][:, 0:1], o["cls_lp"][:, 1:2] + self.cls_prior_lp], dim=1)
+            o["cls_lp"] = torch.cat([o["cls_lp"][:, 0:1], o["cls_lp"][:, 1:2] + self.cls_prior_lp + self.cls_lp_bias], dim=1)
             return o
 
         def track_proj(self, data, tmp_mask):
@@ -926,6 +901,43 @@ def gen_tracker_loop(ref_te, ref_mb, cfg):
         p0 = mb.hm_net.ShareFeature(pair[:, :1])
         f0 = mb.hm_net.avgpool(mb.hm_net.backbone(torch.cat((p0, p0), dim=1))).flatten(1)
         mb.hm_net.fc.bias.data = fc_bias - (f0 @ mb.hm_net.fc.weight.data.t())[0]
+
+    return mb, frames, corners, init, out
+
+
+def gen_tracker_loop(ref_te, ref_mb, cfg):
+    """hdnTrackerHomo.init / track_new (hdn/tracker/hdn_tracker_proj_e2e.py:60-120,141-285) EXECUTED, verbatim, around the reference's
+    real ModelBuilder (83.6 M parameters, production YAML) over a synthetic sequence (tools/synth_sequence.py) -> tracker_loop.npz.
+
+    What runs is the reference's own code: init's size arithmetic, get_subwindow / get_subwindow_for_homo (crop, padding),
+    getPolarImg, _convert_score / _convert_c / _convert_logpolar_simi, the window blend and both gates, img_rot_around_center,
+    get_search_info / get_template_info / merge_tmp_search, ModelBuilder.template / track_new / track_new_lp / track_proj, the
+    inverse / normalise / compose of the residual, the un-scale / un-shift block, the `> 2.5` gate, the H_total recurrence, the singular
+    reset.  The only stand-ins are the six OpenCV entry points (tests/golden/cv2_shim.py -> oracle restatements; parity-unpinned).
+
+    The model is seeded, not trained (no snapshot exists in the image), so it is prepared to behave like a tracker's model:
+      * hm_net: BatchNorm statistics / fc as gen_homo_model seeds them (corner offsets of a few pixels);
+      * similarity branch: BatchNorm running statistics calibrated on the first frame's crops (default statistics let a random
+        50-layer network's activations grow to 1e6); loc_scale 0.5 / 0.05; and a fixed Gaussian prior added to the class-1 logit maps by
+        a subclass of the reference's ModelBuilder (an untrained head has no peak; with the prior the argmax sits near the centre and
+        moves between neighbouring cells with the data).
+    Two events exercise the rarely taken branches: at frame `gate_frame` the homography score returned by track_proj is raised by 10
+    (the `homo_score > 2.5` branch, :261-262), before frame `singular_frame` the generator sets tracker.H_total to a singular matrix
+    (the reset, :150-153).
+
+    Stored per frame: the four head maps and track_proj's outputs (so that tests can replay the networks), the trunk output x, and what the
+    reference computed from them — read from track_new's own local variables when it returns (s_x, best_idx, centre, sim_lp, scale_delta,
+    rot_delta, H_sim, H_hm, crop_points, H_hm_comp) and from the tracker object (H_total, center_pos, scale, rot) — plus CRC-32 of the
+    stabilised frame, the rotated frame and the three crops (frame 1: the crops themselves).  A second, shorter run under
+    cfg.TRACK.INSTANCE_SIZE = 303 (BASELINE configs[4]: 31 x 31 score map; the model keeps its STN_Polar(255), the reference's own
+    log-polar branch cannot run at 303, DESIGN §2) is stored under the prefix `b__`."""
+    root = os.path.dirname(os.path.dirname(HERE))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import cv2_shim
+    from tools.synth_sequence import make_sequence
+
+    mb, frames, corners, init, out = _conditioned_model(ref_te, ref_mb, cfg)
 
     rec = {}
     fc_out = []
@@ -1008,6 +1020,109 @@ def gen_tracker_loop(ref_te, ref_mb, cfg):
     run("b__", 303, 5, {"gate_frame": 3})
     save("tracker_loop", **out)
 
+TRACKER_LOOP_SIMI_EVENTS = {"lp_gate_frame": 4, "stop_frame": 8}
+
+
+def gen_tracker_loop_simi(ref_te, ref_mb, ref_ht, cfg):
+    """hdnTracker.init / track_new / update_template (hdn/tracker/hdn_tracker.py:109-301) EXECUTED, verbatim, around the same conditioned
+    ModelBuilder and synthetic sequence as gen_tracker_loop -> tracker_loop_simi.npz.  This is TRACKS['hdnTracker']
+    (hdn/tracker/tracker_builder.py:13), the similarity-only tracker: the search window follows the target (center_pos / size recurrences on
+    the host), and every frame ends with update_template — the FIRST frame rotated by the accumulated rotation, cropped and pushed through
+    ModelBuilder.template again.  OpenCV entry points: tests/golden/cv2_shim.py (parity-unpinned, as for tracker_loop.npz).
+    Events: at `lp_gate_frame` the log-polar class-1 logits are lowered by 20 (score_lp < 0.25 -> sim_lp = [1, 1, 0, 0], :245-246), at
+    `stop_frame` the translation head's (pscore < 0.05 -> centre frozen, stop flag, :207-209; also the lost_count branch :214-222).
+    Stored per frame: the four head maps (replayable), track_new's locals at return, the tracker's recurrence state WITH the dtypes numpy gave it
+    (rot / lp_shift[1] turn float32 on the first un-gated frame), the result dictionary, CRC-32 of both search crops, of the rotated first
+    frame and of the refreshed template crop (frame 1: the crops themselves)."""
+    root = os.path.dirname(os.path.dirname(HERE))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import cv2_shim
+
+    mb, frames, corners, init, out = _conditioned_model(ref_te, ref_mb, cfg)
+    out["scale_score_thresh"] = np.array(float(cfg.TRACK.SCALE_SCORE_THRESH))
+    out["seq__lp_gate_frame"], out["seq__stop_frame"] = np.array(TRACKER_LOOP_SIMI_EVENTS["lp_gate_frame"]), np.array(TRACKER_LOOP_SIMI_EVENTS["stop_frame"])
+    out = {k: v for k, v in out.items() if not k.startswith("sf__") and k not in ("seq__gate_frame", "seq__singular_frame")}
+    cfg.CUDA = False
+    rec = {}
+    for name in ("template", "track_new", "track_new_lp"):
+        def wrap(name=name, orig=getattr(mb, name)):
+            def f(*a, **k):
+                r = orig(*a, **k)
+                keep = {kk: vv.clone() for kk, vv in r.items()} if isinstance(r, dict) else r
+                rec[name] = (a, keep)
+                return r
+            return f
+        setattr(mb, name, wrap())
+    rotated = {}
+    orig_rot = ref_ht.img_rot_around_center
+
+    def rot_spy(img, cx, cy, w, h, rot):
+        r = orig_rot(img, cx, cy, w, h, rot)
+        rotated["img"], rotated["rot"] = r, rot
+        return r
+    ref_ht.img_rot_around_center = rot_spy
+
+    def num(v):      # a recurrence value and the dtype numpy left it in ('i' python int, 'd' python float / float64, 'f' float32)
+        kind = "f" if isinstance(v, np.float32) else ("i" if isinstance(v, (int, np.integer)) and not isinstance(v, bool) else "d")
+        return np.array(float(v), np.float64), np.array(kind)
+
+    try:
+        trk = ref_ht.hdnTracker(mb)
+        P = "s__"
+        n_track = TRACKER_LOOP_SEQ["n_frames"] - 1
+        with torch.no_grad():
+            trk.init(frames[0], init["bbox"], init["poly"], np.array([init["first_point"]]))
+        z0 = rec["template"][0][0].numpy()
+        out.update({P + "instance_size": np.array(int(cfg.TRACK.INSTANCE_SIZE)), P + "score_size": np.array(trk.score_size), P + "n_track": np.array(n_track),
+                    P + "init__z_crop_crc": _crc(z0.astype(np.uint8)), P + "init__z_crop": z0.astype(np.uint8), P + "init__init_s_z": np.array(trk.init_s_z),
+                    P + "init__channel_average": np.array(trk.channel_average), P + "init__center_pos": np.array(trk.center_pos),
+                    P + "init__size": np.array(trk.size), P + "init__poly_shift_l": np.array(int(trk.poly_shift_l)),
+                    P + "init__scale_coeff": np.array(float(trk.scale_coeff))})
+        assert np.array_equal(z0, z0.astype(np.uint8))
+        for i in range(1, n_track + 1):
+            mb.cls_lp_bias = -20.0 if i == TRACKER_LOOP_SIMI_EVENTS["lp_gate_frame"] else 0.0
+            mb.cls_bias = -20.0 if i == TRACKER_LOOP_SIMI_EVENTS["stop_frame"] else 0.0
+            del cv2_shim.CALLS[:]
+            with torch.no_grad(), _LocalsAtReturn(ref_ht.hdnTracker.track_new.__code__) as cap:
+                res = trk.track_new(i, frames[i], None, None)
+            L = cap.locals
+            names = [c[0] for c in cv2_shim.CALLS]
+            assert names == ["resize", "resize", "warpAffine", "resize", "logPolar"], names
+            k = f"{P}f{i}__"
+            zc = rec["template"][0][0].numpy()
+            rot_v, rot_t = num(trk.rot)
+            lp_v, lp_t = num(trk.lp_shift[1])
+            out.update({
+                k + "cls": rec["track_new"][1]["cls"].numpy(), k + "loc_c": rec["track_new"][1]["loc_c"].numpy(),
+                k + "cls_lp": rec["track_new_lp"][1]["cls_lp"].numpy(), k + "loc_lp": rec["track_new_lp"][1]["loc_lp"].numpy(),
+                k + "s_x": np.array(L["s_x"]), k + "s_z": np.array(L["s_z"]), k + "scale_z": np.array(L["scale_z"]), k + "best_idx": np.array(L["best_idx"]),
+                k + "pscore_best": np.array(L["pscore"][L["best_idx"]]), k + "stop": np.array(L["stop_update_flag"]),
+                k + "center": np.array([L["center"][0], L["center"][1]], np.float64), k + "cxcy": np.array([L["cx"], L["cy"]], np.float64),
+                k + "best_idx_lp": np.array(L["best_idx_lp"]), k + "score_lp_best": np.array(L["pscore_lp"][L["best_idx_lp"]]),
+                k + "sim_lp": np.array(L["sim_lp"], np.float64), k + "width": np.array(float(L["width"])), k + "height": np.array(float(L["height"])),
+                k + "center_pos": np.array(trk.center_pos), k + "size": np.array(trk.size), k + "rot": rot_v, k + "rot_kind": rot_t,
+                k + "lp_shift1": lp_v, k + "lp_shift1_kind": lp_t, k + "scale": np.array(float(trk.scale)), k + "v": np.array(float(trk.v)),
+                k + "lost_count": np.array(int(trk.lost_count)), k + "last_lost": np.array(bool(trk.last_lost)),
+                k + "window_scale_factor": np.array(float(trk.window_scale_factor)),
+                k + "bbox": np.array(res["bbox"], np.float64), k + "bbox_aligned": np.array(res["bbox_aligned"], np.float64),
+                k + "best_score": np.array(res["best_score"]), k + "res_rot": np.array(float(res["rot"])), k + "polygon": np.array(res["polygon"], np.float64),
+                k + "x_crop_crc": _crc(L["x_crop"].numpy().astype(np.uint8)), k + "x_crop_moved_crc": _crc(L["x_crop_moved"].numpy().astype(np.uint8)),
+                k + "rot_init_img_crc": _crc(rotated["img"]), k + "template_rot": np.array(float(rotated["rot"])), k + "z_crop_crc": _crc(zc.astype(np.uint8)),
+            })
+            assert np.array_equal(zc, zc.astype(np.uint8))
+            if i == 1:
+                out.update({k + "x_crop": L["x_crop"].numpy().astype(np.uint8), k + "x_crop_moved": L["x_crop_moved"].numpy().astype(np.uint8),
+                            k + "z_crop": zc.astype(np.uint8)})
+            c = corners[i]
+            gt_c = c.mean(0)
+            print(f"    {P}frame {i}: best_idx {int(L['best_idx'])} lp {int(L['best_idx_lp'])} stop {int(L['stop_update_flag'])} centre ({L['center'][0]:+.3f}, {L['center'][1]:+.3f}) "
+                  f"sim_lp ({float(L['sim_lp'][0]):.5f}, {float(L['sim_lp'][2]):+.5f}) size ({float(L['width']):.3f}, {float(L['height']):.3f}) rot {float(trk.rot):+.5f} [{rot_t}] "
+                  f"centre error vs ground truth {np.hypot(L['cx'] - gt_c[0], L['cy'] - gt_c[1]):.2f} px")
+    finally:
+        ref_ht.img_rot_around_center = orig_rot
+    save("tracker_loop_simi", **out)
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -1074,6 +1189,11 @@ def main():
         import hdn.models.model_builder_e2e_unconstrained_v2 as ref_mb
         import hdn.tracker.hdn_tracker_proj_e2e as ref_te
         gen_tracker_loop(ref_te, ref_mb, cfg)
+    if want("tracker_loop_simi"):
+        import hdn.models.model_builder_e2e_unconstrained_v2 as ref_mb
+        import hdn.tracker.hdn_tracker as ref_ht
+        import hdn.tracker.hdn_tracker_proj_e2e as ref_te
+        gen_tracker_loop_simi(ref_te, ref_mb, ref_ht, cfg)
     print("torch", torch.__version__, "numpy", np.__version__)
 
 

@@ -1,0 +1,184 @@
+"""TRACKS['hdnTracker'] on the device (hdn_amd.simi_tracker, -m gpu): the similarity-only tracker with its per-frame template refresh
+(hdn/tracker/hdn_tracker.py:109-301) against (a) what the reference's OWN init / track_new / update_template computed when they were executed
+around the real ModelBuilder (tests/golden/tracker_loop_simi.npz, networks replayed) and (b) the CPU restatement of the loop
+(oracle/tracker_oracle.SimiTrackerOracle, itself held to that fixture exactly) with live stand-in networks, eagerly and as one hipGraph."""
+import copy
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+class _ReplayNet(torch.nn.Module):
+    """The reference's ModelBuilder interface with the recorded head maps of tracker_loop_simi.npz; template() keeps the crop it was handed
+    and sets (dummy) template features the way ModelBuilder.template does (model_builder_e2e_unconstrained_v2.py:87-96)."""
+
+    def __init__(self, g, prefix, dev):
+        super().__init__()
+        from tracker_loop_replay import ReplayModel
+        self.anchor = torch.nn.Parameter(torch.zeros(1))
+        self.replay = ReplayModel(g, prefix, to=lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev))
+        self.zf = self.zf_lp = None
+        self.templates = 0
+
+    def template(self, z):
+        self.replay.template(z)
+        self.templates += 1
+        self.zf = [z[:, 0:3, :7, :7].contiguous() * 0 + self.templates for _ in range(3)]
+        self.zf_lp = [z[:, 3:6, :15, :15].contiguous() * 0 + self.templates for _ in range(3)]
+
+    def track_new(self, x, delta=[0, 0]):
+        return self.replay.track_new(x)
+
+    def track_new_lp(self, x, delta=[0, 0]):
+        return self.replay.track_new_lp(x, delta)
+
+
+def test_device_simi_tracker_vs_executed_reference(dev):
+    """Networks replayed; crops, decodes, the recurrences (centre, size, rot, lp_shift, scale, v, lost_count), the result dictionary and the
+    template refresh (rotation of the resident first frame, crop + log-polar channels) run on the device.  uint8 crops bit for bit
+    (CRC-32 of what the reference's model.template / track_new / track_new_lp were handed); indices, gates, float32-accumulated rot /
+    lp_shift exactly; float64 geometry to 1e-9 relative; the polygon (np.cos / np.sin of a float32 angle in the reference) to 1e-4 px."""
+    from conftest import load_golden
+    from tracker_loop_replay import crc, tracker_loop_sequence
+    from hdn_amd.simi_tracker import SimiTracker
+    from hdn_amd.similarity import TrackerConfig
+    g = load_golden("tracker_loop_simi")
+    frames, init = tracker_loop_sequence(g)
+    P = "s__"
+    model = _ReplayNet(g, P, dev).to(dev).eval()
+    cfg = TrackerConfig(instance_size=int(g[P + "instance_size"]), window_influence=float(g["window_influence"]))
+    trk = SimiTracker(model, cfg=cfg, scale_score_thresh=float(g["scale_score_thresh"]))
+    trk.init(frames[0], g["seq__bbox"].tolist(), g["seq__poly"].tolist(), np.array([g["seq__first_point"].tolist()]))
+    rp = model.replay
+    assert trk.init_s_z == float(g[P + "init__init_s_z"]) and trk.poly_shift_l == int(g[P + "init__poly_shift_l"])
+    np.testing.assert_allclose(trk.channel_average, g[P + "init__channel_average"], rtol=1e-13)
+    np.testing.assert_array_equal(rp.seen["z_crop"].cpu().numpy().astype(np.uint8), g[P + "init__z_crop"])
+    syncs0 = trk.host_syncs
+    worst = {"poly_px": 0.0, "geom_rel": 0.0}
+    for i in range(1, int(g[P + "n_track"]) + 1):
+        k = f"{P}f{i}__"
+        rp.frame = i
+        res = trk.track_new(i, frames[i], None, None)
+        assert set(res) == {"bbox", "bbox_aligned", "best_score", "rot", "polygon"} and res["polygon"].shape == (4, 2)
+        # what the networks were handed: both search crops and the refreshed template crop (the rotated first frame is inside the latter)
+        assert crc(rp.seen["x_crop"].cpu().numpy().astype(np.uint8)) == int(g[k + "x_crop_crc"]), f"frame {i}: x_crop"
+        assert crc(rp.seen["x_crop_moved"].cpu().numpy().astype(np.uint8)) == int(g[k + "x_crop_moved_crc"]), f"frame {i}: x_crop_moved"
+        assert crc(rp.seen["z_crop"].cpu().numpy().astype(np.uint8)) == int(g[k + "z_crop_crc"]), f"frame {i}: refreshed template crop"
+        st = trk.state.view(-1).cpu().numpy()
+        ts = trk.track_state()
+        assert int(st[6]) == int(g[k + "best_idx"]) and int(st[4]) == int(g[k + "stop"]) and int(st[18]) == int(g[k + "best_idx_lp"]), i
+        # float32-accumulated quantities: exact; their numpy dtype as the reference ended up with
+        assert ts["rot"] == float(g[k + "rot"]) and ts["lp_shift"][1] == float(g[k + "lp_shift1"]), (i, ts["rot"], float(g[k + "rot"]))
+        assert ts["rot_is_float32"] == (str(g[k + "rot_kind"]) == "f") and ts["lp_shift_is_float32"] == (str(g[k + "lp_shift1_kind"]) == "f")
+        assert ts["lost_count"] == int(g[k + "lost_count"]) and ts["last_lost"] == bool(g[k + "last_lost"])
+        assert ts["window_scale_factor"] == float(g[k + "window_scale_factor"])
+        assert float(res["best_score"]) == pytest.approx(float(g[k + "best_score"]), abs=1e-6)
+        assert float(res["rot"]) == float(g[k + "res_rot"])
+        for name, got, want in (("center", st[0:2], g[k + "center"]), ("center_pos", ts["center_pos"], g[k + "center_pos"]), ("size", ts["size"], g[k + "size"]),
+                                ("scale", ts["scale"], g[k + "scale"]), ("v", ts["v"], g[k + "v"]), ("bbox", res["bbox"], g[k + "bbox"])):
+            d = float(np.max(np.abs(np.asarray(got, np.float64) - np.asarray(want, np.float64)))) / max(1.0, float(np.max(np.abs(want))))
+            worst["geom_rel"] = max(worst["geom_rel"], d)
+            assert d <= 1e-9, f"frame {i}: {name} differs by {d} (relative)"
+        dp = float(np.max(np.abs(res["polygon"] - g[k + "polygon"])))
+        da = float(np.max(np.abs(np.asarray(res["bbox_aligned"]) - g[k + "bbox_aligned"])))
+        worst["poly_px"] = max(worst["poly_px"], dp, da)
+        assert dp <= 1e-4 and da <= 2e-4, (i, dp, da)
+        # the next frame's search window follows the new size (:176-188)
+        seq = trk.seq.view(-1).cpu().numpy()
+        if i < int(g[P + "n_track"]):
+            assert seq[2] == float(g[f"{P}f{i + 1}__s_z"]) and seq[3] == float(g[f"{P}f{i + 1}__s_x"])
+    assert trk.host_syncs - syncs0 == 2 * int(g[P + "n_track"])        # (one read per frame by track_new + this test's own track_state)
+    assert model.templates == 1 + int(g[P + "n_track"])                # init + one refresh per frame
+    print("device hdnTracker loop vs the executed reference:", worst)
+
+
+def _standin(dev, **kw):
+    import standin_model as SM
+    from test_gpu_parity import _seeded_net
+    from hdn_amd.similarity import TrackerConfig
+    twin = SM.StandInSiamese(_seeded_net(), **kw).eval()
+    cpu = SM.StandInSiameseCPU(twin)
+    return twin.to(dev), cpu, TrackerConfig(cls_out_channels=twin.cls_out)
+
+
+def test_simi_tracker_stream_device_vs_cpu_loop_eager_and_graph(dev):
+    """Live (stand-in) networks: the device loop — eager and as ONE hipGraph per frame — against the CPU restatement frame by frame.  The
+    template refresh feeds back: the template features differ from frame to frame, and a tracker whose refresh is disabled drifts away."""
+    from synth_sequence import make_sequence
+    from hdn_amd.simi_tracker import SimiTracker
+    from oracle.tracker_oracle import SimiTrackerOracle
+    frames, corners, init = make_sequence(n_frames=11, frame_hw=(360, 640), target_wh=(150, 100), seed=7)
+    twin, cpu, cfg = _standin(dev, loc_scale_lp=0.3)
+    ref = SimiTrackerOracle(cpu)
+    fp = np.array([init["first_point"]])
+    ref.init(frames[0], init["bbox"], init["poly"], fp)
+    eager = SimiTracker(twin, cfg=cfg)
+    eager.init(frames[0], init["bbox"], init["poly"], init["gt_points"], fp)      # (the launchers' five-argument spelling)
+    twin_g = copy.deepcopy(twin)
+    graphed = SimiTracker(twin_g, cfg=cfg, graph=True)
+    graphed.init(frames[0], init["bbox"], init["poly"], fp)
+    z0 = [t.clone() for t in twin.zf]
+    worst_e = worst_g = 0.0
+    rots = []
+    for i in range(1, len(frames)):
+        a, gph, b = eager.track_new(i, frames[i]), graphed.track_new(i, frames[i]), ref.track_new(i, frames[i])
+        de = float(np.max(np.abs(a["polygon"] - b["polygon"])))
+        dg = float(np.max(np.abs(gph["polygon"] - b["polygon"])))
+        worst_e, worst_g = max(worst_e, de), max(worst_g, dg)
+        # same argmax cells and gates -> sub-pixel agreement; a cell off would be 8 px * s_z / 127
+        assert de <= (2e-3 if i <= 3 else 5e-2) and dg <= (2e-3 if i <= 3 else 5e-2), (i, de, dg)
+        assert abs(float(a["rot"]) - float(b["rot"])) <= 2e-4 and abs(float(a["best_score"]) - float(b["best_score"])) <= 1e-4
+        np.testing.assert_allclose(a["bbox"], b["bbox"], atol=5e-2)
+        rots.append(float(b["rot"]))
+    assert graphed._graph is not None
+    assert max(abs(r) for r in rots) > 1e-3, "the stand-in must rotate the template for this test to mean anything"
+    assert not torch.equal(z0[0], twin.zf[0]), "the refreshed template features must differ from the first frame's"
+    # the static buffers ARE the model's template (refreshed in place): same storage after ten refreshes
+    assert twin.zf[0].data_ptr() == z0[0].data_ptr() or twin.zf[0].data_ptr() == eager._zf_static[0][0].data_ptr()
+    print(f"hdnTracker device loop vs CPU loop, worst polygon distance: eager {worst_e:.2e} px, hipGraph {worst_g:.2e} px; final rot {rots[-1]:+.4f}")
+    # sync=False: the device record, no host read
+    s0 = eager.host_syncs
+    rec = eager.track_new(99, frames[-1], sync=False)["record"]
+    assert rec.is_cuda and rec.shape == (20,) and eager.host_syncs == s0
+
+
+def test_device_tracker_simi_production_shape(dev):
+    """DeviceTrackerSimi(model) — what install(tracker=True) registers under TRACKS['hdnTracker'] — around the production-shaped stand-in
+    (ResNet-50 on PyTorch-ROCm, 256-channel heads: 4 backbone passes per frame incl. the template refresh), one hipGraph per frame, against the CPU loop."""
+    import production_standin as PS
+    from synth_sequence import make_sequence
+    from test_gpu_parity import _seeded_net
+    from hdn_amd.simi_tracker import DeviceTrackerSimi
+    from oracle.tracker_oracle import SimiTrackerOracle
+    frames, corners, init = make_sequence(n_frames=6, frame_hw=(480, 854), target_wh=(200, 140), seed=20260928)
+    twin = PS.ProductionStandIn(_seeded_net())
+    twin.calibrate(*PS.calibration_crops(frames, init))
+    ref = SimiTrackerOracle(PS.ProductionStandInCPU(twin))
+    fp = np.array([init["first_point"]])
+    ref.init(frames[0], init["bbox"], init["poly"], fp)
+    model = twin.to(dev).eval()
+    trk = DeviceTrackerSimi(model)
+    assert trk.use_graph is True and trk.folded == ["backbone", "neck", "neck_lp"]
+    trk.init(frames[0], init["bbox"], init["poly"], fp)
+    errs = []
+    for i in range(1, len(frames)):
+        a, b = trk.track_new(i, frames[i]), ref.track_new(i, frames[i])
+        errs.append(float(np.max(np.abs(a["polygon"] - b["polygon"]))))
+    print("production-shaped hdnTracker device loop vs CPU loop, polygon distance (px):", " ".join(f"{e:.1e}" for e in errs))
+    assert trk._graph is not None
+    assert errs[0] <= 5e-2 and max(errs) <= 0.5, errs        # (50 fp32 layers, MIOpen vs oneDNN; a decode cell off would be >= 10 px)

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_library_loads_and_reports_abi():
     lib = _lib.load()
-    assert lib.hdn_abi_version() == _lib.ABI_VERSION == 8
+    assert lib.hdn_abi_version() == _lib.ABI_VERSION == 9
     assert lib.hdn_last_xcorr_variant() == b"none"
 
 
@@ -260,9 +260,10 @@ def test_install_rebinds_the_reference_sites():
     assert tb.TRACKS["hdnTrackerHomoProje2e"] is sentinel          # the tracker is only registered on request
     hinstall.uninstall()
     done = hinstall.install(modules=mods, tracker=True)
-    assert len(done) == len(hinstall.REBINDINGS) + 5
+    assert len(done) == len(hinstall.REBINDINGS) + 6
     from hdn_amd.tracker import DeviceTrackerHomo
-    assert tb.TRACKS["hdnTrackerHomoProje2e"] is DeviceTrackerHomo and tb.TRACKS["hdnTracker"] is sentinel
+    from hdn_amd.simi_tracker import DeviceTrackerSimi
+    assert tb.TRACKS["hdnTrackerHomoProje2e"] is DeviceTrackerHomo and tb.TRACKS["hdnTracker"] is DeviceTrackerSimi     # both registry entries
     assert "forward" in MultiBAN.__dict__ and "forward" in MultiCircBAN.__dict__
     assert mods["hdn.models.head.ban"].xcorr_depthwise is hdn_amd.xcorr_depthwise
     assert mods["hdn.models.head.ban_lp"].xcorr_depthwise_circular is hdn_amd.xcorr_depthwise_circular
@@ -285,7 +286,7 @@ def test_install_rebinds_the_reference_sites():
     assert MultiBAN().forward([], []) is sentinel and "forward" not in MultiCircBAN.__dict__
     assert "_hdn_orig_forward" not in MultiBAN.__dict__
     assert ModelBuilder().track_proj(None, None) is sentinel
-    assert tb.TRACKS["hdnTrackerHomoProje2e"] is sentinel
+    assert tb.TRACKS["hdnTrackerHomoProje2e"] is sentinel and tb.TRACKS["hdnTracker"] is sentinel
     assert hinstall.uninstall() == 0
 
 
@@ -370,7 +371,7 @@ from hdn.core.config import cfg
 cfg.merge_from_file("/root/reference/experiments/tracker_homo_config/proj_e2e_GOT_unconstrained_v2.yaml")
 import hdn_amd, hdn_amd.install as hi
 done = hi.install(strict=True, tracker=True)
-assert len(done) == len(hi.REBINDINGS) + 7, done
+assert len(done) == len(hi.REBINDINGS) + 8, done
 import hdn.models.head.ban as ban, hdn.models.head.ban_lp as ban_lp
 assert ban.xcorr_depthwise is hdn_amd.xcorr_depthwise and ban_lp.xcorr_depthwise_circular is hdn_amd.xcorr_depthwise_circular
 from hdn.models.model_builder_e2e_unconstrained_v2 import ModelBuilder
@@ -386,6 +387,12 @@ trk = build_tracker(m)
 assert type(trk) is DeviceTrackerHomo and trk.net is m.hm_net and isinstance(trk.similarity, DeviceSimilarity) and trk.similarity.model is m
 assert trk.cfg.window_influence == cfg.TRACK.WINDOW_INFLUENCE and trk.cfg.score_size == 25 and not m.training
 assert all(hasattr(trk, a) for a in ("init", "track_new"))
+# ... and cfg.TRACK.TYPE = 'hdnTracker' (hdn/core/config.py:517, experiments/siamban_r50_l234_pot/config.yaml:43) the similarity-only device loop
+from hdn_amd.simi_tracker import DeviceTrackerSimi
+assert TRACKS["hdnTracker"] is DeviceTrackerSimi
+old = cfg.TRACK.TYPE; cfg.TRACK.TYPE = "hdnTracker"
+trk2 = build_tracker(m); cfg.TRACK.TYPE = old
+assert type(trk2) is DeviceTrackerSimi and trk2.model is m and trk2.scale_score_thresh == cfg.TRACK.SCALE_SCORE_THRESH and trk2.cfg.score_size == 25
 # template() still runs the reference's statements, then drops the heads' cached template features
 class _Probe(dict): pass
 m.head._hdn_template_cache = "stale"; m.head_lp._hdn_template_cache = "stale"
@@ -393,7 +400,7 @@ with torch.no_grad():
     m.template(torch.zeros(1, 6, 127, 127))
 assert m.head._hdn_template_cache is None and m.head_lp._hdn_template_cache is None and len(m.zf) == 3 and len(m.zf_lp) == 3
 n = hi.uninstall()
-assert TRACKS["hdnTrackerHomoProje2e"].__name__ == "hdnTrackerHomo" and "_hdn_wraps" not in vars(ModelBuilder.template)
+assert TRACKS["hdnTrackerHomoProje2e"].__name__ == "hdnTrackerHomo" and TRACKS["hdnTracker"].__name__ == "hdnTracker" and "_hdn_wraps" not in vars(ModelBuilder.template)
 hi.install(strict=True, tracker=True)
 # the reference's own HomoModelBuilder and ours agree on parameter names, so snapshots load either way
 ours = hdn_amd.HomoModelBuilder()

@@ -416,3 +416,54 @@ def test_tracker_loop_oracle_vs_executed_reference(prefix):
         assert tr["H_hm"].dtype == g[k + "H_hm"].dtype == np.float32 and trk.H_total.dtype == g[k + "H_total"].dtype
         np.testing.assert_array_equal(res["points"], g[k + "points"])
     assert worst <= 1e-12, (worst, worst_at)    # observed: 0.0 (the same numpy operations in the same order)
+
+
+def test_simi_tracker_loop_oracle_vs_executed_reference():
+    """oracle/tracker_oracle.SimiTrackerOracle against what the reference's OWN hdnTracker.init / track_new / update_template
+    (hdn/tracker/hdn_tracker.py:109-301; TRACKS['hdnTracker']) produced when make_golden.py:gen_tracker_loop_simi executed them around the
+    real ModelBuilder (tests/golden/tracker_loop_simi.npz, 12 frames, one log-polar-gated frame, one frame under SCALE_SCORE_THRESH).
+    Networks replayed, everything else recomputed: crops / rotated first frame bit for bit (CRC-32), the recurrences (centre, size, rot,
+    lp_shift, scale, v, lost_count) and the result dictionary exactly, incl. the dtype numpy leaves rot / lp_shift[1] in."""
+    from oracle import tracker_oracle as TO
+    g = load_golden("tracker_loop_simi")
+    frames, init = tracker_loop_sequence(g)
+    P = "s__"
+    model = ReplayModel(g, P)
+    trk = TO.SimiTrackerOracle(model, window_influence=float(g["window_influence"]), instance_size=int(g[P + "instance_size"]),
+                               scale_score_thresh=float(g["scale_score_thresh"]))
+    assert trk.score_size == int(g[P + "score_size"])
+    trk.init(frames[0], g["seq__bbox"].tolist(), g["seq__poly"].tolist(), np.array([g["seq__first_point"].tolist()]))
+    assert float(trk.init_s_z) == float(g[P + "init__init_s_z"]) and int(trk.poly_shift_l) == int(g[P + "init__poly_shift_l"])
+    np.testing.assert_array_equal(trk.channel_average, g[P + "init__channel_average"])
+    np.testing.assert_array_equal(model.seen["z_crop"].numpy().astype(np.uint8), g[P + "init__z_crop"])
+    kinds = {"f": np.float32, "d": float, "i": int}
+    seen_gate = seen_lost = 0
+    for i in range(1, int(g[P + "n_track"]) + 1):
+        k = f"{P}f{i}__"
+        model.frame = i
+        res = trk.track_new(i, frames[i])
+        tr = trk.trace
+        assert crc(tr["x_crop"].astype(np.uint8)) == int(g[k + "x_crop_crc"]), f"frame {i}: x_crop"
+        assert crc(tr["x_crop_moved"].astype(np.uint8)) == int(g[k + "x_crop_moved_crc"]), f"frame {i}: x_crop_moved"
+        assert crc(tr["rot_init_img"]) == int(g[k + "rot_init_img_crc"]), f"frame {i}: rotated first frame"
+        assert crc(tr["z_crop"].astype(np.uint8)) == int(g[k + "z_crop_crc"]), f"frame {i}: refreshed template crop"
+        assert crc(model.seen["z_crop"].numpy().astype(np.uint8)) == int(g[k + "z_crop_crc"])       # what model.template was handed
+        if k + "z_crop" in g.files:
+            np.testing.assert_array_equal(tr["z_crop"].astype(np.uint8), g[k + "z_crop"])
+            np.testing.assert_array_equal(tr["x_crop"].astype(np.uint8), g[k + "x_crop"])
+        assert float(tr["s_x"]) == float(g[k + "s_x"]) and float(tr["s_z"]) == float(g[k + "s_z"])
+        assert tr["best_idx"] == int(g[k + "best_idx"]) and tr["stop"] == int(g[k + "stop"]) and tr["best_idx_lp"] == int(g[k + "best_idx_lp"])
+        for name, got, want in (("center", tr["center"], g[k + "center"]), ("sim_lp", tr["sim_lp"], g[k + "sim_lp"]),
+                                ("center_pos", trk.center_pos, g[k + "center_pos"]), ("size", trk.size, g[k + "size"]),
+                                ("rot", float(trk.rot), g[k + "rot"]), ("lp_shift1", float(trk.lp_shift[1]), g[k + "lp_shift1"]),
+                                ("scale", float(trk.scale), g[k + "scale"]), ("v", float(trk.v), g[k + "v"]),
+                                ("bbox", res["bbox"], g[k + "bbox"]), ("bbox_aligned", res["bbox_aligned"], g[k + "bbox_aligned"]),
+                                ("polygon", res["polygon"], g[k + "polygon"]), ("best_score", float(res["best_score"]), g[k + "best_score"]),
+                                ("res_rot", float(res["rot"]), g[k + "res_rot"])):
+            np.testing.assert_array_equal(np.asarray(got, np.float64), np.asarray(want, np.float64), err_msg=f"frame {i}: {name}")
+        assert isinstance(trk.rot, kinds[str(g[k + "rot_kind"])]) and isinstance(trk.lp_shift[1], kinds[str(g[k + "lp_shift1_kind"])]), (i, type(trk.rot))
+        assert int(trk.lost_count) == int(g[k + "lost_count"]) and bool(trk.last_lost) == bool(g[k + "last_lost"])
+        assert float(trk.window_scale_factor) == float(g[k + "window_scale_factor"])
+        seen_gate += int(list(tr["sim_lp"]) == [1, 1, 0, 0])
+        seen_lost += int(float(g[k + "window_scale_factor"]) == 1.5)
+    assert seen_gate == 1 and seen_lost >= 1          # the log-polar gate and the SCALE_SCORE_THRESH branch are in the fixture
