@@ -11,7 +11,7 @@
 // piece products are accumulated in fp32 in two accumulator sets: hi += x0 w0, lo += x0 w1 + x1 w0, result = hi + 2^-11 lo (the
 // dropped x1 w1 is below 2^-22 of the product).  3 x 32 clk per K = 16 against 8 x 64 clk on v_mfma_f32_32x32x2_f32 and against
 // the 6 x 32 clk of round 3's three-bf16-piece form; measured against float64 the result has the error of an fp32 convolution
-// (rms 6.6e-8 of the output scale on K = 2,304 sums, fp32 sgemm: 6.6e-8, the bf16 form: 2.8e-8).  Range: |x| < 65,504 (fp16);
+// (rms 6.6e-8 of the output scale on K = 2,304 sums, fp32 sgemm: 6.6e-8, the bf16 form: 2.8e-8).  Range: |x| < 1.67e7 (activations are split as x 2^-8, mfma_split.h), weights < 65,504 (fp16);
 // the trunk's activations (BatchNorm-folded, ReLU) are O(10).  The weights are split once on the host
 // (hdn_amd.trunk.pack_conv3x3), the activations while they are staged into LDS.
 //
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __r
         constexpr int row0 = mt * 32 + mrow_to_pixel<Cf>(i0), row1 = mt * 32 + mrow_to_pixel<Cf>(i0 + 4);
         float* const q = obase + (row0 + g * (row1 - row0)) * Cf::EPI_STRIDE;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) q[nt * 32] = acc[mt][nt][r] + accl[mt][nt][r] * LO_UNSCALE;
+        for (int nt = 0; nt < NT; ++nt) q[nt * 32] = join(acc[mt][nt][r], accl[mt][nt][r]);
       });
     });
   }
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __r
           constexpr int row0 = mt * 32 + mrow_to_pixel<Cf>(i0), row1 = mt * 32 + mrow_to_pixel<Cf>(i0 + 4);
           float* const q = obase + (row0 + g * (row1 - row0)) * Cf::EPI_STRIDE;
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) q[nt * 32] = accd[DS ? mt : 0][DS ? nt : 0][r] + accdl[DS ? mt : 0][DS ? nt : 0][r] * LO_UNSCALE;
+          for (int nt = 0; nt < NT; ++nt) q[nt * 32] = join(accd[DS ? mt : 0][DS ? nt : 0][r], accdl[DS ? mt : 0][DS ? nt : 0][r]);
         });
       });
     }
@@ -945,7 +945,7 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_v2_kernel(const float* 
         constexpr int row0 = mt * 32 + mrow_to_pixel_s1<S>(i0), row1 = mt * 32 + mrow_to_pixel_s1<S>(i0 + 4);
         float* const q = rbase + (row0 + g * (row1 - row0)) * Cf::EPI_STRIDE;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) q[nt * 32] = acc[mt][nt][r] + accl[mt][nt][r] * LO_UNSCALE;
+        for (int nt = 0; nt < NT; ++nt) q[nt * 32] = join(acc[mt][nt][r], accl[mt][nt][r]);
       });
     });
     HDN_ABL_CONV3X3_14_END

@@ -265,8 +265,8 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3s2_v2_kernel(const float
     float* const q = rbase + row * Cf::EPI_STRIDE;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      q[nt * 32] = acc[nt][r] + accl[nt][r] * LO_UNSCALE;
-      q[Cf::RED_FLOATS + nt * 32] = dacc[nt][r] + daccl[nt][r] * LO_UNSCALE;
+      q[nt * 32] = join(acc[nt][r], accl[nt][r]);
+      q[Cf::RED_FLOATS + nt * 32] = join(dacc[nt][r], daccl[nt][r]);
     }
   });
   __syncthreads();                                     // the partial sums are in LDS (the producers take them from there)

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(512) void head_conv_kernel(Ptrs P, const u32x4* __r
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r)                            // C/D layout: row (r & 3) + 8 (r >> 2) + 4 g = channel, column li = pixel
-        red[((r & 3) + 8 * (r >> 2) + 4 * g) * TILE_N + nt * 32 + li] = hi[nt][r] + lo[nt][r] * LO_UNSCALE;
+        red[((r & 3) + 8 * (r >> 2) + 4 * g) * TILE_N + nt * 32 + li] = join(hi[nt][r], lo[nt][r]);
   }
   __syncthreads();
   // ---- all 512 threads: sum of the four K slices in slice order + bias + ReLU -> NCHW rows

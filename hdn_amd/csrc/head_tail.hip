@@ -165,8 +165,8 @@ __global__ __launch_bounds__(2 * H) void head_tail_kernel(const float* __restric
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const f4 bq = b1l[2 * q];
-      hv[q] = f4{fmaxf(hi[4 * q] + lo[4 * q] * LO_UNSCALE + bq.x, 0.f), fmaxf(hi[4 * q + 1] + lo[4 * q + 1] * LO_UNSCALE + bq.y, 0.f),
-                 fmaxf(hi[4 * q + 2] + lo[4 * q + 2] * LO_UNSCALE + bq.z, 0.f), fmaxf(hi[4 * q + 3] + lo[4 * q + 3] * LO_UNSCALE + bq.w, 0.f)};
+      hv[q] = f4{fmaxf(join(hi[4 * q], lo[4 * q]) + bq.x, 0.f), fmaxf(join(hi[4 * q + 1], lo[4 * q + 1]) + bq.y, 0.f),
+                 fmaxf(join(hi[4 * q + 2], lo[4 * q + 2]) + bq.z, 0.f), fmaxf(join(hi[4 * q + 3], lo[4 * q + 3]) + bq.w, 0.f)};
     }
 #pragma unroll
     for (int o = 0; o < MAX_OUT; ++o)

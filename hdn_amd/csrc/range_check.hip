@@ -1,5 +1,5 @@
 // HDN_CHECK_RANGE: the debug guard of the two-fp16-piece kernels (conv3x3.hip, head_conv.hip, head_tail.hip).  They carry an fp32
-// value x as fp16(x) + 2^-11 fp16((x - fp16(x)) 2^11), which needs |x| < 65,504: beyond it the first piece is inf and the result
+// value x as fp16(x') + 2^-11 fp16((x' - fp16(x')) 2^11) with x' = x 2^-8 (mfma_split.h), which needs |x| < 65,520 x 256 = 1.67e7: beyond it the first piece is inf and the result
 // NaN, where the reference's fp32 convolution (homo_estimator/.../backbone/resnet.py:78-94, hdn/models/head/ban.py:55-66) stays finite.
 // The packers check the WEIGHTS on the host; the ACTIVATIONS are device data, so checking them costs a reduction and a host round trip
 // per call — off by default (the trunk's BatchNorm-folded, ReLU'd activations are O(10)), on with HDN_CHECK_RANGE=1 or
@@ -36,7 +36,7 @@ bool check_range_enabled() {
   return v > 0;
 }
 
-// HDN_OK, or HDN_E_LIMIT when some |x[i]| >= 65,520 (or is NaN).  No-op when the guard is off or the stream is capturing.
+// HDN_OK, or HDN_E_LIMIT when some |x[i]| >= 65,520 x 256 (or is NaN).  No-op when the guard is off or the stream is capturing.
 int check_fp16_range(const float* x, long long n, hipStream_t stream) {
   if (!check_range_enabled() || !x || n <= 0) return HDN_OK;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -52,10 +52,10 @@ int check_fp16_range(const float* x, long long n, hipStream_t stream) {
   if (e == hipSuccess) e = hipStreamSynchronize(stream);
   (void)hipFreeAsync(word, stream);
   if (e != hipSuccess) return -(1000 + (int)e);
-  if (host >= 0x477ff000u) {                                      // 65,520.0f: the first value v_cvt_f16_f32 (round-to-nearest-even) turns into inf
+  if (host >= 0x4b7ff000u) {                                      // 65,520 x 2^8: x 2^-8 is then the first value v_cvt_f16_f32 (round-to-nearest-even) turns into inf
     float v;
     memcpy(&v, &host, sizeof v);
-    fprintf(stderr, "hdn_amd: HDN_CHECK_RANGE: max |x| = %g over %lld fp32 inputs of a two-fp16-piece kernel (they need |x| < 65,520): HDN_E_LIMIT\n", (double)v, n);
+    fprintf(stderr, "hdn_amd: HDN_CHECK_RANGE: max |x| = %g over %lld fp32 inputs of a two-fp16-piece kernel (they need |x| < 16,773,120): HDN_E_LIMIT\n", (double)v, n);
     return HDN_E_LIMIT;
   }
   return HDN_OK;

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(128 * STREAMS) void trunk_stem_mfma_kernel(const fl
     for (int mt = M0; mt < 4; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        acc[mt][r] = bias_c;
+        acc[mt][r] = bias_c * ACT_SCALE;      // (the accumulators hold sums of activations x 2^-8: join() gives the bias back exactly)
         accl[mt][r] = 0.f;
       }
     static_for<NSTEP>([&](auto Sc) {
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(128 * STREAMS) void trunk_stem_mfma_kernel(const fl
 #pragma unroll
       for (int ch = 0; ch < 2; ++ch)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) carry[ch][r] = fmaxf(acc[2 + ch][r] + accl[2 + ch][r] * LO_UNSCALE, 0.f);
+        for (int r = 0; r < 16; ++r) carry[ch][r] = fmaxf(join(acc[2 + ch][r], accl[2 + ch][r]), 0.f);
     } else {
       // rows 2p - 1 (carry), 2p, 2p + 1 -> vertical max; then columns 2 px - 1 .. 2 px + 1.  Lane (li, g) holds columns 32 ch + 8 j + 4 g + (0..3).
       const int p = (Rw >> 1) + t;
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(128 * STREAMS) void trunk_stem_mfma_kernel(const fl
         float v[16], tl[4];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float v0 = acc[ch][r] + accl[ch][r] * LO_UNSCALE, v1 = acc[2 + ch][r] + accl[2 + ch][r] * LO_UNSCALE;
+          const float v0 = join(acc[ch][r], accl[ch][r]), v1 = join(acc[2 + ch][r], accl[2 + ch][r]);
           v[r] = max3(v0, v1, carry[ch][r]);                   // (carry >= 0: the ReLU of all three)
           carry[ch][r] = fmaxf(v1, 0.f);
         }

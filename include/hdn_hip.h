@@ -407,8 +407,9 @@ int hdn_head_conv3x3_f32(const float* const* xs, const void* w_packed, const flo
  * Any other shape returns HDN_E_LIMIT (the caller keeps MIOpen for it).  fp32 accuracy from the 16-bit matrix pipe (ABI 5): activations
  * and weights are split into two fp16 pieces each, v = p0 + 2^-11 p1 with p0 = fp16(v), p1 = fp16((v - p0) * 2^11) (22 significand
  * bits), and three piece products are accumulated in fp32 (x0 w0 in one accumulator set, x0 w1 + x1 w0 in a second one that is
- * added with the factor 2^-11; conv3x3.hip); against float64 the result has the error of an fp32 convolution.  Values must lie in
- * fp16's range, |v| < 65,504 (the packer checks the weights; the trunk's activations are O(10)).
+ * added with the factor 2^-11; conv3x3.hip); against float64 the result has the error of an fp32 convolution.  Range (ABI 9): weights
+ * |w| < 65,504 (fp16; the packer checks them), activations |x| < 65,520 x 256 = 1.67e7 — the kernels split an activation as x 2^-8 and
+ * scale the sums back by 2^8 (exact), csrc/mfma_split.h; the trunk's activations are O(10).
  * wpacked: the BatchNorm-folded weights split and laid out by the host (hdn_amd.trunk.pack_conv3x3 / pack_conv3x3s2_ds) as
  *   [CO / BN][CI / (16 KS)][3 kernel rows][T taps][KS k steps][2 pieces][2 k halves][BN][8] fp16, input channel = chunk * 16 KS +
  *   step * 16 + half * 8 + j, (BN, KS) = hdn_conv3x3_pack_info(S, CI, stride); T = 3, or 4 for the stride-2 form, whose 4th tap holds
@@ -422,10 +423,11 @@ int hdn_head_conv3x3_f32(const float* const* xs, const void* w_packed, const flo
  */
 /*
  * Range guard of the two-fp16-piece kernels (ABI 6): hdn_conv3x3_bias_relu_f32, hdn_conv3x3s2_ds_f32, hdn_conv3x3_v2_f32,
- * hdn_conv3x3_chain_f32 (activation inputs), hdn_head_conv3x3_f32 and hdn_head_tail_f32 need |x| < 65,504 on their fp32 INPUTS as
- * well as on their weights (beyond it the first fp16 piece is inf and the result NaN, where the reference's fp32 convolution stays
- * finite).  With HDN_CHECK_RANGE=1 in the environment, or after hdn_set_check_range(1) (returns the previous setting), each of those
- * entry points first reduces max |x| over its input and returns HDN_E_LIMIT when it is >= 65,504 or NaN, launching nothing.  The check
+ * hdn_conv3x3_chain_f32 (activation inputs), hdn_trunk_stem_mfma_f32, hdn_head_conv3x3_f32 and hdn_head_tail_f32 are finite and fp32-accurate
+ * for |x| < 1.67e7 on their fp32 INPUTS by default (since ABI 9; 65,504 before).  Beyond that the first fp16 piece is inf and the result NaN,
+ * where the reference's fp32 convolution stays finite up to 3.4e38.  With HDN_CHECK_RANGE=1 in the environment, or after hdn_set_check_range(1)
+ * (returns the previous setting), each of those entry points first reduces max |x| over its input and returns HDN_E_LIMIT when it is
+ * >= 16,773,120 or NaN, launching nothing.  The check
  * costs a reduction launch and a stream synchronisation per call: a debug switch, off by default, skipped inside stream captures.
  */
 int hdn_set_check_range(int on);

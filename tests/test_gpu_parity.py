@@ -1551,64 +1551,46 @@ def test_head_conv_search_one_launch_vs_float64(dev, Hi, Wi, n, CO, nhwc):
     assert torch.equal(HD.head_conv_search(xd, pk).cpu().double(), got)          # deterministic
 
 
-# --------------------------------------------------------------------------- HDN_CHECK_RANGE: the fp16-piece kernels' input range
+# --------------------------------------------------------------------------- the fp16-piece kernels' input range
 def test_fp16_piece_range_guard(dev):
-    """The two-fp16-piece kernels need |x| < 65,504 on their fp32 inputs (beyond it the first piece is inf and the result NaN, where the
-    reference's fp32 convolutions stay finite: backbone/resnet.py:78-94, hdn/models/head/ban.py:55-66).  With the guard on
-    (hdn_set_check_range / HDN_CHECK_RANGE=1; the -m gpu suite runs with it, tests/conftest.py) an input of 7e4 is refused with HDN_E_LIMIT
-    by every entry point — nothing is launched, the output stays untouched — and an input of 6e4 still meets the float64 bound."""
+    """The two-fp16-piece kernels split their ACTIVATIONS as x 2^-8 (csrc/mfma_split.h), so with the guard OFF — the default — inputs far
+    beyond fp16's 65,504 give finite results inside the float64 bound, as the reference's fp32 convolutions do (backbone/resnet.py:78-94,
+    hdn/models/head/ban.py:55-66): checked at 7e4 (round-5 verdict) and 1e7, for every matrix-core entry point, on the outputs the large
+    element reaches AND on the others (each set against its own scale).  The format ends at 65,520 x 256 = 1.67e7: beyond it (and for
+    NaN) the guard (hdn_set_check_range / HDN_CHECK_RANGE=1; on in the -m gpu suite, tests/conftest.py) refuses the call with HDN_E_LIMIT."""
     import torch.nn.functional as F
     from hdn_amd import _lib, heads as HD
-    from hdn_amd.trunk import pack_conv3x3, pack_conv3x3_v2, pack_conv3x3s2_ds, conv3x3_bias_relu, conv3x3s2_ds
+    from hdn_amd.trunk import pack_conv3x3, pack_conv3x3_v2, pack_conv3x3s2_ds, conv3x3_bias_relu, conv3x3s2_ds, FusedStem
     lib = _lib.load()
-    prev = lib.hdn_set_check_range(1)
+    prev = lib.hdn_set_check_range(0)
+    cl = torch.channels_last
+
+    def held(y, t64, ref32, reached, what):
+        """y (device result), the float64 truth, the fp32 reference; `reached`: bool mask of outputs whose sum contains the large element."""
+        y, t64, ref32 = y.detach().cpu().double(), t64.double(), ref32.double()
+        assert torch.isfinite(y).all(), what
+        for name, m in (("reached", reached), ("others", ~reached)):
+            if m.any():
+                e_ref, scale = float((ref32[m] - t64[m]).abs().max()), float(t64[m].abs().max())
+                err = float((y[m] - t64[m]).abs().max())
+                assert err <= 4 * e_ref + 1e-5 * scale, (what, name, err, e_ref, scale)
+
     try:
         g = torch.Generator().manual_seed(5)
-        cl = torch.channels_last
         C, S, B = 256, 8, 24
         w = torch.randn(C, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5
         b = torch.randn(C, generator=g) * 0.1
         wp, wp2, bd = pack_conv3x3(w).to(dev), pack_conv3x3_v2(w).to(dev), b.to(dev)
         x = torch.randn(B, C, S, S, generator=g).clamp_min_(0)
-        for big, ok in ((7.0e4, False), (6.0e4, True), (float("nan"), False)):
-            xb = x.clone()
-            xb[B - 1, 17, 3, 5] = big
-            xd = xb.to(dev).contiguous(memory_format=cl)
-            for kw in ({}, {"wpacked_v2": wp2}):                      # the round-4 kernel and the large-batch form
-                if not ok:
-                    with pytest.raises(ValueError, match="HDN_E_LIMIT"):
-                        conv3x3_bias_relu(xd, wp, bd, **kw)
-                    continue
-                y = conv3x3_bias_relu(xd, wp, bd, **kw).cpu()
-                t = torch.relu(F.conv2d(xb.double(), w.double(), b.double(), padding=1))
-                ref = torch.relu(F.conv2d(xb, w, b, padding=1))
-                e_ref, scale = float((ref.double() - t).abs().max()), float(t.abs().max())
-                assert torch.isfinite(y).all() and float((y.double() - t).abs().max()) <= 4 * e_ref + 1e-5 * scale
-        # stride 2 + downsample
-        CI = 64
-        w2 = torch.randn(2 * CI, CI, 3, 3, generator=g) * 0.05
-        wd = torch.randn(2 * CI, CI, 1, 1, generator=g) * 0.1
-        x2 = torch.randn(3, CI, 32, 32, generator=g)
-        x2[1, 5, 7, 9] = -7.0e4                                          # (the magnitude counts)
-        with pytest.raises(ValueError, match="HDN_E_LIMIT"):
-            conv3x3s2_ds(x2.to(dev).contiguous(memory_format=cl), pack_conv3x3s2_ds(w2, wd).to(dev), torch.zeros(2 * CI, device=dev))
-        # the trunk's first stage on the matrix cores
-        from hdn_amd.trunk import FusedStem
-        st = FusedStem(torch.nn.Conv2d(2, 64, 7, 2, 3), True).to(dev)
-        xs0 = torch.randn(8, 2, 127, 127, generator=g)
-        assert torch.isfinite(st(xs0.to(dev))).all()
-        xs0[7, 1, 126, 126] = -7.0e4
-        with pytest.raises(ValueError, match="HDN_E_LIMIT"):
-            st(xs0.to(dev))
-        # the heads' two kernels
+        w2 = torch.randn(128, 64, 3, 3, generator=g) * 0.05
+        wd = torch.randn(128, 64, 1, 1, generator=g) * 0.1
+        wpd = pack_conv3x3s2_ds(w2, wd).to(dev)
+        conv1 = torch.nn.Conv2d(2, 64, 7, 2, 3)
+        st = FusedStem(conv1, True).to(dev)
         pk = HD._PackedHead()
-        pk.wsp = HD._pack_conv_search([(torch.randn(64, 256, 3, 3, generator=g) * 0.03).to(dev)])
+        ws = torch.randn(64, 256, 3, 3, generator=g) * 0.03
+        pk.wsp = HD._pack_conv_search([ws.to(dev)])
         pk.bsp = torch.zeros(1, 64, device=dev)
-        xs = torch.randn(1, 256, 9, 14, generator=g)
-        assert torch.isfinite(HD.head_conv_search([xs.to(dev)], pk)).all()
-        xs[0, 200, 8, 13] = 7.0e4
-        with pytest.raises(ValueError, match="HDN_E_LIMIT"):
-            HD.head_conv_search([xs.to(dev)], pk)
         H, P, n = 256, 169, 3
         pt = HD._PackedHead()
         pt.w1 = (torch.randn(2 * n, H, H, generator=g) * 0.06).to(dev)
@@ -1616,20 +1598,83 @@ def test_fp16_piece_range_guard(dev):
         pt.wf = (torch.randn(2, 4, n * H, generator=g) * 0.05).to(dev)
         pt.bf = torch.zeros(2, 4, 1, device=dev)
         pt.w1p = HD._pack_w1(pt.w1)
+        f64 = lambda t: t.detach().cpu().double()
+        for big in (7.0e4, -1.0e7):
+            # 3x3 stride 1, both forms (the large element: sample B - 1, pixel (3, 5))
+            xb = x.clone()
+            xb[B - 1, 17, 3, 5] = abs(big)
+            xd = xb.to(dev).contiguous(memory_format=cl)
+            t = torch.relu(F.conv2d(xb.double(), w.double(), b.double(), padding=1))
+            ref = torch.relu(F.conv2d(xb, w, b, padding=1))
+            reached = torch.zeros_like(t, dtype=torch.bool)
+            reached[B - 1, :, 2:5, 4:7] = True
+            for kw in ({}, {"wpacked_v2": wp2}):
+                held(conv3x3_bias_relu(xd, wp, bd, **kw), t, ref, reached, f"conv3x3 {big} {list(kw)}")
+            # stride 2 + downsample
+            x2 = torch.randn(3, 64, 32, 32, generator=g)
+            x2[1, 5, 7, 9] = big
+            o1, o2 = conv3x3s2_ds(x2.to(dev).contiguous(memory_format=cl), wpd, torch.zeros(128, device=dev))
+            reach2 = torch.zeros((3, 128, 16, 16), dtype=torch.bool)
+            reach2[1, :, 3:5, 4:6] = True                                 # input pixel (7, 9) under a 3 x 3 / stride 2 / pad 1 window
+            held(o1, torch.relu(F.conv2d(x2.double(), w2.double(), None, stride=2, padding=1)), torch.relu(F.conv2d(x2, w2, None, stride=2, padding=1)),
+                 reach2, f"conv3x3s2 {big}")
+            held(o2, F.conv2d(x2.double(), wd.double(), None, stride=2), F.conv2d(x2, wd, None, stride=2), torch.zeros_like(reach2), f"downsample {big}")
+            # the trunk's first stage on the matrix cores (conv 7x7 / 2 + ReLU + max-pool 3 / 2): the large element at the last pixel
+            xs0 = torch.randn(8, 2, 127, 127, generator=g)
+            xs0[7, 1, 126, 126] = big
+            ys = st(xs0.to(dev))
+            with torch.no_grad():
+                ts = F.max_pool2d(torch.relu(F.conv2d(xs0.double(), conv1.weight.double(), conv1.bias.double(), stride=2, padding=3)), 3, 2, 1)
+                rs = F.max_pool2d(torch.relu(conv1(xs0)), 3, 2, 1)
+            reach_s = torch.zeros_like(ts, dtype=torch.bool)
+            reach_s[7, :, -2:, -2:] = True
+            held(ys, ts, rs, reach_s, f"stem {big}")
+            # the heads' two kernels
+            xs = torch.randn(1, 256, 9, 14, generator=g)
+            xs[0, 200, 8, 13] = big
+            yh = HD.head_conv_search([xs.to(dev)], pk)
+            th, rh = torch.relu(F.conv2d(xs.double(), ws.double())), torch.relu(F.conv2d(xs, ws))
+            reach_h = torch.zeros_like(th, dtype=torch.bool)
+            reach_h[0, :, -1, -1] = True
+            held(yh.reshape(th.shape), th, rh, reach_h, f"head conv_search {big}")
+            feats = torch.randn(2 * n, H, P, 1, generator=g).relu_()
+            feats[5, 255, 168, 0] = abs(big)
+            yt = HD.head_tail(feats.to(dev), pt, n)
+            hid = torch.baddbmm(f64(pt.b1), f64(pt.w1), f64(feats).view(2 * n, H, -1)).relu()
+            tt = torch.baddbmm(f64(pt.bf), f64(pt.wf), hid.view(2, n * H, -1))
+            hid32 = torch.baddbmm(pt.b1.cpu(), pt.w1.cpu(), feats.view(2 * n, H, -1)).relu()
+            rt = torch.baddbmm(pt.bf.cpu(), pt.wf.cpu(), hid32.view(2, n * H, -1))
+            reach_t = torch.zeros_like(tt, dtype=torch.bool)
+            reach_t[:, :, 168] = True
+            held(yt.reshape(tt.shape), tt, rt, reach_t, f"head tail {big}")
+        # the guard: beyond 1.67e7 (and NaN) every entry point refuses, nothing is launched
+        lib.hdn_set_check_range(1)
+        for bad in (2.0e7, float("nan")):
+            xb = x.clone()
+            xb[B - 1, 17, 3, 5] = bad
+            xd = xb.to(dev).contiguous(memory_format=cl)
+            for kw in ({}, {"wpacked_v2": wp2}):
+                with pytest.raises(ValueError, match="HDN_E_LIMIT"):
+                    conv3x3_bias_relu(xd, wp, bd, **kw)
+        x2 = torch.randn(3, 64, 32, 32, generator=g)
+        x2[1, 5, 7, 9] = -2.0e7                                          # (the magnitude counts)
+        with pytest.raises(ValueError, match="HDN_E_LIMIT"):
+            conv3x3s2_ds(x2.to(dev).contiguous(memory_format=cl), wpd, torch.zeros(128, device=dev))
+        xs0 = torch.randn(8, 2, 127, 127, generator=g)
+        xs0[7, 1, 126, 126] = -2.0e7
+        with pytest.raises(ValueError, match="HDN_E_LIMIT"):
+            st(xs0.to(dev))
+        xs = torch.randn(1, 256, 9, 14, generator=g)
+        xs[0, 200, 8, 13] = 2.0e7
+        with pytest.raises(ValueError, match="HDN_E_LIMIT"):
+            HD.head_conv_search([xs.to(dev)], pk)
         feats = torch.randn(2 * n, H, P, 1, generator=g).relu_()
-        assert torch.isfinite(HD.head_tail(feats.to(dev), pt, n)).all()
-        feats[5, 255, 168, 0] = 7.0e4
+        feats[5, 255, 168, 0] = 2.0e7
         with pytest.raises(ValueError, match="HDN_E_LIMIT"):
             HD.head_tail(feats.to(dev), pt, n)
-        # off: the call goes through and is WRONG at that pixel (inf / NaN inside; the ReLU's fmax may even hand back a finite value): what
-        # the guard is for
-        lib.hdn_set_check_range(0)
-        y = HD.head_tail(feats.to(dev), pt, n).cpu().double()
-        f64 = lambda t: t.detach().cpu().double()
-        hid = torch.baddbmm(f64(pt.b1), f64(pt.w1), f64(feats).view(2 * n, H, -1)).relu()
-        ref = torch.baddbmm(f64(pt.bf), f64(pt.wf), hid.view(2, n * H, -1))
-        bad = ~torch.isfinite(y[:, :, 168]) | ((y[:, :, 168] - ref[:, :, 168]).abs() > 1e-2 * ref[:, :, 168].abs().max())
-        assert bool(bad.any()) and float((y[:, :, :168] - ref[:, :, :168]).abs().max()) <= 1e-3 * float(ref.abs().max())
+        # 1.6e7 is still inside
+        xs[0, 200, 8, 13] = 1.6e7
+        assert torch.isfinite(HD.head_conv_search([xs.to(dev)], pk)).all()
     finally:
         lib.hdn_set_check_range(prev)
 
