@@ -75,6 +75,9 @@ def parse():
     ap.add_argument("--no-sequence", action="store_true", help="skip the `sequence` block (BASELINE configs[3]: the end-to-end tracker loop "
                                                                "with a production-shaped model, N = 1 only)")
     ap.add_argument("--sequence-frames", type=int, default=501, help="frames of the synthetic 1280x720 sequence (POT: 501, hdn/core/config.py:285)")
+    ap.add_argument("--multi-sequence", type=str, default="16", help="comma-separated n: the `sequence.lockstep` rows — n sequences advancing in lock step on this GPU "
+                    "(hdn_amd.batched_tracker); '' skips them.  Default 16 only (MIOpen's find at every new batch size costs ~30 s); the 1 / 4 / 16 / 32 table: "
+                    "profiles/round6_multi_sequence.txt")
     ap.add_argument("--collective", choices=["c_abi", "torch", "oneshot"], default="c_abi",
                     help="N > 1: hdn_allgather_offsets of the C ABI on RCCL (default), torch.distributed.all_gather_into_tensor, or the "
                          "direct-write hdn_gather_offsets_oneshot (hipIpc windows; validated on one device only)")
@@ -462,7 +465,7 @@ def main():
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             result["full_head"]["cpu_baseline"] = cpu_full_head(d, full_cpu_sd)
     if rank == 0 and world == 1 and not args.no_sequence and not args.only_north:
-        result["sequence"] = sequence_block(args.sequence_frames, dev)
+        result["sequence"] = sequence_block(args.sequence_frames, dev, args.multi_sequence)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(d, sf_cpu_sd)
     if world > 1:
@@ -602,7 +605,7 @@ def run_config5(args, dev, rank, world, dist, hdist, comm, sf, folded):
                          "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms}}), flush=True)
 
 
-def sequence_block(n_frames, dev):
+def sequence_block(n_frames, dev, multi=""):
     """BASELINE configs[3]: the end-to-end per-frame loop — hdn_amd.tracker.DeviceTrackerHomo(model), the object
     install(tracker=True) registers, one hipGraph per frame, the host reading the 4 corners every frame — over a synthetic
     1280x720 sequence of `n_frames` frames with a PRODUCTION-SHAPED model (tests/production_standin.py: ResNet-50 / stride-8
@@ -616,6 +619,17 @@ def sequence_block(n_frames, dev):
     res = SB.run_production(n_frames=n_frames, n_parity=0, components=True, dev=dev, quiet=True)
     res["wall_s_incl_generation_and_miopen_find"] = time.perf_counter() - t0
     res["metric"], res["unit"], res["value"] = "end-to-end frames/sec, tracker.track() loop, 1280x720 frames, 127/255 crops", "frames/s", res["fps"]
+    ns = tuple(int(x) for x in multi.split(",") if x)
+    if ns:
+        # the reference's only inference-time parallelism: several videos at once (tools/test.py:91-103, hand-split ranges, one process each).  Here n
+        # sequences advance one frame per step on ONE GPU: one pinned [n,720,1280,3] upload, one hipGraph replay, one host read of [n, 9] per step.
+        t0 = time.perf_counter()
+        m = SB.run_multi(ns, n_steps=40, dev=dev, quiet=True)
+        for r in m["rows"]:
+            r["speedup_vs_single_sequence_loop"] = r["frames_per_s"] / res["fps"]
+        res["lockstep"] = {"tracker": m["tracker"], "rows": m["rows"], "wall_s": time.perf_counter() - t0,
+                           "bound": "the frame is ~110 GFLOP of fp32 convolutions in the PyTorch-ROCm backbone (89 at 255 px + 21 at 127 px), which the library runs at "
+                                    "78-82 % of the 157 TFLOP/s fp32 matrix peak from n = 16 on (profiles/round6_multi_sequence.txt): at most ~4.0 x the n = 1 loop at 100 %"}
     return res
 
 

@@ -348,9 +348,10 @@ def run_multi(ns=(1, 4, 16, 32), n_steps=60, dev=None, quiet=False, offset=3, di
             f"graph={row['graph']}  [{time.perf_counter() - t0:.1f} s]")
         del trk, steps, dsteps
         torch.cuda.empty_cache()
-    base = next((r for r in rows if r["n"] == 1), rows[0])
-    for r in rows:
-        r["speedup_vs_n1"] = r["frames_per_s"] / base["frames_per_s"] * (base["n"] if base["n"] != 1 else 1)
+    base = next((r for r in rows if r["n"] == 1), None)
+    if base is not None:
+        for r in rows:
+            r["speedup_vs_n1"] = r["frames_per_s"] / base["frames_per_s"]
     return {"tracker": "hdn_amd.batched_tracker.BatchedDeviceTracker(model, n): n independent sequences advance one frame per step; one pinned "
                        "[n,720,1280,3] upload, one hipGraph replay, one host read of [n, 9] per step",
             "model": "tests/production_standin.py (ResNet-50 stride-8 dilated backbone x2, 256-channel heads, ResNet-34 estimator; seeded; fp32; channels-last; MIOpen find)",
