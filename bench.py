@@ -677,11 +677,28 @@ def measured_copy(dev, mbytes=370):
                                   "ten launches back to back in one hipGraph (csrc/ubench.hip)"}
 
 
-def _sclk_sampler():
-    """(start, stop) around a region: shader clock in MHz from hwmon every 10 ms -> list (empty when the box does not expose it)."""
+def _hwmon_of(dev):
+    """The hwmon freq1_input (shader clock) of THIS device: the drm card whose PCI address is the device's.  A host with several GPUs exposes
+    all of them under /sys whichever one the process was given; reading card0 then samples an idle neighbour (95 MHz on a round-6 box)."""
     import glob
+    cands = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input"))
+    if not cands:
+        return None
+    try:
+        p = torch.cuda.get_device_properties(dev)
+        want = "%04x:%02x:%02x." % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        for c in cands:
+            if os.path.basename(os.path.realpath(c.split("/hwmon/")[0])).startswith(want):
+                return c
+    except Exception:
+        pass
+    return cands[0] if len(cands) == 1 else None
+
+
+def _sclk_sampler(dev=None):
+    """(start, stop) around a region: shader clock in MHz from hwmon every 10 ms -> list (empty when the box does not expose it)."""
     import threading
-    hw = (glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input") or [None])[0]
+    hw = _hwmon_of(dev if dev is not None else torch.cuda.current_device())
     samples, halt = [], threading.Event()
 
     def run():
@@ -733,7 +750,7 @@ def north_issue_fractions(in_step_ms, sustained_ms, launch, dev, rank):
     torch.cuda.current_stream().wait_stream(side)
     with torch.cuda.graph(g):
         keep = [launch() for _ in range(10)]
-    start, stop = _sclk_sampler()
+    start, stop = _sclk_sampler(dev)
     g.replay()
     torch.cuda.synchronize()
     start()
@@ -744,10 +761,13 @@ def north_issue_fractions(in_step_ms, sustained_ms, launch, dev, rank):
         torch.cuda.synchronize()
     mhz = stop()
     del keep
-    if len(mhz) >= 5:
-        clock_ghz, clock_src = float(np.median(mhz)) / 1e3, "hwmon freq1_input, median of %d samples over 0.3 s of back-to-back launches" % len(mhz)
+    # a reading outside what this chip can run at under load (its range is 0.5 ... 2.4 GHz) is another device's or a stale one: not used
+    if len(mhz) >= 5 and 1000.0 <= float(np.median(mhz)) <= 2600.0:
+        clock_ghz, clock_src = float(np.median(mhz)) / 1e3, "hwmon freq1_input of this device, median of %d samples over 0.3 s of back-to-back launches" % len(mhz)
     else:
-        clock_ghz, clock_src = 2.0, "not readable on this box; 2.0 GHz = GRBM_GUI_ACTIVE / duration of profiles/round3_north_experiments.txt"
+        clock_ghz = 2.05
+        clock_src = ("hwmon not usable on this box (%s); 2.05 GHz = s_memtime / s_memrealtime per worker of the instrumented build, "
+                     "profiles/round3_north_experiments.txt" % ("median %.0f MHz" % float(np.median(mhz)) if mhz else "no freq1_input for this device"))
     pairs_per_simd = PAIRS * C / 2 / 1024.0
     out = {"instructions_per_pair": rec["issued_per_pair"], "valu_packed_per_pair": rec["valu_packed_per_pair"],
            "instruction_count_source": "profiles/round6_north_instr.json (static, hot loop of the shipped code object)",

@@ -149,7 +149,7 @@ def test_sharded_offsets_two_ranks_on_one_gpu(dev, pairs):
     assert res == {0: ok, 1: ok}, "\n----\n".join(o[-2000:] for o in outs)
 
 
-@pytest.mark.parametrize("workload", ["full", "kernels", "kernels-oneshot"])
+@pytest.mark.parametrize("workload", ["full", "kernels", "kernels-oneshot", "config5"])
 def test_bench_two_ranks_one_device_json_contract(dev, workload):
     """bench.py's N > 1 path (`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...`) on the one-GPU box:
     HDN_BENCH_ONE_DEVICE=1 puts both ranks on GPU 0 over gloo (RCCL refuses two ranks on a device).  Rank 0 prints ONE JSON
@@ -164,6 +164,8 @@ def test_bench_two_ranks_one_device_json_contract(dev, workload):
         cmd += ["--workload", "full"]
     if workload == "kernels-oneshot":      # the exchange as the direct-write gather between the two processes
         cmd += ["--collective", "oneshot"]
+    if workload == "config5":              # BASELINE configs[4]: `bench.py --config 5 --gpus N` (round-5 verdict: was outside this contract test)
+        cmd += ["--config", "5"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-3000:]
@@ -174,6 +176,10 @@ def test_bench_two_ranks_one_device_json_contract(dev, workload):
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["unit"] == "frames/s" and d["dtype"] == "f32"
     assert abs(d["value"] - 2 * 64 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]      # whole-job aggregate over both ranks
     assert "workload" in d["config"] and "model" not in d["config"]
+    if workload == "config5":
+        assert "configs[4]" in d["config"]["workload"] and d["roofline"]["bound"] == "hbm" and "xcorr_cfg5_kernel" in d["roofline"]["kernel"]
+        assert 0 < d["roofline"]["frac"] < 1 and d["roofline"]["algorithmic_bytes_per_launch"] == 6 * 4 * 256 * (35 * 35 + 25 + 31 * 31) * 64
+        return
     if workload.startswith("kernels"):
         assert "roofline" in d and d["roofline"]["bound"] == "hbm" and "all-gather" in d["config"]["workload"]
         assert ("hdn_gather_offsets_oneshot" in d["config"]["workload"]) == (workload == "kernels-oneshot")

@@ -329,6 +329,7 @@ def run_multi(ns=(1, 4, 16, 32), n_steps=60, dev=None, quiet=False, offset=3, di
             a = time.perf_counter(); res = trk.track_new(k, steps[k % distinct_steps]); per.append(time.perf_counter() - a)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t1) / n_steps * 1e3
+        syncs_per_step = (trk.host_syncs - s0) / n_steps
         assert len(res) == n and all(np.isfinite(r["points"]).all() for r in res)
         # the same with the frames already on the device (no PCIe in the step): what the kernels + networks alone sustain
         dsteps = [s.to(dev) for s in steps[:4]]
@@ -338,7 +339,7 @@ def run_multi(ns=(1, 4, 16, 32), n_steps=60, dev=None, quiet=False, offset=3, di
         torch.cuda.synchronize()
         ms_res = (time.perf_counter() - t2) / n_steps * 1e3
         row = {"n": n, "ms_per_step": ms, "frames_per_s": n * 1e3 / ms, "ms_per_frame": ms / n, "p99_ms_per_step": float(np.percentile(per, 99) * 1e3),
-               "host_syncs_per_step": (trk.host_syncs - s0) / n_steps, "graph": trk._graph is not None,
+               "host_syncs_per_step": syncs_per_step, "graph": trk._graph is not None,
                "ms_per_step_frames_resident": ms_res, "frames_per_s_frames_resident": n * 1e3 / ms_res,
                "upload_MB_per_step": steps[0].numel() / 1e6}
         if kprofile_n is not None and n == kprofile_n:
