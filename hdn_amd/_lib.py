@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libhdn_hip.so"
 LIB_PATH = os.environ.get("HDN_LIB_PATH", os.path.join(_HERE, LIB_NAME))  # override: A/B builds of the kernels
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _c_float_p = ctypes.c_void_p  # device pointers travel as integers
 _i = ctypes.c_int
@@ -61,6 +61,20 @@ SIGNATURES = {
     "hdn_head_tail_f32": (_i, [_c_float_p, ctypes.c_void_p] + [_c_float_p] * 4 + [_i] * 4 + [ctypes.c_void_p]),
     "hdn_head_conv3x3_f32": (_i, [ctypes.c_void_p, ctypes.c_void_p, _c_float_p, ctypes.c_void_p] + [_i] * 5 + [ctypes.c_void_p]),
     "hdn_set_check_range": (_i, [_i]),
+    "hdn_pack_conv3x3_bytes": (ctypes.c_longlong, [_i]),
+    "hdn_pack_conv3x3_f32": (_i, [_c_float_p, _i, ctypes.c_void_p, ctypes.c_longlong]),
+    "hdn_pack_conv3x3s2_ds_bytes": (ctypes.c_longlong, [_i]),
+    "hdn_pack_conv3x3s2_ds_f32": (_i, [_c_float_p, _c_float_p, _i, ctypes.c_void_p, ctypes.c_longlong]),
+    "hdn_pack_conv3x3_v2_bytes": (ctypes.c_longlong, [_i]),
+    "hdn_pack_conv3x3_v2_f32": (_i, [_c_float_p, _i, ctypes.c_void_p, ctypes.c_longlong]),
+    "hdn_pack_conv3x3s2_v2_bytes": (ctypes.c_longlong, [_i]),
+    "hdn_pack_conv3x3s2_v2_f32": (_i, [_c_float_p, _c_float_p, _i, ctypes.c_void_p, ctypes.c_longlong]),
+    "hdn_pack_stem_mfma_bytes": (ctypes.c_longlong, []),
+    "hdn_pack_stem_mfma_f32": (_i, [_c_float_p, ctypes.c_void_p, ctypes.c_longlong]),
+    "hdn_pack_head_conv3x3_bytes": (ctypes.c_longlong, [_i, _i]),
+    "hdn_pack_head_conv3x3_f32": (_i, [ctypes.c_void_p, _i, _i, ctypes.c_void_p, ctypes.c_longlong]),
+    "hdn_pack_head_tail_bytes": (ctypes.c_longlong, [_i, _i]),
+    "hdn_pack_head_tail_f32": (_i, [_c_float_p, _i, _i, ctypes.c_void_p, ctypes.c_longlong]),
     "hdn_ubench_copy_f32": (_i, [_c_float_p] * 2 + [ctypes.c_longlong, ctypes.c_void_p]),
     "hdn_conv3x3_pack_info": (_i, [_i, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "hdn_conv3x3_workspace_bytes": (ctypes.c_longlong, [_i, _i, _i, _i]),

@@ -190,25 +190,30 @@ def _fold_bn(conv, bn):
 
 
 def _pack_w1(w1):
-    """[G, H, H] fp32 (row = output channel) -> the layout hdn_head_tail_f32 streams (include/hdn_hip.h): two fp16 pieces
-    (v = p0 + 2^-11 p1), MFMA A-fragment order [G][H / 32][H / 16][piece][lane = 32 * k half + row][8] as int16 bit patterns."""
+    """[G, H, H] fp32 (row = output channel) -> the stream hdn_head_tail_f32 takes (hdn_pack_head_tail_f32, csrc/pack.hip), on w1's device."""
+    from . import _lib
+    from .trunk import _c_pack, _host_f32
+
     G, H, _ = w1.shape
-    w = w1.detach().to(torch.float32)
-    p0 = w.to(torch.float16)
-    p1 = ((w - p0.float()) * 2048.0).to(torch.float16)
-    t = torch.stack([p0, p1]).view(2, G, H // 32, 32, H // 16, 2, 8)        # [piece, g, m tile, row, k step, k half, j]
-    return t.permute(1, 2, 4, 0, 5, 3, 6).contiguous().view(torch.int16)   # [g, m tile, k step, piece, k half, row, j]
+    lib, w = _lib.load(), _host_f32(w1)
+    return _c_pack("pack_head_tail", lib.hdn_pack_head_tail_bytes(G, H), lambda o, n: lib.hdn_pack_head_tail_f32(w.data_ptr(), G, H, o, n)).to(w1.device)
 
 
 def _pack_conv_search(ws):
-    """n folded conv_search weights [CO, 256, 3, 3] fp32 -> the layout hdn_head_conv3x3_f32 streams (include/hdn_hip.h): two fp16 pieces,
-    [n][CO / 32][4 chunks][4 k slices][9 taps][piece][lane = 32 * k half + output channel][8] as int16 bit patterns."""
-    w = torch.stack([t.detach().to(torch.float32) for t in ws])                # [n, CO, CI, 3, 3]
-    n, CO, CI = w.shape[0], w.shape[1], w.shape[2]
-    p0 = w.to(torch.float16)
-    p1 = ((w - p0.float()) * 2048.0).to(torch.float16)
-    t = torch.stack([p0, p1]).reshape(2, n, CO // 32, 32, CI // 64, 4, 2, 8, 9)    # [piece, n, cb, m, chunk, k slice, k half, j, tap]
-    return t.permute(1, 2, 4, 5, 8, 0, 6, 3, 7).contiguous().view(torch.int16)   # [n, cb, chunk, k slice, tap, piece, k half, m, j]
+    """n folded conv_search weights [CO, 256, 3, 3] fp32 -> the stream hdn_head_conv3x3_f32 takes (hdn_pack_head_conv3x3_f32), on their device."""
+    import ctypes
+
+    from . import _lib
+    from .trunk import _c_pack, _host_f32
+
+    host = [_host_f32(t) for t in ws]
+    n, CO = len(host), host[0].shape[0]
+    if any(tuple(t.shape) != (CO, 256, 3, 3) for t in host):
+        raise ValueError("conv_search weights must be [CO, 256, 3, 3]")
+    lib = _lib.load()
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in host])
+    return _c_pack("pack_head_conv3x3", lib.hdn_pack_head_conv3x3_bytes(n, CO),
+                   lambda o, nb: lib.hdn_pack_head_conv3x3_f32(ptrs, n, CO, o, nb)).to(ws[0].device)
 
 
 def head_conv_search(x_fs, pk):

@@ -76,18 +76,37 @@ def resnet34_homo():
 STEM_MFMA_MIN_BATCH = int(os.environ.get("HDN_STEM_MFMA_MIN_BATCH", "1"))
 
 
-def pack_stem_mfma(weight):
-    """[64, 2, 7, 7] fp32 weights (BatchNorm folded in) -> the fragment-ordered stream of hdn_trunk_stem_mfma_f32 (include/hdn_hip.h):
-    [7 k steps][2 n tiles][2 pieces][k half g][n][8] fp16 bit patterns, element j = w[32 tile + n][ci][ky][kx = j] with
-    ci * 7 + ky = 2 step + g, zero at j = 7."""
+def _c_pack(what, n_bytes, call):
+    """Run one of the library's packers (csrc/pack.hip, host code): -> int16 CPU tensor holding the opaque stream."""
     import torch
+
+    from . import _lib
+
+    if n_bytes < 0:
+        raise ValueError(f"{what}: no matrix-core kernel takes weights of this shape")
+    out = torch.empty(n_bytes // 2, dtype=torch.int16)
+    rc = call(out.data_ptr(), n_bytes)
+    if rc == -3:                                   # HDN_E_LIMIT
+        raise ValueError(f"{what}: weights beyond the fp16 range (|w| >= 65,504) or NaN")
+    _lib.check(rc, what)
+    return out
+
+
+def _host_f32(t):
+    import torch
+
+    return t.detach().to(device="cpu", dtype=torch.float32).contiguous()
+
+
+def pack_stem_mfma(weight):
+    """[64, 2, 7, 7] fp32 weights (BatchNorm folded in) -> the stream hdn_trunk_stem_mfma_f32 takes (hdn_pack_stem_mfma_f32; the layout is
+    the library's: csrc/pack.hip)."""
+    from . import _lib
 
     if tuple(weight.shape) != (64, 2, 7, 7):
         raise ValueError(f"pack_stem_mfma takes [64, 2, 7, 7] weights, got {tuple(weight.shape)}")
-    w8 = torch.zeros(64, 14, 8, dtype=torch.float32)
-    w8[:, :, :7] = weight.detach().to(torch.float32).cpu().reshape(64, 14, 7)                # [co][r = ci * 7 + ky][kx]
-    t = _split_f16(w8).reshape(SPLIT_PIECES, 2, 32, 7, 2, 8)                                 # [pc, tile, n, step, g, j]
-    return t.permute(3, 1, 0, 4, 2, 5).contiguous().view(torch.int16).reshape(-1)            # [step, tile, pc, g, n, j]
+    lib, w = _lib.load(), _host_f32(weight)
+    return _c_pack("pack_stem_mfma", lib.hdn_pack_stem_mfma_bytes(), lambda o, n: lib.hdn_pack_stem_mfma_f32(w.data_ptr(), o, n))
 
 
 class FusedStem(nn.Module):
@@ -167,100 +186,56 @@ def bias_relu_(y, bias, residual=None):
 SPLIT_PIECES = 2
 
 
-def _split_f16(w):
-    """fp32 -> two fp16 pieces, w = p0 + 2^-11 p1 (round-to-nearest-even each; the residual w - p0 and its product with 2^11 are
-    exact in fp32): the split the kernel applies to the activations (conv3x3.hip, split2x2)."""
-    import torch
-
-    if float(w.abs().max()) >= 65504.0:
-        raise ValueError("conv3x3 matrix-core kernel: weights beyond the fp16 range")
-    p0 = w.to(torch.float16)
-    p1 = ((w - p0.float()) * 2048.0).to(torch.float16)
-    return torch.stack([p0, p1])
-
-
-def _pack(w4, S, CI, stride):
-    """w4 [CO, CI, 3, T] fp32 (T taps per kernel row) -> [CO / BN][CI / (16 KS)][3][T][KS][2 pieces][2][BN][8] int16 bit patterns (fp16)."""
-    import ctypes
-
-    import torch
-
+def pack_conv3x3(weight):
+    """[C, C, 3, 3] fp32 weights of a stride-1 convolution -> the stream hdn_conv3x3_bias_relu_f32 / hdn_conv3x3_chain_f32 take
+    (hdn_pack_conv3x3_f32).  The side S is implied by C in the trunk (64 -> 32, 128 -> 16, 256 -> 8, 512 -> 4)."""
     from . import _lib
 
-    bn, ks = ctypes.c_int(0), ctypes.c_int(0)
-    if _lib.load().hdn_conv3x3_pack_info(S, CI, stride, ctypes.byref(bn), ctypes.byref(ks)) != 0:
-        raise ValueError(f"no matrix-core kernel for {CI} input channels at output side {S}, stride {stride}")
-    BN, KS = bn.value, ks.value
-    CO, T = w4.shape[0], w4.shape[3]
-    pieces = _split_f16(w4.detach().to(torch.float32).cpu())            # [2, CO, CI, ky, t]
-    t = pieces.permute(0, 1, 3, 4, 2).reshape(SPLIT_PIECES, CO // BN, BN, 3, T, CI // (16 * KS), KS, 2, 8)   # [piece, nb, n, ky, t, chunk, ks, g, 8]
-    t = t.permute(1, 5, 3, 4, 6, 0, 7, 2, 8).contiguous()               # [nb, chunk, ky, t, ks, piece, g, n, 8]
-    return t.view(torch.int16)
-
-
-def pack_conv3x3(weight):
-    """[C, C, 3, 3] fp32 weights of a stride-1 convolution -> the layout hdn_conv3x3_bias_relu_f32 streams (include/hdn_hip.h).
-    The side S is implied by C in the trunk (64 -> 32, 128 -> 16, 256 -> 8, 512 -> 4)."""
     C = weight.shape[0]
     if tuple(weight.shape) != (C, C, 3, 3):
         raise ValueError(f"pack_conv3x3 takes [C, C, 3, 3] weights, got {tuple(weight.shape)}")
-    return _pack(weight, _MC_SIDE.get(C, 0), C, 1)
+    lib, w = _lib.load(), _host_f32(weight)
+    return _c_pack("pack_conv3x3", lib.hdn_pack_conv3x3_bytes(C), lambda o, n: lib.hdn_pack_conv3x3_f32(w.data_ptr(), C, o, n))
 
 
 def pack_conv3x3_v2(weight):
-    """[C, C, 3, 3] fp32 weights -> the fragment-ordered stream of hdn_conv3x3_v2_f32 (include/hdn_hip.h):
-    [C / (32 NT)][chunk][k slice][tap][k step of the slice][n tile][piece][k half][n][8] fp16 bit patterns."""
-    import ctypes
-
-    import torch
-
+    """[C, C, 3, 3] fp32 weights -> the stream of hdn_conv3x3_v2_f32 (hdn_pack_conv3x3_v2_f32)."""
     from . import _lib
 
     C = weight.shape[0]
     if tuple(weight.shape) != (C, C, 3, 3):
         raise ValueError(f"pack_conv3x3_v2 takes [C, C, 3, 3] weights, got {tuple(weight.shape)}")
-    wk, ks, nt = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
-    if _lib.load().hdn_conv3x3_v2_pack_info(_MC_SIDE.get(C, 0), C, ctypes.byref(wk), ctypes.byref(ks), ctypes.byref(nt)) != 0:
-        raise ValueError(f"no large-batch matrix-core kernel for {C} channels")
-    WK, KS, NT = wk.value, ks.value, nt.value
-    pieces = _split_f16(weight.detach().to(torch.float32).cpu()).reshape(SPLIT_PIECES, C, C, 9)        # [piece, co, ci, tap]
-    # co = nb * 32 NT + nt * 32 + n;  ci = chunk * 16 KS + (j * WK + slice) * 16 + g * 8 + e
-    t = pieces.reshape(SPLIT_PIECES, C // (32 * NT), NT, 32, C // (16 * KS), KS // WK, WK, 2, 8, 9)    # [pc, nb, nt, n, ch, j, wk, g, e, tap]
-    t = t.permute(1, 4, 6, 9, 5, 2, 0, 7, 3, 8).contiguous()                                           # [nb, ch, wk, tap, j, nt, pc, g, n, e]
-    return t.view(torch.int16).reshape(-1)
+    lib, w = _lib.load(), _host_f32(weight)
+    return _c_pack("pack_conv3x3_v2", lib.hdn_pack_conv3x3_v2_bytes(C), lambda o, n: lib.hdn_pack_conv3x3_v2_f32(w.data_ptr(), C, o, n))
 
 
 V2_MIN_BATCH = 24      # below: the chained / K-sliced form of conv3x3_kernel (CHAIN_MAX_BATCH = 16 pairs and the sizes between)
 
 
-def pack_conv3x3s2_ds(weight, ds_weight):
-    """[2C, C, 3, 3] weights of the stride-2 convolution + [2C, C, 1, 1] weights of the block's downsample branch -> the 4-tap layout of
-    hdn_conv3x3s2_ds_f32: the 1x1 weights ride as a 4th tap of the middle kernel row."""
-    import torch
-
+def _s2_weights(weight, ds_weight, what):
     CO, CI = weight.shape[0], weight.shape[1]
     if tuple(weight.shape) != (2 * CI, CI, 3, 3) or tuple(ds_weight.shape) != (2 * CI, CI, 1, 1):
-        raise ValueError(f"pack_conv3x3s2_ds takes [2C, C, 3, 3] and [2C, C, 1, 1] weights, got {tuple(weight.shape)}, {tuple(ds_weight.shape)}")
-    w4 = torch.zeros(CO, CI, 3, 4, dtype=torch.float32)
-    w4[:, :, :, :3] = weight.detach().float().cpu()
-    w4[:, :, 1, 3] = ds_weight.detach().float().cpu()[:, :, 0, 0]
-    return _pack(w4, _MC_SIDE.get(CO, 0), CI, 2)
+        raise ValueError(f"{what} takes [2C, C, 3, 3] and [2C, C, 1, 1] weights, got {tuple(weight.shape)}, {tuple(ds_weight.shape)}")
+    return CI, _host_f32(weight), _host_f32(ds_weight)
+
+
+def pack_conv3x3s2_ds(weight, ds_weight):
+    """[2C, C, 3, 3] weights of the stride-2 convolution + [2C, C, 1, 1] weights of the block's downsample branch -> the stream of
+    hdn_conv3x3s2_ds_f32 (hdn_pack_conv3x3s2_ds_f32)."""
+    from . import _lib
+
+    CI, w, wd = _s2_weights(weight, ds_weight, "pack_conv3x3s2_ds")
+    lib = _lib.load()
+    return _c_pack("pack_conv3x3s2_ds", lib.hdn_pack_conv3x3s2_ds_bytes(CI), lambda o, n: lib.hdn_pack_conv3x3s2_ds_f32(w.data_ptr(), wd.data_ptr(), CI, o, n))
 
 
 def pack_conv3x3s2_ds_v2(weight, ds_weight):
-    """[2C, C, 3, 3] + [2C, C, 1, 1] fp32 weights -> the fragment-ordered stream of hdn_conv3x3s2_v2_f32 (include/hdn_hip.h):
-    [2C / 64][C / 32 chunks][2 k steps][10 steps: nine taps + the downsample branch][2 n tiles][piece][k half][n][8] fp16 bit patterns."""
-    import torch
+    """The same two weight tensors -> the stream of hdn_conv3x3s2_v2_f32 (hdn_pack_conv3x3s2_v2_f32)."""
+    from . import _lib
 
-    CO, CI = weight.shape[0], weight.shape[1]
-    if tuple(weight.shape) != (2 * CI, CI, 3, 3) or tuple(ds_weight.shape) != (2 * CI, CI, 1, 1) or CI % 32 or CO % 64:
-        raise ValueError(f"pack_conv3x3s2_ds_v2 takes [2C, C, 3, 3] and [2C, C, 1, 1] weights, got {tuple(weight.shape)}, {tuple(ds_weight.shape)}")
-    w10 = torch.zeros(CO, CI, 10, dtype=torch.float32)
-    w10[:, :, :9] = weight.detach().float().cpu().reshape(CO, CI, 9)
-    w10[:, :, 9] = ds_weight.detach().float().cpu()[:, :, 0, 0]
-    # co = nb * 64 + nt * 32 + n;  ci = chunk * 32 + wk * 16 + g * 8 + e
-    t = _split_f16(w10).reshape(SPLIT_PIECES, CO // 64, 2, 32, CI // 32, 2, 2, 8, 10)      # [pc, nb, nt, n, chunk, wk, g, e, step]
-    return t.permute(1, 4, 5, 8, 2, 0, 6, 3, 7).contiguous().view(torch.int16).reshape(-1)  # [nb, chunk, wk, step, nt, pc, g, n, e]
+    CI, w, wd = _s2_weights(weight, ds_weight, "pack_conv3x3s2_ds_v2")
+    lib = _lib.load()
+    return _c_pack("pack_conv3x3s2_ds_v2", lib.hdn_pack_conv3x3s2_v2_bytes(CI), lambda o, n: lib.hdn_pack_conv3x3s2_v2_f32(w.data_ptr(), wd.data_ptr(), CI, o, n))
 
 
 def conv3x3_bias_relu(x, wpacked, bias, residual=None, wpacked_v2=None):

@@ -33,7 +33,7 @@ extern "C" {
 /* RCCL failures are returned as -(2000 + ncclResult_t). */
 
 /* ABI version of this header; hdn_abi_version() of the loaded library must match. */
-#define HDN_ABI_VERSION 9
+#define HDN_ABI_VERSION 10
 int hdn_abi_version(void);
 
 /* Name of the kernel variant the last hdn_xcorr_* call on this thread dispatched to
@@ -338,7 +338,7 @@ int hdn_trunk_stem_f32(const float* x, const float* wT, const float* bias, float
  * The same stage on the matrix cores, for the batches that fill the chip (one workgroup per quarter image: B >= 32 at 127 px is where it pays;
  * hdn_amd.trunk.FusedStem dispatches): x [B,2,127,127] (NCHW) -> out [B,32,32,64] (channels-last in memory).  H, W: 127 only (else
  * HDN_E_LIMIT).  fp32 carried as two fp16 pieces, three piece products, fp32 accumulation: the error of an fp32 convolution.
- * wfrag: the folded conv weights in MFMA-fragment order, [7 k steps][2 n tiles][2 pieces][64 lanes = (k half g, n)][8] fp16: element j is
+ * wfrag: the stream hdn_pack_stem_mfma_f32 wrote (opaque since ABI 10).  Current order, informative: the folded conv weights in MFMA-fragment order, [7 k steps][2 n tiles][2 pieces][64 lanes = (k half g, n)][8] fp16: element j is
  * piece pc (p0 = fp16(w), p1 = fp16((w - p0) * 2048)) of w[co = 32 tile + n][ci][ky][kx = j], ci * 7 + ky = 2 * k step + g, and 0 at j = 7
  * (hdn_amd.trunk.pack_stem_mfma); 16-byte aligned, 28,672 bytes.  bias[64] as above.  Same reference lines as hdn_trunk_stem_f32.
  */
@@ -375,7 +375,7 @@ int hdn_avgpool_fc_f32(const float* x, const float* w, const float* bias, float*
  * feats [2 n_levels, hidden, pixels] (the stacked correlation outputs, cls groups first), b1 [2 n_levels, hidden], wf [2, n_out, n_levels * hidden],
  * bf [2, n_out], out [2, n_out, pixels], all fp32 contiguous; hidden = 128 or 256, n_out <= 8, n_levels <= 4 (and the staged operands must fit the LDS: HDN_E_LIMIT otherwise).  w1_packed: W1 [2 n_levels, hidden, hidden]
  * as two fp16 pieces (v = p0 + 2^-11 p1, as for hdn_conv3x3_bias_relu_f32) in MFMA fragment order
- * [group][hidden / 32 row tiles][hidden / 16 k steps][2 pieces][64 lanes][8] with lane = 32 * (k half) + row: hdn_amd.heads._pack_w1; 16-byte aligned.
+ * [group][hidden / 32 row tiles][hidden / 16 k steps][2 pieces][64 lanes][8] with lane = 32 * (k half) + row — written by hdn_pack_head_tail_f32 (opaque since ABI 10; the order is informative); 16-byte aligned.
  * The first product runs on the matrix cores with the error of an fp32 product, the second in fp32 FMAs; the sum over the levels is a fixed-order
  * register accumulation (deterministic).
  */
@@ -390,7 +390,7 @@ int hdn_head_tail_f32(const float* feats, const void* w1_packed, const float* b1
  * (nhwc = 0) or channels-last (nhwc = 1) strides; out[i]: contiguous NCHW planes (what hdn_xcorr_depthwise_multi_f32 reads); bias [n, CO]; CO a
  * multiple of 32.  w_packed: the folded weights as two fp16 pieces (v = p0 + 2^-11 p1, as for hdn_conv3x3_bias_relu_f32) in MFMA fragment order
  * [problem][CO / 32][4 chunks of 64 input channels][4 k slices of 16][9 taps][2 pieces][64 lanes][8], lane = 32 * (k half) + output channel,
- * hdn_amd.heads._pack_conv_search; 16-byte aligned.  The patch of 64 consecutive output pixels (their rows + 2, full width) must fit 224 pixels
+ * written by hdn_pack_head_conv3x3_f32 (opaque since ABI 10; the order is informative); 16-byte aligned.  The patch of 64 consecutive output pixels (their rows + 2, full width) must fit 224 pixels
  * (HDN_E_LIMIT otherwise: widths up to ~60).  Error class of an fp32 convolution; deterministic.
  */
 int hdn_head_conv3x3_f32(const float* const* xs, const void* w_packed, const float* bias, float* const* outs, int n, int CO, int Hi, int Wi, int nhwc,
@@ -410,7 +410,8 @@ int hdn_head_conv3x3_f32(const float* const* xs, const void* w_packed, const flo
  * added with the factor 2^-11; conv3x3.hip); against float64 the result has the error of an fp32 convolution.  Range (ABI 9): weights
  * |w| < 65,504 (fp16; the packer checks them), activations |x| < 65,520 x 256 = 1.67e7 — the kernels split an activation as x 2^-8 and
  * scale the sums back by 2^8 (exact), csrc/mfma_split.h; the trunk's activations are O(10).
- * wpacked: the BatchNorm-folded weights split and laid out by the host (hdn_amd.trunk.pack_conv3x3 / pack_conv3x3s2_ds) as
+ * wpacked: the stream hdn_pack_conv3x3_f32 / hdn_pack_conv3x3s2_ds_f32 wrote from the BatchNorm-folded weights (opaque since ABI 10).  Its
+ *   current order, for readers of conv3x3.hip only:
  *   [CO / BN][CI / (16 KS)][3 kernel rows][T taps][KS k steps][2 pieces][2 k halves][BN][8] fp16, input channel = chunk * 16 KS +
  *   step * 16 + half * 8 + j, (BN, KS) = hdn_conv3x3_pack_info(S, CI, stride); T = 3, or 4 for the stride-2 form, whose 4th tap holds
  *   the 1x1 weights in the middle kernel row (zeros in the other two); 16-byte aligned.
@@ -432,6 +433,37 @@ int hdn_head_conv3x3_f32(const float* const* xs, const void* w_packed, const flo
  */
 int hdn_set_check_range(int on);
 
+/*
+ * Weight packers (ABI 10; csrc/pack.hip; HOST pointers in and out, no device work).  The matrix-core entry points below and above take their
+ * weights as an opaque stream: hand the packer the fp32 weights in the reference's own order ([CO][CI][kh][kw] row major, i.e. what a
+ * state_dict holds, BatchNorm folded in by the caller), upload the bytes it wrote (16-byte aligned) and pass them as `wpacked` / `wfrag` /
+ * `w_packed` / `w1_packed`.  The ORDER inside a stream is the kernel's business and may change between library builds (the layout notes further
+ * down describe the current one for readers of the kernels, they are not part of the contract); pack and run with the same library.
+ * Every stream holds two fp16 pieces per (padded) weight, v = p0 + 2^-11 p1; a weight with |w| >= 65,504 or NaN -> HDN_E_LIMIT.
+ * hdn_pack_*_bytes: size of the stream (negative = HDN_E_SHAPE for a shape no kernel serves); the packers check `out_bytes` against it.
+ *   hdn_pack_conv3x3_f32       w [C][C][3][3]                          -> hdn_conv3x3_bias_relu_f32 / hdn_conv3x3_chain_f32, C = 64 / 128 / 256 / 512
+ *   hdn_pack_conv3x3s2_ds_f32  w [2CI][CI][3][3], w_ds [2CI][CI]       -> hdn_conv3x3s2_ds_f32 (backbone/resnet.py:78-94 conv1 and :162-169 downsample)
+ *   hdn_pack_conv3x3_v2_f32    w [C][C][3][3]                          -> hdn_conv3x3_v2_f32
+ *   hdn_pack_conv3x3s2_v2_f32  w [2CI][CI][3][3], w_ds [2CI][CI]       -> hdn_conv3x3s2_v2_f32
+ *   hdn_pack_stem_mfma_f32     w [64][2][7][7]                         -> hdn_trunk_stem_mfma_f32 (backbone/resnet.py:141-147)
+ *   hdn_pack_head_conv3x3_f32  ws[n] -> [CO][256][3][3]                -> hdn_head_conv3x3_f32 (hdn/models/head/ban.py:55-59)
+ *   hdn_pack_head_tail_f32     w1 [G][H][H]                            -> hdn_head_tail_f32 (ban.py:60-66)
+ */
+long long hdn_pack_conv3x3_bytes(int C);
+int hdn_pack_conv3x3_f32(const float* w, int C, void* out, long long out_bytes);
+long long hdn_pack_conv3x3s2_ds_bytes(int CI);
+int hdn_pack_conv3x3s2_ds_f32(const float* w, const float* w_ds, int CI, void* out, long long out_bytes);
+long long hdn_pack_conv3x3_v2_bytes(int C);
+int hdn_pack_conv3x3_v2_f32(const float* w, int C, void* out, long long out_bytes);
+long long hdn_pack_conv3x3s2_v2_bytes(int CI);
+int hdn_pack_conv3x3s2_v2_f32(const float* w, const float* w_ds, int CI, void* out, long long out_bytes);
+long long hdn_pack_stem_mfma_bytes(void);
+int hdn_pack_stem_mfma_f32(const float* w, void* out, long long out_bytes);
+long long hdn_pack_head_conv3x3_bytes(int n, int CO);
+int hdn_pack_head_conv3x3_f32(const float* const* ws, int n, int CO, void* out, long long out_bytes);
+long long hdn_pack_head_tail_bytes(int G, int H);
+int hdn_pack_head_tail_f32(const float* w1, int G, int H, void* out, long long out_bytes);
+
 int hdn_conv3x3_pack_info(int S, int CI, int stride, int* block_n, int* k_steps);
 long long hdn_conv3x3_workspace_bytes(int B, int S, int CI, int stride);
 int hdn_conv3x3_bias_relu_f32(const float* x, const void* wpacked, const float* bias, const float* residual, float* out, float* workspace,
@@ -445,8 +477,8 @@ int hdn_conv3x3s2_ds_f32(const float* x, const void* wpacked, const float* bias,
  * consumer wave owns a 64 x 64 output tile, the four consumers of a workgroup are WM pixel tiles x WK slices of K, and the weights
  * stream L2 -> registers in fragment order (they never touch the LDS).  hdn_amd.trunk uses it from B = 24 pairs on (below that the
  * chained form is faster).
- * wpacked: [C / (32 NT)][C / (16 KS)][WK k slices][9 taps x KS / WK k steps][NT n tiles][2 pieces][64 lanes = k half x 32 + n][8] fp16
- *   (hdn_amd.trunk.pack_conv3x3_v2), input channel = chunk * 16 KS + (j * WK + slice) * 16 + half * 8 + e for the j-th k step of a
+ * wpacked: the stream hdn_pack_conv3x3_v2_f32 wrote (opaque since ABI 10); current order, informative:
+ *   [C / (32 NT)][C / (16 KS)][WK k slices][9 taps x KS / WK k steps][NT n tiles][2 pieces][64 lanes = k half x 32 + n][8] fp16, input channel = chunk * 16 KS + (j * WK + slice) * 16 + half * 8 + e for the j-th k step of a
  *   slice, output channel = block * 32 NT + tile * 32 + n; (WK, KS, NT) = hdn_conv3x3_v2_pack_info(S, C); 16-byte aligned.
  * Workspace as above (K split over workgroups when the tiles do not fill the chip: S = 4 at B = 64): hdn_conv3x3_v2_workspace_bytes.
  * Replaces homo_estimator/Deep_homography/Oneline_DLTv1/backbone/resnet.py:78-94 (eval mode only).
@@ -461,9 +493,10 @@ int hdn_conv3x3_v2_f32(const float* x, const void* wpacked, const float* bias, c
  *   out = relu(conv3x3/s2/p1(x, w) + bias),  out_ds = conv1x1/s2(x, w_ds) (raw),  x [B,2S,2S,CI] -> out, out_ds [B,S,S,2 CI] (channels-last),
  * (S, CI) = (16, 64), (8, 128), (4, 256) (else HDN_E_LIMIT), no workspace.  Same arithmetic as above (two fp16 pieces, three products, hi / lo
  * fp32 accumulators; summation order: chunks of 32 input channels, inside a chunk the 9 taps, the two 16-channel k steps added last).
- * wpacked: [2 CI / 64][CI / 32][2 k steps][10 steps][2 n tiles][2 pieces][k half g][n][8] fp16 - element e of lane (g, n) = piece of
+ * wpacked: the stream hdn_pack_conv3x3s2_v2_f32 wrote (opaque since ABI 10); current order, informative:
+ * [2 CI / 64][CI / 32][2 k steps][10 steps][2 n tiles][2 pieces][k half g][n][8] fp16 - element e of lane (g, n) = piece of
  * w[co = 64 block + 32 tile + n][ci = 32 chunk + 16 k step + 8 g + e][tap t = 3 ky + kx] for step t < 9, of w_ds[co][ci] for step 9
- * (hdn_amd.trunk.pack_conv3x3s2_ds_v2); 16-byte aligned.  Replaces conv1 + bn1 + relu and downsample(x) of a BasicBlock with stride 2,
+ * ; 16-byte aligned.  Replaces conv1 + bn1 + relu and downsample(x) of a BasicBlock with stride 2,
  * backbone/resnet.py:78-94.
  */
 int hdn_conv3x3s2_v2_f32(const float* x, const void* wpacked, const float* bias, float* out, float* out_ds, int B, int S, int CI, void* stream);

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_library_loads_and_reports_abi():
     lib = _lib.load()
-    assert lib.hdn_abi_version() == _lib.ABI_VERSION == 9
+    assert lib.hdn_abi_version() == _lib.ABI_VERSION == 10
     assert lib.hdn_last_xcorr_variant() == b"none"
 
 
@@ -784,3 +784,53 @@ def test_committed_roofline_records_match_the_kernel_source():
     # no measurement block inside a production translation unit
     for f in glob.glob(os.path.join(ROOT, "hdn_amd", "csrc", "*.hip")):
         assert "defined(HDN_ABLATION)" not in open(f).read(), f
+
+
+def test_c_packers_match_the_layout_reference_bit_for_bit():
+    """csrc/pack.hip (ABI 10: the weight streams are built by the library from plain [CO][CI][kh][kw] fp32 weights) against
+    tests/reference_packers.py (the torch reshape / permute packers shipped until ABI 9) on random weights: every stream bit for bit, for every
+    shape a kernel serves.  Host code only: runs without a GPU.  Also: sizes, range check (|w| >= 65,504 / NaN -> HDN_E_LIMIT -> ValueError),
+    shapes no kernel serves."""
+    import ctypes
+    import reference_packers as R
+    from hdn_amd import _lib, heads as HD, trunk as T
+    g = torch.Generator().manual_seed(3)
+    rn = lambda *s_: torch.randn(*s_, generator=g) * 0.1
+    eq = lambda a, b: torch.equal(a.reshape(-1).cpu(), b.reshape(-1).cpu())
+    for C in (64, 128, 256, 512):
+        w = rn(C, C, 3, 3)
+        assert eq(T.pack_conv3x3(w), R.pack_conv3x3(w)), C
+        assert eq(T.pack_conv3x3_v2(w), R.pack_conv3x3_v2(w)), C
+    for CI in (64, 128, 256):
+        w, wd = rn(2 * CI, CI, 3, 3), rn(2 * CI, CI, 1, 1)
+        assert eq(T.pack_conv3x3s2_ds(w, wd), R.pack_conv3x3s2_ds(w, wd)), CI
+        assert eq(T.pack_conv3x3s2_ds_v2(w, wd), R.pack_conv3x3s2_ds_v2(w, wd)), CI
+    ws = rn(64, 2, 7, 7)
+    assert eq(T.pack_stem_mfma(ws), R.pack_stem_mfma(ws))
+    for n, CO in ((3, 512), (1, 64), (4, 256)):
+        wl = [rn(CO, 256, 3, 3) for _ in range(n)]
+        assert eq(HD._pack_conv_search(wl), R._pack_conv_search(wl)), (n, CO)
+    for G, H in ((6, 256), (2, 128), (8, 256)):
+        w1 = rn(G, H, H)
+        assert eq(HD._pack_w1(w1), R._pack_w1(w1)), (G, H)
+    # values that exercise the split: exact halves, subnormal second pieces, the largest finite fp16, negative zero
+    w = torch.zeros(64, 64, 3, 3)
+    w.view(-1)[:6] = torch.tensor([65503.9, -65000.0, 1.0009765625, 6.1e-5, 5.9e-8, -0.0])
+    assert eq(T.pack_conv3x3(w), R.pack_conv3x3(w))
+    # range / shape errors
+    for bad in (65504.0, float("nan"), -float("inf")):
+        w = rn(64, 64, 3, 3)
+        w[5, 6, 1, 2] = bad
+        with pytest.raises(ValueError, match="fp16 range"):
+            T.pack_conv3x3(w)
+    with pytest.raises(ValueError):
+        T.pack_conv3x3(rn(96, 96, 3, 3))
+    with pytest.raises(ValueError):
+        T.pack_conv3x3s2_ds(rn(128, 64, 3, 3), rn(128, 32, 1, 1))
+    lib = _lib.load()
+    assert lib.hdn_pack_conv3x3_bytes(256) == 2 * 2 * 256 * 256 * 9 and lib.hdn_pack_conv3x3_bytes(100) < 0
+    assert lib.hdn_pack_conv3x3s2_ds_bytes(64) == 2 * 2 * 128 * 64 * 12 and lib.hdn_pack_stem_mfma_bytes() == 2 * 2 * 64 * 14 * 8
+    buf = torch.empty(16, dtype=torch.int16)
+    w = rn(64, 64, 3, 3).contiguous()
+    assert lib.hdn_pack_conv3x3_f32(w.data_ptr(), 64, buf.data_ptr(), 32) != 0          # wrong size: refused, nothing written
+    assert lib.hdn_pack_conv3x3_f32(None, 64, buf.data_ptr(), lib.hdn_pack_conv3x3_bytes(64)) != 0
