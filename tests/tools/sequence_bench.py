@@ -360,6 +360,35 @@ def run_multi(ns=(1, 4, 16, 32), n_steps=60, dev=None, quiet=False, offset=3, di
 
 
 
+def run_simi(n_frames=201, dev=None):
+    """hdn_amd.simi_tracker.DeviceTrackerSimi(model) — what install(tracker=True) registers under TRACKS['hdnTracker'] — over the synthetic 1280x720
+    sequence with the production-shaped model; the host reads the result every frame."""
+    from hdn_amd.simi_tracker import DeviceTrackerSimi
+    dev = dev or torch.device("cuda:0")
+    frames, corners, init = make_sequence(n_frames=n_frames, frame_hw=(720, 1280), target_wh=(300, 200), **LONG_WALK)
+    model, _ = build_production_model(frames, init, dev)
+    out = {"tracker": "hdn_amd.simi_tracker.DeviceTrackerSimi (TRACKS['hdnTracker']): search crop, backbone, head, decode, moved crop, backbone, log-polar head, decode, "
+                      "recurrences + polygon, template refresh (rotate the first frame, crop, two backbone passes); one host read of 20 doubles per frame",
+           "frames": n_frames}
+    for graph in (True, False):
+        t = DeviceTrackerSimi(model, graph=graph)
+        t.init(frames[0], init["bbox"], init["poly"], np.array([init["first_point"]]))
+        for i in range(1, 8):
+            t.track_new(i, frames[i])
+        torch.cuda.synchronize(); s0 = t.host_syncs
+        n = n_frames if graph else min(n_frames, 81)
+        t0 = time.perf_counter()
+        for i in range(8, n):
+            r = t.track_new(i, frames[i])
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / (n - 8) * 1e3
+        assert np.isfinite(r["polygon"]).all()
+        out["ms_per_frame" + ("" if graph else "_eager")] = ms
+        if graph:
+            out["fps"], out["host_syncs_per_frame"], out["graph"] = 1e3 / ms, (t.host_syncs - s0) / (n - 8), t._graph is not None
+    return out
+
+
 def format_table(res):
     lines = [f"{res['frames']} frames, {res['ms_per_frame']:.3f} ms per frame as one hipGraph ({res['fps']:.0f} frames/s), {res['ms_per_frame_eager']:.3f} ms eager",
              f"{'stage':<100s} {'ms':>8s}  owner"]
@@ -388,9 +417,15 @@ def main():
     ap.add_argument("--production-shape", action="store_true"); ap.add_argument("--nchw", action="store_true")
     ap.add_argument("--no-components", action="store_true", help="skip the per-stage table (profiling runs)")
     ap.add_argument("--kernel-profile", action="store_true", help="torch.profiler over 20 graph frames: device time per kernel, hdn:: vs library")
+    ap.add_argument("--simi-tracker", action="store_true", help="TRACKS['hdnTracker'] (hdn_amd.simi_tracker.DeviceTrackerSimi) around the production-shaped model: "
+                    "ms per frame as one hipGraph and eagerly (4 backbone passes per frame: two searches + the template refresh's two)")
     ap.add_argument("--multi", type=str, default=None, help="comma-separated n: BatchedDeviceTracker over n sequences in lock step (production-shaped model)")
     ap.add_argument("--multi-profile", type=int, default=None, help="with --multi: torch.profiler kernel table at this n")
     args = ap.parse_args()
+    if args.simi_tracker:
+        res = run_simi(args.frames or 201)
+        print(json.dumps(res))
+        return
     if args.multi:
         res = run_multi(tuple(int(x) for x in args.multi.split(",")), n_steps=args.frames or 60, kprofile_n=args.multi_profile)
         for r in res["rows"]:
