@@ -33,6 +33,7 @@ The JSON line also carries
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -191,6 +192,29 @@ def main():
 
     north_ev = []
     full_net = full_data = None
+    # Brackets of the 31x31 launch.  Default: the launch itself carries a start / stop hipEvent (hdn_xcorr_north_launch_events -> hipExtLaunchKernelGGL):
+    # the dispatch's own timestamps, on the stream the kernel runs on, no marker packets around it.  HDN_BENCH_BRACKETS=record: a torch.cuda.Event pair
+    # recorded on the stream before / after the call (rounds 1-5; each record is a marker packet: 7.5 us per step, profiles/round6_experiments.txt section 3).
+    bracket_mode = os.environ.get("HDN_BENCH_BRACKETS", "launch")
+    if (args.north or os.environ.get("HDN_NORTH", "fft")) != "fft":
+        bracket_mode = "record"      # (the hook is the FFT kernel's launch site's)
+    hip_rt = ctypes.CDLL("libamdhip64.so") if bracket_mode == "launch" else None
+
+    class LaunchEvent:
+        """hipEvent_t with torch.cuda.Event's elapsed_time()."""
+        def __init__(self):
+            self.h = ctypes.c_void_p()
+            if hip_rt.hipEventCreate(ctypes.byref(self.h)) != 0:
+                raise RuntimeError("hipEventCreate failed")
+
+        def elapsed_time(self, other):
+            ms = ctypes.c_float()
+            rc = hip_rt.hipEventElapsedTime(ctypes.byref(ms), self.h, other.h)
+            if rc != 0:
+                raise RuntimeError(f"hipEventElapsedTime -> {rc}")
+            return ms.value
+
+    from hdn_amd import _lib as hlib
 
     def build_full():
         return build_full_head(dev, d["imgs"], d["h4p"])
@@ -236,12 +260,16 @@ def main():
         mode = "inline" if args.only_north else (mode or args.head_stream)
         if mode == "parallel":
             fork_head()
-        if record:
+        if record and bracket_mode == "launch":
+            e0, e1 = LaunchEvent(), LaunchEvent()
+            hlib.load().hdn_xcorr_north_launch_events(e0.h, e1.h)
+        elif record:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         X.xcorr_depthwise(d["north_x"], d["north_k"])
         if record:
-            e1.record()
+            if bracket_mode != "launch":
+                e1.record()
             (north_ev if sink is None else sink).append((e0, e1))
         if args.only_north:
             return
@@ -271,11 +299,16 @@ def main():
     for _ in range(args.warmup + (5 if args.workload == "full" else 0)):
         step(False)
     fence()
+    no_brackets = os.environ.get("HDN_BENCH_NO_BRACKETS") == "1"      # A/B switch (profiles/round6_experiments.txt section 3): what the event pairs cost the step
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(True)
+        step(not no_brackets)
     fence()
     elapsed = time.perf_counter() - t0
+    if no_brackets and args.workload != "full":
+        for _ in range(max(1, args.roofline_steps)):
+            step(True, collective=False)
+        torch.cuda.synchronize()
     if hasattr(comm, "check_status"):
         comm.check_status()       # one-shot gather: a peer that did not deliver within 2 s leaves NaN rows and a sticky status: fail loudly
     oneshot_used = type(comm).__name__ == "OneShotGather"   # (from_process_group hands back an RcclComm when a pair of ranks lacks peer access)
@@ -400,6 +433,8 @@ def main():
             "avg_launch_ms": north_ms,
             "min_launch_ms": float(solo.min()),
             "median_launch_ms": float(np.median(solo)),
+            "bracket": ("hipEvent pair carried by the launch itself (hipExtLaunchKernelGGL through hdn_xcorr_north_launch_events): the dispatch's start / end "
+                        "timestamps on its own stream" if bracket_mode == "launch" else "torch.cuda.Event pair recorded on the launch stream before / after the call"),
             "timing": ("in-step, %d brackets: HIP events on the launch stream around every 31x31 launch of the timed region (after-north "
                        "schedule: the head stream is forked behind that launch, it has the chip to itself); achieved / frac use the mean"
                        % len(solo)) if timed_is_clean else

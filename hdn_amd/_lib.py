@@ -61,6 +61,7 @@ SIGNATURES = {
     "hdn_head_tail_f32": (_i, [_c_float_p, ctypes.c_void_p] + [_c_float_p] * 4 + [_i] * 4 + [ctypes.c_void_p]),
     "hdn_head_conv3x3_f32": (_i, [ctypes.c_void_p, ctypes.c_void_p, _c_float_p, ctypes.c_void_p] + [_i] * 5 + [ctypes.c_void_p]),
     "hdn_set_check_range": (_i, [_i]),
+    "hdn_xcorr_north_launch_events": (_i, [ctypes.c_void_p, ctypes.c_void_p]),
     "hdn_pack_conv3x3_bytes": (ctypes.c_longlong, [_i]),
     "hdn_pack_conv3x3_f32": (_i, [_c_float_p, _i, ctypes.c_void_p, ctypes.c_longlong]),
     "hdn_pack_conv3x3s2_ds_bytes": (ctypes.c_longlong, [_i]),

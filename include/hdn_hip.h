@@ -434,6 +434,14 @@ int hdn_head_conv3x3_f32(const float* const* xs, const void* w_packed, const flo
 int hdn_set_check_range(int on);
 
 /*
+ * Measurement hook (ABI 10): the NEXT 31x31 (x) 61x61 launch the calling thread makes through hdn_xcorr_depthwise_f32 / _multi_f32 carries these two
+ * hipEvent_t (either may be NULL) as hipExtLaunchKernelGGL's start / stop events: they take the dispatch's own timestamps, so hipEventElapsedTime(start,
+ * stop) is the kernel's duration on its stream with no marker packets around it (a hipEventRecord pair costs the stream ~4 us on each side of the kernel).
+ * One-shot: cleared by the launch.  bench.py brackets the roofline kernel of every timed step this way.
+ */
+int hdn_xcorr_north_launch_events(void* start_event, void* stop_event);
+
+/*
  * Weight packers (ABI 10; csrc/pack.hip; HOST pointers in and out, no device work).  The matrix-core entry points below and above take their
  * weights as an opaque stream: hand the packer the fp32 weights in the reference's own order ([CO][CI][kh][kw] row major, i.e. what a
  * state_dict holds, BatchNorm folded in by the caller), upload the bytes it wrote (16-byte aligned) and pass them as `wpacked` / `wfrag` /
