@@ -10,4 +10,5 @@ cp gpurun_out/kernel_stats.csv profiles/${r}_kernel_stats.csv
 cp gpurun_out/prof_full/kernel_stats.csv profiles/${r}_kernel_stats_full_head.csv
 cp gpurun_out/bench_final.json profiles/${r}_bench_line.json
 cp gpurun_out/bench_cfg5.json profiles/${r}_bench_line_config5.json
+cp gpurun_out/north_trace_split.txt profiles/${r}_north_trace_split.txt
 ls -la profiles/${r}_*

@@ -9,5 +9,6 @@ python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
 python bench.py --config 5 --no-cpu-baseline > gpurun_out/bench_cfg5.json 2>/dev/null
 bash tools/prof_full_head.sh > gpurun_out/prof_full_head.log 2>&1
 find gpurun_out/prof_round -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/kernel_stats.csv
+python tools/north_trace_split.py gpurun_out/prof_round/stats > gpurun_out/north_trace_split.txt 2>&1     # in-step against back-to-back launches of the roofline kernel, from the same trace
 find gpurun_out/prof_round gpurun_out/prof_full -name "*kernel_trace.csv" -delete     # (the traces exceed what gpurun copies back)
 tail -c 400 gpurun_out/bench_final.json
