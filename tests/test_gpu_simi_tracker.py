@@ -182,3 +182,112 @@ def test_device_tracker_simi_production_shape(dev):
     print("production-shaped hdnTracker device loop vs CPU loop, polygon distance (px):", " ".join(f"{e:.1e}" for e in errs))
     assert trk._graph is not None
     assert errs[0] <= 5e-2 and max(errs) <= 0.5, errs        # (50 fp32 layers, MIOpen vs oneDNN; a decode cell off would be >= 10 px)
+
+
+class _ScriptedNet(torch.nn.Module):
+    """ModelBuilder's interface with SCRIPTED head maps: frame i's maps put the translation peak in a chosen cell with a chosen offset and make the
+    log-polar head answer a chosen (scale, rotation) — so that a test can steer the recurrences of hdnTracker.track_new into their rare branches.
+    Works on CPU tensors (the oracle's loop) and on the device alike; keeps the crops it was handed."""
+
+    def __init__(self, script, dev=None):
+        super().__init__()
+        self.anchor = torch.nn.Parameter(torch.zeros(1))
+        self.script, self.dev, self.frame, self.seen = script, dev, 0, {}
+        self.zf = self.zf_lp = None
+
+    def _t(self, a):
+        t = torch.from_numpy(np.ascontiguousarray(a, np.float32))
+        return t.to(self.dev) if self.dev is not None else t
+
+    def template(self, z):
+        self.seen["z_crop"] = z
+        self.zf = [z[:, 0:3, :7, :7].contiguous() * 0 for _ in range(3)]
+        self.zf_lp = [z[:, 3:6, :15, :15].contiguous() * 0 for _ in range(3)]
+
+    def track_new(self, x, delta=[0, 0]):
+        self.seen["x_crop"] = x
+        s = self.script[self.frame]
+        cls = np.zeros((1, 2, 25, 25), np.float32)
+        cls[0, 1] = -6.0
+        cls[0, 1].reshape(-1)[s["cell"]] = s.get("logit", 6.0)
+        loc = np.zeros((1, 2, 25, 25), np.float32)
+        loc[0, 0], loc[0, 1] = s["dx"], s["dy"]
+        return {"cls": self._t(cls), "loc_c": self._t(loc)}
+
+    def track_new_lp(self, x, delta=[0, 0]):
+        self.seen["x_crop_moved"] = x
+        s = self.script[self.frame]
+        cls = np.zeros((1, 2, 13, 13), np.float32)
+        cls[0, 1] = -6.0
+        cls[0, 1].reshape(-1)[s.get("cell_lp", 84)] = s.get("logit_lp", 6.0)
+        loc = np.zeros((1, 4, 13, 13), np.float32)
+        loc[0, 0], loc[0, 2] = s["lp_scale"], s["lp_rot"]     # sim_lp[0] = exp((px - 8 lp_scale) mag), sim_lp[2] = (py - 8 lp_rot) 2 pi / 127
+        return {"cls_lp": self._t(cls), "loc_lp": self._t(loc)}
+
+
+def test_simi_tracker_rare_branches_vs_cpu_loop(dev):
+    """The branches a well-behaved sequence never takes, forced by scripted head maps and held to the CPU restatement of hdnTracker.track_new
+    (itself pinned to the executed reference): rotation past +2 pi and below -2 pi (both wraps, hdn_tracker.py:264-269, in float32 as numpy has it),
+    the size clamps at the image (`min(width, W)`), at 10 px and at 10 * w0 / h0 (:249-250), a log-polar-gated frame, frames under
+    SCALE_SCORE_THRESH (the lost_count bookkeeping, :214-222) — and the crops the kernels cut at the window sizes those produce (search windows of
+    a few pixels and of several frame widths, all padding)."""
+    from synth_sequence import make_sequence
+    from tracker_loop_replay import crc
+    from hdn_amd.simi_tracker import SimiTracker
+    from hdn_amd.similarity import TrackerConfig
+    from oracle.tracker_oracle import SimiTrackerOracle
+    frames, corners, init = make_sequence(n_frames=3, frame_hw=(240, 320), target_wh=(80, 50), seed=11)
+    g = np.random.default_rng(4)
+    base = dict(cell=312, dx=0.3, dy=-0.2, lp_scale=0.0, lp_rot=0.0)
+    script = {}
+    n = 0
+    def add(k, **kw):
+        nonlocal n
+        for _ in range(k):
+            n += 1
+            script[n] = dict(base, **kw)
+    add(4, lp_rot=-5.0)                  # +1.98 rad per frame (py = 0 at the centre row): past +2 pi on the 4th -> wrap down
+    add(8, lp_rot=5.0)                   # -1.98 rad per frame: below -2 pi -> wrap up
+    add(3, lp_scale=-3.0)                # sim_lp[0] = exp(240 mag) = 2.2 per frame: width -> clamped at the frame's 320, height at 240
+    add(1, logit_lp=-9.0)                # log-polar gate: sim_lp = [1, 1, 0, 0]
+    add(6, lp_scale=4.0)                 # 0.35 per frame: height -> 10, width -> 10 * w0 / h0
+    add(2, logit=-3.0)                   # pscore under SCALE_SCORE_THRESH: lost_count
+    add(2, cell=0, dx=-3.0, dy=2.5)      # the corner cell: a long jump of the window (padding on two sides)
+    cpu_model, dev_model = _ScriptedNet(script), _ScriptedNet(script, dev).to(dev)
+    ref = SimiTrackerOracle(cpu_model)
+    trk = SimiTracker(dev_model, cfg=TrackerConfig())
+    fp = np.array([init["first_point"]])
+    poly = list(init["poly"][:4]) + [0.3]          # a rotated initial box: python float theta
+    ref.init(frames[0], init["bbox"], poly, fp)
+    trk.init(frames[0], init["bbox"], poly, fp)
+    seen = {"wrap_down": 0, "wrap_up": 0, "w_max": 0, "h_min": 0, "w_min": 0, "gated": 0, "lost": 0}
+    lo = 10 * init["poly"][2] / init["poly"][3]
+    prev_rot = 0.3
+    for i in range(1, n + 1):
+        cpu_model.frame = dev_model.frame = i
+        img = frames[i % len(frames)]
+        b = ref.track_new(i, img)
+        a = trk.track_new(i, img)
+        ts = trk.track_state()
+        for name, got, want in (("center_pos", ts["center_pos"], ref.center_pos), ("size", ts["size"], ref.size), ("scale", ts["scale"], float(ref.scale)),
+                                ("v", ts["v"], float(ref.v)), ("bbox", a["bbox"], b["bbox"])):
+            d = float(np.max(np.abs(np.asarray(got, np.float64) - np.asarray(want, np.float64)))) / max(1.0, float(np.max(np.abs(np.asarray(want, np.float64)))))
+            assert d <= 1e-9, (i, name, got, want)
+        assert ts["rot"] == float(ref.rot) and ts["lp_shift"][1] == float(ref.lp_shift[1]), (i, ts["rot"], float(ref.rot))
+        assert ts["rot_is_float32"] == isinstance(ref.rot, np.float32) and ts["lp_shift_is_float32"] == isinstance(ref.lp_shift[1], np.float32)
+        assert ts["lost_count"] == int(ref.lost_count) and ts["last_lost"] == bool(ref.last_lost) and ts["window_scale_factor"] == float(ref.window_scale_factor)
+        assert float(np.max(np.abs(a["polygon"] - b["polygon"]))) <= 2e-3 and float(np.max(np.abs(np.asarray(a["bbox_aligned"]) - np.asarray(b["bbox_aligned"])))) <= 4e-3, i
+        # the crops the networks were handed, at whatever window size the recurrences produced
+        for k in ("x_crop", "x_crop_moved", "z_crop"):
+            assert crc(dev_model.seen[k].cpu().numpy().astype(np.uint8)) == crc(cpu_model.seen[k].numpy().astype(np.uint8)), (i, k, float(ref.trace["s_x"]))
+        r = float(ref.rot)
+        seen["wrap_down"] += int(r < prev_rot - 3.0)
+        seen["wrap_up"] += int(r > prev_rot + 3.0)
+        prev_rot = r
+        seen["w_max"] += int(ref.size[0] == 320 and ref.size[1] == 240)
+        seen["h_min"] += int(ref.size[1] == 10)
+        seen["w_min"] += int(abs(ref.size[0] - lo) < 1e-12)
+        seen["gated"] += int(list(ref.trace["sim_lp"]) == [1, 1, 0, 0])
+        seen["lost"] += int(float(ref.window_scale_factor) == 1.5)
+    assert all(v >= 1 for v in seen.values()), seen
+    print("rare branches taken:", seen)
