@@ -215,6 +215,8 @@ def main():
             return ms.value
 
     from hdn_amd import _lib as hlib
+    fork_on_event = os.environ.get("HDN_BENCH_FORK", "event") == "event"
+    join_every_step = os.environ.get("HDN_BENCH_JOIN", "step") == "step"      # A/B switch: "fence" = the head stream is only joined by the region's synchronize
 
     def build_full():
         return build_full_head(dev, d["imgs"], d["h4p"])
@@ -245,8 +247,14 @@ def main():
             pf = SF.share_feature(warped, folded)
             G.l1_score2(feats[0, 1], pf[0, 0], feats[0, 0], 1.0 / (127 * 127))
 
-        def fork_head():
-            head_stream.wait_stream(main)
+        def fork_head(after=None):
+            # `after`: the 31x31 launch's own stop event (launch-carried brackets): the head stream waits for THAT, and the main stream gets no marker
+            # packet between the 31x31 launch and the 13x13 one (HDN_BENCH_FORK=stream: the ordinary wait_stream; A/B in profiles/round6_experiments.txt section 4)
+            if after is not None and fork_on_event:
+                if hip_rt.hipStreamWaitEvent(ctypes.c_void_p(head_stream.cuda_stream), after.h, 0) != 0:
+                    raise RuntimeError("hipStreamWaitEvent failed")
+            else:
+                head_stream.wait_stream(main)
             with torch.cuda.stream(head_stream):
                 head()
                 if world > 1 and collective:  # the head's results are gathered while the correlation stream is still busy
@@ -274,13 +282,13 @@ def main():
         if args.only_north:
             return
         if mode == "after-north":
-            fork_head()
+            fork_head(e1 if (record and bracket_mode == "launch") else None)
         # 13x13 before the write-heavy 5x5 (x) 29x29 launch: 2 % faster than the other way round (tools/experiments/exp_step_order.py)
         X.xcorr_depthwise_multi(d["circ_x"], d["circ_k"], circular=True)
         if mode == "inline":
             head()
         X.xcorr_depthwise_multi(d["prod_x"], d["prod_k"])
-        if mode != "inline":
+        if mode != "inline" and join_every_step:
             main.wait_stream(head_stream)
         elif world > 1 and collective:
             hdist.all_gather_offsets(d["off"], PAIRS * world, comm=comm)
