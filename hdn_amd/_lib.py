@@ -54,10 +54,10 @@ SIGNATURES = {
     "hdn_track_prepare_f64": (_i, [_c_float_p] * 3 + [_i, ctypes.c_void_p]),
     "hdn_track_accumulate_f64": (_i, [_c_float_p] * 6 + [_i] + [_c_float_p] * 2 + [_i, ctypes.c_void_p]),
     "hdn_trunk_stem_f32": (_i, [_c_float_p] * 4 + [_i] * 4 + [ctypes.c_void_p]),
-    "hdn_conv3x3s2_v2_f32": (_i, [_c_float_p, ctypes.c_void_p, _c_float_p, _c_float_p, _c_float_p] + [_i] * 3 + [ctypes.c_void_p]),
-    "hdn_trunk_stem_mfma_f32": (_i, [_c_float_p, ctypes.c_void_p, _c_float_p, _c_float_p] + [_i] * 3 + [ctypes.c_void_p]),
+    "hdn_conv3x3s2_v2_f32": (_i, [_c_float_p, ctypes.c_void_p, _c_float_p, _c_float_p, _c_float_p] + [_i] * 4 + [ctypes.c_void_p]),
+    "hdn_trunk_stem_mfma_f32": (_i, [_c_float_p, ctypes.c_void_p, _c_float_p, _c_float_p] + [_i] * 4 + [ctypes.c_void_p]),
     "hdn_bias_relu_f32": (_i, [_c_float_p] * 3 + [_i] * 4 + [ctypes.c_void_p]),
-    "hdn_avgpool_fc_f32": (_i, [_c_float_p] * 4 + [_i] * 5 + [ctypes.c_void_p]),
+    "hdn_avgpool_fc_f32": (_i, [_c_float_p] * 4 + [_i] * 6 + [ctypes.c_void_p]),
     "hdn_head_tail_f32": (_i, [_c_float_p, ctypes.c_void_p] + [_c_float_p] * 4 + [_i] * 4 + [ctypes.c_void_p]),
     "hdn_head_conv3x3_f32": (_i, [ctypes.c_void_p, ctypes.c_void_p, _c_float_p, ctypes.c_void_p] + [_i] * 5 + [ctypes.c_void_p]),
     "hdn_set_check_range": (_i, [_i]),
@@ -79,13 +79,13 @@ SIGNATURES = {
     "hdn_ubench_copy_f32": (_i, [_c_float_p] * 2 + [ctypes.c_longlong, ctypes.c_void_p]),
     "hdn_conv3x3_pack_info": (_i, [_i, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "hdn_conv3x3_workspace_bytes": (ctypes.c_longlong, [_i, _i, _i, _i]),
-    "hdn_conv3x3s2_ds_f32": (_i, [_c_float_p] * 6 + [ctypes.c_longlong] + [_i] * 3 + [ctypes.c_void_p]),
-    "hdn_conv3x3_bias_relu_f32": (_i, [_c_float_p] * 6 + [ctypes.c_longlong] + [_i] * 3 + [ctypes.c_void_p]),
+    "hdn_conv3x3s2_ds_f32": (_i, [_c_float_p] * 6 + [ctypes.c_longlong] + [_i] * 4 + [ctypes.c_void_p]),
+    "hdn_conv3x3_bias_relu_f32": (_i, [_c_float_p] * 6 + [ctypes.c_longlong] + [_i] * 4 + [ctypes.c_void_p]),
     "hdn_conv3x3_v2_pack_info": (_i, [_i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "hdn_conv3x3_v2_workspace_bytes": (ctypes.c_longlong, [_i, _i, _i]),
-    "hdn_conv3x3_v2_f32": (_i, [_c_float_p] * 6 + [ctypes.c_longlong] + [_i] * 3 + [ctypes.c_void_p]),
+    "hdn_conv3x3_v2_f32": (_i, [_c_float_p] * 6 + [ctypes.c_longlong] + [_i] * 4 + [ctypes.c_void_p]),
     "hdn_conv3x3_chain_slices": (_i, [_i, _i, _i, _i]),
-    "hdn_conv3x3_chain_f32": (_i, [_c_float_p, _i, _c_float_p, _c_float_p, _i, _c_float_p, ctypes.c_void_p, _c_float_p, _c_float_p] + [_i] * 4 + [ctypes.c_void_p]),
+    "hdn_conv3x3_chain_f32": (_i, [_c_float_p, _i, _c_float_p, _c_float_p, _i, _c_float_p, ctypes.c_void_p, _c_float_p, _c_float_p] + [_i] * 5 + [ctypes.c_void_p]),
     "hdn_conv3x3_finish_f32": (_i, [_c_float_p, _i, _c_float_p, _c_float_p, _i, _c_float_p] + [_i] * 3 + [ctypes.c_void_p]),
     "hdn_allgather_offsets": (_i, [_c_float_p] * 2 + [_i, ctypes.c_void_p, ctypes.c_void_p]),
     "hdn_rccl_available": (_i, []),

@@ -169,7 +169,7 @@ __device__ __forceinline__ void sum_slices(const float* p, size_t MX, int z, f4&
 // of an LDS store; the two roles meet at the one barrier per stage, and the producers run TWO stages ahead, so that a consumer can
 // read the first fragments of stage s + 1 while it still issues the MFMAs of stage s.
 // LAZY: x is a LazyIn's slices (mode 2 only: the chained form of the small-batch trunk, launch_chain).
-template <class Cf, int MODE, bool LAZY = false>
+template <class Cf, int MODE, bool LAZY = false, bool SD = false>
 __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __restrict__ x, const u32x4* __restrict__ wp, const float* __restrict__ bias,
                                                             const float* __restrict__ res, float* __restrict__ out, float* __restrict__ out2, int B,
                                                             int cps, LazyIn lz) {
@@ -258,10 +258,10 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __r
       if (item < Cf::AITEMS) {
         const int px = item / (2 * KS), sub = item % (2 * KS);   // sub = k step * 2 + k half
         unsigned q0[4], q1[4];
-        split2x2(av[q][0].x, av[q][0].y, q0[0], q1[0]);
-        split2x2(av[q][0].z, av[q][0].w, q0[1], q1[1]);
-        split2x2(av[q][1].x, av[q][1].y, q0[2], q1[2]);
-        split2x2(av[q][1].z, av[q][1].w, q0[3], q1[3]);
+        split2x2<SD>(av[q][0].x, av[q][0].y, q0[0], q1[0]);
+        split2x2<SD>(av[q][0].z, av[q][0].w, q0[1], q1[1]);
+        split2x2<SD>(av[q][1].x, av[q][1].y, q0[2], q1[2]);
+        split2x2<SD>(av[q][1].z, av[q][1].w, q0[3], q1[3]);
         unsigned char* dst = sA + ab * Cf::A_BYTES + sub * Cf::KG_BYTES + px * 16;
         *reinterpret_cast<u32x4*>(dst) = u32x4{q0[0], q0[1], q0[2], q0[3]};
         *reinterpret_cast<u32x4*>(dst + Cf::PIECE_BYTES) = u32x4{q1[0], q1[1], q1[2], q1[3]};
@@ -301,10 +301,10 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __r
         }
       }
       unsigned q0[4], q1[4];
-      split2x2(s0.x, s0.y, q0[0], q1[0]);
-      split2x2(s0.z, s0.w, q0[1], q1[1]);
-      split2x2(s1.x, s1.y, q0[2], q1[2]);
-      split2x2(s1.z, s1.w, q0[3], q1[3]);
+      split2x2<SD>(s0.x, s0.y, q0[0], q1[0]);
+      split2x2<SD>(s0.z, s0.w, q0[1], q1[1]);
+      split2x2<SD>(s1.x, s1.y, q0[2], q1[2]);
+      split2x2<SD>(s1.z, s1.w, q0[3], q1[3]);
       unsigned char* dst = sA + chunk * Cf::A_BYTES + sub * Cf::KG_BYTES + px * 16;
       *reinterpret_cast<u32x4*>(dst) = u32x4{q0[0], q0[1], q0[2], q0[3]};
       *reinterpret_cast<u32x4*>(dst + Cf::PIECE_BYTES) = u32x4{q1[0], q1[1], q1[2], q1[3]};
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __r
         constexpr int row0 = mt * 32 + mrow_to_pixel<Cf>(i0), row1 = mt * 32 + mrow_to_pixel<Cf>(i0 + 4);
         float* const q = obase + (row0 + g * (row1 - row0)) * Cf::EPI_STRIDE;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) q[nt * 32] = join(acc[mt][nt][r], accl[mt][nt][r]);
+        for (int nt = 0; nt < NT; ++nt) q[nt * 32] = join<SD>(acc[mt][nt][r], accl[mt][nt][r]);
       });
     });
   }
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_kernel(const float* __r
           constexpr int row0 = mt * 32 + mrow_to_pixel<Cf>(i0), row1 = mt * 32 + mrow_to_pixel<Cf>(i0 + 4);
           float* const q = obase + (row0 + g * (row1 - row0)) * Cf::EPI_STRIDE;
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) q[nt * 32] = join(accd[DS ? mt : 0][DS ? nt : 0][r], accdl[DS ? mt : 0][DS ? nt : 0][r]);
+          for (int nt = 0; nt < NT; ++nt) q[nt * 32] = join<SD>(accd[DS ? mt : 0][DS ? nt : 0][r], accdl[DS ? mt : 0][DS ? nt : 0][r]);
         });
       });
     }
@@ -578,7 +578,7 @@ static size_t workspace_bytes(int B) {
   return z > 1 ? (size_t)(Cf::DS ? 2 : 1) * z * B * Cf::S * Cf::S * Cf::CO * sizeof(float) : 0;
 }
 
-template <class Cf>
+template <class Cf, bool SD = false>
 static int launch(const float* x, const void* wp, const float* bias, const float* res, float* out, float* out2, float* ws, size_t ws_bytes, int B,
                   hipStream_t stream) {
   const long long M = (long long)B * Cf::S * Cf::S;
@@ -590,8 +590,8 @@ static int launch(const float* x, const void* wp, const float* bias, const float
   static PerDeviceOnce attr;
   const int dev_ = PerDeviceOnce::device();
   if (!attr.done(dev_)) {
-    for (const void* fn : {reinterpret_cast<const void*>(&conv3x3_kernel<Cf, 0>), reinterpret_cast<const void*>(&conv3x3_kernel<Cf, 1>),
-                           reinterpret_cast<const void*>(&conv3x3_kernel<Cf, 2>)}) {
+    for (const void* fn : {reinterpret_cast<const void*>(&conv3x3_kernel<Cf, 0, false, SD>), reinterpret_cast<const void*>(&conv3x3_kernel<Cf, 1, false, SD>),
+                           reinterpret_cast<const void*>(&conv3x3_kernel<Cf, 2, false, SD>)}) {
       hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS_BYTES);
       if (e != hipSuccess) return -(1000 + (int)e);
     }
@@ -600,12 +600,12 @@ static int launch(const float* x, const void* wp, const float* bias, const float
   const dim3 grid((unsigned)((M + Cf::BM - 1) / Cf::BM), Cf::NB, z), blk(2 * HDN_BLOCK);
   const u32x4* w4 = (const u32x4*)wp;
   if (z == 1) {
-    if (res) hipLaunchKernelGGL((conv3x3_kernel<Cf, 1>), grid, blk, Cf::LDS_BYTES, stream, x, w4, bias, res, out, out2, B, Cf::NCHUNK, LazyIn{});
-    else hipLaunchKernelGGL((conv3x3_kernel<Cf, 0>), grid, blk, Cf::LDS_BYTES, stream, x, w4, bias, res, out, out2, B, Cf::NCHUNK, LazyIn{});
+    if (res) hipLaunchKernelGGL((conv3x3_kernel<Cf, 1, false, SD>), grid, blk, Cf::LDS_BYTES, stream, x, w4, bias, res, out, out2, B, Cf::NCHUNK, LazyIn{});
+    else hipLaunchKernelGGL((conv3x3_kernel<Cf, 0, false, SD>), grid, blk, Cf::LDS_BYTES, stream, x, w4, bias, res, out, out2, B, Cf::NCHUNK, LazyIn{});
     return launch_status();
   }
   float* ws2 = ws + (size_t)z * M * Cf::CO;
-  hipLaunchKernelGGL((conv3x3_kernel<Cf, 2>), grid, blk, Cf::LDS_BYTES, stream, x, w4, bias, res, ws, ws2, B, Cf::NCHUNK / z, LazyIn{});
+  hipLaunchKernelGGL((conv3x3_kernel<Cf, 2, false, SD>), grid, blk, Cf::LDS_BYTES, stream, x, w4, bias, res, ws, ws2, B, Cf::NCHUNK / z, LazyIn{});
   const unsigned n4 = (unsigned)(M * Cf::CO / 4);
   const int blocks = (int)((n4 + HDN_BLOCK - 1) / HDN_BLOCK < 1024 ? (n4 + HDN_BLOCK - 1) / HDN_BLOCK : 1024);
   const f4* b4 = (const f4*)bias;
@@ -618,7 +618,7 @@ static int launch(const float* x, const void* wp, const float* bias, const float
 // The chained form (small batches): raw K-slice sums out ([z][M][CO], z = k_slices; the downsample branch to out2), whatever z is,
 // from an activation (lz.zx == 0) or from the previous convolution's slices (LazyIn).  Nothing is reduced here: the next
 // convolution of the chain does that while it stages, the last one's slices go through finish().
-template <class Cf>
+template <class Cf, bool SD = false>
 static int launch_chain(const float* x, const LazyIn& lz, const void* wp, float* out, float* out2, int B, hipStream_t stream) {
   const long long M = (long long)B * Cf::S * Cf::S;
   const int z = k_slices_chain<Cf>(B);
@@ -626,7 +626,7 @@ static int launch_chain(const float* x, const LazyIn& lz, const void* wp, float*
   static PerDeviceOnce attr;
   const int dev_ = PerDeviceOnce::device();
   if (!attr.done(dev_)) {
-    for (const void* fn : {reinterpret_cast<const void*>(&conv3x3_kernel<Cf, 2, false>), reinterpret_cast<const void*>(&conv3x3_kernel<Cf, 2, true>)}) {
+    for (const void* fn : {reinterpret_cast<const void*>(&conv3x3_kernel<Cf, 2, false, SD>), reinterpret_cast<const void*>(&conv3x3_kernel<Cf, 2, true, SD>)}) {
       hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS_BYTES);
       if (e != hipSuccess) return -(1000 + (int)e);
     }
@@ -634,8 +634,8 @@ static int launch_chain(const float* x, const LazyIn& lz, const void* wp, float*
   }
   const dim3 grid((unsigned)((M + Cf::BM - 1) / Cf::BM), Cf::NB, z), blk(2 * HDN_BLOCK);
   const u32x4* w4 = (const u32x4*)wp;
-  if (lz.zx > 0) hipLaunchKernelGGL((conv3x3_kernel<Cf, 2, true>), grid, blk, Cf::LDS_BYTES, stream, x, w4, nullptr, nullptr, out, out2, B, Cf::NCHUNK / z, lz);
-  else hipLaunchKernelGGL((conv3x3_kernel<Cf, 2, false>), grid, blk, Cf::LDS_BYTES, stream, x, w4, nullptr, nullptr, out, out2, B, Cf::NCHUNK / z, LazyIn{});
+  if (lz.zx > 0) hipLaunchKernelGGL((conv3x3_kernel<Cf, 2, true, SD>), grid, blk, Cf::LDS_BYTES, stream, x, w4, nullptr, nullptr, out, out2, B, Cf::NCHUNK / z, lz);
+  else hipLaunchKernelGGL((conv3x3_kernel<Cf, 2, false, SD>), grid, blk, Cf::LDS_BYTES, stream, x, w4, nullptr, nullptr, out, out2, B, Cf::NCHUNK / z, LazyIn{});
   return launch_status();
 }
 
@@ -701,7 +701,7 @@ struct Cfg2 {
 };
 
 // MODE 0: out = relu(conv + bias); 1: out = relu(conv + bias + res); 2: raw sums of the K slice blockIdx.z (`cps` chunks) to out[blockIdx.z][M][C]
-template <class Cf, int MODE>
+template <class Cf, int MODE, bool SD = false>
 __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_v2_kernel(const float* __restrict__ x, const u32x4* __restrict__ wp, const float* __restrict__ bias,
                                                                const float* __restrict__ res, float* __restrict__ out, int B, int cps) {
   constexpr bool RES = MODE == 1, PARTIAL = MODE == 2;
@@ -751,10 +751,10 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_v2_kernel(const float* 
         if (item < Cf::AITEMS) {
           const int px = item / (2 * KS), sub = item % (2 * KS);
           unsigned q0[4], q1[4];
-          split2x2(av[q][0].x, av[q][0].y, q0[0], q1[0]);
-          split2x2(av[q][0].z, av[q][0].w, q0[1], q1[1]);
-          split2x2(av[q][1].x, av[q][1].y, q0[2], q1[2]);
-          split2x2(av[q][1].z, av[q][1].w, q0[3], q1[3]);
+          split2x2<SD>(av[q][0].x, av[q][0].y, q0[0], q1[0]);
+          split2x2<SD>(av[q][0].z, av[q][0].w, q0[1], q1[1]);
+          split2x2<SD>(av[q][1].x, av[q][1].y, q0[2], q1[2]);
+          split2x2<SD>(av[q][1].z, av[q][1].w, q0[3], q1[3]);
           unsigned char* dst = smem + ab * Cf::A_BYTES + sub * Cf::KG_BYTES + px * 16;
           *reinterpret_cast<u32x4*>(dst) = u32x4{q0[0], q0[1], q0[2], q0[3]};
           *reinterpret_cast<u32x4*>(dst + Cf::PIECE_BYTES) = u32x4{q1[0], q1[1], q1[2], q1[3]};
@@ -945,7 +945,7 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3_v2_kernel(const float* 
         constexpr int row0 = mt * 32 + mrow_to_pixel_s1<S>(i0), row1 = mt * 32 + mrow_to_pixel_s1<S>(i0 + 4);
         float* const q = rbase + (row0 + g * (row1 - row0)) * Cf::EPI_STRIDE;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) q[nt * 32] = join(acc[mt][nt][r], accl[mt][nt][r]);
+        for (int nt = 0; nt < NT; ++nt) q[nt * 32] = join<SD>(acc[mt][nt][r], accl[mt][nt][r]);
       });
     });
     HDN_ABL_CONV3X3_14_END
@@ -965,7 +965,7 @@ static int k_slices_v2(int B) {
   return z;
 }
 
-template <class Cf>
+template <class Cf, bool SD = false>
 static int launch_v2(const float* x, const void* wp, const float* bias, const float* res, float* out, float* ws, size_t ws_bytes, int B, hipStream_t stream) {
   static_assert(Cf::NCHUNK % Cf::PER == 0, "whole periods");
   const long long M = (long long)B * Cf::S * Cf::S;
@@ -977,8 +977,8 @@ static int launch_v2(const float* x, const void* wp, const float* bias, const fl
   static PerDeviceOnce attr;
   const int dev_ = PerDeviceOnce::device();
   if (!attr.done(dev_)) {
-    for (const void* fn : {reinterpret_cast<const void*>(&conv3x3_v2_kernel<Cf, 0>), reinterpret_cast<const void*>(&conv3x3_v2_kernel<Cf, 1>),
-                           reinterpret_cast<const void*>(&conv3x3_v2_kernel<Cf, 2>)}) {
+    for (const void* fn : {reinterpret_cast<const void*>(&conv3x3_v2_kernel<Cf, 0, SD>), reinterpret_cast<const void*>(&conv3x3_v2_kernel<Cf, 1, SD>),
+                           reinterpret_cast<const void*>(&conv3x3_v2_kernel<Cf, 2, SD>)}) {
       hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS_BYTES);
       if (e != hipSuccess) return -(1000 + (int)e);
     }
@@ -989,11 +989,11 @@ static int launch_v2(const float* x, const void* wp, const float* bias, const fl
   const dim3 grid(Cf::NB, (unsigned)wgs_m, z), blk(2 * HDN_BLOCK);
   const u32x4* w4 = (const u32x4*)wp;
   if (z == 1) {
-    if (res) hipLaunchKernelGGL((conv3x3_v2_kernel<Cf, 1>), grid, blk, Cf::LDS_BYTES, stream, x, w4, bias, res, out, B, Cf::NCHUNK);
-    else hipLaunchKernelGGL((conv3x3_v2_kernel<Cf, 0>), grid, blk, Cf::LDS_BYTES, stream, x, w4, bias, res, out, B, Cf::NCHUNK);
+    if (res) hipLaunchKernelGGL((conv3x3_v2_kernel<Cf, 1, SD>), grid, blk, Cf::LDS_BYTES, stream, x, w4, bias, res, out, B, Cf::NCHUNK);
+    else hipLaunchKernelGGL((conv3x3_v2_kernel<Cf, 0, SD>), grid, blk, Cf::LDS_BYTES, stream, x, w4, bias, res, out, B, Cf::NCHUNK);
     return launch_status();
   }
-  hipLaunchKernelGGL((conv3x3_v2_kernel<Cf, 2>), grid, blk, Cf::LDS_BYTES, stream, x, w4, bias, res, ws, B, Cf::NCHUNK / z);
+  hipLaunchKernelGGL((conv3x3_v2_kernel<Cf, 2, SD>), grid, blk, Cf::LDS_BYTES, stream, x, w4, bias, res, ws, B, Cf::NCHUNK / z);
   return finish(ws, z, bias, res, res ? 1 : 0, out, M * Cf::C, Cf::C, stream);
 }
 
@@ -1059,30 +1059,34 @@ static int cv_check(const void* x, const void* w, const void* bias, const void* 
 }
 
 extern "C" int hdn_conv3x3_bias_relu_f32(const float* x, const void* wpacked, const float* bias, const float* residual, float* out, float* workspace,
-                                         long long workspace_bytes, int B, int S, int C, void* stream) {
-  if (B <= 0 || S <= 0 || C <= 0) return HDN_E_SHAPE;
+                                         long long workspace_bytes, int B, int S, int C, int act_domain, void* stream) {
+  if (B <= 0 || S <= 0 || C <= 0 || (act_domain != 0 && act_domain != 1)) return HDN_E_SHAPE;
   const int rc = cv_check(x, wpacked, bias, out, (long long)B * S * S * C);  // (out == residual is fine: each element is read before it is written, by the same lane)
   if (rc) return rc;
   if (residual && !hdn::aligned16(residual)) return HDN_E_LIMIT;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (const int rr = hdn::check_fp16_range(x, (long long)B * S * S * C, s)) return rr;
+  if (const int rr = hdn::check_fp16_range(x, (long long)B * S * S * C, s, act_domain)) return rr;
   return cv_dispatch(S, C, 1, B, [&](auto cfg) {
-    return hdn::cv::launch<decltype(cfg)>(x, wpacked, bias, residual, out, nullptr, workspace, workspace_bytes > 0 ? (size_t)workspace_bytes : 0, B, s);
+    const size_t wb = workspace_bytes > 0 ? (size_t)workspace_bytes : 0;
+    return act_domain ? hdn::cv::launch<decltype(cfg), true>(x, wpacked, bias, residual, out, nullptr, workspace, wb, B, s)
+                      : hdn::cv::launch<decltype(cfg), false>(x, wpacked, bias, residual, out, nullptr, workspace, wb, B, s);
   });
 }
 
 extern "C" int hdn_conv3x3s2_ds_f32(const float* x, const void* wpacked, const float* bias, float* out, float* out_ds, float* workspace,
-                                    long long workspace_bytes, int B, int S, int CI, void* stream) {
-  if (B <= 0 || S <= 0 || CI <= 0) return HDN_E_SHAPE;
+                                    long long workspace_bytes, int B, int S, int CI, int act_domain, void* stream) {
+  if (B <= 0 || S <= 0 || CI <= 0 || (act_domain != 0 && act_domain != 1)) return HDN_E_SHAPE;
   const int rc = cv_check(x, wpacked, bias, out, (long long)B * S * S * CI * 4);   // (the input has 2S x 2S x CI elements = the output's count x 2)
   if (rc) return rc;
   if (!out_ds) return HDN_E_NULL;
   if (out_ds == out || out_ds == x) return HDN_E_ALIAS;
   if (!hdn::aligned16(out_ds)) return HDN_E_LIMIT;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (const int rr = hdn::check_fp16_range(x, (long long)B * S * S * CI * 4, s)) return rr;
+  if (const int rr = hdn::check_fp16_range(x, (long long)B * S * S * CI * 4, s, act_domain)) return rr;
   return cv_dispatch(S, CI, 2, B, [&](auto cfg) {
-    return hdn::cv::launch<decltype(cfg)>(x, wpacked, bias, nullptr, out, out_ds, workspace, workspace_bytes > 0 ? (size_t)workspace_bytes : 0, B, s);
+    const size_t wb = workspace_bytes > 0 ? (size_t)workspace_bytes : 0;
+    return act_domain ? hdn::cv::launch<decltype(cfg), true>(x, wpacked, bias, nullptr, out, out_ds, workspace, wb, B, s)
+                      : hdn::cv::launch<decltype(cfg), false>(x, wpacked, bias, nullptr, out, out_ds, workspace, wb, B, s);
   });
 }
 
@@ -1127,15 +1131,17 @@ extern "C" long long hdn_conv3x3_v2_workspace_bytes(int B, int S, int C) {
 }
 
 extern "C" int hdn_conv3x3_v2_f32(const float* x, const void* wpacked, const float* bias, const float* residual, float* out, float* workspace,
-                                  long long workspace_bytes, int B, int S, int C, void* stream) {
-  if (B <= 0 || S <= 0 || C <= 0) return HDN_E_SHAPE;
+                                  long long workspace_bytes, int B, int S, int C, int act_domain, void* stream) {
+  if (B <= 0 || S <= 0 || C <= 0 || (act_domain != 0 && act_domain != 1)) return HDN_E_SHAPE;
   const int rc = cv_check(x, wpacked, bias, out, (long long)B * S * S * C);
   if (rc) return rc;
   if (residual && !hdn::aligned16(residual)) return HDN_E_LIMIT;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (const int rr = hdn::check_fp16_range(x, (long long)B * S * S * C, s)) return rr;
+  if (const int rr = hdn::check_fp16_range(x, (long long)B * S * S * C, s, act_domain)) return rr;
   return cv2_dispatch(S, C, [&](auto cfg) {
-    return hdn::cv::launch_v2<decltype(cfg)>(x, wpacked, bias, residual, out, workspace, workspace_bytes > 0 ? (size_t)workspace_bytes : 0, B, s);
+    const size_t wb = workspace_bytes > 0 ? (size_t)workspace_bytes : 0;
+    return act_domain ? hdn::cv::launch_v2<decltype(cfg), true>(x, wpacked, bias, residual, out, workspace, wb, B, s)
+                      : hdn::cv::launch_v2<decltype(cfg), false>(x, wpacked, bias, residual, out, workspace, wb, B, s);
   });
 }
 
@@ -1146,8 +1152,8 @@ extern "C" int hdn_conv3x3_chain_slices(int B, int S, int CI, int stride) {
 }
 
 extern "C" int hdn_conv3x3_chain_f32(const float* x, int x_slices, const float* x_bias, const float* x_res, int res_slices, float* x_out, const void* wpacked,
-                                     float* out_slices, float* out_ds_slices, int B, int S, int CI, int stride, void* stream) {
-  if (B <= 0 || S <= 0 || CI <= 0 || x_slices < 0 || res_slices < 0 || (stride != 1 && stride != 2)) return HDN_E_SHAPE;
+                                     float* out_slices, float* out_ds_slices, int B, int S, int CI, int stride, int act_domain, void* stream) {
+  if (B <= 0 || S <= 0 || CI <= 0 || x_slices < 0 || res_slices < 0 || (stride != 1 && stride != 2) || (act_domain != 0 && act_domain != 1)) return HDN_E_SHAPE;
   if (!x || !wpacked || !out_slices || (stride == 2 && !out_ds_slices)) return HDN_E_NULL;
   if (x_slices > 0 && !x_bias) return HDN_E_NULL;
   if (x_slices == 0 && (x_res || x_out)) return HDN_E_SHAPE;          // an activation needs no finishing
@@ -1161,10 +1167,11 @@ extern "C" int hdn_conv3x3_chain_f32(const float* x, int x_slices, const float* 
   // (an activation is checked; an input still in K slices is finished inside the kernel and cannot be seen from here: the guard covers
   //  the chain's first convolution and every un-chained call)
   if (x_slices == 0)
-    if (const int rr = hdn::check_fp16_range(x, n_in, s)) return rr;
+    if (const int rr = hdn::check_fp16_range(x, n_in, s, act_domain)) return rr;
   const hdn::cv::LazyIn lz{x_bias, x_res, x_out, x_slices, res_slices};
   return cv_dispatch(S, CI, stride, B, [&](auto cfg) {
-    return hdn::cv::launch_chain<decltype(cfg)>(x, lz, wpacked, out_slices, out_ds_slices, B, s);
+    return act_domain ? hdn::cv::launch_chain<decltype(cfg), true>(x, lz, wpacked, out_slices, out_ds_slices, B, s)
+                      : hdn::cv::launch_chain<decltype(cfg), false>(x, lz, wpacked, out_slices, out_ds_slices, B, s);
   });
 }
 

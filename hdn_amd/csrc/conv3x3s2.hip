@@ -69,7 +69,7 @@ struct CfgS {
   static_assert(E4 % HDN_BLOCK == 0, "epilogue items");
 };
 
-template <class Cf>
+template <class Cf, bool SD = false>
 __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3s2_v2_kernel(const float* __restrict__ x, const u32x4* __restrict__ wp, const float* __restrict__ bias,
                                                                  float* __restrict__ out, float* __restrict__ out_ds, int B) {
   constexpr int SO = Cf::SO, SI = Cf::SI, CI = Cf::CI, CO = Cf::CO, BM = Cf::BM, BN = Cf::BN, KS = Cf::KS, WK = Cf::WK, NS = Cf::NS, NT = Cf::NT, PF = Cf::PF;
@@ -121,10 +121,10 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3s2_v2_kernel(const float
       for (int q = 0; q < Cf::AITER; ++q) {
         if (tid + q * HDN_BLOCK < Cf::AITEMS) {
           unsigned q0[4], q1[4];
-          split2x2(av[set][q][0].x, av[set][q][0].y, q0[0], q1[0]);
-          split2x2(av[set][q][0].z, av[set][q][0].w, q0[1], q1[1]);
-          split2x2(av[set][q][1].x, av[set][q][1].y, q0[2], q1[2]);
-          split2x2(av[set][q][1].z, av[set][q][1].w, q0[3], q1[3]);
+          split2x2<SD>(av[set][q][0].x, av[set][q][0].y, q0[0], q1[0]);
+          split2x2<SD>(av[set][q][0].z, av[set][q][0].w, q0[1], q1[1]);
+          split2x2<SD>(av[set][q][1].x, av[set][q][1].y, q0[2], q1[2]);
+          split2x2<SD>(av[set][q][1].z, av[set][q][1].w, q0[3], q1[3]);
           unsigned char* dst = smem + ab * Cf::A_BYTES + a_dst[q];
           *reinterpret_cast<u32x4*>(dst) = u32x4{q0[0], q0[1], q0[2], q0[3]};
           *reinterpret_cast<u32x4*>(dst + Cf::PIECE_BYTES) = u32x4{q1[0], q1[1], q1[2], q1[3]};
@@ -265,27 +265,27 @@ __global__ __launch_bounds__(2 * HDN_BLOCK) void conv3x3s2_v2_kernel(const float
     float* const q = rbase + row * Cf::EPI_STRIDE;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      q[nt * 32] = join(acc[nt][r], accl[nt][r]);
-      q[Cf::RED_FLOATS + nt * 32] = join(dacc[nt][r], daccl[nt][r]);
+      q[nt * 32] = join<SD>(acc[nt][r], accl[nt][r]);
+      q[Cf::RED_FLOATS + nt * 32] = join<SD>(dacc[nt][r], daccl[nt][r]);
     }
   });
   __syncthreads();                                     // the partial sums are in LDS (the producers take them from there)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the surplus B loads at the tail)
 }
 
-template <class Cf>
+template <class Cf, bool SD = false>
 static int launch(const float* x, const void* wp, const float* bias, float* out, float* out_ds, int B, hipStream_t stream) {
   const long long M = (long long)B * Cf::SO * Cf::SO;
   static PerDeviceOnce attr;
   const int dev_ = PerDeviceOnce::device();
   if (!attr.done(dev_)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3s2_v2_kernel<Cf>), hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3s2_v2_kernel<Cf, SD>), hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS_BYTES);
     if (e != hipSuccess) return -(1000 + (int)e);
     attr.set(dev_);
   }
   if ((M + Cf::BM - 1) / Cf::BM > 65535) return HDN_E_LIMIT;      // grid.y (as launch_v2 of conv3x3.hip)
   const dim3 grid(Cf::NB, (unsigned)((M + Cf::BM - 1) / Cf::BM)), blk(2 * HDN_BLOCK);
-  hipLaunchKernelGGL((conv3x3s2_v2_kernel<Cf>), grid, blk, Cf::LDS_BYTES, stream, x, static_cast<const u32x4*>(wp), bias, out, out_ds, B);
+  hipLaunchKernelGGL((conv3x3s2_v2_kernel<Cf, SD>), grid, blk, Cf::LDS_BYTES, stream, x, static_cast<const u32x4*>(wp), bias, out, out_ds, B);
   return launch_status();
 }
 
@@ -295,8 +295,9 @@ static int launch(const float* x, const void* wp, const float* bias, float* out,
 // wpacked (hdn_amd.trunk.pack_conv3x3s2_ds_v2): [2C / 64][C / 32 chunks][2 k steps][10 steps][2 n tiles][2 pieces][k half g][n][8] fp16; element e of
 // lane (g, n) of (block nb, chunk, k step wk, step t, n tile nt) = piece of w[co = 64 nb + 32 nt + n][ci = 32 chunk + 16 wk + 8 g + e][tap t] for
 // t < 9 (t = 3 ky + kx), of the downsample branch's w_ds[co][ci] for t = 9.
-extern "C" int hdn_conv3x3s2_v2_f32(const float* x, const void* wpacked, const float* bias, float* out, float* out_ds, int B, int S, int CI, void* stream) {
-  if (B <= 0 || S <= 0 || CI <= 0) return HDN_E_SHAPE;
+extern "C" int hdn_conv3x3s2_v2_f32(const float* x, const void* wpacked, const float* bias, float* out, float* out_ds, int B, int S, int CI, int act_domain,
+                                    void* stream) {
+  if (B <= 0 || S <= 0 || CI <= 0 || (act_domain != 0 && act_domain != 1)) return HDN_E_SHAPE;
   if (!x || !wpacked || !bias || !out || !out_ds) return HDN_E_NULL;
   if (out == x || out_ds == x || out_ds == out) return HDN_E_ALIAS;
   const long long n_in = (long long)B * S * S * CI * 4;       // the input has 2S x 2S x CI elements = an output's count x 2
@@ -304,9 +305,13 @@ extern "C" int hdn_conv3x3s2_v2_f32(const float* x, const void* wpacked, const f
   for (const void* p : {(const void*)x, wpacked, (const void*)bias, (const void*)out, (const void*)out_ds})
     if (!hdn::aligned16(p)) return HDN_E_LIMIT;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (const int rr = hdn::check_fp16_range(x, n_in, s)) return rr;
-  if (S == 16 && CI == 64) return hdn::cvs::launch<hdn::cvs::CfgS<16, 64>>(x, wpacked, bias, out, out_ds, B, s);
-  if (S == 8 && CI == 128) return hdn::cvs::launch<hdn::cvs::CfgS<8, 128>>(x, wpacked, bias, out, out_ds, B, s);
-  if (S == 4 && CI == 256) return hdn::cvs::launch<hdn::cvs::CfgS<4, 256>>(x, wpacked, bias, out, out_ds, B, s);
+  if (const int rr = hdn::check_fp16_range(x, n_in, s, act_domain)) return rr;
+  auto go = [&](auto cfg) {
+    using Cf = decltype(cfg);
+    return act_domain ? hdn::cvs::launch<Cf, true>(x, wpacked, bias, out, out_ds, B, s) : hdn::cvs::launch<Cf, false>(x, wpacked, bias, out, out_ds, B, s);
+  };
+  if (S == 16 && CI == 64) return go(hdn::cvs::CfgS<16, 64>{});
+  if (S == 8 && CI == 128) return go(hdn::cvs::CfgS<8, 128>{});
+  if (S == 4 && CI == 256) return go(hdn::cvs::CfgS<4, 256>{});
   return HDN_E_LIMIT;
 }

@@ -10,6 +10,7 @@
 // Arithmetic: (y + bias) + residual, individually rounded, then max(., 0) - the order PyTorch's own kernels use
 // (conv bias first, `out += residual` second).
 #include "hdn_common.h"
+#include "mfma_split.h"
 
 #pragma clang fp contract(off)
 
@@ -69,11 +70,11 @@ static void launch_vec(float* y, const float* res, const float* bias, unsigned n
 constexpr int AF_MAX_OUT = 16, AF_THREADS = 512;
 template <bool NHWC>
 __global__ __launch_bounds__(AF_THREADS) void avgpool_fc_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                                float* __restrict__ out, int C, int HW, int O) {
+                                                                float* __restrict__ out, int C, int HW, int O, float in_unscale) {
   __shared__ float part[AF_THREADS / HDN_WAVE][AF_MAX_OUT];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & (HDN_WAVE - 1), wave = tid >> 6;
   const float* xb = x + (size_t)b * C * HW;
-  const float inv = 1.0f / (float)HW;
+  const float inv = (1.0f / (float)HW) * in_unscale;     // (in_unscale = 2^8 for activations of the scaled domain: a power of two, exact)
   float acc[AF_MAX_OUT];
 #pragma unroll
   for (int o = 0; o < AF_MAX_OUT; ++o) acc[o] = 0.f;
@@ -118,14 +119,14 @@ __global__ __launch_bounds__(AF_THREADS) void avgpool_fc_kernel(const float* __r
 
 }  // namespace hdn
 
-extern "C" int hdn_avgpool_fc_f32(const float* x, const float* w, const float* bias, float* out, int B, int C, int HW, int O, int nhwc, void* stream) {
+extern "C" int hdn_avgpool_fc_f32(const float* x, const float* w, const float* bias, float* out, int B, int C, int HW, int O, int nhwc, int in_domain, void* stream) {
   if (!x || !w || !out) return HDN_E_NULL;
   if (B <= 0 || C <= 0 || HW <= 0 || O <= 0) return HDN_E_SHAPE;
   if (O > hdn::AF_MAX_OUT || (long long)B * C * HW > 0x7fffffffLL) return HDN_E_LIMIT;
   if ((const void*)out == (const void*)x) return HDN_E_ALIAS;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (nhwc) hipLaunchKernelGGL((hdn::avgpool_fc_kernel<true>), dim3(B), dim3(hdn::AF_THREADS), 0, s, x, w, bias, out, C, HW, O);
-  else hipLaunchKernelGGL((hdn::avgpool_fc_kernel<false>), dim3(B), dim3(hdn::AF_THREADS), 0, s, x, w, bias, out, C, HW, O);
+  if (nhwc) hipLaunchKernelGGL((hdn::avgpool_fc_kernel<true>), dim3(B), dim3(hdn::AF_THREADS), 0, s, x, w, bias, out, C, HW, O, in_domain ? hdn::mc::ACT_UNSCALE : 1.0f);
+  else hipLaunchKernelGGL((hdn::avgpool_fc_kernel<false>), dim3(B), dim3(hdn::AF_THREADS), 0, s, x, w, bias, out, C, HW, O, in_domain ? hdn::mc::ACT_UNSCALE : 1.0f);
   return hdn::launch_status();
 }
 

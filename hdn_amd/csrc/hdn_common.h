@@ -35,7 +35,7 @@ struct PerDeviceOnce {
 
 // range_check.hip: HDN_OK, or HDN_E_LIMIT when an fp32 input of a two-fp16-piece kernel leaves fp16's range (HDN_CHECK_RANGE=1 /
 // hdn_set_check_range; a no-op otherwise and inside stream captures)
-int check_fp16_range(const float* x, long long n, hipStream_t stream);
+int check_fp16_range(const float* x, long long n, hipStream_t stream, int act_domain = 0);   // act_domain 1: x is already x_real * 2^-8
 
 inline int launch_status() {
   hipError_t e = hipGetLastError();

@@ -12,6 +12,9 @@
 // activation below 2^-14 x 2^8 = 0.0156 becomes an fp16 subnormal, an ABSOLUTE error of at most 2^-36 x 2^8 = 3.7e-9 per activation instead of a
 // relative 2^-23 — below the rounding of the fp32 sums these values enter.  WEIGHTS are split by the packers on the host, unscaled, and checked
 // there (|w| < 65,504 or the packer raises).  Beyond 1.67e7 the result is inf / NaN as before; HDN_CHECK_RANGE=1 (range_check.hip) reports it.
+// The multiply is paid once per TRUNK, not once per layer: the entry points take `act_domain` (0: activations in real units in and out; 1: in and out are
+// x 2^-8), hdn_amd.trunk enters the scaled domain at the first stage's output and leaves it at the pooled regressor (hdn_avgpool_fc_f32 multiplies by 2^8),
+// biases are handed over pre-scaled (exact) — inside, the kernels are the 6-operation split of ABI <= 8 with the range of ABI 9.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -49,18 +52,26 @@ __device__ __forceinline__ f32x16 mfma(const u32x4& a, const u32x4& b, const f32
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-// two fp32 values -> their two pieces, packed (low half = first value): 6 VALU operations per pair
+// two fp32 values -> their two pieces, packed (low half = first value): 7 VALU operations per pair, 6 in the scaled domain.
+// SD ("scaled domain", the fused trunk's interior): the value in memory is already x * ACT_SCALE — no multiply here, and join<true> leaves the sum scaled.
+template <bool SD = false>
 __device__ __forceinline__ void split2(f2 v, unsigned& p0, unsigned& p1) {
-  v = v * ACT_SCALE;
+  if constexpr (!SD) v = v * ACT_SCALE;
   const f16x2 h = __builtin_convertvector(v, f16x2);
   p0 = __builtin_bit_cast(unsigned, h);
   const f2 r = (v - __builtin_convertvector(h, f2)) * LO_SCALE;
   p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
 }
-__device__ __forceinline__ void split2x2(float x, float y, unsigned& p0, unsigned& p1) { split2(f2{x, y}, p0, p1); }
+template <bool SD = false>
+__device__ __forceinline__ void split2x2(float x, float y, unsigned& p0, unsigned& p1) { split2<SD>(f2{x, y}, p0, p1); }
 
 // the fp32 sum of a "hi" and a "lo" accumulator of split activations: (hi + 2^-11 lo) 2^8, one rounding (the two scalings are exact)
-__device__ __forceinline__ float join(float hi, float lo) { return hi * ACT_UNSCALE + lo * (LO_UNSCALE * ACT_UNSCALE); }
+// (SD: the result stays in the scaled domain, hi + 2^-11 lo)
+template <bool SD = false>
+__device__ __forceinline__ float join(float hi, float lo) {
+  if constexpr (SD) return hi + lo * LO_UNSCALE;
+  else return hi * ACT_UNSCALE + lo * (LO_UNSCALE * ACT_UNSCALE);
+}
 
 }  // namespace mc
 }  // namespace hdn

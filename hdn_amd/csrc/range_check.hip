@@ -37,7 +37,7 @@ bool check_range_enabled() {
 }
 
 // HDN_OK, or HDN_E_LIMIT when some |x[i]| >= 65,520 x 256 (or is NaN).  No-op when the guard is off or the stream is capturing.
-int check_fp16_range(const float* x, long long n, hipStream_t stream) {
+int check_fp16_range(const float* x, long long n, hipStream_t stream, int act_domain) {
   if (!check_range_enabled() || !x || n <= 0) return HDN_OK;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); return HDN_OK; }
@@ -52,10 +52,12 @@ int check_fp16_range(const float* x, long long n, hipStream_t stream) {
   if (e == hipSuccess) e = hipStreamSynchronize(stream);
   (void)hipFreeAsync(word, stream);
   if (e != hipSuccess) return -(1000 + (int)e);
-  if (host >= 0x4b7ff000u) {                                      // 65,520 x 2^8: x 2^-8 is then the first value v_cvt_f16_f32 (round-to-nearest-even) turns into inf
+  // 65,520 x 2^8: x 2^-8 is then the first value v_cvt_f16_f32 (round-to-nearest-even) turns into inf; in the scaled domain the stored value is the converted one
+  if (host >= (act_domain ? 0x477ff000u : 0x4b7ff000u)) {
     float v;
     memcpy(&v, &host, sizeof v);
-    fprintf(stderr, "hdn_amd: HDN_CHECK_RANGE: max |x| = %g over %lld fp32 inputs of a two-fp16-piece kernel (they need |x| < 16,773,120): HDN_E_LIMIT\n", (double)v, n);
+    fprintf(stderr, "hdn_amd: HDN_CHECK_RANGE: max |x| = %g over %lld fp32 inputs of a two-fp16-piece kernel (they need |x| < %s): HDN_E_LIMIT\n", (double)v, n,
+            act_domain ? "65,520 in the scaled domain" : "16,773,120");
     return HDN_E_LIMIT;
   }
   return HDN_OK;

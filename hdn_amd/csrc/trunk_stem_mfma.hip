@@ -55,7 +55,7 @@ struct __attribute__((packed, aligned(4))) Frag {              // 8 halves at a 
 
 __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
-template <int ROWS, int STREAMS>
+template <int ROWS, int STREAMS, bool OUT_SD = false>
 __global__ __launch_bounds__(128 * STREAMS) void trunk_stem_mfma_kernel(const float* __restrict__ x, const u32x4* __restrict__ wfrag,
                                                                         const float* __restrict__ bias, float* __restrict__ out) {
   using G = Geo<ROWS, STREAMS>;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(128 * STREAMS) void trunk_stem_mfma_kernel(const fl
 #pragma unroll
       for (int ch = 0; ch < 2; ++ch)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) carry[ch][r] = fmaxf(join(acc[2 + ch][r], accl[2 + ch][r]), 0.f);
+        for (int r = 0; r < 16; ++r) carry[ch][r] = fmaxf(join<OUT_SD>(acc[2 + ch][r], accl[2 + ch][r]), 0.f);
     } else {
       // rows 2p - 1 (carry), 2p, 2p + 1 -> vertical max; then columns 2 px - 1 .. 2 px + 1.  Lane (li, g) holds columns 32 ch + 8 j + 4 g + (0..3).
       const int p = (Rw >> 1) + t;
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(128 * STREAMS) void trunk_stem_mfma_kernel(const fl
         float v[16], tl[4];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float v0 = join(acc[ch][r], accl[ch][r]), v1 = join(acc[2 + ch][r], accl[2 + ch][r]);
+          const float v0 = join<OUT_SD>(acc[ch][r], accl[ch][r]), v1 = join<OUT_SD>(acc[2 + ch][r], accl[2 + ch][r]);
           v[r] = max3(v0, v1, carry[ch][r]);                   // (carry >= 0: the ReLU of all three)
           carry[ch][r] = fmaxf(v1, 0.f);
         }
@@ -186,18 +186,18 @@ __global__ __launch_bounds__(128 * STREAMS) void trunk_stem_mfma_kernel(const fl
   for (int t = 0; t < G::TILES; ++t) tile(std::false_type{}, t);
 }
 
-template <int ROWS, int STREAMS>
+template <int ROWS, int STREAMS, bool OUT_SD = false>
 int launch(const float* x, const void* wfrag, const float* bias, float* out, int B, hipStream_t stream) {
   using G = Geo<ROWS, STREAMS>;
   static PerDeviceOnce attr;
   const int dev_ = PerDeviceOnce::device();
   if (!attr.done(dev_)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&trunk_stem_mfma_kernel<ROWS, STREAMS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&trunk_stem_mfma_kernel<ROWS, STREAMS, OUT_SD>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        G::LDS_BYTES);
     if (e != hipSuccess) return -(1000 + (int)e);
     attr.set(dev_);
   }
-  hipLaunchKernelGGL((trunk_stem_mfma_kernel<ROWS, STREAMS>), dim3((unsigned)B * G::NBLK), dim3(G::THREADS), G::LDS_BYTES, stream, x,
+  hipLaunchKernelGGL((trunk_stem_mfma_kernel<ROWS, STREAMS, OUT_SD>), dim3((unsigned)B * G::NBLK), dim3(G::THREADS), G::LDS_BYTES, stream, x,
                      static_cast<const u32x4*>(wfrag), bias, out);
   return launch_status();
 }
@@ -207,9 +207,10 @@ int launch(const float* x, const void* wfrag, const float* bias, float* out, int
 
 // wfrag: [7 k steps][2 n tiles][2 pieces][64 lanes = k half x 32 + n][8] fp16 (hdn_amd.trunk.pack_stem_mfma): element j of lane (g, n) of k step s is
 // piece pc of w[co = tile * 32 + n][ci][ky][kx = j] with ci * 7 + ky = 2 s + g, and 0 for j = 7.
-extern "C" int hdn_trunk_stem_mfma_f32(const float* x, const void* wfrag, const float* bias, float* out, int B, int H, int W, void* stream) {
+extern "C" int hdn_trunk_stem_mfma_f32(const float* x, const void* wfrag, const float* bias, float* out, int B, int H, int W, int out_domain,
+                                       void* stream) {
   if (!x || !wfrag || !bias || !out) return HDN_E_NULL;
-  if (B <= 0) return HDN_E_SHAPE;
+  if (B <= 0 || (out_domain != 0 && out_domain != 1)) return HDN_E_SHAPE;
   if (H != hdn::stem_mc::H || W != hdn::stem_mc::W || B > (1 << 20)) return HDN_E_LIMIT;       // 127-px crops only; hdn_trunk_stem_f32 takes the rest
   if (static_cast<const void*>(out) == static_cast<const void*>(x)) return HDN_E_ALIAS;
   if (!hdn::aligned16(wfrag) || !hdn::aligned16(out)) return HDN_E_LIMIT;
@@ -222,6 +223,12 @@ extern "C" int hdn_trunk_stem_mfma_f32(const float* x, const void* wfrag, const 
   // 4 workgroups per image from 48 images on, 8 from 8 on, 16 for the tracker's few-image calls (B = 1, cold: 8.8 us against 11.7 at 8 rows, 12.0 on
   // the vector pipe): the shorter the workgroup's chain of dependent steps the better when nothing else is on the chip
   const int rows = rows_env ? rows_env : (B >= 48 ? 16 : B >= 8 ? 8 : 4);
+  // out_domain 1: the pooled output is left as relu(conv) x 2^-8 (the input is split as x 2^-8 either way; only the final multiply by 2^8 is dropped)
+  if (out_domain) {
+    if (rows == 16) return hdn::stem_mc::launch<16, 4, true>(x, wfrag, bias, out, B, st);
+    if (rows == 4) return hdn::stem_mc::launch<4, 2, true>(x, wfrag, bias, out, B, st);
+    return hdn::stem_mc::launch<8, 2, true>(x, wfrag, bias, out, B, st);
+  }
   if (rows == 16) return hdn::stem_mc::launch<16, 4>(x, wfrag, bias, out, B, st);
   if (rows == 4) return hdn::stem_mc::launch<4, 2>(x, wfrag, bias, out, B, st);
   return hdn::stem_mc::launch<8, 2>(x, wfrag, bias, out, B, st);

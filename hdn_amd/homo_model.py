@@ -16,8 +16,9 @@ from .share_feature import PreShareFeature
 from .trunk import resnet34_homo
 
 
-def avgpool_fc(x, fc):
-    """fc(avgpool(x).flatten(1)) as one launch (hdn_avgpool_fc_f32); x [B,C,H,W] float32, NCHW-contiguous or channels-last."""
+def avgpool_fc(x, fc, in_domain=0):
+    """fc(avgpool(x).flatten(1)) as one launch (hdn_avgpool_fc_f32); x [B,C,H,W] float32, NCHW-contiguous or channels-last; in_domain = 1: x is the
+    trunk's scaled-domain output (x_real * 2^-8): the pooled means are multiplied by 2^8 (exact) before the fully connected layer."""
     from . import _lib
 
     dev = _lib.require_device(x, fc.weight)
@@ -29,7 +30,7 @@ def avgpool_fc(x, fc):
     out = torch.empty((B, w.shape[0]), dtype=torch.float32, device=dev)
     with _lib.device_guard(dev):
         rc = _lib.load().hdn_avgpool_fc_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(fc.bias.detach()) if fc.bias is not None else None, _lib.ptr(out),
-                                            B, C, H * W, w.shape[0], nhwc, _lib.stream_ptr(dev))
+                                            B, C, H * W, w.shape[0], nhwc, int(in_domain), _lib.stream_ptr(dev))
     _lib.check(rc, "avgpool_fc")
     return out
 
@@ -37,10 +38,16 @@ def avgpool_fc(x, fc):
 def _regress(net, feats):
     fast = getattr(net, "_hdn_fast_trunk", None)
     if fast is not None and not net.training:
-        x = fast(feats.contiguous(memory_format=torch.channels_last) if getattr(net, "_hdn_fast_nhwc", False) else feats)
-        # the tail of the optimised trunk: AdaptiveAvgPool2d(1) + Linear(512, 8) in one launch
-        if (x.is_cuda and x.dtype == torch.float32 and isinstance(net.avgpool, nn.AdaptiveAvgPool2d) and net.avgpool.output_size in (1, (1, 1))
-                and isinstance(net.fc, nn.Linear) and net.fc.out_features <= 16 and net.fc.weight.dtype == torch.float32):
+        inp = feats.contiguous(memory_format=torch.channels_last) if getattr(net, "_hdn_fast_nhwc", False) else feats
+        # the tail of the optimised trunk: AdaptiveAvgPool2d(1) + Linear(512, 8) in one launch — which also takes the trunk's output straight from its
+        # scaled activation domain (hdn_amd.trunk.ACT_SCALE_LOG2) when the folded copy runs in it
+        tail = (feats.is_cuda and feats.dtype == torch.float32 and isinstance(net.avgpool, nn.AdaptiveAvgPool2d) and net.avgpool.output_size in (1, (1, 1))
+                and isinstance(net.fc, nn.Linear) and net.fc.out_features <= 16 and net.fc.weight.dtype == torch.float32)
+        dom = int(getattr(fast, "act_domain", 0))
+        if tail and dom and hasattr(fast, "forward_scaled"):
+            return avgpool_fc(fast.forward_scaled(inp).detach(), net.fc, in_domain=1)
+        x = fast(inp)
+        if tail:
             return avgpool_fc(x.detach(), net.fc)
     else:
         x = net.backbone(feats)

@@ -61,10 +61,23 @@ class HomoResNet(nn.Module):
         mods += [BasicBlock(planes, planes) for _ in range(1, blocks)]
         return nn.Sequential(*mods)
 
-    def forward(self, x):
+    act_domain = 0       # 1 on a folded copy whose stages all run in the scaled domain (fold_for_inference): activations are x * 2^-ACT_SCALE_LOG2 inside
+
+    def forward_scaled(self, x):
+        """The trunk's output in ITS activation domain (x 2^-8 when act_domain == 1: what hdn_avgpool_fc_f32 takes with in_domain = 1)."""
         x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         return x.finish() if isinstance(x, LazyAct) else x       # (the chained small-batch form of the folded trunk: FusedBasicBlock)
+
+    def forward(self, x):
+        x = self.forward_scaled(x)
+        return x.mul_(float(1 << ACT_SCALE_LOG2)) if self.act_domain else x      # (a fresh tensor of this forward: in place is safe; exact)
+
+
+# The matrix-core kernels split an activation as x * 2^-8 (csrc/mfma_split.h: finite and fp32-accurate to |x| < 1.67e7).  A fully fused trunk pays that
+# multiply ONCE: its first stage writes relu(conv) * 2^-8, every block runs with act_domain = 1 (activations already scaled in memory, biases handed over
+# scaled: exact), and the exit multiplies by 2^8 (hdn_avgpool_fc_f32's in_domain, or HomoResNet.forward).
+ACT_SCALE_LOG2 = 8
 
 
 def resnet34_homo():
@@ -113,8 +126,9 @@ class FusedStem(nn.Module):
     """conv1 + folded bn1 + relu + maxpool of the trunk as ONE HIP kernel (hdn_trunk_stem_f32): the 64-channel 64 x 64 conv output
     never goes through HBM.  Built from a folded conv (weight [64,2,7,7], bias [64]); eval / no-grad only; CUDA tensors only."""
 
-    def __init__(self, conv: nn.Conv2d, channels_last: bool):
+    def __init__(self, conv: nn.Conv2d, channels_last: bool, out_domain: int = 0):
         super().__init__()
+        self.out_domain = int(out_domain)        # 1: the output is relu(...) * 2^-ACT_SCALE_LOG2 (the scaled domain of a fully fused trunk)
         if tuple(conv.weight.shape) != (64, 2, 7, 7) or conv.stride != (2, 2) or conv.padding != (3, 3) or conv.bias is None:
             raise ValueError("FusedStem replaces Conv2d(2, 64, 7, 2, 3) with a folded bias")
         self.register_buffer("wT", conv.weight.detach().permute(1, 2, 3, 0).contiguous())  # [ci][ky][kx][co]
@@ -133,7 +147,8 @@ class FusedStem(nn.Module):
             import torch.nn.functional as F
 
             y = F.conv2d(x, self.wT.permute(3, 0, 1, 2), self.b, stride=2, padding=3)
-            return F.max_pool2d(F.relu(y), 3, 2, 1)
+            y = F.max_pool2d(F.relu(y), 3, 2, 1)
+            return y.mul_(2.0 ** -ACT_SCALE_LOG2) if self.out_domain else y
         dev = _lib.require_device(x, self.wT, self.b)
         if self.wfrag.device != dev:
             raise _lib.HdnHipError(f"FusedStem weights on {self.wfrag.device}, input on {dev}")
@@ -146,7 +161,7 @@ class FusedStem(nn.Module):
                           memory_format=torch.channels_last if self.channels_last else torch.contiguous_format)
         if self.channels_last and H == 127 and W == 127 and B >= STEM_MFMA_MIN_BATCH and not self.mfma_disabled:
             with _lib.device_guard(dev):
-                rc = _lib.load().hdn_trunk_stem_mfma_f32(_lib.ptr(xs), _lib.ptr(self.wfrag), _lib.ptr(self.b), _lib.ptr(out), B, H, W,
+                rc = _lib.load().hdn_trunk_stem_mfma_f32(_lib.ptr(xs), _lib.ptr(self.wfrag), _lib.ptr(self.b), _lib.ptr(out), B, H, W, self.out_domain,
                                                          _lib.stream_ptr(dev))
             _lib.check(rc, "trunk_stem_mfma")
             return out
@@ -154,7 +169,7 @@ class FusedStem(nn.Module):
             rc = _lib.load().hdn_trunk_stem_f32(_lib.ptr(xs), _lib.ptr(self.wT), _lib.ptr(self.b), _lib.ptr(out), B, H, W,
                                                 1 if self.channels_last else 0, _lib.stream_ptr(dev))
         _lib.check(rc, "trunk_stem")
-        return out
+        return out.mul_(2.0 ** -ACT_SCALE_LOG2) if self.out_domain else out
 
 
 def bias_relu_(y, bias, residual=None):
@@ -238,9 +253,10 @@ def pack_conv3x3s2_ds_v2(weight, ds_weight):
     return _c_pack("pack_conv3x3s2_ds_v2", lib.hdn_pack_conv3x3s2_v2_bytes(CI), lambda o, n: lib.hdn_pack_conv3x3s2_v2_f32(w.data_ptr(), wd.data_ptr(), CI, o, n))
 
 
-def conv3x3_bias_relu(x, wpacked, bias, residual=None, wpacked_v2=None):
+def conv3x3_bias_relu(x, wpacked, bias, residual=None, wpacked_v2=None, act_domain=0):
     """relu(conv3x3(x) + bias (+ residual)) through hdn_conv3x3_bias_relu_f32 — or, given `wpacked_v2` (pack_conv3x3_v2) and a batch of
-    V2_MIN_BATCH or more, through hdn_conv3x3_v2_f32; x / residual channels-last [B,C,S,S] float32."""
+    V2_MIN_BATCH or more, through hdn_conv3x3_v2_f32; x / residual channels-last [B,C,S,S] float32.  act_domain = 1: x, residual and the result are
+    x_real * 2^-8 in memory and `bias` is bias * 2^-8 (include/hdn_hip.h, "Activation domain")."""
     import torch
 
     from . import _lib
@@ -264,7 +280,7 @@ def conv3x3_bias_relu(x, wpacked, bias, residual=None, wpacked_v2=None):
     with _lib.device_guard(dev):
         fn = lib.hdn_conv3x3_v2_f32 if v2 else lib.hdn_conv3x3_bias_relu_f32
         rc = fn(_lib.ptr(x), _lib.ptr(wpacked_v2 if v2 else wpacked), _lib.ptr(bias), _lib.ptr(residual) if residual is not None else None,
-                _lib.ptr(out), _lib.ptr(ws) if ws is not None else None, nws, B, S, C, _lib.stream_ptr(dev))
+                _lib.ptr(out), _lib.ptr(ws) if ws is not None else None, nws, B, S, C, int(act_domain), _lib.stream_ptr(dev))
     _lib.check(rc, "conv3x3_bias_relu")
     return out
 
@@ -275,7 +291,7 @@ MATRIX_CORE_CHANNELS = (64, 128, 256, 512)
 _MC_SIDE = {64: 32, 128: 16, 256: 8, 512: 4}
 
 
-def conv3x3s2_ds(x, wpacked, bias, wpacked_v2=None):
+def conv3x3s2_ds(x, wpacked, bias, wpacked_v2=None, act_domain=0):
     """(relu(conv3x3/s2(x) + bias), conv1x1/s2(x)) through hdn_conv3x3s2_ds_f32 - or, given `wpacked_v2` (pack_conv3x3s2_ds_v2) and a batch of
     V2_MIN_BATCH or more, through hdn_conv3x3s2_v2_f32; x channels-last [B,C,2S,2S] -> two [B,2C,S,S]."""
     import torch
@@ -295,7 +311,7 @@ def conv3x3s2_ds(x, wpacked, bias, wpacked_v2=None):
         out_ds = torch.empty_like(out, memory_format=cl)
         with _lib.device_guard(dev):
             rc = _lib.load().hdn_conv3x3s2_v2_f32(_lib.ptr(x), _lib.ptr(wpacked_v2), _lib.ptr(bias), _lib.ptr(out), _lib.ptr(out_ds), B, S, CI,
-                                                  _lib.stream_ptr(dev))
+                                                  int(act_domain), _lib.stream_ptr(dev))
         _lib.check(rc, "conv3x3s2_v2")
         return out, out_ds
     if wpacked.dtype != torch.int16 or wpacked.device != dev or wpacked.numel() != SPLIT_PIECES * 3 * 4 * CI * CO or bias.numel() != CO:
@@ -309,7 +325,7 @@ def conv3x3s2_ds(x, wpacked, bias, wpacked_v2=None):
     ws = torch.empty(nws // 4, dtype=torch.float32, device=dev) if nws else None
     with _lib.device_guard(dev):
         rc = lib.hdn_conv3x3s2_ds_f32(_lib.ptr(x), _lib.ptr(wpacked), _lib.ptr(bias), _lib.ptr(out), _lib.ptr(out_ds),
-                                      _lib.ptr(ws) if ws is not None else None, nws, B, S, CI, _lib.stream_ptr(dev))
+                                      _lib.ptr(ws) if ws is not None else None, nws, B, S, CI, int(act_domain), _lib.stream_ptr(dev))
     _lib.check(rc, "conv3x3s2_ds")
     return out, out_ds
 
@@ -370,7 +386,7 @@ class LazyAct:
         return out
 
 
-def chain_conv(x, wpacked, stride=1, want_x=False):
+def chain_conv(x, wpacked, stride=1, want_x=False, act_domain=0):
     """One convolution of the chained trunk (hdn_conv3x3_chain_f32): x a channels-last activation [B,CI,SI,SI] or a LazyAct; returns
     (slices [z,B,S,S,CO], downsample slices or None (stride 2), the finished input as an activation or None (want_x, LazyAct input))."""
     import torch
@@ -398,7 +414,7 @@ def chain_conv(x, wpacked, stride=1, want_x=False):
     with _lib.device_guard(dev):
         rc = lib.hdn_conv3x3_chain_f32(_lib.ptr(src), src.shape[0] if lazy else 0, _lib.ptr(x.bias) if lazy else None, rp, rz,
                                        _lib.ptr(x_out) if x_out is not None else None, _lib.ptr(wpacked), _lib.ptr(out),
-                                       _lib.ptr(out_ds) if out_ds is not None else None, B, S, CI, stride, _lib.stream_ptr(dev))
+                                       _lib.ptr(out_ds) if out_ds is not None else None, B, S, CI, stride, int(act_domain), _lib.stream_ptr(dev))
     _lib.check(rc, "conv3x3_chain")
     return out, out_ds, x_out
 
@@ -410,9 +426,11 @@ class FusedBasicBlock(nn.Module):
     `relu(y + b2 + residual)` as one HIP pass each (hdn_bias_relu_f32).  A folded downsample branch contributes its bias to b2 and
     its raw convolution as the residual.  GPU / eval only."""
 
-    def __init__(self, blk: "BasicBlock", matrix_core: bool = False):
+    def __init__(self, blk: "BasicBlock", matrix_core: bool = False, act_domain: int = 0):
         super().__init__()
         import torch
+
+        self.act_domain = int(act_domain)     # 1: input, output and residuals are x * 2^-ACT_SCALE_LOG2 in memory (a fully fused trunk's interior)
 
         for c in (blk.conv1, blk.conv2) + ((blk.downsample,) if blk.downsample is not None else ()):
             if not isinstance(c, nn.Conv2d) or c.bias is None:
@@ -429,6 +447,9 @@ class FusedBasicBlock(nn.Module):
         else:
             self.wd = None
         self.register_buffer("b2", b2)
+        if self.act_domain:      # the biases of the scaled domain (exact: a power of two); b1 / b2 stay the real ones
+            self.register_buffer("b1d", self.b1 * 2.0 ** -ACT_SCALE_LOG2, persistent=False)
+            self.register_buffer("b2d", self.b2 * 2.0 ** -ACT_SCALE_LOG2, persistent=False)
         # packed split-fp16 weights for the matrix-core kernel (stride 1, C -> C only)
         dev = self.w1.device
         cin, cout = self.w1.shape[1], self.w1.shape[0]
@@ -465,20 +486,22 @@ class FusedBasicBlock(nn.Module):
         chained = self._chained(x)
         if chained is not None:
             return chained
+        dom = self.act_domain
+        b1, b2 = (self.b1d, self.b2d) if dom else (self.b1, self.b2)
         if isinstance(x, LazyAct):
             x = x.finish()
         if (self.p1s2 is not None and x.is_contiguous(memory_format=torch.channels_last)
                 and x.shape[2] == x.shape[3] == 2 * _MC_SIDE.get(2 * x.shape[1], -1)):
-            y, idt = conv3x3s2_ds(x, self.p1s2, self.b1, wpacked_v2=self._packed_v2("s2", x.shape[0]))   # stride-2 convolution + the downsample branch from one staged input
+            y, idt = conv3x3s2_ds(x, self.p1s2, b1, wpacked_v2=self._packed_v2("s2", x.shape[0]), act_domain=dom)   # stride-2 convolution + the downsample branch from one staged input
         else:
             if self.p1 is not None and shape_ok(x):
-                y = conv3x3_bias_relu(x, self.p1, self.b1, wpacked_v2=self._packed_v2(1, x.shape[0]))
+                y = conv3x3_bias_relu(x, self.p1, b1, wpacked_v2=self._packed_v2(1, x.shape[0]), act_domain=dom)
             else:
-                y = bias_relu_(F.conv2d(x, self.w1, None, self.stride, 1), self.b1)
+                y = bias_relu_(F.conv2d(x, self.w1, None, self.stride, 1), b1)       # (linear + ReLU: the same in either domain, with the domain's bias)
             idt = x if self.wd is None else F.conv2d(x, self.wd, None, self.ds_stride)
         if self.p2 is not None and shape_ok(y) and idt.is_contiguous(memory_format=torch.channels_last):
-            return conv3x3_bias_relu(y, self.p2, self.b2, idt, wpacked_v2=self._packed_v2(2, y.shape[0]))
-        return bias_relu_(F.conv2d(y, self.w2, None, 1, 1), self.b2, idt)
+            return conv3x3_bias_relu(y, self.p2, b2, idt, wpacked_v2=self._packed_v2(2, y.shape[0]), act_domain=dom)
+        return bias_relu_(F.conv2d(y, self.w2, None, 1, 1), b2, idt)
 
     chain_disabled = False     # A/B switch for every block at once (tests, tools/experiments)
 
@@ -493,14 +516,16 @@ class FusedBasicBlock(nn.Module):
         B, C, S, S2 = x.shape
         if not lazy and not (x.is_cuda and x.dtype == torch.float32 and B <= CHAIN_MAX_BATCH and x.is_contiguous(memory_format=torch.channels_last)):
             return None
+        dom = self.act_domain
+        b1, b2 = (self.b1d, self.b2d) if dom else (self.b1, self.b2)
         if self.p1s2 is not None and S == S2 == 2 * _MC_SIDE.get(2 * C, -1):
-            s1, sd, _ = chain_conv(x, self.p1s2, 2)
-            s2, _, _ = chain_conv(LazyAct(s1, self.b1), self.p2)
-            return LazyAct(s2, self.b2, sd)
+            s1, sd, _ = chain_conv(x, self.p1s2, 2, act_domain=dom)
+            s2, _, _ = chain_conv(LazyAct(s1, b1), self.p2, act_domain=dom)
+            return LazyAct(s2, b2, sd)
         if self.p1 is not None and self.wd is None and S == S2 == _MC_SIDE.get(C, -1):
-            s1, _, idt = chain_conv(x, self.p1, 1, want_x=True)
-            s2, _, _ = chain_conv(LazyAct(s1, self.b1), self.p2)
-            return LazyAct(s2, self.b2, idt if lazy else x)
+            s1, _, idt = chain_conv(x, self.p1, 1, want_x=True, act_domain=dom)
+            s2, _, _ = chain_conv(LazyAct(s1, b1), self.p2, act_domain=dom)
+            return LazyAct(s2, b2, idt if lazy else x)
         return None
 
 
@@ -540,14 +565,17 @@ def fold_for_inference(net: HomoResNet, channels_last: bool = True, fused_stem: 
     if channels_last:
         import torch as _t
         net = net.to(memory_format=_t.channels_last)
+    mc = bool(channels_last) if matrix_core is None else bool(matrix_core)
+    # every stage fused and on the matrix cores: the interior runs in the scaled activation domain (ACT_SCALE_LOG2 above)
+    dom = 1 if (fused_epilogue and fused_stem and mc and channels_last and os.environ.get("HDN_TRUNK_SCALED_DOMAIN", "1") not in ("", "0")) else 0
     if fused_epilogue:
         for name in ("layer1", "layer2", "layer3", "layer4"):
-            setattr(net, name, nn.Sequential(*[FusedBasicBlock(blk, bool(channels_last) if matrix_core is None else bool(matrix_core))
-                                               for blk in getattr(net, name)]))
+            setattr(net, name, nn.Sequential(*[FusedBasicBlock(blk, mc, act_domain=dom) for blk in getattr(net, name)]))
         if channels_last:
             import torch as _t
             net = net.to(memory_format=_t.channels_last)
     if fused_stem:  # conv1 (+ folded bn1) + relu + maxpool in one HIP kernel; the stages behind it stay on MIOpen
-        net.conv1 = FusedStem(net.conv1, channels_last)
+        net.conv1 = FusedStem(net.conv1, channels_last, out_domain=dom)
         net.relu, net.maxpool = nn.Identity(), nn.Identity()
+    net.act_domain = dom
     return net

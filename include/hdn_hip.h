@@ -342,7 +342,7 @@ int hdn_trunk_stem_f32(const float* x, const float* wT, const float* bias, float
  * piece pc (p0 = fp16(w), p1 = fp16((w - p0) * 2048)) of w[co = 32 tile + n][ci][ky][kx = j], ci * 7 + ky = 2 * k step + g, and 0 at j = 7
  * (hdn_amd.trunk.pack_stem_mfma); 16-byte aligned, 28,672 bytes.  bias[64] as above.  Same reference lines as hdn_trunk_stem_f32.
  */
-int hdn_trunk_stem_mfma_f32(const float* x, const void* wfrag, const float* bias, float* out, int B, int H, int W, void* stream);
+int hdn_trunk_stem_mfma_f32(const float* x, const void* wfrag, const float* bias, float* out, int B, int H, int W, int out_domain, void* stream);
 
 /*
  * Residual-block epilogues of the same trunk, in place:
@@ -363,7 +363,7 @@ int hdn_bias_relu_f32(float* y, const float* bias, const float* residual, int B,
  * fp32, W [O,C] row-major, bias [O] or NULL, O <= 16.  The mean is the fp32 sum in position order times 1 / HW (ATen's reduction
  * may associate differently: last-bit differences).
  */
-int hdn_avgpool_fc_f32(const float* x, const float* w, const float* bias, float* out, int B, int C, int HW, int O, int nhwc, void* stream);
+int hdn_avgpool_fc_f32(const float* x, const float* w, const float* bias, float* out, int B, int C, int HW, int O, int nhwc, int in_domain, void* stream);
 
 /*
  * Everything of a MultiBAN / MultiCircBAN forward behind the correlations, at the tracker's B = 1, as one launch:
@@ -423,6 +423,13 @@ int hdn_head_conv3x3_f32(const float* const* xs, const void* w_packed, const flo
  * (eval mode only).
  */
 /*
+ * Activation domain (ABI 10).  `act_domain` of the trunk's convolution entry points: 0 = activations (x, residual, out, out_ds, slices) are in real units, the
+ * kernels split them as x 2^-8 and scale the sums back (one packed multiply per staged pair: +3.8 % on the full head); 1 = they are ALREADY x_real 2^-8 in
+ * memory, in and out — no multiply anywhere, `bias` must be handed over as bias 2^-8 (exact).  hdn_amd.trunk runs the whole fused trunk in domain 1: it is
+ * entered at hdn_trunk_stem_mfma_f32 (`out_domain` = 1: real input, scaled output) and left at hdn_avgpool_fc_f32 (`in_domain` = 1: multiplies the pooled
+ * means by 2^8), so the multiply is paid once per trunk and the range of ABI 9 (|x_real| < 1.67e7) holds at the speed of ABI 8.  ReLU, max-pool, residual
+ * addition and hdn_bias_relu_f32 / hdn_conv3x3_finish_f32 are the same in either domain (they are positively homogeneous / linear with the scaled bias).
+ *
  * Range guard of the two-fp16-piece kernels (ABI 6): hdn_conv3x3_bias_relu_f32, hdn_conv3x3s2_ds_f32, hdn_conv3x3_v2_f32,
  * hdn_conv3x3_chain_f32 (activation inputs), hdn_trunk_stem_mfma_f32, hdn_head_conv3x3_f32 and hdn_head_tail_f32 are finite and fp32-accurate
  * for |x| < 1.67e7 on their fp32 INPUTS by default (since ABI 9; 65,504 before).  Beyond that the first fp16 piece is inf and the result NaN,
@@ -475,9 +482,9 @@ int hdn_pack_head_tail_f32(const float* w1, int G, int H, void* out, long long o
 int hdn_conv3x3_pack_info(int S, int CI, int stride, int* block_n, int* k_steps);
 long long hdn_conv3x3_workspace_bytes(int B, int S, int CI, int stride);
 int hdn_conv3x3_bias_relu_f32(const float* x, const void* wpacked, const float* bias, const float* residual, float* out, float* workspace,
-                              long long workspace_bytes, int B, int S, int C, void* stream);
+                              long long workspace_bytes, int B, int S, int C, int act_domain, void* stream);
 int hdn_conv3x3s2_ds_f32(const float* x, const void* wpacked, const float* bias, float* out, float* out_ds, float* workspace,
-                         long long workspace_bytes, int B, int S, int CI, void* stream);
+                         long long workspace_bytes, int B, int S, int CI, int act_domain, void* stream);
 
 /*
  * The stride-1 convolutions above in the form for batches that fill the chip (ABI 6; conv3x3.hip, conv3x3_v2_kernel): same arithmetic (two
@@ -494,7 +501,7 @@ int hdn_conv3x3s2_ds_f32(const float* x, const void* wpacked, const float* bias,
 int hdn_conv3x3_v2_pack_info(int S, int C, int* k_slices, int* k_steps, int* n_tiles);
 long long hdn_conv3x3_v2_workspace_bytes(int B, int S, int C);
 int hdn_conv3x3_v2_f32(const float* x, const void* wpacked, const float* bias, const float* residual, float* out, float* workspace,
-                       long long workspace_bytes, int B, int S, int C, void* stream);
+                       long long workspace_bytes, int B, int S, int C, int act_domain, void* stream);
 
 /*
  * hdn_conv3x3s2_ds_f32's large-batch form (round 5, conv3x3s2.hip; hdn_amd.trunk dispatches from B = 24): the same two outputs,
@@ -507,7 +514,7 @@ int hdn_conv3x3_v2_f32(const float* x, const void* wpacked, const float* bias, c
  * ; 16-byte aligned.  Replaces conv1 + bn1 + relu and downsample(x) of a BasicBlock with stride 2,
  * backbone/resnet.py:78-94.
  */
-int hdn_conv3x3s2_v2_f32(const float* x, const void* wpacked, const float* bias, float* out, float* out_ds, int B, int S, int CI, void* stream);
+int hdn_conv3x3s2_v2_f32(const float* x, const void* wpacked, const float* bias, float* out, float* out_ds, int B, int S, int CI, int act_domain, void* stream);
 
 /*
  * The same convolutions chained (ABI 5, the tracker's B = 1, where every launch is a dependent step of ~5 us and the launches that only
@@ -528,7 +535,7 @@ int hdn_conv3x3s2_v2_f32(const float* x, const void* wpacked, const float* bias,
  */
 int hdn_conv3x3_chain_slices(int B, int S, int CI, int stride);
 int hdn_conv3x3_chain_f32(const float* x, int x_slices, const float* x_bias, const float* x_res, int res_slices, float* x_out, const void* wpacked,
-                          float* out_slices, float* out_ds_slices, int B, int S, int CI, int stride, void* stream);
+                          float* out_slices, float* out_ds_slices, int B, int S, int CI, int stride, int act_domain, void* stream);
 int hdn_conv3x3_finish_f32(const float* slices, int n_slices, const float* bias, const float* res, int res_slices, float* out, int B, int S, int C,
                            void* stream);
 

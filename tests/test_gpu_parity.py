@@ -1313,10 +1313,10 @@ def test_conv3x3_chain_vs_unchained_and_float64(dev, C, S, B):
     for got, truth in ((y1c, t1), (y2c, t2), (y2, t2)):
         assert float((got.cpu().double() - truth).abs().max()) <= 2e-5 * float(truth.abs().max())
     one = ctypes.c_void_p(64)
-    assert lib.hdn_conv3x3_chain_f32(one, 0, None, None, 0, None, one, None, None, 1, S, C, 1, None) == -1          # no output
-    assert lib.hdn_conv3x3_chain_f32(one, 2, None, None, 0, None, one, ctypes.c_void_p(128), None, 1, S, C, 1, None) == -1   # slices without their bias
-    assert lib.hdn_conv3x3_chain_f32(one, 0, None, one, 1, None, one, ctypes.c_void_p(128), None, 1, S, C, 1, None) == -2    # an activation with a residual
-    assert lib.hdn_conv3x3_chain_f32(one, 0, None, None, 0, None, one, one, None, 1, S, C, 1, None) == -4                   # in place
+    assert lib.hdn_conv3x3_chain_f32(one, 0, None, None, 0, None, one, None, None, 1, S, C, 1, 0, None) == -1          # no output
+    assert lib.hdn_conv3x3_chain_f32(one, 2, None, None, 0, None, one, ctypes.c_void_p(128), None, 1, S, C, 1, 0, None) == -1   # slices without their bias
+    assert lib.hdn_conv3x3_chain_f32(one, 0, None, one, 1, None, one, ctypes.c_void_p(128), None, 1, S, C, 1, 0, None) == -2    # an activation with a residual
+    assert lib.hdn_conv3x3_chain_f32(one, 0, None, None, 0, None, one, one, None, 1, S, C, 1, 0, None) == -4                   # in place
     assert lib.hdn_conv3x3_finish_f32(one, 0, one, None, 0, ctypes.c_void_p(128), 1, S, C, None) == -2
 
 
@@ -1362,6 +1362,52 @@ def test_conv3x3_chain_downsample_block(dev, CI, S, B):
     yt = torch.relu(F.conv2d(at, w1.double(), b1.double(), stride=2, padding=1))
     tt = torch.relu(F.conv2d(yt, w2.double(), b2.double(), padding=1) + F.conv2d(at, wd.double(), None, stride=2))
     assert float((outc.cpu().double() - tt).abs().max()) <= 2e-5 * float(tt.abs().max())
+
+
+def test_trunk_scaled_activation_domain_is_exact(dev, monkeypatch):
+    """A fully fused trunk runs its interior in the scaled activation domain (hdn_amd.trunk.ACT_SCALE_LOG2: the first stage writes relu(conv) * 2^-8,
+    every block takes and gives x * 2^-8 with biases * 2^-8, the exit multiplies by 2^8), so that the 2^-8 multiply of the fp16 split is paid once per
+    trunk instead of once per layer.  All of those scalings are powers of two, so the result must be BIT-IDENTICAL to the same trunk with every kernel in
+    real units (HDN_TRUNK_SCALED_DOMAIN=0: act_domain = 0 everywhere) — at the chained batch sizes, the single-launch ones and the large-batch form, on
+    ordinary inputs and on inputs of 7e4 (beyond fp16, inside the format's 1.67e7), through forward() and through the fused avgpool + fc tail."""
+    import hdn_amd
+    from hdn_amd import trunk as T
+    from hdn_amd.homo_model import _regress
+    torch.manual_seed(9)
+    net = hdn_amd.HomoModelBuilder().to(dev).eval()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.uniform_(-0.2, 0.2)
+            m.running_var.uniform_(0.8, 1.2)
+    folds = {}
+    for dom in ("1", "0"):
+        monkeypatch.setenv("HDN_TRUNK_SCALED_DOMAIN", dom)
+        folds[dom] = T.fold_for_inference(net.backbone, channels_last=True, fused_stem=True, fused_epilogue=True)
+    a, b = folds["1"], folds["0"]
+    assert a.act_domain == 1 and b.act_domain == 0 and a.conv1.out_domain == 1 and all(m.act_domain == 1 for m in a.modules() if isinstance(m, T.FusedBasicBlock))
+    g = torch.Generator().manual_seed(2)
+    with torch.no_grad():
+        for B, big in ((1, 0.0), (3, 0.0), (T.CHAIN_MAX_BATCH + 2, 0.0), (T.V2_MIN_BATCH + 1, 0.0), (2, 7.0e4), (T.V2_MIN_BATCH, -7.0e4)):
+            x = torch.randn(B, 2, 127, 127, generator=g)
+            if big:
+                x[B - 1, 1, 64, 70] = big
+            x = x.to(dev)
+            ya, yb = a(x), b(x)
+            assert torch.isfinite(ya).all() and torch.equal(ya, yb), (B, big, float((ya - yb).abs().max()))
+            sa = a.forward_scaled(x)
+            assert torch.equal(sa * 256.0, yb)                                   # the interior really is x 2^-8
+            # the first stage alone, and the regressor through the fused tail (hdn_avgpool_fc_f32 with in_domain = 1)
+            assert torch.equal(a.conv1(x) * 256.0, b.conv1(x))
+            outs = []
+            for f in (a, b):
+                object.__setattr__(net, "_hdn_fast_trunk", f)
+                object.__setattr__(net, "_hdn_fast_nhwc", False)
+                outs.append(_regress(net, x))
+            assert outs[0].shape == (B, 8) and torch.equal(outs[0], outs[1])
+            if not big:
+                ref = net.fc(net.avgpool(net.backbone(x)).flatten(1))
+                assert float((outs[0] - ref).abs().max()) <= 2e-4 * max(1.0, float(ref.abs().max()))
+    object.__setattr__(net, "_hdn_fast_trunk", None)
 
 
 def test_chained_trunk_equals_unchained(dev):

@@ -67,37 +67,37 @@ def test_c_abi_argument_errors_need_no_gpu():
     assert lib.hdn_rccl_unique_id(None) == -1 and lib.hdn_rccl_available() in (0, 1)
     assert lib.hdn_bias_relu_f32(one, None, None, 1, 4, 4, 1, None) == -1 and lib.hdn_bias_relu_f32(one, one, None, 1, 0, 4, 1, None) == -2
     assert lib.hdn_bias_relu_f32(one, one, one, 1, 4, 4, 1, None) == -4 and lib.hdn_bias_relu_f32(one, one, None, 65536, 512, 4096, 1, None) == -3
-    assert lib.hdn_trunk_stem_mfma_f32(one, None, one, one, 8, 127, 127, None) == -1 and lib.hdn_trunk_stem_mfma_f32(one, one, one, ctypes.c_void_p(32), 0, 127, 127, None) == -2
-    assert lib.hdn_trunk_stem_mfma_f32(one, one, one, ctypes.c_void_p(32), 8, 126, 127, None) == -3 and lib.hdn_trunk_stem_mfma_f32(one, one, one, one, 8, 127, 127, None) == -4
-    assert lib.hdn_conv3x3s2_v2_f32(one, one, one, ctypes.c_void_p(32), None, 24, 16, 64, None) == -1
-    assert lib.hdn_conv3x3s2_v2_f32(one, one, one, ctypes.c_void_p(32), ctypes.c_void_p(48), 0, 16, 64, None) == -2
-    assert lib.hdn_conv3x3s2_v2_f32(one, one, one, ctypes.c_void_p(32), ctypes.c_void_p(32), 24, 16, 64, None) == -4   # the two outputs alias
-    assert lib.hdn_conv3x3s2_v2_f32(one, one, one, ctypes.c_void_p(32), ctypes.c_void_p(48), 24, 16, 128, None) == -3  # not one of the trunk's stages
-    assert lib.hdn_conv3x3_bias_relu_f32(one, one, one, None, None, None, 0, 1, 32, 64, None) == -1
-    assert lib.hdn_conv3x3_bias_relu_f32(one, one, one, None, ctypes.c_void_p(32), None, 0, 1, 30, 64, None) == -3      # unsupported (S, C)
-    assert lib.hdn_conv3x3_bias_relu_f32(one, one, one, None, ctypes.c_void_p(32), None, 0, 1, 32, 64, None) == -1      # needs a workspace at B = 1
+    assert lib.hdn_trunk_stem_mfma_f32(one, None, one, one, 8, 127, 127, 0, None) == -1 and lib.hdn_trunk_stem_mfma_f32(one, one, one, ctypes.c_void_p(32), 0, 127, 127, 0, None) == -2
+    assert lib.hdn_trunk_stem_mfma_f32(one, one, one, ctypes.c_void_p(32), 8, 126, 127, 0, None) == -3 and lib.hdn_trunk_stem_mfma_f32(one, one, one, one, 8, 127, 127, 0, None) == -4
+    assert lib.hdn_conv3x3s2_v2_f32(one, one, one, ctypes.c_void_p(32), None, 24, 16, 64, 0, None) == -1
+    assert lib.hdn_conv3x3s2_v2_f32(one, one, one, ctypes.c_void_p(32), ctypes.c_void_p(48), 0, 16, 64, 0, None) == -2
+    assert lib.hdn_conv3x3s2_v2_f32(one, one, one, ctypes.c_void_p(32), ctypes.c_void_p(32), 24, 16, 64, 0, None) == -4   # the two outputs alias
+    assert lib.hdn_conv3x3s2_v2_f32(one, one, one, ctypes.c_void_p(32), ctypes.c_void_p(48), 24, 16, 128, 0, None) == -3  # not one of the trunk's stages
+    assert lib.hdn_conv3x3_bias_relu_f32(one, one, one, None, None, None, 0, 1, 32, 64, 0, None) == -1
+    assert lib.hdn_conv3x3_bias_relu_f32(one, one, one, None, ctypes.c_void_p(32), None, 0, 1, 30, 64, 0, None) == -3      # unsupported (S, C)
+    assert lib.hdn_conv3x3_bias_relu_f32(one, one, one, None, ctypes.c_void_p(32), None, 0, 1, 32, 64, 0, None) == -1      # needs a workspace at B = 1
     assert lib.hdn_conv3x3_workspace_bytes(64, 32, 64, 1) == 0 and lib.hdn_conv3x3_workspace_bytes(1, 32, 64, 1) > 0 and lib.hdn_conv3x3_workspace_bytes(1, 5, 7, 1) == -3
     bn, ks = ctypes.c_int(0), ctypes.c_int(0)
     assert lib.hdn_conv3x3_pack_info(4, 512, 1, ctypes.byref(bn), ctypes.byref(ks)) == 0 and bn.value == 64 and ks.value >= 1
     assert lib.hdn_conv3x3_pack_info(16, 64, 2, ctypes.byref(bn), ctypes.byref(ks)) == 0 and lib.hdn_conv3x3_pack_info(16, 64, 3, None, None) == -3
-    assert lib.hdn_conv3x3s2_ds_f32(one, one, one, ctypes.c_void_p(32), None, None, 0, 1, 16, 64, None) == -1
-    assert lib.hdn_conv3x3s2_ds_f32(one, one, one, ctypes.c_void_p(32), ctypes.c_void_p(32), None, 0, 1, 16, 64, None) == -4
-    assert lib.hdn_conv3x3s2_ds_f32(one, one, one, ctypes.c_void_p(32), ctypes.c_void_p(48), None, 0, 64, 16, 96, None) == -3
+    assert lib.hdn_conv3x3s2_ds_f32(one, one, one, ctypes.c_void_p(32), None, None, 0, 1, 16, 64, 0, None) == -1
+    assert lib.hdn_conv3x3s2_ds_f32(one, one, one, ctypes.c_void_p(32), ctypes.c_void_p(32), None, 0, 1, 16, 64, 0, None) == -4
+    assert lib.hdn_conv3x3s2_ds_f32(one, one, one, ctypes.c_void_p(32), ctypes.c_void_p(48), None, 0, 64, 16, 96, 0, None) == -3
     # the chained form: slice counts are a pure host computation (>= NCHUNK / 2, so that a launch stages at most two chunks)
     assert lib.hdn_conv3x3_chain_slices(1, 32, 64, 1) == 4 and lib.hdn_conv3x3_chain_slices(1, 4, 512, 1) == 32 and lib.hdn_conv3x3_chain_slices(64, 4, 512, 1) == 16
     assert lib.hdn_conv3x3_chain_slices(64, 32, 64, 1) == 2 and lib.hdn_conv3x3_chain_slices(1, 8, 128, 2) == 8
     assert lib.hdn_conv3x3_chain_slices(0, 32, 64, 1) == -2 and lib.hdn_conv3x3_chain_slices(1, 30, 64, 1) == -3
     two = ctypes.c_void_p(128)
-    assert lib.hdn_conv3x3_chain_f32(one, 0, None, None, 0, None, one, None, None, 1, 32, 64, 1, None) == -1
-    assert lib.hdn_conv3x3_chain_f32(one, 0, None, None, 0, None, one, two, None, 1, 16, 64, 2, None) == -1          # stride 2 writes two outputs
-    assert lib.hdn_conv3x3_chain_f32(one, 4, None, None, 0, None, one, two, None, 1, 32, 64, 1, None) == -1          # slices without their bias
-    assert lib.hdn_conv3x3_chain_f32(one, 0, None, None, 0, two, one, ctypes.c_void_p(256), None, 1, 32, 64, 1, None) == -2   # an activation has nothing to write out
-    assert lib.hdn_conv3x3_chain_f32(one, 4, one, None, 1, None, one, two, None, 1, 32, 64, 1, None) == -2           # residual count without a residual
-    assert lib.hdn_conv3x3_chain_f32(one, 4, one, None, 0, two, one, two, None, 1, 32, 64, 1, None) == -4
-    assert lib.hdn_conv3x3_chain_f32(one, 0, None, None, 0, None, one, two, None, 1, 32, 64, 3, None) == -2
+    assert lib.hdn_conv3x3_chain_f32(one, 0, None, None, 0, None, one, None, None, 1, 32, 64, 1, 0, None) == -1
+    assert lib.hdn_conv3x3_chain_f32(one, 0, None, None, 0, None, one, two, None, 1, 16, 64, 2, 0, None) == -1          # stride 2 writes two outputs
+    assert lib.hdn_conv3x3_chain_f32(one, 4, None, None, 0, None, one, two, None, 1, 32, 64, 1, 0, None) == -1          # slices without their bias
+    assert lib.hdn_conv3x3_chain_f32(one, 0, None, None, 0, two, one, ctypes.c_void_p(256), None, 1, 32, 64, 1, 0, None) == -2   # an activation has nothing to write out
+    assert lib.hdn_conv3x3_chain_f32(one, 4, one, None, 1, None, one, two, None, 1, 32, 64, 1, 0, None) == -2           # residual count without a residual
+    assert lib.hdn_conv3x3_chain_f32(one, 4, one, None, 0, two, one, two, None, 1, 32, 64, 1, 0, None) == -4
+    assert lib.hdn_conv3x3_chain_f32(one, 0, None, None, 0, None, one, two, None, 1, 32, 64, 3, 0, None) == -2
     assert lib.hdn_conv3x3_finish_f32(one, 4, None, None, 0, two, 1, 32, 64, None) == -1 and lib.hdn_conv3x3_finish_f32(one, 4, one, None, 0, one, 1, 32, 64, None) == -4
     assert lib.hdn_conv3x3_finish_f32(one, 4, one, None, 2, two, 1, 32, 64, None) == -2 and lib.hdn_conv3x3_finish_f32(one, 4, one, None, 0, two, 1, 32, 66, None) == -2
-    assert lib.hdn_avgpool_fc_f32(one, one, None, two, 1, 512, 16, 17, 1, None) == -3 and lib.hdn_avgpool_fc_f32(one, one, None, None, 1, 512, 16, 8, 1, None) == -1
+    assert lib.hdn_avgpool_fc_f32(one, one, None, two, 1, 512, 16, 17, 1, 0, None) == -3 and lib.hdn_avgpool_fc_f32(one, one, None, None, 1, 512, 16, 8, 1, 0, None) == -1
     assert lib.hdn_similarity_translation_f32(one, one, one, one, one, None, 1, 25, 0.16, 8.0, 127.0, 2, None) == -1
     assert lib.hdn_similarity_translation_f32(one, one, one, one, one, one, 1, 0, 0.16, 8.0, 127.0, 2, None) == -2
     assert lib.hdn_similarity_logpolar_f32(one, one, None, one, one, 1, 13, 8.0, 0.03, 0.05, 2, None) == -1

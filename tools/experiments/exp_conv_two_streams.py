@@ -11,7 +11,7 @@ lib = _lib.load()
 def conv(x, wp2, bd, r, out, ws):
     B, C, S, _ = x.shape
     rc = lib.hdn_conv3x3_v2_f32(_lib.ptr(x), _lib.ptr(wp2), _lib.ptr(bd), _lib.ptr(r), _lib.ptr(out), _lib.ptr(ws) if ws is not None else None,
-                                ws.numel() * 4 if ws is not None else 0, B, S, C, _lib.stream_ptr(dev))
+                                ws.numel() * 4 if ws is not None else 0, B, S, C, 0, _lib.stream_ptr(dev))
     _lib.check(rc, "conv")
 def graph_time(fn, reps=10):
     side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
