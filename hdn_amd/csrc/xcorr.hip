@@ -881,6 +881,7 @@ static int launch_north(const XcorrPtrs& P, int n, int planes, hipStream_t strea
 // xcorr_fft.hip
 int launch_north_fft(const float* x, const float* k, float* out, int planes, int max_blocks, hipStream_t stream, int pair0);
 int launch_north_fft4(const float* x, const float* k, float* out, int planes, int max_blocks, hipStream_t stream);
+void disarm_north_launch_events();      // xcorr_fft.hip: hdn_xcorr_north_launch_events is one-shot and must not outlive the call it was armed for
 
 
 
@@ -900,8 +901,18 @@ static int launch_circ13(const XcorrPtrs& P, int n, int planes, hipStream_t stre
   return launch_status();
 }
 
-static int xcorr_dispatch(const XcorrPtrs& P, int n, int circular, int B, int C, int Hx, int Wx, int Hk, int Wk,
-                          hipStream_t stream) {
+static int xcorr_dispatch_(const XcorrPtrs& P, int n, int circular, int B, int C, int Hx, int Wx, int Hk, int Wk, hipStream_t stream);
+
+// Whatever this call launches (or refuses), events armed by hdn_xcorr_north_launch_events do not survive it: they belong to "the next correlation call",
+// and a caller is free to destroy them afterwards.
+static int xcorr_dispatch(const XcorrPtrs& P, int n, int circular, int B, int C, int Hx, int Wx, int Hk, int Wk, hipStream_t stream) {
+  const int rc = xcorr_dispatch_(P, n, circular, B, C, Hx, Wx, Hk, Wk, stream);
+  disarm_north_launch_events();
+  return rc;
+}
+
+static int xcorr_dispatch_(const XcorrPtrs& P, int n, int circular, int B, int C, int Hx, int Wx, int Hk, int Wk,
+                           hipStream_t stream) {
   const long long planes_ll = (long long)B * C;
   if (planes_ll > 0x7fffffffLL / 4) return HDN_E_LIMIT;
   const int planes = (int)planes_ll;

@@ -444,7 +444,8 @@ int hdn_set_check_range(int on);
  * Measurement hook (ABI 10): the NEXT 31x31 (x) 61x61 launch the calling thread makes through hdn_xcorr_depthwise_f32 / _multi_f32 carries these two
  * hipEvent_t (either may be NULL) as hipExtLaunchKernelGGL's start / stop events: they take the dispatch's own timestamps, so hipEventElapsedTime(start,
  * stop) is the kernel's duration on its stream with no marker packets around it (a hipEventRecord pair costs the stream ~4 us on each side of the kernel).
- * One-shot: cleared by the launch.  bench.py brackets the roofline kernel of every timed step this way.
+ * One-shot: cleared by the launch, and by the end of the calling thread's next hdn_xcorr_depthwise* call whatever that call launched (another shape, the direct
+ * variant, an argument error): the events never outlive the call they were armed for.  bench.py brackets the roofline kernel of every timed step this way.
  */
 int hdn_xcorr_north_launch_events(void* start_event, void* stop_event);
 

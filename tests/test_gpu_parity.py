@@ -1767,3 +1767,51 @@ def test_backbone_folding_on_the_device(dev, nhwc):
         assert "_hdn_fused" not in vars(model.backbone) and type(model.backbone) is PS.AtrousResNet50
         # (two runs of MIOpen's convolutions are not bit-identical: a tolerance, not torch.equal)
         assert all(float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) for a, b in zip(again, ref[0][0]))
+
+
+def test_north_launch_events_are_one_shot_and_time_the_kernel(dev):
+    """hdn_xcorr_north_launch_events: the next 31x31 (x) 61x61 launch carries the caller's hipEvent pair (hipExtLaunchKernelGGL) — elapsed time = the kernel's own
+    duration; the hook is one-shot, and a correlation call of another shape in between DISARMS it (the events are never touched afterwards)."""
+    import ctypes
+    from hdn_amd import _lib
+    hip = ctypes.CDLL("libamdhip64.so")
+    lib = _lib.load()
+
+    def ev():
+        h = ctypes.c_void_p()
+        assert hip.hipEventCreate(ctypes.byref(h)) == 0
+        return h
+
+    def elapsed(a, b):
+        ms = ctypes.c_float(-1.0)
+        return hip.hipEventElapsedTime(ctypes.byref(ms), a, b), ms.value
+
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(8, 256, 61, 61, generator=g).clamp_min_(0).to(dev)
+    k = torch.randn(8, 256, 31, 31, generator=g).clamp_min_(0).to(dev)
+    xs = torch.randn(2, 256, 29, 29, generator=g).to(dev)
+    ks = torch.randn(2, 256, 5, 5, generator=g).to(dev)
+    ref = X.xcorr_depthwise(x, k)
+    assert X.last_variant() == "north_fftc_61x61_31x31"
+    torch.cuda.synchronize()
+    # armed -> the launch records them; the result is the same launch's
+    e0, e1 = ev(), ev()
+    assert lib.hdn_xcorr_north_launch_events(e0, e1) == 0
+    y = X.xcorr_depthwise(x, k)
+    torch.cuda.synchronize()
+    rc, ms = elapsed(e0, e1)
+    assert rc == 0 and 0.003 < ms < 5.0, (rc, ms)          # 2,048 planes: ~15 us of kernel, not a host-side interval
+    assert torch.equal(y, ref)
+    # one-shot: the next launch does not re-record them
+    X.xcorr_depthwise(x, k)
+    torch.cuda.synchronize()
+    assert elapsed(e0, e1) == (rc, ms)
+    # armed, then a call of ANOTHER shape: disarmed, the following 31x31 launch leaves the pair untouched (never recorded -> an error from hipEventElapsedTime)
+    f0, f1 = ev(), ev()
+    assert lib.hdn_xcorr_north_launch_events(f0, f1) == 0
+    X.xcorr_depthwise(xs, ks)
+    X.xcorr_depthwise(x, k)
+    torch.cuda.synchronize()
+    assert elapsed(f0, f1)[0] != 0
+    for h in (e0, e1, f0, f1):
+        hip.hipEventDestroy(h)
