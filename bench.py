@@ -268,9 +268,10 @@ def main():
         mode = "inline" if args.only_north else (mode or args.head_stream)
         if mode == "parallel":
             fork_head()
+        stop_only = record == "stop"          # (A/B: HDN_BENCH_BRACKET_EVERY) the launch carries only the stop event the head stream forks on
         if record and bracket_mode == "launch":
-            e0, e1 = LaunchEvent(), LaunchEvent()
-            hlib.load().hdn_xcorr_north_launch_events(e0.h, e1.h)
+            e0, e1 = (None if stop_only else LaunchEvent()), LaunchEvent()
+            hlib.load().hdn_xcorr_north_launch_events(e0.h if e0 is not None else None, e1.h)
         elif record:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -278,7 +279,8 @@ def main():
         if record:
             if bracket_mode != "launch":
                 e1.record()
-            (north_ev if sink is None else sink).append((e0, e1))
+            if not stop_only:
+                (north_ev if sink is None else sink).append((e0, e1))
         if args.only_north:
             return
         if mode == "after-north":
@@ -309,8 +311,9 @@ def main():
     fence()
     no_brackets = os.environ.get("HDN_BENCH_NO_BRACKETS") == "1"      # A/B switch (profiles/round6_experiments.txt section 3): what the event pairs cost the step
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(not no_brackets)
+    every = max(1, int(os.environ.get("HDN_BENCH_BRACKET_EVERY", "1")))     # A/B switch: start + stop events on every N-th timed step only
+    for i_ in range(args.steps):
+        step(False if no_brackets else (True if (i_ % every == 0 or bracket_mode != "launch") else "stop"))
     fence()
     elapsed = time.perf_counter() - t0
     if no_brackets and args.workload != "full":
