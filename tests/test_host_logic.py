@@ -784,6 +784,25 @@ def test_committed_roofline_records_match_the_kernel_source():
     # no measurement block inside a production translation unit
     for f in glob.glob(os.path.join(ROOT, "hdn_amd", "csrc", "*.hip")):
         assert "defined(HDN_ABLATION)" not in open(f).read(), f
+    # the committed bench line of the round: the driver's contract fields, a roofline block that is consistent with itself and was produced on THIS kernel
+    # source, the CPU baseline, and the round-6 additions (launch-carried brackets, measured copy rate, issue fractions, lock-step rows)
+    d = json.loads([l for l in open(os.path.join(ROOT, "profiles", "round6_bench_line.json")) if l.startswith("{")][0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["dtype"] == "f32" and d["vs_baseline"] is None and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 64 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and r["algorithmic_bytes_per_launch"] == 5778432 * 64
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) <= 1e-6 * r["achieved"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-9 and 0.3 < r["frac"] < 1.0
+    assert r["traffic_source_matches_kernel_source"] is True and 0.98 <= r["traffic"] / r["algorithmic_bytes_per_launch"] <= 1.1
+    assert r["instruction_count_matches_kernel_source"] is True and 0 < r["valu_frac"] < r["issue_frac"] < 1.0
+    assert 1.0 <= r["shader_clock_GHz"] <= 2.6 and 3000 < r["measured_copy_GBps"] < 8000 and "hipExtLaunchKernelGGL" in r["bracket"]
+    assert r["avg_launch_ms"] < d["ms_per_step"] and r["sustained_launch_ms"] >= r["min_launch_ms"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    rows = d["sequence"]["lockstep"]["rows"]
+    assert rows and all(row["host_syncs_per_step"] == 1.0 and row["graph"] is True and row["frames_per_s"] > d["sequence"]["fps"] for row in rows)
 
 
 def test_c_packers_match_the_layout_reference_bit_for_bit():
