@@ -56,6 +56,29 @@ def _transform_poly(polygon, m):
     return (out @ m.transpose(1, 0))[:, 0:2]
 
 
+def sequence_records(poly, first_point, channel_average, cfg: TrackerConfig):
+    """The host arithmetic of hdnTracker.init for ONE sequence (hdn_tracker.py:117-136) -> (track record [48], seq record [8], poly_shift_l, init_s_z)."""
+    poly = [float(p) for p in np.asarray(poly, np.float64).reshape(-1)]
+    theta = poly[4] if len(poly) > 4 else 0.0
+    first_point = np.asarray(first_point, np.float64).reshape(-1)[:2]
+    size = np.array([poly[2], poly[3]], np.float64)
+    polygon = _transform_poly(_center2poly(poly[:4]), _rot_matrix(poly[0], poly[1], theta))           # :120-125
+    fir = (polygon - first_point) ** 2
+    shift = int(np.argmin(fir[:, 0] + fir[:, 1]))
+    w_z = size[0] + cfg.context_amount * np.sum(size)                                                  # :132-136
+    h_z = size[1] + cfg.context_amount * np.sum(size)
+    s_z = float(np.floor(np.sqrt(w_z * h_z)))
+    s_x = float(np.floor(s_z * float(np.round(cfg.instance_size / cfg.exemplar_size))))
+    avg = [float(a) for a in np.asarray(channel_average).reshape(-1)]
+    tr = np.zeros(TRACK_DOUBLES, np.float64)
+    tr[0:2], tr[2:4], tr[4], tr[6], tr[8] = poly[0:2], size, theta, 1.0, 1.0
+    tr[14:16], tr[16], tr[17:19], tr[19], tr[20:23] = size, s_z, poly[0:2], shift, avg
+    tr[24:30] = [poly[0], poly[1], s_x] + avg
+    tr[32:38] = [1, 0, 0, 0, 1, 0]
+    tr[40:46] = [poly[0], poly[1], s_z] + avg
+    return tr, np.array([poly[0], poly[1], s_z, s_x, 0.0] + avg, np.float64), shift, s_z
+
+
 class SimiTracker:
     def __init__(self, model, cfg: TrackerConfig = None, graph: bool = False, scale_score_thresh: float = 0.5):
         """model: the reference's ModelBuilder interface (template / track_new / track_new_lp) in eval mode on the GPU.
@@ -66,6 +89,7 @@ class SimiTracker:
         self.scale_score_thresh = float(scale_score_thresh)
         self.host_syncs = 0
         self._zf_static = None
+        self.n = 1          # sequences advanced per call (BatchedSimiTracker: n > 1)
 
     # -------------------------------------------------------------------------------------------------- template (init + refresh)
     def _template(self, z_crop):
@@ -92,35 +116,18 @@ class SimiTracker:
         gt_points, first_point (what tools/test.py passes); first_point: (x, y) of the first ground-truth corner."""
         if not rest:
             raise TypeError("init(img, bbox, poly, first_point) or init(img, bbox, poly, gt_points, first_point)")
-        first_point = np.asarray(rest[-1], np.float64).reshape(-1)[:2]
         c = self.cfg
         self.dev = next(self.model.parameters()).device
-        poly = [float(p) for p in np.asarray(poly, np.float64).reshape(-1)]
-        theta = poly[4] if len(poly) > 4 else 0.0
-        self.init_pos = np.array([poly[0], poly[1]], np.float64)
-        self.init_size = np.array([poly[2], poly[3]], np.float64)
-        polygon = _transform_poly(_center2poly(poly[:4]), _rot_matrix(poly[0], poly[1], theta))           # :120-125
-        fir = (polygon - first_point) ** 2
-        self.poly_shift_l = int(np.argmin(fir[:, 0] + fir[:, 1]))
-        w_z = self.init_size[0] + c.context_amount * np.sum(self.init_size)                                # :132-136
-        h_z = self.init_size[1] + c.context_amount * np.sum(self.init_size)
-        self.init_s_z = float(np.floor(np.sqrt(w_z * h_z)))
         self.ratio = float(np.round(c.instance_size / c.exemplar_size))
         frame = FR.upload(img)
         self.init_frame = frame.clone() if isinstance(img, torch.Tensor) and img.is_cuda else frame        # update_template rotates THIS frame, every frame
         self.channel_average = frame.to(torch.float64).mean(dim=(0, 1)).cpu().numpy()                     # :138 (one read per sequence)
         self.host_syncs += 1
         self.frame_hw = (int(frame.shape[0]), int(frame.shape[1]))
-        avg = [float(a) for a in self.channel_average]
-        s_x = float(np.floor(self.init_s_z * self.ratio))
-        tr = np.zeros(TRACK_DOUBLES, np.float64)
-        tr[0:2], tr[2:4], tr[4], tr[6], tr[8] = self.init_pos, self.init_size, theta, 1.0, 1.0
-        tr[14:16], tr[16], tr[17:19], tr[19], tr[20:23] = self.init_size, self.init_s_z, self.init_pos, self.poly_shift_l, avg
-        tr[24:30] = [poly[0], poly[1], s_x] + avg
-        tr[32:38] = [1, 0, 0, 0, 1, 0]
-        tr[40:46] = [poly[0], poly[1], self.init_s_z] + avg
+        tr, sq, self.poly_shift_l, self.init_s_z = sequence_records(poly, rest[-1], self.channel_average, c)
+        self.init_pos, self.init_size = tr[17:19].copy(), tr[14:16].copy()
         self.track = torch.from_numpy(tr).to(self.dev).view(1, -1)
-        self.seq = torch.tensor([[poly[0], poly[1], self.init_s_z, s_x, 0.0] + avg], dtype=torch.float64, device=self.dev)
+        self.seq = torch.from_numpy(sq).to(self.dev).view(1, -1)
         assert self.seq.shape[1] == SEQ_DOUBLES
         self._dec = SimilarityDecoder(self.dev, c)
         self.state = self._dec.new_state(1)
@@ -143,7 +150,7 @@ class SimiTracker:
             o = m.track_new_lp(x_moved, [0, 0])
         dec.logpolar(o["cls_lp"], o["loc_lp"], self.seq, self.state)                                                  # :241-246
         with _lib.device_guard(self.dev):                                                                             # :213-227, :247-283 and the next :176-188
-            _lib.check(_lib.load().hdn_simi_track_update_f64(_lib.ptr(self.state), _lib.ptr(self.track), _lib.ptr(self.seq), _lib.ptr(self._out), 1,
+            _lib.check(_lib.load().hdn_simi_track_update_f64(_lib.ptr(self.state), _lib.ptr(self.track), _lib.ptr(self.seq), _lib.ptr(self._out), self.n,
                                                              self.frame_hw[1], self.frame_hw[0], self.scale_score_thresh, c.context_amount, self.ratio,
                                                              _lib.stream_ptr(self.dev)), "simi track update")
         rot_img = FR.warp_affine_cubic(self.init_frame, self.track[:, 32:38])                                          # update_template, :156-162
@@ -218,6 +225,87 @@ class SimiTracker:
         return {"center_pos": t[0:2].copy(), "size": t[2:4].copy(), "rot": float(t[4]), "lp_shift": [0, float(t[5])], "scale": float(t[6]), "v": float(t[7]),
                 "window_scale_factor": float(t[8]), "lost_count": int(t[9]), "last_lost": bool(t[10]), "rot_is_float32": bool(t[11]),
                 "lp_shift_is_float32": bool(t[12]), "frames": int(t[13])}
+
+
+class BatchedSimiTracker(SimiTracker):
+    """n independent sequences of the similarity-only tracker in lock step on ONE GPU (what hdn_amd.batched_tracker is for the homography tracker; the
+    reference: several videos at once by hand-split ranges, tools/test.py:91-103).  Every kernel of the frame body already takes a batch — the crops and
+    the rotation of the resident first frames (blockIdx.y = sequence, per-sequence records read out of the [n, 48] arrays), the two decodes, the update
+    kernel — and the model's own forward code is batch-general (n templates, refreshed in place every step).  One step = one upload of [n,H,W,3], one
+    hipGraph replay, one host read of [n, 20].  Sequence b of a batch runs exactly the code it runs alone: tests/test_gpu_simi_tracker.py holds every
+    sequence to its own B = 1 run and to the CPU loop."""
+
+    def __init__(self, model, n: int, cfg: TrackerConfig = None, graph: bool = False, scale_score_thresh: float = 0.5):
+        super().__init__(model, cfg=cfg, graph=graph, scale_score_thresh=scale_score_thresh)
+        if n < 1:
+            raise ValueError("n must be >= 1")
+        self.n = int(n)
+        self._staging = self._copy_done = None
+
+    def _upload(self, imgs, into=None):
+        from .batched_tracker import BatchedHomoTracker
+        return BatchedHomoTracker._upload(self, imgs, into)          # (one pinned staging buffer, one asynchronous copy; the same checks)
+
+    def init(self, imgs, bboxes, polys, *rest):
+        """imgs n x BGR uint8 [H,W,3] (one size); bboxes, polys (cx, cy, w, h, theta) and first_points per sequence (hdnTracker.init's arguments; the
+        launchers' extra gt_points list is accepted in front of first_points)."""
+        if not rest:
+            raise TypeError("init(imgs, bboxes, polys, first_points) or init(imgs, bboxes, polys, gt_points, first_points)")
+        first_points, c, n = rest[-1], self.cfg, self.n
+        if not (len(bboxes) == len(polys) == len(first_points) == n):
+            raise ValueError(f"init takes {n} bboxes / polys / first_points")
+        self.dev = next(self.model.parameters()).device
+        self.ratio = float(np.round(c.instance_size / c.exemplar_size))
+        frames = self._upload(imgs)
+        self.init_frame = frames.clone()                              # update_template rotates THESE frames, every step
+        self.channel_average = frames.to(torch.float64).mean(dim=(1, 2)).cpu().numpy()
+        self.host_syncs += 1
+        self.frame_hw = (int(frames.shape[1]), int(frames.shape[2]))
+        recs = [sequence_records(polys[b], first_points[b], self.channel_average[b], c) for b in range(n)]
+        self.track = torch.from_numpy(np.stack([r[0] for r in recs])).to(self.dev).contiguous()
+        self.seq = torch.from_numpy(np.stack([r[1] for r in recs])).to(self.dev).contiguous()
+        self.poly_shift_l, self.init_s_z = [r[2] for r in recs], [r[3] for r in recs]
+        self._dec = SimilarityDecoder(self.dev, c)
+        self.state = self._dec.new_state(n)
+        self._out = torch.zeros((n, OUT_DOUBLES), dtype=torch.float64, device=self.dev)
+        self._zf_static, self._graph = None, None
+        z_crop = FR.get_subwindow(frames, None, c.exemplar_size, None, None, params=self.track[:, 40:46], islog=1)
+        self._template(z_crop)
+        return z_crop
+
+    def track_new(self, fr_idx, imgs, gt_box=None, gt_poly=None, gt_points=None, sync: bool = True):
+        """One frame of every sequence -> n result dictionaries with hdnTracker.track_new's keys (sync=True: one host read for all), or the float64 device
+        records [n, 20] (sync=False)."""
+        n = self.n
+        shape = tuple(imgs.shape) if isinstance(imgs, torch.Tensor) else (len(imgs),) + tuple(np.asarray(imgs[0]).shape)
+        if shape[0] != n or tuple(shape[1:3]) != self.frame_hw:
+            raise ValueError(f"a step takes {n} frames of {self.frame_hw}, got {shape}")
+        if self.use_graph:
+            if self._graph is None:
+                try:
+                    self._capture(shape)
+                except RuntimeError as e:
+                    import warnings
+                    warnings.warn(f"hdn_amd: the batched per-frame body could not be captured as a hipGraph ({type(e).__name__}: {e}); running it eagerly")
+                    self.use_graph, self._graph = False, None
+                    return self.track_new(fr_idx, imgs, sync=sync)
+            self._upload(imgs, into=self._static_frame)
+            self._graph.replay()
+            out = self._g_out
+        else:
+            out = self._body(self._upload(imgs))
+        if not sync:
+            return {"record": out.clone()}
+        h = out.cpu().numpy()
+        self.host_syncs += 1
+        return [{"bbox": list(h[b, 0:4]), "bbox_aligned": list(h[b, 4:8]), "best_score": np.float32(h[b, 8]), "rot": h[b, 9],
+                 "polygon": h[b, 10:18].reshape(4, 2).copy()} for b in range(n)]
+
+    def track_state(self) -> list:
+        t = self.track.cpu().numpy()
+        self.host_syncs += 1
+        return [{"center_pos": r[0:2].copy(), "size": r[2:4].copy(), "rot": float(r[4]), "lp_shift": [0, float(r[5])], "scale": float(r[6]), "v": float(r[7]),
+                 "lost_count": int(r[9]), "frames": int(r[13])} for r in t]
 
 
 class DeviceTrackerSimi(SimiTracker):

@@ -291,3 +291,47 @@ def test_simi_tracker_rare_branches_vs_cpu_loop(dev):
         seen["lost"] += int(float(ref.window_scale_factor) == 1.5)
     assert all(v >= 1 for v in seen.values()), seen
     print("rare branches taken:", seen)
+
+
+def test_batched_simi_tracker_equals_single_runs_and_cpu_loop(dev):
+    """BatchedSimiTracker (n = 3 sequences of different targets in lock step, eager and as one hipGraph per step): every sequence against its own SimiTracker
+    run (same kernels at B = 1) and against the CPU restatement of hdnTracker's loop; one host read per step for all of them."""
+    from synth_sequence import make_sequence
+    from hdn_amd.simi_tracker import BatchedSimiTracker, SimiTracker
+    from oracle.tracker_oracle import SimiTrackerOracle
+    n, T = 3, 8
+    sizes = [(150, 100), (120, 90), (170, 110)]
+    seqs = [make_sequence(n_frames=T, frame_hw=(360, 640), target_wh=sizes[b], seed=80 + b) for b in range(n)]
+    twin, cpu, cfg = _standin(dev, loc_scale_lp=0.3)
+    single, ref = [], []
+    for frames, _, init in seqs:
+        fp = np.array([init["first_point"]])
+        t, r = SimiTracker(twin, cfg=cfg), SimiTrackerOracle(cpu)
+        t.init(frames[0], init["bbox"], init["poly"], fp)
+        r.init(frames[0], init["bbox"], init["poly"], fp)
+        single.append([t.track_new(i, frames[i]) for i in range(1, T)])
+        ref.append([r.track_new(i, frames[i]) for i in range(1, T)])
+    args = ([s[0][0] for s in seqs], [s[2]["bbox"] for s in seqs], [s[2]["poly"] for s in seqs], [np.array([s[2]["first_point"]]) for s in seqs])
+    worst = {}
+    for graph in (False, True):
+        bt = BatchedSimiTracker(twin, n, cfg=cfg, graph=graph)
+        bt.init(*args)
+        assert [int(z.shape[0]) for z in twin.zf] == [n] * len(twin.zf)
+        s0 = bt.host_syncs
+        ws = wc = 0.0
+        for i in range(1, T):
+            res = bt.track_new(i, [s[0][i] for s in seqs])
+            assert len(res) == n and set(res[0]) == {"bbox", "bbox_aligned", "best_score", "rot", "polygon"}
+            for b in range(n):
+                ds = float(np.max(np.abs(res[b]["polygon"] - single[b][i - 1]["polygon"])))
+                dc = float(np.max(np.abs(res[b]["polygon"] - ref[b][i - 1]["polygon"])))
+                ws, wc = max(ws, ds), max(wc, dc)
+                assert ds <= (2e-3 if i <= 3 else 5e-2) and dc <= (2e-3 if i <= 3 else 5e-2), (graph, i, b, ds, dc)
+                assert abs(float(res[b]["rot"]) - float(single[b][i - 1]["rot"])) <= 2e-4
+        assert bt.host_syncs - s0 == T - 1 and (bt._graph is not None) == graph
+        worst[graph] = (ws, wc)
+        st = bt.track_state()
+        assert len(st) == n and all(s_["frames"] == T - 1 for s_ in st)
+    print("batched hdnTracker loop (n = 3), worst polygon distance (to the B = 1 runs, to the CPU loop):", {("hipGraph" if k else "eager"): tuple(f"{v:.1e}" for v in w) for k, w in worst.items()})
+    with pytest.raises(ValueError):
+        bt.track_new(99, [seqs[0][0][1]])
