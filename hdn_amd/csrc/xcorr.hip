@@ -63,7 +63,13 @@ constexpr int SX = 37, LPLANE = HX * SX;   // re-strided LDS plane (1073 floats)
 constexpr int PPB = 4;
 constexpr int UNITS = 5 * WO;              // 5 row blocks x 25 columns = 125 strips
 constexpr int XFLOATS = round_up(PPB * LPLANE + 8, 4);
-constexpr int LDS_FLOATS = XFLOATS + PPB * OPLANE;
+#ifndef PROD29_ALIAS
+#define PROD29_ALIAS 0                     // 1: the outputs are staged OVER the dead inputs (17.2 instead of 27.2 KB of LDS: 8 instead of 5 workgroups per CU), as in
+#endif                                     //    xcorr_cfg5_kernel.  Round 2 and round 6 (profiles/round6_experiments.txt section 6) measured it in the step.
+#ifndef PROD29_PAD_FLOATS
+#define PROD29_PAD_FLOATS 0                // measurement: unused LDS that lowers the number of resident workgroups per CU (5 at 27.2 KB; 3,200: 4; 6,500: 3)
+#endif
+constexpr int LDS_FLOATS = (PROD29_ALIAS ? XFLOATS : XFLOATS + PPB * OPLANE) + PROD29_PAD_FLOATS;
 constexpr int N4 = PPB * XPLANE / 4;       // 841 16-byte loads per workgroup
 constexpr int ITER = cdiv(N4, HDN_BLOCK);
 }  // namespace prod29
@@ -73,7 +79,7 @@ __global__ __launch_bounds__(HDN_BLOCK) void xcorr_prod29_kernel(XcorrPtrs P, in
   HDN_ABL_XCORR_0()
   __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
   float* sx = smem;
-  float* so = smem + XFLOATS;
+  float* so = PROD29_ALIAS ? smem : smem + XFLOATS;
 
   const int tid = threadIdx.x;
   const int lane = tid & (HDN_WAVE - 1);
@@ -118,6 +124,7 @@ __global__ __launch_bounds__(HDN_BLOCK) void xcorr_prod29_kernel(XcorrPtrs P, in
   __syncthreads();
 
   // ---- correlate: one wave per plane, one lane per 5x1 output strip --------------------------------------
+  float held[2][5];     // (PROD29_ALIAS: the strips wait in registers until every wave is done reading the image)
   if (wave < np) {  // wave-uniform
     const float* __restrict__ kp = k + size_t(plane0 + wave) * KPLANE;  // wave-uniform -> scalar loads
     const float* xs = sx + wave * LPLANE;
@@ -141,13 +148,31 @@ __global__ __launch_bounds__(HDN_BLOCK) void xcorr_prod29_kernel(XcorrPtrs P, in
           for (int t = 0; t < 5; ++t) acc[t] = __builtin_fmaf(col[t + u], kv, acc[t]);
         }
       }
-      if (unit < UNITS) {
+      if constexpr (PROD29_ALIAS) {
+#pragma unroll
+        for (int t = 0; t < 5; ++t) held[rd][t] = acc[t];
+      } else if (unit < UNITS) {
 #pragma unroll
         for (int t = 0; t < 5; ++t) os[(5 * b + t) * WO + j] = acc[t];
       }
     }
   }
   __syncthreads();
+  if constexpr (PROD29_ALIAS) {   // nobody reads the inputs any more
+    if (wave < np) {
+      float* os = so + wave * OPLANE;
+#pragma unroll
+      for (int rd = 0; rd < 2; ++rd) {
+        const int unit = rd * HDN_WAVE + lane;
+        if (unit < UNITS) {
+          const int b = unit / WO, j = unit - b * WO;
+#pragma unroll
+          for (int t = 0; t < 5; ++t) os[(5 * b + t) * WO + j] = held[rd][t];
+        }
+      }
+    }
+    __syncthreads();
+  }
 
   float* og = out + size_t(plane0) * OPLANE;
   if (np == PPB && aligned16(og)) copy_l2g_full<PPB * OPLANE>(so, og, tid);
