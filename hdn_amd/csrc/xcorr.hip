@@ -685,7 +685,10 @@ __device__ __forceinline__ void planes_out(const float* lds, float* __restrict__
 __global__ __launch_bounds__(HDN_BLOCK, 3) void xcorr_circ13f_kernel(XcorrPtrs P, int planes, int groups_per_problem, int total_groups) {
   using namespace circ13f;
   HDN_ABL_XCORR_1()
-  __shared__ __attribute__((aligned(16))) float smem[WAVES * WAVE_FLOATS];
+#ifndef CIRC13_PAD_FLOATS
+#define CIRC13_PAD_FLOATS 0      // measurement: unused LDS that lowers the resident workgroups per CU from 3 (6,600: 2)
+#endif
+  __shared__ __attribute__((aligned(16))) float smem[WAVES * WAVE_FLOATS + CIRC13_PAD_FLOATS];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = blockIdx.x * WAVES + wave;
