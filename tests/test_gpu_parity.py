@@ -1813,5 +1813,9 @@ def test_north_launch_events_are_one_shot_and_time_the_kernel(dev):
     X.xcorr_depthwise(x, k)
     torch.cuda.synchronize()
     assert elapsed(f0, f1)[0] != 0
+    hip.hipGetLastError()          # (the expected failure above is also HIP's "last error": clear it, or the next launch check of this process reports it)
     for h in (e0, e1, f0, f1):
         hip.hipEventDestroy(h)
+    assert hip.hipGetLastError() == 0
+    X.xcorr_depthwise(xs, ks)      # and the library's own launch check is clean again
+    torch.cuda.synchronize()
