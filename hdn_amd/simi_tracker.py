@@ -80,10 +80,14 @@ def sequence_records(poly, first_point, channel_average, cfg: TrackerConfig):
 
 
 class SimiTracker:
-    def __init__(self, model, cfg: TrackerConfig = None, graph: bool = False, scale_score_thresh: float = 0.5):
+    def __init__(self, model, cfg: TrackerConfig = None, graph: bool = False, scale_score_thresh: float = 0.5, batch_template: bool = None):
         """model: the reference's ModelBuilder interface (template / track_new / track_new_lp) in eval mode on the GPU.
-        scale_score_thresh: cfg.TRACK.SCALE_SCORE_THRESH (0.5 in hdn/core/config.py:527 and every shipped YAML)."""
+        scale_score_thresh: cfg.TRACK.SCALE_SCORE_THRESH (0.5 in hdn/core/config.py:527 and every shipped YAML).
+        batch_template: refresh the template with one backbone pass over (crop, log-polar crop) instead of template()'s two (checked against
+        template() at init; default: HDN_SIMI_BATCH_TEMPLATE, on)."""
         self.model = model
+        self.batch_template = (os.environ.get("HDN_SIMI_BATCH_TEMPLATE", "1") not in ("", "0")) if batch_template is None else bool(batch_template)
+        self._batched_ok = False
         self.cfg = cfg or TrackerConfig()
         self.use_graph, self._graph = bool(graph), None
         self.scale_score_thresh = float(scale_score_thresh)
@@ -92,13 +96,52 @@ class SimiTracker:
         self.n = 1          # sequences advanced per call (BatchedSimiTracker: n > 1)
 
     # -------------------------------------------------------------------------------------------------- template (init + refresh)
-    def _template(self, z_crop):
+    def _template_features(self, z_crop):
+        """(zf, zf_lp) of ModelBuilder.template(z_crop) (model_builder_e2e_unconstrained_v2.py:87-96).  With `batch_template` the crop and its
+        log-polar image go through the backbone as ONE batch of 2n instead of two passes of n (the 127-px passes are launch-bound; the necks keep
+        their own halves) — used only after _check_batched_template found it equal to the model's own template() on this sequence's first crop."""
+        m = self.model
+        with torch.no_grad():
+            if not self._batched_ok:
+                m.template(z_crop)
+                return m.zf, m.zf_lp
+            n = z_crop.shape[0]
+            f = m.feature_extractor(torch.cat((z_crop[:, 0:3], z_crop[:, 3:6]), 0))
+            levels = isinstance(f, (list, tuple))
+            a, b = ([t[:n] for t in f], [t[n:] for t in f]) if levels else (f[:n], f[n:])
+            if hasattr(m, "neck"):                                 # cfg.ADJUST.ADJUST (the attribute exists exactly then, :47-51)
+                a, b = m.neck(a), m.neck_lp(b)
+        return a, b
+
+    def _check_batched_template(self, z_crop, rtol: float = 1e-4) -> bool:
+        """Is the one-pass form this model's template()?  Compared on the sequence's first crop (max difference against the largest magnitude of the
+        level: a different convolution algorithm at 2n is rounding, a model whose template() does something else is not); on any doubt the
+        model's own method stays."""
+        m = self.model
+        if not (self.batch_template and hasattr(m, "feature_extractor") and hasattr(m, "neck") == hasattr(m, "neck_lp")):
+            return False
+        flat = lambda f: list(f) if isinstance(f, (list, tuple)) else [f]
+        self._batched_ok = False
+        own = [t.detach().clone() for f in self._template_features(z_crop) for t in flat(f)]
+        try:
+            self._batched_ok = True
+            got = [t for f in self._template_features(z_crop) for t in flat(f)]
+        except Exception:
+            return False
+        finally:
+            self._batched_ok = False
+        if len(got) != len(own) or any(g.shape != o.shape for g, o in zip(got, own)):
+            return False
+        return all(float((g - o).abs().max()) <= rtol * max(float(o.abs().max()), 1e-30) for g, o in zip(got, own))
+
+    def _template(self, z_crop, first: bool = False):
         """ModelBuilder.template(z_crop) with the resulting features COPIED into buffers that stay where they are: the per-frame refresh
         is then an in-place update (capturable; the heads' template cache keys on the tensors' version counters)."""
         m = self.model
-        with torch.no_grad():
-            m.template(z_crop)
-        new = [m.zf, m.zf_lp]
+        if first:
+            self._batched_ok = False
+            self._batched_ok = self._check_batched_template(z_crop)       # (two host reads per level, once per sequence)
+        new = list(self._template_features(z_crop))
         if self._zf_static is None:
             self._zf_static = [[t.detach().clone() for t in f] if isinstance(f, (list, tuple)) else f.detach().clone() for f in new]
         else:
@@ -134,7 +177,7 @@ class SimiTracker:
         self._out = torch.zeros((1, OUT_DOUBLES), dtype=torch.float64, device=self.dev)
         self._zf_static, self._graph = None, None
         z_crop = FR.get_subwindow(frame, None, c.exemplar_size, None, None, params=self.track[:, 40:46], islog=1)    # :140-143
-        self._template(z_crop)
+        self._template(z_crop, first=True)
         return z_crop
 
     # -------------------------------------------------------------------------------------------------- one frame
@@ -235,8 +278,8 @@ class BatchedSimiTracker(SimiTracker):
     hipGraph replay, one host read of [n, 20].  Sequence b of a batch runs exactly the code it runs alone: tests/test_gpu_simi_tracker.py holds every
     sequence to its own B = 1 run and to the CPU loop."""
 
-    def __init__(self, model, n: int, cfg: TrackerConfig = None, graph: bool = False, scale_score_thresh: float = 0.5):
-        super().__init__(model, cfg=cfg, graph=graph, scale_score_thresh=scale_score_thresh)
+    def __init__(self, model, n: int, cfg: TrackerConfig = None, graph: bool = False, scale_score_thresh: float = 0.5, batch_template: bool = None):
+        super().__init__(model, cfg=cfg, graph=graph, scale_score_thresh=scale_score_thresh, batch_template=batch_template)
         if n < 1:
             raise ValueError("n must be >= 1")
         self.n = int(n)
@@ -270,7 +313,7 @@ class BatchedSimiTracker(SimiTracker):
         self._out = torch.zeros((n, OUT_DOUBLES), dtype=torch.float64, device=self.dev)
         self._zf_static, self._graph = None, None
         z_crop = FR.get_subwindow(frames, None, c.exemplar_size, None, None, params=self.track[:, 40:46], islog=1)
-        self._template(z_crop)
+        self._template(z_crop, first=True)
         return z_crop
 
     def track_new(self, fr_idx, imgs, gt_box=None, gt_poly=None, gt_points=None, sync: bool = True):
@@ -312,7 +355,7 @@ class DeviceTrackerSimi(SimiTracker):
     """Drop-in for hdnTracker behind build_tracker(model) (hdn/tracker/tracker_builder.py:18-19).  One hipGraph per frame, BatchNorm-folded
     backbone / necks and MIOpen find mode around this tracker's calls, exactly as hdn_amd.tracker.DeviceTrackerHomo."""
 
-    def __init__(self, model, graph: bool = None, cfg: TrackerConfig = None, fold_backbone: bool = None):
+    def __init__(self, model, graph: bool = None, cfg: TrackerConfig = None, fold_backbone: bool = None, batch_template: bool = None):
         thresh = 0.5
         if cfg is None:
             cfg = TrackerConfig()
@@ -328,7 +371,7 @@ class DeviceTrackerSimi(SimiTracker):
         self.miopen_find = os.environ.get("HDN_MIOPEN_FIND", "1") not in ("", "0") and next(model.parameters()).is_cuda
         from . import backbone as BB
         self.folded = BB.optimize_similarity_model(model) if (BB.enabled() if fold_backbone is None else fold_backbone) else []
-        super().__init__(model, cfg=cfg, graph=graph, scale_score_thresh=thresh)
+        super().__init__(model, cfg=cfg, graph=graph, scale_score_thresh=thresh, batch_template=batch_template)
 
     def _find_mode(self):
         import contextlib

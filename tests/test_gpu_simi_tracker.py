@@ -182,6 +182,60 @@ def test_device_tracker_simi_production_shape(dev):
     print("production-shaped hdnTracker device loop vs CPU loop, polygon distance (px):", " ".join(f"{e:.1e}" for e in errs))
     assert trk._graph is not None
     assert errs[0] <= 5e-2 and max(errs) <= 0.5, errs        # (50 fp32 layers, MIOpen vs oneDNN; a decode cell off would be >= 10 px)
+    # the template refresh ran as ONE backbone pass over (crop, log-polar crop): accepted for this model by the check at init, and the
+    # tracker that calls the model's own template() — two passes — gives the same polygons
+    assert trk.batch_template and trk._batched_ok
+    two = DeviceTrackerSimi(model, batch_template=False)
+    two.init(frames[0], init["bbox"], init["poly"], fp)
+    assert not two._batched_ok
+    one = DeviceTrackerSimi(model)
+    one.init(frames[0], init["bbox"], init["poly"], fp)
+    d = [float(np.max(np.abs(one.track_new(i, frames[i])["polygon"] - two.track_new(i, frames[i])["polygon"]))) for i in range(1, len(frames))]
+    print("one-pass template refresh vs template(): polygon distance (px):", " ".join(f"{e:.1e}" for e in d))
+    assert max(d) <= 2e-2, d
+
+
+def test_batched_template_is_refused_for_models_it_does_not_describe(dev):
+    """_check_batched_template: a model without feature_extractor / with one neck only keeps its own template(); a model whose template() is NOT
+    `neck(backbone(z)), neck_lp(backbone(z_lp))` is caught by the numerical comparison on the first crop."""
+    from hdn_amd.simi_tracker import SimiTracker
+
+    class Net(torch.nn.Module):
+        def __init__(self, twist):
+            super().__init__()
+            self.conv = torch.nn.Conv2d(3, 8, 3, bias=False)
+            self.neck = torch.nn.Conv2d(8, 8, 1)
+            self.neck_lp = torch.nn.Conv2d(8, 8, 1)
+            self.twist = twist
+
+        def feature_extractor(self, x):
+            return self.conv(x)
+
+        def template(self, z):
+            self.zf = self.neck(self.feature_extractor(z[:, 0:3]))
+            self.zf_lp = self.neck_lp(self.feature_extractor(z[:, 3:6])) * self.twist
+
+    torch.manual_seed(5)
+    z = torch.randn(2, 6, 31, 31, device=dev)
+    for twist, want in ((1.0, True), (1.001, False)):
+        net = Net(twist).to(dev).eval()
+        t = SimiTracker(net, batch_template=True)
+        t._template(z, first=True)
+        assert t._batched_ok is want, (twist, t._batched_ok)
+        ref = Net(twist).to(dev).eval()
+        ref.load_state_dict(net.state_dict())
+        ref.template(z)
+        torch.testing.assert_close(net.zf, ref.zf, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(net.zf_lp, ref.zf_lp, rtol=1e-5, atol=1e-6)
+    net = Net(1.0).to(dev).eval()
+    del net.neck_lp
+    net.template = lambda z: (setattr(net, "zf", net.conv(z[:, 0:3])), setattr(net, "zf_lp", net.conv(z[:, 3:6])))
+    t = SimiTracker(net, batch_template=True)
+    t._template(z, first=True)
+    assert t._batched_ok is False
+    t = SimiTracker(Net(1.0).to(dev).eval(), batch_template=False)
+    t._template(z, first=True)
+    assert t._batched_ok is False
 
 
 class _ScriptedNet(torch.nn.Module):

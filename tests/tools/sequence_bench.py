@@ -368,7 +368,7 @@ def run_simi(n_frames=201, dev=None):
     frames, corners, init = make_sequence(n_frames=n_frames, frame_hw=(720, 1280), target_wh=(300, 200), **LONG_WALK)
     model, _ = build_production_model(frames, init, dev)
     out = {"tracker": "hdn_amd.simi_tracker.DeviceTrackerSimi (TRACKS['hdnTracker']): search crop, backbone, head, decode, moved crop, backbone, log-polar head, decode, "
-                      "recurrences + polygon, template refresh (rotate the first frame, crop, two backbone passes); one host read of 20 doubles per frame",
+                      "recurrences + polygon, template refresh (rotate the first frame, crop, the two template passes as one batch of 2 unless HDN_SIMI_BATCH_TEMPLATE=0); one host read of 20 doubles per frame",
            "frames": n_frames}
     for graph in (True, False):
         t = DeviceTrackerSimi(model, graph=graph)
