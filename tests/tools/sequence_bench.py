@@ -297,14 +297,17 @@ def init_from_corners(c0, target_wh):
             "gt_points": c0.reshape(-1).tolist(), "first_point": c0[0].tolist()}
 
 
-def run_multi(ns=(1, 4, 16, 32), n_steps=60, dev=None, quiet=False, offset=3, distinct_steps=8, kprofile_n=None):
+def run_multi(ns=(1, 4, 16, 32), n_steps=60, dev=None, quiet=False, offset=3, distinct_steps=8, kprofile_n=None, simi=False):
     """hdn_amd.batched_tracker.BatchedDeviceTracker(model, n) over n sequences in lock step on ONE GPU, production-shaped model.
     Sequence b = the synthetic 1280x720 sequence started `offset * b` frames later (its own first frame, template, corners, H_total).
     A step's n frames arrive as ONE pinned uint8 [n,720,1280,3] buffer (what a decoder / loader thread hands over); the timed loop
     does, per step: one host->device copy, one hipGraph replay, one host read of [n, 9].  `distinct_steps` pinned step buffers are
     cycled (the seeded stand-in does not track, so which frame follows which does not matter for the timing).
+    simi=True: hdn_amd.simi_tracker.BatchedSimiTracker (the similarity-only tracker with its per-step template refresh) the same way.
     -> rows {n, ms_per_step, frames_per_s, ms_per_step_frames_resident, ...}."""
     from hdn_amd.batched_tracker import BatchedDeviceTracker
+    from hdn_amd.simi_tracker import BatchedSimiTracker
+    from hdn_amd import backbone as BB
     dev = dev or torch.device("cuda:0")
     log = (lambda *a: None) if quiet else (lambda *a: print(*a, file=sys.stderr, flush=True))
     nmax = max(ns)
@@ -317,8 +320,13 @@ def run_multi(ns=(1, 4, 16, 32), n_steps=60, dev=None, quiet=False, offset=3, di
         t0 = time.perf_counter()
         offs = [b * offset for b in range(n)]
         inits = [init_from_corners(corners[o], target) for o in offs]
-        trk = BatchedDeviceTracker(model, n)
-        trk.init([frames[o] for o in offs], [i["bbox"] for i in inits], [i["poly"] for i in inits], [i["gt_points"] for i in inits])
+        if simi:
+            BB.optimize_similarity_model(model)
+            trk = BatchedSimiTracker(model, n, graph=True)
+            trk.init([frames[o] for o in offs], [i["bbox"] for i in inits], [i["poly"] for i in inits], [np.array([i["first_point"]]) for i in inits])
+        else:
+            trk = BatchedDeviceTracker(model, n)
+            trk.init([frames[o] for o in offs], [i["bbox"] for i in inits], [i["poly"] for i in inits], [i["gt_points"] for i in inits])
         steps = [torch.from_numpy(np.stack([frames[o + 1 + k] for o in offs])).pin_memory() for k in range(distinct_steps)]
         for k in range(6):                                  # MIOpen find at this batch size, graph capture, clocks
             trk.track_new(k, steps[k % distinct_steps])
@@ -330,7 +338,7 @@ def run_multi(ns=(1, 4, 16, 32), n_steps=60, dev=None, quiet=False, offset=3, di
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t1) / n_steps * 1e3
         syncs_per_step = (trk.host_syncs - s0) / n_steps
-        assert len(res) == n and all(np.isfinite(r["points"]).all() for r in res)
+        assert len(res) == n and all(np.isfinite(r["polygon" if simi else "points"]).all() for r in res)
         # the same with the frames already on the device (no PCIe in the step): what the kernels + networks alone sustain
         dsteps = [s.to(dev) for s in steps[:4]]
         torch.cuda.synchronize(); t2 = time.perf_counter()
@@ -353,7 +361,9 @@ def run_multi(ns=(1, 4, 16, 32), n_steps=60, dev=None, quiet=False, offset=3, di
     if base is not None:
         for r in rows:
             r["speedup_vs_n1"] = r["frames_per_s"] / base["frames_per_s"]
-    return {"tracker": "hdn_amd.batched_tracker.BatchedDeviceTracker(model, n): n independent sequences advance one frame per step; one pinned "
+    return {"tracker": ("hdn_amd.simi_tracker.BatchedSimiTracker(model, n): n independent sequences of the similarity-only tracker (template refreshed every "
+                        "step) advance one frame per step; one pinned [n,720,1280,3] upload, one hipGraph replay, one host read of [n, 20] per step") if simi else
+                       "hdn_amd.batched_tracker.BatchedDeviceTracker(model, n): n independent sequences advance one frame per step; one pinned "
                        "[n,720,1280,3] upload, one hipGraph replay, one host read of [n, 9] per step",
             "model": "tests/production_standin.py (ResNet-50 stride-8 dilated backbone x2, 256-channel heads, ResNet-34 estimator; seeded; fp32; channels-last; MIOpen find)",
             "steps_timed": n_steps, "rows": rows}
@@ -422,12 +432,12 @@ def main():
     ap.add_argument("--multi", type=str, default=None, help="comma-separated n: BatchedDeviceTracker over n sequences in lock step (production-shaped model)")
     ap.add_argument("--multi-profile", type=int, default=None, help="with --multi: torch.profiler kernel table at this n")
     args = ap.parse_args()
-    if args.simi_tracker:
+    if args.simi_tracker and not args.multi:
         res = run_simi(args.frames or 201)
         print(json.dumps(res))
         return
     if args.multi:
-        res = run_multi(tuple(int(x) for x in args.multi.split(",")), n_steps=args.frames or 60, kprofile_n=args.multi_profile)
+        res = run_multi(tuple(int(x) for x in args.multi.split(",")), n_steps=args.frames or 60, kprofile_n=args.multi_profile, simi=args.simi_tracker)
         for r in res["rows"]:
             k = r.get("kernel_profile")
             if k:
